@@ -1,0 +1,563 @@
+"""In-memory stand-ins for the `isaaclab*` module surface the reference imports.
+
+`install()` registers module objects named `isaaclab`, `isaaclab.utils`, `isaaclab.managers`, ...
+in `sys.modules` so that the reference's *unmodified* `locotouch.mdp` / `locotouch.config` files
+import.  IsaacLab / IsaacSim / PhysX are not installable here (no network, closed source), so the
+base classes below (`ManagerTermBase`, `CommandTerm`, `UniformVelocityCommand`,
+`JointPositionAction`, ...) restate IsaacLab 2.2's documented behaviour; parity at this boundary
+is unpinned.
+
+Nothing in here touches the GPU; the shim is host-side glue only.
+"""
+from __future__ import annotations
+
+import re
+import sys
+import types
+from collections.abc import Sequence
+from dataclasses import MISSING
+
+import torch
+
+from . import math as _math
+from .configclass import configclass
+
+
+# --------------------------------------------------------------------------------------------
+# managers
+# --------------------------------------------------------------------------------------------
+@configclass
+class SceneEntityCfg:
+    name: str = MISSING
+    joint_names: str | list | None = None
+    joint_ids: list | slice = slice(None)
+    fixed_tendon_names: str | list | None = None
+    fixed_tendon_ids: list | slice = slice(None)
+    body_names: str | list | None = None
+    body_ids: list | slice = slice(None)
+    object_collection_names: str | list | None = None
+    object_collection_ids: list | slice = slice(None)
+    preserve_order: bool = False
+
+    def resolve(self, scene):
+        entity = scene[self.name]
+        if self.joint_names is not None and hasattr(entity, "find_joints"):
+            ids, _ = entity.find_joints(self.joint_names, preserve_order=self.preserve_order)
+            self.joint_ids = slice(None) if len(ids) == entity.num_joints and ids == list(range(len(ids))) else ids
+        if self.body_names is not None and hasattr(entity, "find_bodies"):
+            ids, _ = entity.find_bodies(self.body_names, preserve_order=self.preserve_order)
+            self.body_ids = slice(None) if len(ids) == entity.num_bodies and ids == list(range(len(ids))) else ids
+
+
+def resolve_matching_names(keys, list_of_strings, preserve_order: bool = False):
+    """Regex full-match name resolution (IsaacLab string utils semantics)."""
+    if isinstance(keys, str):
+        keys = [keys]
+    index_list, names_list = [], []
+    if preserve_order:
+        for key in keys:
+            for i, s in enumerate(list_of_strings):
+                if re.fullmatch(key, s):
+                    index_list.append(i), names_list.append(s)
+    else:
+        for i, s in enumerate(list_of_strings):
+            if any(re.fullmatch(key, s) for key in keys):
+                index_list.append(i), names_list.append(s)
+    for key in keys:
+        if not any(re.fullmatch(key, s) for s in list_of_strings):
+            raise ValueError(f"Not all regular expressions are matched: '{key}' in {list_of_strings}")
+    return index_list, names_list
+
+
+@configclass
+class ManagerTermBaseCfg:
+    func: object = MISSING
+    params: dict = {}
+
+
+@configclass
+class ObservationTermCfg(ManagerTermBaseCfg):
+    modifiers: list | None = None
+    noise: object | None = None
+    clip: tuple | None = None
+    scale: object | None = None
+    history_length: int = 0
+    flatten_history_dim: bool = True
+
+
+@configclass
+class ObservationGroupCfg:
+    concatenate_terms: bool = True
+    concatenate_dim: int = -1
+    enable_corruption: bool = False
+    history_length: int | None = None
+    flatten_history_dim: bool = True
+
+
+@configclass
+class RewardTermCfg(ManagerTermBaseCfg):
+    weight: float = MISSING
+
+
+@configclass
+class TerminationTermCfg(ManagerTermBaseCfg):
+    time_out: bool = False
+
+
+@configclass
+class EventTermCfg(ManagerTermBaseCfg):
+    mode: str = MISSING
+    interval_range_s: tuple | None = None
+    is_global_time: bool = False
+    min_step_count_between_reset: int = 0
+
+
+@configclass
+class CurriculumTermCfg(ManagerTermBaseCfg):
+    pass
+
+
+@configclass
+class CommandTermCfg:
+    class_type: type = MISSING
+    resampling_time_range: tuple = MISSING
+    debug_vis: bool = False
+
+
+@configclass
+class ActionTermCfg:
+    class_type: type = MISSING
+    asset_name: str = MISSING
+    debug_vis: bool = False
+    clip: dict | None = None
+
+
+class ManagerTermBase:
+    def __init__(self, cfg, env):
+        self.cfg = cfg
+        self._env = env
+
+    @property
+    def num_envs(self) -> int:
+        return self._env.num_envs
+
+    @property
+    def device(self):
+        return self._env.device
+
+    def reset(self, env_ids: Sequence[int] | None = None) -> None:
+        pass
+
+    def __call__(self, *args, **kwargs):
+        raise NotImplementedError
+
+
+class CommandTerm(ManagerTermBase):
+    """Restatement of IsaacLab's CommandTerm."""
+
+    def __init__(self, cfg, env):
+        super().__init__(cfg, env)
+        self.metrics = dict()
+        self.time_left = torch.zeros(self.num_envs, device=self.device)
+        self.command_counter = torch.zeros(self.num_envs, device=self.device, dtype=torch.long)
+
+    @property
+    def command(self) -> torch.Tensor:
+        raise NotImplementedError
+
+    def reset(self, env_ids: Sequence[int] | None = None) -> dict:
+        if env_ids is None:
+            env_ids = slice(None)
+        extras = {}
+        for name, value in self.metrics.items():
+            extras[name] = torch.mean(value[env_ids]).item()
+            value[env_ids] = 0.0
+        self.command_counter[env_ids] = 0
+        self._resample(env_ids)
+        return extras
+
+    def compute(self, dt: float):
+        self._update_metrics()
+        self.time_left -= dt
+        resample_env_ids = (self.time_left <= 0.0).nonzero().flatten()
+        if len(resample_env_ids) > 0:
+            self._resample(resample_env_ids)
+        self._update_command()
+
+    def _resample(self, env_ids):
+        if isinstance(env_ids, slice):
+            env_ids = torch.arange(self.num_envs, device=self.device)[env_ids]
+        if len(env_ids) != 0:
+            self.time_left[env_ids] = self.time_left[env_ids].uniform_(*self.cfg.resampling_time_range)
+            self._resample_command(env_ids)
+            self.command_counter[env_ids] += 1
+
+    def _update_metrics(self):
+        raise NotImplementedError
+
+    def _resample_command(self, env_ids):
+        raise NotImplementedError
+
+    def _update_command(self):
+        raise NotImplementedError
+
+
+class UniformVelocityCommand(CommandTerm):
+    """Restatement of IsaacLab's stock uniform velocity command (heading control unused by the reference:
+    locotouch/config/base/locomotion_base_env_cfg.py:58-59 sets heading_command=False)."""
+
+    def __init__(self, cfg, env):
+        super().__init__(cfg, env)
+        self.robot = env.scene[cfg.asset_name]
+        self.vel_command_b = torch.zeros(self.num_envs, 3, device=self.device)
+        self.heading_target = torch.zeros(self.num_envs, device=self.device)
+        self.is_heading_env = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        self.is_standing_env = torch.zeros_like(self.is_heading_env)
+        self.metrics["error_vel_xy"] = torch.zeros(self.num_envs, device=self.device)
+        self.metrics["error_vel_yaw"] = torch.zeros(self.num_envs, device=self.device)
+
+    @property
+    def command(self) -> torch.Tensor:
+        return self.vel_command_b
+
+    def _update_metrics(self):
+        max_command_step = self.cfg.resampling_time_range[1] / self._env.step_dt
+        self.metrics["error_vel_xy"] += (
+            torch.norm(self.vel_command_b[:, :2] - self.robot.data.root_lin_vel_b[:, :2], dim=-1) / max_command_step)
+        self.metrics["error_vel_yaw"] += (
+            torch.abs(self.vel_command_b[:, 2] - self.robot.data.root_ang_vel_b[:, 2]) / max_command_step)
+
+    def _resample_command(self, env_ids):
+        r = torch.empty(len(env_ids), device=self.device)
+        self.vel_command_b[env_ids, 0] = r.uniform_(*self.cfg.ranges.lin_vel_x)
+        self.vel_command_b[env_ids, 1] = r.uniform_(*self.cfg.ranges.lin_vel_y)
+        self.vel_command_b[env_ids, 2] = r.uniform_(*self.cfg.ranges.ang_vel_z)
+        self.is_standing_env[env_ids] = r.uniform_(0.0, 1.0) <= self.cfg.rel_standing_envs
+
+    def _update_command(self):
+        standing_env_ids = self.is_standing_env.nonzero(as_tuple=False).flatten()
+        self.vel_command_b[standing_env_ids, :] = 0.0
+
+
+@configclass
+class UniformVelocityCommandCfg(CommandTermCfg):
+    class_type: type = UniformVelocityCommand
+    asset_name: str = MISSING
+    heading_command: bool = False
+    heading_control_stiffness: float = 1.0
+    rel_standing_envs: float = 0.0
+    rel_heading_envs: float = 1.0
+
+    @configclass
+    class Ranges:
+        lin_vel_x: tuple = MISSING
+        lin_vel_y: tuple = MISSING
+        ang_vel_z: tuple = MISSING
+        heading: tuple | None = None
+
+    ranges: Ranges = MISSING
+
+
+class ActionTerm(ManagerTermBase):
+    def __init__(self, cfg, env):
+        super().__init__(cfg, env)
+        self._asset = env.scene[cfg.asset_name]
+
+
+class JointPositionAction(ActionTerm):
+    """Restatement of IsaacLab's JointPositionAction: raw = a; processed = raw * scale + offset."""
+
+    def __init__(self, cfg, env):
+        super().__init__(cfg, env)
+        self._joint_ids, self._joint_names = self._asset.find_joints(cfg.joint_names, preserve_order=cfg.preserve_order)
+        self._num_joints = len(self._joint_ids)
+        if self._num_joints == self._asset.num_joints and not cfg.preserve_order:
+            self._joint_ids = slice(None)
+        self._raw_actions = torch.zeros(self.num_envs, self._num_joints, device=self.device)
+        self._processed_actions = torch.zeros_like(self._raw_actions)
+        self._scale = float(cfg.scale) if isinstance(cfg.scale, (int, float)) else 1.0
+        self._offset = float(cfg.offset) if isinstance(cfg.offset, (int, float)) else 0.0
+        if cfg.use_default_offset:
+            self._offset = self._asset.data.default_joint_pos[:, self._joint_ids].clone()
+
+    @property
+    def action_dim(self) -> int:
+        return self._num_joints
+
+    @property
+    def raw_actions(self) -> torch.Tensor:
+        return self._raw_actions
+
+    @property
+    def processed_actions(self) -> torch.Tensor:
+        return self._processed_actions
+
+    def process_actions(self, actions: torch.Tensor):
+        self._raw_actions[:] = actions
+        self._processed_actions = self._raw_actions * self._scale + self._offset
+
+    def apply_actions(self):
+        self._asset.set_joint_position_target(self._processed_actions, joint_ids=self._joint_ids)
+
+    def reset(self, env_ids: Sequence[int] | None = None) -> None:
+        self._raw_actions[env_ids] = 0.0
+
+
+@configclass
+class JointActionCfg(ActionTermCfg):
+    joint_names: list = MISSING
+    scale: float | dict = 1.0
+    offset: float | dict = 0.0
+    preserve_order: bool = False
+
+
+@configclass
+class JointPositionActionCfg(JointActionCfg):
+    class_type: type = JointPositionAction
+    use_default_offset: bool = True
+
+
+# --------------------------------------------------------------------------------------------
+# generic cfg records: accept any keyword, keep them as attributes
+# --------------------------------------------------------------------------------------------
+class _AnyCfg:
+    """Permissive cfg record for spawn / physics-property classes the env engine only reads fields from."""
+
+    def __init__(self, *args, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def replace(self, **kwargs):
+        import copy
+
+        new = copy.deepcopy(self)
+        for k, v in kwargs.items():
+            setattr(new, k, v)
+        return new
+
+    def copy(self):
+        import copy
+
+        return copy.deepcopy(self)
+
+    def to_dict(self):
+        from .configclass import _to_dict
+
+        return {k: _to_dict(v) for k, v in self.__dict__.items()}
+
+    def __getattr__(self, name):  # missing optional fields read as None
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return None
+
+
+def _anycfg(name: str, **defaults):
+    def __init__(self, *args, **kwargs):
+        for k, v in defaults.items():
+            import copy
+
+            setattr(self, k, copy.deepcopy(v))
+        _AnyCfg.__init__(self, *args, **kwargs)
+
+    return type(name, (_AnyCfg,), {"__init__": __init__})
+
+
+class _Placeholder:
+    """Runtime classes that only appear in type hints / isinstance checks of the reference."""
+
+
+def _module(name: str, **attrs) -> types.ModuleType:
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__path__ = []  # behave like a package so that `import a.b.c` resolves through sys.modules
+    sys.modules[name] = m
+    parent, _, child = name.rpartition(".")
+    if parent and parent in sys.modules:
+        setattr(sys.modules[parent], child, m)
+    return m
+
+
+_INSTALLED = False
+
+
+def install(extra_mdp: dict | None = None, import_subpackages: bool = True) -> None:
+    """Register the stand-in modules.  Idempotent.
+
+    `import_subpackages=False` turns `isaaclab_tasks.utils.import_packages` into a no-op (used when only
+    `locotouch.mdp` is needed, e.g. by tools/gen_golden.py)."""
+    global _INSTALLED
+    if _INSTALLED:
+        return
+    _INSTALLED = True
+
+    class Articulation(_Placeholder):
+        pass
+
+    class RigidObject(_Placeholder):
+        pass
+
+    class ContactSensor(_Placeholder):
+        pass
+
+    class RayCaster(_Placeholder):
+        pass
+
+    InitialStateCfgA = _anycfg("InitialStateCfg", pos=(0.0, 0.0, 0.0), rot=(1.0, 0.0, 0.0, 0.0),
+                               lin_vel=(0.0, 0.0, 0.0), ang_vel=(0.0, 0.0, 0.0), joint_pos={".*": 0.0},
+                               joint_vel={".*": 0.0})
+    ArticulationCfg = _anycfg("ArticulationCfg", class_type=Articulation)
+    ArticulationCfg.InitialStateCfg = InitialStateCfgA
+    RigidObjectCfg = _anycfg("RigidObjectCfg", class_type=RigidObject)
+    RigidObjectCfg.InitialStateCfg = _anycfg("InitialStateCfg", pos=(0.0, 0.0, 0.0), rot=(1.0, 0.0, 0.0, 0.0),
+                                             lin_vel=(0.0, 0.0, 0.0), ang_vel=(0.0, 0.0, 0.0))
+    AssetBaseCfg = _anycfg("AssetBaseCfg")
+
+    _module("isaaclab")
+    _module("isaaclab.utils", configclass=configclass)
+    _module("isaaclab.utils.math", **{k: v for k, v in _math.__dict__.items() if not k.startswith("_")})
+    _module("isaaclab.utils.noise", AdditiveUniformNoiseCfg=_anycfg("AdditiveUniformNoiseCfg", n_min=-1.0, n_max=1.0,
+                                                                      operation="add"),
+            NoiseCfg=_anycfg("NoiseCfg"))
+    _module("isaaclab.utils.dict", print_dict=lambda d, nesting=0: print(d))
+    _module("isaaclab.utils.io", dump_yaml=_dump_yaml, dump_pickle=_dump_pickle)
+    _module("isaaclab.assets", Articulation=Articulation, RigidObject=RigidObject, ArticulationCfg=ArticulationCfg,
+            RigidObjectCfg=RigidObjectCfg, AssetBaseCfg=AssetBaseCfg)
+    _module("isaaclab.assets.articulation", Articulation=Articulation, ArticulationCfg=ArticulationCfg)
+    _module("isaaclab.actuators", DCMotorCfg=_anycfg("DCMotorCfg"), ImplicitActuatorCfg=_anycfg("ImplicitActuatorCfg"),
+            IdealPDActuatorCfg=_anycfg("IdealPDActuatorCfg"))
+    _module("isaaclab.sensors", ContactSensor=ContactSensor, RayCaster=RayCaster,
+            ContactSensorCfg=_anycfg("ContactSensorCfg", class_type=ContactSensor, history_length=0,
+                                     track_air_time=False, update_period=0.0, force_threshold=1.0),
+            RayCasterCfg=_anycfg("RayCasterCfg"), patterns=types.SimpleNamespace(GridPatternCfg=_anycfg("GridPatternCfg")))
+    _module("isaaclab.scene", InteractiveSceneCfg=_make_scene_cfg())
+    _module("isaaclab.terrains", TerrainImporterCfg=_anycfg("TerrainImporterCfg"),
+            TerrainGeneratorCfg=_anycfg("TerrainGeneratorCfg"))
+    sim_names = ["UsdFileCfg", "RigidBodyPropertiesCfg", "CollisionPropertiesCfg", "ArticulationRootPropertiesCfg",
+                 "RigidBodyMaterialCfg", "MassPropertiesCfg", "CylinderCfg", "CuboidCfg", "SphereCfg", "CapsuleCfg",
+                 "MultiAssetSpawnerCfg", "PreviewSurfaceCfg", "DistantLightCfg", "DomeLightCfg", "SimulationCfg",
+                 "PhysxCfg", "GroundPlaneCfg"]
+    _module("isaaclab.sim", **{n: _anycfg(n) for n in sim_names})
+    mgr = dict(SceneEntityCfg=SceneEntityCfg, ManagerTermBase=ManagerTermBase, ManagerTermBaseCfg=ManagerTermBaseCfg,
+               ObservationGroupCfg=ObservationGroupCfg, ObservationTermCfg=ObservationTermCfg,
+               RewardTermCfg=RewardTermCfg, TerminationTermCfg=TerminationTermCfg, EventTermCfg=EventTermCfg,
+               CurriculumTermCfg=CurriculumTermCfg, CommandTerm=CommandTerm, CommandTermCfg=CommandTermCfg,
+               ActionTerm=ActionTerm, ActionTermCfg=ActionTermCfg)
+    _module("isaaclab.managers", **mgr)
+    _module("isaaclab.managers.action_manager", ActionTerm=ActionTerm)
+    _module("isaaclab.envs", **_env_cfg_classes())
+    mdp_ns = dict(extra_mdp or {})
+    _module("isaaclab.envs.mdp", **mdp_ns)
+    _module("isaaclab.envs.mdp.commands", UniformVelocityCommand=UniformVelocityCommand,
+            UniformVelocityCommandCfg=UniformVelocityCommandCfg)
+    _module("isaaclab.envs.mdp.actions", JointPositionAction=JointPositionAction,
+            JointPositionActionCfg=JointPositionActionCfg, JointActionCfg=JointActionCfg)
+    _module("isaaclab.envs.mdp.rewards")
+    _module("isaaclab_tasks")
+    _module("isaaclab_tasks.utils", import_packages=_import_packages if import_subpackages else (lambda *a, **k: None))
+    if "git" not in sys.modules:  # loco_rl/utils/utils.py:8 imports GitPython at module level
+        try:
+            import git  # noqa: F401
+        except ImportError:
+            _module("git")
+
+
+def _make_scene_cfg():
+    @configclass
+    class InteractiveSceneCfg:
+        num_envs: int = MISSING
+        env_spacing: float = MISSING
+        lazy_sensor_update: bool = True
+        replicate_physics: bool = True
+        filter_collisions: bool = True
+
+    return InteractiveSceneCfg
+
+
+def _env_cfg_classes():
+    SimulationCfg = _anycfg("SimulationCfg", dt=1.0 / 60.0, render_interval=1, device="cuda:0",
+                            physx=_AnyCfg(), physics_material=None, disable_contact_processing=False)
+
+    @configclass
+    class ViewerCfg:
+        eye: tuple = (7.5, 7.5, 7.5)
+        lookat: tuple = (0.0, 0.0, 0.0)
+        cam_prim_path: str = "/OmniverseKit_Persp"
+        resolution: tuple = (1280, 720)
+        origin_type: str = "world"
+        env_index: int = 0
+        asset_name: str | None = None
+        body_name: str | None = None
+
+    @configclass
+    class ManagerBasedEnvCfg:
+        viewer: ViewerCfg = ViewerCfg()
+        sim: object = SimulationCfg()
+        ui_window_class_type: object = None
+        seed: int | None = None
+        decimation: int = MISSING
+        scene: object = MISSING
+        recorders: object = None
+        observations: object = MISSING
+        actions: object = MISSING
+        events: object = None
+        rerender_on_reset: bool = False
+        wait_for_textures: bool = True
+
+    @configclass
+    class ManagerBasedRLEnvCfg(ManagerBasedEnvCfg):
+        is_finite_horizon: bool = False
+        episode_length_s: float = MISSING
+        rewards: object = MISSING
+        terminations: object = MISSING
+        curriculum: object = None
+        commands: object = None
+
+    class _Abstract:
+        pass
+
+    return dict(ViewerCfg=ViewerCfg, ManagerBasedEnvCfg=ManagerBasedEnvCfg, ManagerBasedRLEnvCfg=ManagerBasedRLEnvCfg,
+                ManagerBasedEnv=type("ManagerBasedEnv", (_Abstract,), {}),
+                ManagerBasedRLEnv=type("ManagerBasedRLEnv", (_Abstract,), {}),
+                DirectMARLEnv=type("DirectMARLEnv", (_Abstract,), {}),
+                DirectMARLEnvCfg=type("DirectMARLEnvCfg", (_Abstract,), {}),
+                DirectRLEnvCfg=type("DirectRLEnvCfg", (_Abstract,), {}),
+                multi_agent_to_single_agent=lambda env: env)
+
+
+def _import_packages(package_name: str, blacklist_pkgs: list | None = None):
+    """Recursive import of sub-packages (triggers the `gym.register` calls in config/**/__init__.py)."""
+    import importlib
+    import pkgutil
+
+    blacklist_pkgs = blacklist_pkgs or []
+    package = importlib.import_module(package_name)
+    for info in pkgutil.walk_packages(package.__path__, package.__name__ + ".",
+                                      onerror=lambda name: None):
+        if any(b in info.name for b in blacklist_pkgs):
+            continue
+        importlib.import_module(info.name)
+
+
+def _dump_yaml(filename: str, data, sort_keys: bool = False):
+    import os
+
+    import yaml
+
+    if not filename.endswith("yaml"):
+        filename += ".yaml"
+    os.makedirs(os.path.dirname(filename), exist_ok=True)
+    if hasattr(data, "to_dict"):
+        data = data.to_dict()
+    with open(filename, "w") as f:
+        yaml.dump(data, f, default_flow_style=False, sort_keys=sort_keys)
+
+
+def _dump_pickle(filename: str, data):
+    import os
+    import pickle
+
+    if not filename.endswith("pkl"):
+        filename += ".pkl"
+    os.makedirs(os.path.dirname(filename), exist_ok=True)
+    with open(filename, "wb") as f:
+        pickle.dump(data, f)

@@ -1,0 +1,26 @@
+"""Seeded synthetic rollout for BASELINE.json configs[0] (64 envs x 24 steps, obs 348, 12 actions).
+
+Shared by tools/gen_golden_rl.py (which feeds it to the reference's loco_rl) and
+tests/test_rl_parity.py (which feeds it to locotouch_amd.rl); the data is regenerated from the seed
+on both sides, so only the reference's *outputs* are stored in tests/golden/rl_ppo_cfg1.npz.
+Hyper-parameters: reference locotouch/config/locotouch/agents/rsl_rl_ppo_cfg.py:11-30.
+"""
+import torch
+
+N_ENVS, N_STEPS, N_OBS, N_ACT = 64, 24, 348, 12
+POLICY_CFG = dict(init_noise_std=1.0, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], activation="elu")
+PPO_CFG = dict(value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2, entropy_coef=0.01, num_learning_epochs=5,
+               num_mini_batches=4, learning_rate=1.0e-3, schedule="adaptive", gamma=0.99, lam=0.95, desired_kl=0.01,
+               max_grad_norm=1.0)
+
+
+def synth_rollout(seed: int = 123):
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randn(N_STEPS, N_ENVS, N_OBS, generator=g)
+    critic_obs = obs + 0.05 * torch.randn(N_STEPS, N_ENVS, N_OBS, generator=g)
+    rewards = torch.randn(N_STEPS, N_ENVS, generator=g)
+    dones = (torch.rand(N_STEPS, N_ENVS, generator=g) < 0.05)
+    time_outs = dones & (torch.rand(N_STEPS, N_ENVS, generator=g) < 0.4)
+    last_critic_obs = torch.randn(N_ENVS, N_OBS, generator=g)
+    return dict(obs=obs, critic_obs=critic_obs, rewards=rewards, dones=dones.long(), time_outs=time_outs,
+                last_critic_obs=last_critic_obs)
