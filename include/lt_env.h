@@ -1,0 +1,283 @@
+/*
+ * lt_env.h - C ABI of the MI355X-native LocoTouch environment step.
+ *
+ * The reference has no FFI of its own: its hot path is `ManagerBasedRLEnv.step()` (IsaacLab, closed
+ * PhysX underneath) called through the `VecEnv` protocol of loco_rl (reference
+ * loco_rl/loco_rl/env/vec_env.py:12-101, used at loco_rl/loco_rl/runners/on_policy_runner.py:32,121-132,158).
+ * This header is the boundary a maintainer binds instead (ctypes stub: INTEGRATION.md):
+ *
+ *   reference interface                                  entry point here
+ *   ---------------------------------------------------  ---------------------------------------
+ *   gym.make(task, cfg=env_cfg)  (scripts/train.py:98)    lt_cfg_default + lt_env_create + lt_env_bind
+ *   env.reset() / RslRlVecEnvWrapper.__init__ [DEP]       lt_env_reset_all
+ *   env.step(actions) (on_policy_runner.py:158)           lt_env_step
+ *   env.episode_length_buf = ... (on_policy_runner:121)   lt_env_get_view(LT_F_EP_LEN) (int64, writable)
+ *   env.get_observations() (on_policy_runner.py:32,127)   lt_env_get_view(LT_F_OBS_POLICY / _CRITIC)
+ *   env.scene[...].data.* / sensors[...].data.* (B3)      lt_env_get_view(field)
+ *   command_term.set_ranges (mdp/commands.py:471)         device-side in lt_env_step (curriculum kernel),
+ *                                                         host override: lt_env_set_command_ranges
+ *   term-level evaluation for parity tests                lt_env_eval_terms
+ *
+ * Rules: extern "C", plain pointers and sizes, no torch types; every call returns 0 on success or a
+ * negative LT_E* code (never throws); caller owns the device arena; every launch is stream-ordered on
+ * the `stream` argument (a hipStream_t passed as void*) and performs NO host synchronisation, so a
+ * whole rollout step is hipGraph-capturable.
+ */
+#ifndef LT_ENV_H
+#define LT_ENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_ABI_VERSION 1
+
+/* error codes */
+#define LT_OK 0
+#define LT_EINVAL (-22)
+#define LT_ENOMEM (-12)
+#define LT_EFAULT (-14) /* arena not bound / too small */
+#define LT_EHIP (-5)    /* a HIP runtime call failed (lt_last_error() has the text) */
+
+/* tasks (gym ids: reference locotouch/config/locotouch/__init__.py:14,99) */
+#define LT_TASK_LOCOMOTION 0        /* Isaac-Locomotion-LocoTouch-v1 */
+#define LT_TASK_TRANSPORT_TEACHER 1 /* Isaac-RandCylinderTransportTeacher-LocoTouch-v1 */
+
+/* reward terms, in manager order (reference config/base/locomotion_base_env_cfg.py:139-218 then
+ * config/locotouch/object_transport_teacher_env_cfg.py:88-105).  Zero-weight terms are not evaluated. */
+enum lt_reward_term {
+  LT_R_ALIVE = 0, LT_R_TRACK_LIN_VEL_XY, LT_R_TRACK_ANG_VEL_Z, LT_R_FOOT_SLIP, LT_R_FOOT_DRAGGING, LT_R_GAIT,
+  LT_R_TRACK_BASE_HEIGHT, LT_R_BASE_Z_VELOCITY, LT_R_BASE_ROLL_PITCH_ANGLE, LT_R_BASE_ROLL_PITCH_VELOCITY,
+  LT_R_JOINT_POSITION_LIMIT, LT_R_JOINT_POSITION, LT_R_JOINT_ACCELERATION, LT_R_JOINT_VELOCITY, LT_R_JOINT_TORQUE,
+  LT_R_ACTION_RATE, LT_R_THIGH_CALF_COLLISION,
+  LT_R_OBJECT_XY_POSITION, LT_R_OBJECT_XY_VELOCITY, LT_R_OBJECT_Z_CONTACT, LT_R_OBJECT_Z_VELOCITY,
+  LT_R_OBJECT_ROLL_PITCH_ANGLE, LT_R_OBJECT_ROLL_PITCH_VELOCITY, LT_R_OBJECT_YAW_ALIGNMENT, LT_R_OBJECT_DANGEROUS_STATE,
+  LT_NUM_REWARD_TERMS, /* 25 */
+  LT_REWARD_SLOTS = 28 /* padded to a multiple of 4 (7 quad arrays) */
+};
+
+/* termination terms (bit index in LT_F_TERM_BITS) */
+enum lt_term_bit {
+  LT_T_TIME_OUT = 0, LT_T_BASE_ORIENTATION, LT_T_BASE_HEIGHT, LT_T_BASE_CONTACT, LT_T_HIP_CONTACT,
+  LT_T_OBJECT_BELOW_ROBOT, LT_T_OBJECT_BAD_ROLL, LT_NUM_TERM_BITS
+};
+
+/*
+ * Environment configuration.  Every member after `seed` is a 4-byte int32_t or float (arrays of them), so
+ * a binding can mirror the struct mechanically (locotouch_amd/_abi.py parses this very header).
+ * lt_cfg_default() fills the resolved values of SURVEY.md Appendix A for a task.
+ */
+typedef struct lt_cfg {
+  uint64_t seed;
+  int32_t num_envs;
+  int32_t task;
+  /* timing: reference config/base/locomotion_base_env_cfg.py:343-349 */
+  float sim_dt;
+  int32_t decimation;
+  int32_t phys_substeps; /* integrator substeps inside one sim step (engine detail; 1 = 200 Hz) */
+  float episode_length_s;
+  /* action term: reference mdp/actions.py:30-44, cfg locomotion_base_env_cfg.py:126-135 */
+  float action_clip;
+  float action_scale;
+  /* DC-motor PD actuator: reference assets/go1.py:41-49 */
+  float kp;
+  float kd;
+  float effort_limit;
+  float saturation_effort;
+  float velocity_limit;
+  /* command term: reference mdp/commands.py:427-576, cfg locomotion_vel_cur_base_env_cfg.py:14-50 */
+  float cmd_range_init[3][2]; /* lin_vel_x, lin_vel_y, ang_vel_z: (lo, hi) */
+  float cmd_range_max[3];     /* curriculum maximum (symmetric) */
+  float cmd_resample_time[2];
+  float cmd_new_probs;        /* 0.15 -> bins (0.15, 0.70, 0.15) */
+  float cmd_rel_standing;
+  float cmd_rel_standing_final;
+  int32_t cmd_zero_steps;
+  int32_t cmd_zero_steps_final;
+  int32_t cmd_multi_sampling; /* 0: UniformVelocityCommandGaitLogging, 1: ...MultiSampling */
+  /* curriculum: reference mdp/curriculums.py:184-275 */
+  int32_t cur_enabled;
+  int32_t cur_bins[3];
+  float cur_len_threshold;        /* 0.98 * max_episode_length_s, compared with steps (quirk Q4) */
+  float cur_reward_threshold[2];  /* lin, ang: exp(-err/sigma) * weight * max_episode_length_s */
+  int32_t cur_repeat_times[2];
+  int32_t cur_max_distance_bins;
+  /* rewards: weight per lt_reward_term (0 => term skipped), plus parameters */
+  float reward_weight[28];
+  float track_sigma;
+  float foot_slip_threshold;
+  float foot_drag_height;
+  float foot_drag_vel;
+  float base_height_target;
+  float joint_pos_stand_scale;
+  float joint_pos_vel_threshold;
+  float thigh_calf_threshold;
+  float danger_x_max;
+  float danger_y_max;
+  float danger_z_min;
+  float danger_vel_xy_max;
+  int32_t gait_with_object;       /* AdaptiveSymmetricGaitRewardwithObject */
+  float gait_judge_time;
+  float gait_air_bound;
+  float gait_contact_bound;
+  float gait_async_tolerance;
+  float gait_stance_scale;
+  float gait_soft_min_frequency;
+  float gait_tolerance_proportion;
+  float gait_rwd_upper;
+  float gait_rwd_lower;
+  float gait_vel_sigma;
+  float gait_task_ratio;
+  /* terminations: reference locomotion_base_env_cfg.py:296-313, mdp/terminations.py */
+  int32_t term_enabled[8];        /* per lt_term_bit */
+  float term_orientation_limit;
+  float term_min_height;
+  float term_contact_threshold;
+  float term_object_roll_limit;
+  /* observations: reference locomotion_base_env_cfg.py:69-122, object_transport_teacher_env_cfg.py:13-51 */
+  int32_t obs_history;            /* 6 */
+  float obs_noise_ang_vel;
+  float obs_noise_gravity;
+  float obs_noise_joint_pos;
+  float obs_noise_joint_vel;
+  float obs_scale_ang_vel;
+  float obs_scale_joint_vel;
+  float obj_noise[13];            /* half-widths: pos [0..2], lin vel [3..5], euler rpy [6..8], ang vel [9..11], [12] unused */
+  float obj_scale[13];
+  float obj_contact_time_threshold;
+  /* reset events */
+  float reset_root_pos[3][2];     /* x, y, z ranges */
+  float reset_root_rpy[3][2];
+  float reset_root_vel[6][2];
+  float reset_joint_pos[2];
+  float reset_joint_vel[2];
+  float trunk_mass_add[2];        /* startup */
+  float foot_friction[2];         /* startup, static & dynamic from the same range, consistent (min) */
+  float foot_restitution[2];
+  float trunk_friction[2];        /* reset */
+  float trunk_restitution[2];
+  float obj_friction[2];
+  float obj_restitution[2];
+  float obj_mass_add[2];
+  float obj_reset_pos[3][2];
+  float obj_reset_rpy[3][2];
+  float obj_radius[2];            /* per-env cylinder radius range (sampled once, seeded) */
+  float obj_length[2];
+  /* interval events */
+  float push_robot_interval[2];
+  float push_robot_vel[6][2];
+  float push_obj_interval[2];
+  float push_obj_vel[6][2];
+  /* contact-sensor thresholds */
+  float contact_force_threshold;  /* 1.0 N [DEP default] */
+  /* contact model (engine parameters; PhysX has no counterpart - see DESIGN.md "Physics") */
+  float ground_kn;
+  float ground_cn;
+  float ground_ct;
+  float ground_mu;                /* ground material (multiply combine) */
+  float plate_kn;
+  float plate_cn;
+  float plate_ct;
+  float contact_ramp;             /* damping ramp-in depth */
+  float gravity;
+  int32_t enable_corruption;      /* policy-group noise on/off */
+  int32_t debug_terms;            /* 1: write unweighted reward terms to LT_F_REWARD_TERMS every step */
+  int32_t max_episode_length;     /* ceil(episode_length_s / step_dt) = 1000 (kept integral: bit-exact time_out) */
+  int32_t reserved[5];
+} lt_cfg;
+
+/* Fields of the state arena (zero-copy views for the manager-term data contract). */
+enum lt_field {
+  LT_F_ROOT_POS = 0, LT_F_ROOT_QUAT, LT_F_ROOT_LIN_VEL_W, LT_F_ROOT_ANG_VEL_W,
+  LT_F_JOINT_POS, LT_F_JOINT_VEL, LT_F_JOINT_ACC, LT_F_APPLIED_TORQUE,
+  LT_F_ACT_RAW, LT_F_ACT_PREV_RAW, LT_F_ACT_PREV_PREV_RAW,
+  LT_F_FORCE_HIST,      /* |F| history: [slot 3][type 4: hip,thigh,calf,foot] quad arrays (per leg) */
+  LT_F_TRUNK_FORCE_HIST,/* (h0,h1,h2,_) */
+  LT_F_FOOT_CUR_AIR, LT_F_FOOT_CUR_CONTACT, LT_F_FOOT_LAST_AIR, LT_F_FOOT_LAST_CONTACT,
+  LT_F_FOOT_POS_W,      /* 3 quad arrays: x,y,z per leg (derived, written each step) */
+  LT_F_FOOT_VEL_W,      /* 3 quad arrays */
+  LT_F_FOOT_FRICTION,   /* per-leg mu (startup randomisation) */
+  LT_F_OBJ_POS, LT_F_OBJ_QUAT, LT_F_OBJ_LIN_VEL_W, LT_F_OBJ_ANG_VEL_W,
+  LT_F_OBJ_TIMERS,      /* (cur_air, cur_contact, last_air, last_contact) */
+  LT_F_OBJ_PARAMS,      /* (radius, length, mass, mu) */
+  LT_F_ENV_PARAMS,      /* (trunk_mass_add, trunk_mu, trunk_restitution, obj_restitution) */
+  LT_F_GAIT_LAST_AIR, LT_F_GAIT_LAST_CONTACT, LT_F_GAIT_VALID_LAST_AIR, LT_F_GAIT_FLAGS,
+  LT_F_GAIT_CMD,        /* (last_cmd xyz, step_from_changing_cmd) */
+  LT_F_CMD,             /* (vx, vy, wz, time_left) */
+  LT_F_CMD_BUF,         /* (vx, vy, wz, is_standing) */
+  LT_F_EVENT_TIMERS,    /* (push_robot_left, push_obj_left, _, _) */
+  LT_F_EPISODE_SUMS,    /* 7 quad arrays: per reward term, weighted*dt accumulated */
+  LT_F_LAST_EPISODE_SUMS,/* 7 quad arrays: snapshot at the last reset (logging) */
+  LT_F_LAST_EPISODE_INFO,/* (episodes_finished, last_ep_len, last_term_bits, _) */
+  LT_F_CURRICULUM,      /* 3 quad arrays: this step's record (reset, ep_len, sum_lin, sum_ang); trackers
+                         * (reset_lin, len_lin, sum_lin, reset_ang); (len_ang, sum_ang, _, _) */
+  LT_F_REWARD_TERMS,    /* 7 quad arrays: unweighted term values of the last step (diagnostics / parity) */
+  LT_NUM_QUAD_FIELDS,
+  /* plain (non-quad) arrays */
+  LT_F_EP_LEN = 64,     /* int64 [N] */
+  LT_F_OBS_POLICY,      /* float [N][obs_dim] */
+  LT_F_OBS_CRITIC,      /* float [N][obs_dim] */
+  LT_F_REWARD,          /* float [N] */
+  LT_F_DONES,           /* int64 [N] = terminated | time_out */
+  LT_F_TERMINATED,      /* uint8 [N] */
+  LT_F_TIME_OUT,        /* uint8 [N] */
+  LT_F_TERM_BITS,       /* int32 [N] which termination terms fired this step */
+  LT_F_CMD_PARAMS,      /* float [LT_CMD_PARAMS_LEN], device-resident command/curriculum block */
+  LT_F_COUNTERS,        /* int64 [4]: (common_step_counter, ...) */
+  LT_F_END
+};
+
+/* Device-resident command/curriculum block (LT_F_CMD_PARAMS), float[32]:
+ *  [0..5]  current ranges (x_lo,x_hi,y_lo,y_hi,z_lo,z_hi)   [6..11] previous ranges
+ *  [12..14] equal flags (1/0)  [15] zero_steps  [16] rel_standing
+ *  [17] lin_forward_bins [18] ang_forward_bins [19] success_lin [20] success_ang
+ *  [21..23] expansion per dim  [24] lin gate open (1/0)  [25] ang gate open
+ *  [26] any env has a non-zero command (population gate of rewards.py:190) */
+#define LT_CMD_PARAMS_LEN 32
+
+typedef struct lt_view {
+  void* ptr;         /* device pointer of element (env 0, component 0) */
+  int32_t dtype;     /* 0 f32, 1 i64, 2 u8, 3 i32 */
+  int32_t ndim;      /* 1..3 */
+  int64_t shape[3];  /* quad fields: [N][Q][4] with component c = q*4 + lane */
+  int64_t stride[3]; /* in elements */
+} lt_view;
+
+typedef struct lt_env lt_env; /* opaque */
+
+int lt_abi_version(void);
+size_t lt_cfg_sizeof(void);
+const char* lt_last_error(void);
+
+/* Fill `cfg` with the resolved task configuration.  `task` is an LT_TASK_* id. */
+int lt_cfg_default(int task, lt_cfg* cfg);
+/* Observation width of a task (policy and critic groups are equally wide): 270 / 348. */
+int lt_cfg_obs_dim(const lt_cfg* cfg);
+
+int lt_env_create(const lt_cfg* cfg, lt_env** out);
+int lt_env_destroy(lt_env* env);
+/* Size of the caller-owned device arena. */
+int lt_env_state_bytes(const lt_cfg* cfg, size_t* bytes);
+int lt_env_bind(lt_env* env, void* device_arena, size_t bytes);
+/* Startup events + reset of every env + first observation (RslRlVecEnvWrapper.__init__ calls env.reset()). */
+int lt_env_reset_all(lt_env* env, void* stream);
+/* One ManagerBasedRLEnv.step(): actions float[N][12] (device).  Outputs live in the arena views
+ * (OBS_POLICY, OBS_CRITIC, REWARD, DONES, TERMINATED, TIME_OUT). */
+int lt_env_step(lt_env* env, const float* actions, void* stream);
+/* Reward / termination / observation terms on the CURRENT arena contents, without physics, reset or
+ * command update (parity-test hook: lets a test write a golden state into the views and read the terms).
+ * `terminated_in` (uint8[N], device, may be NULL) feeds the `alive` term. */
+int lt_env_eval_terms(lt_env* env, void* stream);
+int lt_env_get_view(lt_env* env, int field, lt_view* view);
+/* Host-side override of the command block (what `set_ranges` does in the reference; resume workflows). */
+int lt_env_set_command_ranges(lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream);
+/* Device kernel names and static resource usage, for profiling scripts. */
+const char* lt_env_kernel_name(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LT_ENV_H */

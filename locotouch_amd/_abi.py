@@ -1,0 +1,135 @@
+"""ctypes mirror of include/lt_env.h and loader of the HIP library (the product path).
+
+The `lt_cfg` structure is parsed mechanically from the header, so the Python mirror cannot drift from
+the C ABI (a size check against `lt_cfg_sizeof()` guards it at load time).  There is deliberately NO
+fallback: if `liblocotouch_env.so` is missing the import fails loudly - nothing on the product path
+ever routes through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(_HERE)
+HEADER = os.path.join(REPO, "include", "lt_env.h")
+LIB_PATH = os.path.join(_HERE, "_lib", "liblocotouch_env.so")
+
+_CTYPES = {"float": ctypes.c_float, "int32_t": ctypes.c_int32, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64}
+
+
+def _parse_header():
+    src = open(HEADER).read()
+    src_nc = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src_nc = re.sub(r"//[^\n]*", "", src_nc)
+    consts = {}
+    for m in re.finditer(r"#define\s+(LT_\w+)\s+\(?(-?\d+)\)?\s*$", src_nc, flags=re.M):
+        consts[m.group(1)] = int(m.group(2))
+    # enums
+    for m in re.finditer(r"enum\s+\w+\s*\{(.*?)\};", src_nc, flags=re.S):
+        val = -1
+        for item in m.group(1).split(","):
+            item = item.strip()
+            if not item:
+                continue
+            if "=" in item:
+                name, v = [x.strip() for x in item.split("=")]
+                val = int(v, 0)
+            else:
+                name = item
+                val += 1
+            consts[name] = val
+    body = re.search(r"typedef struct lt_cfg \{(.*?)\} lt_cfg;", src_nc, flags=re.S).group(1)
+    fields = []
+    for line in body.split(";"):
+        line = line.strip()
+        if not line:
+            continue
+        m = re.match(r"(\w+)\s+(\w+)((?:\[\w+\])*)$", line)
+        if not m:
+            raise RuntimeError(f"cannot parse lt_cfg member: {line!r}")
+        ctype, name, dims = m.groups()
+        t = _CTYPES[ctype]
+        for d in reversed(re.findall(r"\[(\w+)\]", dims)):
+            t = t * (int(d) if d.isdigit() else consts[d])
+        fields.append((name, t))
+    return consts, fields
+
+
+CONSTS, _CFG_FIELDS = _parse_header()
+globals().update(CONSTS)
+
+
+class LtCfg(ctypes.Structure):
+    _fields_ = _CFG_FIELDS
+
+    def copy(self) -> "LtCfg":
+        new = LtCfg()
+        ctypes.memmove(ctypes.byref(new), ctypes.byref(self), ctypes.sizeof(self))
+        return new
+
+
+class LtView(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("dtype", ctypes.c_int32), ("ndim", ctypes.c_int32),
+                ("shape", ctypes.c_int64 * 3), ("stride", ctypes.c_int64 * 3)]
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load liblocotouch_env.so (built in-tree by locotouch_amd.build).  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the HIP extension is mandatory, there is no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.lt_abi_version.restype = ctypes.c_int
+    lib.lt_cfg_sizeof.restype = ctypes.c_size_t
+    lib.lt_last_error.restype = ctypes.c_char_p
+    lib.lt_cfg_default.argtypes = [ctypes.c_int, ctypes.POINTER(LtCfg)]
+    lib.lt_cfg_obs_dim.argtypes = [ctypes.POINTER(LtCfg)]
+    lib.lt_env_create.argtypes = [ctypes.POINTER(LtCfg), ctypes.POINTER(ctypes.c_void_p)]
+    lib.lt_env_destroy.argtypes = [ctypes.c_void_p]
+    lib.lt_env_state_bytes.argtypes = [ctypes.POINTER(LtCfg), ctypes.POINTER(ctypes.c_size_t)]
+    lib.lt_env_bind.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.lt_env_reset_all.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.lt_env_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.lt_env_eval_terms.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.lt_env_get_view.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(LtView)]
+    lib.lt_env_set_command_ranges.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
+                                              ctypes.c_float, ctypes.c_void_p]
+    lib.lt_env_kernel_name.argtypes = [ctypes.c_int]
+    lib.lt_env_kernel_name.restype = ctypes.c_char_p
+    if lib.lt_cfg_sizeof() != ctypes.sizeof(LtCfg):
+        raise ImportError(f"lt_cfg ABI mismatch: C {lib.lt_cfg_sizeof()} vs ctypes {ctypes.sizeof(LtCfg)}")
+    if lib.lt_abi_version() != CONSTS["LT_ABI_VERSION"]:
+        raise ImportError("lt_env.h / liblocotouch_env.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_obs_dim", "lt_env_create",
+           "lt_env_destroy", "lt_env_state_bytes", "lt_env_bind", "lt_env_reset_all", "lt_env_step", "lt_env_eval_terms",
+           "lt_env_get_view", "lt_env_set_command_ranges", "lt_env_kernel_name"]
+
+
+def default_cfg(task: int, num_envs: int | None = None, seed: int | None = None) -> LtCfg:
+    cfg = LtCfg()
+    rc = load().lt_cfg_default(task, ctypes.byref(cfg))
+    if rc != 0:
+        raise ValueError(f"lt_cfg_default({task}) failed: {rc}")
+    if num_envs is not None:
+        cfg.num_envs = num_envs
+    if seed is not None:
+        cfg.seed = seed
+    return cfg
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        err = load().lt_last_error()
+        raise RuntimeError(f"{what} failed with code {rc}: {err.decode() if err else ''}")

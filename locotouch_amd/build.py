@@ -1,0 +1,74 @@
+"""In-tree build of the HIP library: hipcc --offload-arch=gfx950 -> locotouch_amd/_lib/liblocotouch_env.so.
+
+Cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the snapshot.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "_lib")
+LIB = os.path.join(LIB_DIR, "liblocotouch_env.so")
+ARCH = "gfx950"
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (ROCm toolchain required)")
+    return exe
+
+
+def sources() -> list[str]:
+    return sorted(glob.glob(os.path.join(CSRC, "*.cpp")) + glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def deps() -> list[str]:
+    return sources() + sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp"))
+                              + glob.glob(os.path.join(REPO, "include", "*.h")))
+
+
+def up_to_date() -> bool:
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    return all(os.path.getmtime(d) <= t for d in deps())
+
+
+def build_lib(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
+    if not force and up_to_date():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
+           "-Wall", "-Wno-unused-function", "-I", os.path.join(REPO, "include"), "-o", LIB + ".tmp"]
+    cmd += (extra_flags or [])
+    for s in sources():
+        if s.endswith(".hip"):
+            cmd += ["-x", "hip", s]
+        else:
+            cmd += ["-x", "c++", s]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+def build_oracle(force: bool = False) -> str:
+    """The checker (oracle/) - building it is not using it; only tests / smoke / bench cpu_baseline load it."""
+    odir = os.path.join(REPO, "oracle")
+    if force:
+        subprocess.run(["make", "-C", odir, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", odir], check=True, stdout=subprocess.DEVNULL)
+    return os.path.join(odir, "_build", "liblt_oracle.so")
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_oracle())

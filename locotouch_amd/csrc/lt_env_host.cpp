@@ -1,0 +1,142 @@
+// Host side of the C ABI (include/lt_env.h): handle management, arena binding and zero-copy views.
+// No device memory is allocated here - the caller owns the arena (torch allocates it in the Python host
+// layer, any hipMalloc'd block works) - and nothing in this file synchronises with the device.
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "lt_internal.h"
+
+namespace {
+thread_local std::string g_last_error;
+
+bool cfg_valid(const lt_cfg* c) {
+  if (!c) return false;
+  if (c->num_envs <= 0 || c->num_envs > (1 << 24)) return false;
+  if (c->task != LT_TASK_LOCOMOTION && c->task != LT_TASK_TRANSPORT_TEACHER) return false;
+  if (c->decimation < 1 || c->decimation > 64 || c->phys_substeps < 1 || c->phys_substeps > 16) return false;
+  if (c->obs_history != 6) return false;  // the kernels are specialised for the reference's history length
+  if (!(c->sim_dt > 0.f) || c->max_episode_length <= 0) return false;
+  return true;
+}
+}  // namespace
+
+void lt_set_error(const char* msg) { g_last_error = msg ? msg : ""; }
+
+extern "C" {
+
+const char* lt_last_error(void) { return g_last_error.c_str(); }
+
+int lt_env_state_bytes(const lt_cfg* cfg, size_t* bytes) {
+  if (!cfg_valid(cfg) || !bytes) { lt_set_error("lt_env_state_bytes: invalid cfg"); return LT_EINVAL; }
+  lt_layout L;
+  lt_layout_init(&L, cfg->num_envs, lt_cfg_obs_dim(cfg));
+  *bytes = (size_t)L.total_bytes;
+  return LT_OK;
+}
+
+int lt_env_create(const lt_cfg* cfg, lt_env** out) {
+  if (!out) return LT_EINVAL;
+  *out = nullptr;
+  if (!cfg_valid(cfg)) { lt_set_error("lt_env_create: invalid cfg"); return LT_EINVAL; }
+  lt_env* e = new (std::nothrow) lt_env();
+  if (!e) return LT_ENOMEM;
+  e->cfg = *cfg;
+  lt_layout_init(&e->layout, cfg->num_envs, lt_cfg_obs_dim(cfg));
+  *out = e;
+  return LT_OK;
+}
+
+int lt_env_destroy(lt_env* env) {
+  delete env;
+  return LT_OK;
+}
+
+int lt_env_bind(lt_env* env, void* device_arena, size_t bytes) {
+  if (!env || !device_arena) return LT_EINVAL;
+  if (bytes < (size_t)env->layout.total_bytes) { lt_set_error("lt_env_bind: arena too small"); return LT_EFAULT; }
+  if (((uintptr_t)device_arena & 255) != 0) { lt_set_error("lt_env_bind: arena must be 256-byte aligned"); return LT_EINVAL; }
+  env->arena = device_arena;
+  env->arena_bytes = bytes;
+  return LT_OK;
+}
+
+int lt_env_get_view(lt_env* env, int field, lt_view* v) {
+  if (!env || !v) return LT_EINVAL;
+  const lt_layout& L = env->layout;
+  char* base = (char*)env->arena;  // may be null: offsets are then relative to 0 (layout queries before bind)
+  std::memset(v, 0, sizeof(*v));
+  if (field >= 0 && field < LT_NUM_QUAD_FIELDS) {
+    const int q = lt_field_quads(field);
+    v->ptr = base + L.quad_off[field];
+    v->dtype = (field == LT_F_GAIT_FLAGS) ? 3 : 0;
+    v->ndim = 3;
+    v->shape[0] = L.n; v->shape[1] = q; v->shape[2] = 4;
+    v->stride[0] = 4; v->stride[1] = L.npad * 4; v->stride[2] = 1;
+    return LT_OK;
+  }
+  auto plain = [&](int64_t off, int dtype, int64_t d0, int64_t d1) {
+    v->ptr = base + off;
+    v->dtype = dtype;
+    v->ndim = d1 > 0 ? 2 : 1;
+    v->shape[0] = d0; v->stride[0] = d1 > 0 ? d1 : 1;
+    if (d1 > 0) { v->shape[1] = d1; v->stride[1] = 1; }
+  };
+  switch (field) {
+    case LT_F_EP_LEN: plain(L.off_ep_len, 1, L.n, 0); break;
+    case LT_F_OBS_POLICY: plain(L.off_obs_policy, 0, L.n, L.obs_dim); break;
+    case LT_F_OBS_CRITIC: plain(L.off_obs_critic, 0, L.n, L.obs_dim); break;
+    case LT_F_REWARD: plain(L.off_reward, 0, L.n, 0); break;
+    case LT_F_DONES: plain(L.off_dones, 1, L.n, 0); break;
+    case LT_F_TERMINATED: plain(L.off_terminated, 2, L.n, 0); break;
+    case LT_F_TIME_OUT: plain(L.off_time_out, 2, L.n, 0); break;
+    case LT_F_TERM_BITS: plain(L.off_term_bits, 3, L.n, 0); break;
+    case LT_F_CMD_PARAMS: plain(L.off_cmd_params, 0, LT_CMD_PARAMS_LEN, 0); break;
+    case LT_F_COUNTERS: plain(L.off_counters, 1, 4, 0); break;
+    default: lt_set_error("lt_env_get_view: unknown field"); return LT_EINVAL;
+  }
+  return LT_OK;
+}
+
+static int finish(int hip_err, const char* what) {
+  if (hip_err == 0) return LT_OK;
+  std::string m = std::string(what) + ": " + lt_hip_error_string(hip_err);
+  lt_set_error(m.c_str());
+  return LT_EHIP;
+}
+
+int lt_env_reset_all(lt_env* env, void* stream) {
+  if (!env) return LT_EINVAL;
+  if (!env->arena) { lt_set_error("lt_env_reset_all: arena not bound"); return LT_EFAULT; }
+  return finish(lt_launch_reset_all(env, stream), "lt_env_reset_all");
+}
+
+int lt_env_step(lt_env* env, const float* actions, void* stream) {
+  if (!env || !actions) return LT_EINVAL;
+  if (!env->arena) { lt_set_error("lt_env_step: arena not bound"); return LT_EFAULT; }
+  return finish(lt_launch_step(env, actions, stream), "lt_env_step");
+}
+
+int lt_env_eval_terms(lt_env* env, void* stream) {
+  if (!env) return LT_EINVAL;
+  if (!env->arena) { lt_set_error("lt_env_eval_terms: arena not bound"); return LT_EFAULT; }
+  return finish(lt_launch_eval_terms(env, stream), "lt_env_eval_terms");
+}
+
+int lt_env_set_command_ranges(lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream) {
+  if (!env || !ranges) return LT_EINVAL;
+  if (!env->arena) { lt_set_error("lt_env_set_command_ranges: arena not bound"); return LT_EFAULT; }
+  return finish(lt_launch_set_command_ranges(env, ranges, zero_steps, rel_standing, stream), "lt_env_set_command_ranges");
+}
+
+const char* lt_env_kernel_name(int which) {
+  switch (which) {
+    case 0: return "lt_step_kernel";
+    case 1: return "lt_post_kernel";
+    case 2: return "lt_reset_all_kernel";
+    default: return nullptr;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,24 @@
+// Internal declarations shared by the host side (lt_env_host.cpp) and the HIP kernels (lt_env.hip).
+#pragma once
+
+#include <cstdint>
+
+#include "../../include/lt_env.h"
+#include "../../include/lt_layout.h"
+
+struct lt_env {
+  lt_cfg cfg;
+  lt_layout layout;
+  void* arena = nullptr;   // caller-owned device memory
+  size_t arena_bytes = 0;
+};
+
+// implemented in lt_env.hip -------------------------------------------------------------------------
+// Every launcher enqueues on `stream` and returns a hipError_t value as int (0 = hipSuccess).
+int lt_launch_reset_all(const lt_env* env, void* stream);
+int lt_launch_step(const lt_env* env, const float* actions, void* stream);
+int lt_launch_eval_terms(const lt_env* env, void* stream);
+int lt_launch_set_command_ranges(const lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream);
+const char* lt_hip_error_string(int err);
+
+void lt_set_error(const char* msg);

@@ -1,0 +1,71 @@
+/*
+ * ORACLE - TEST INFRASTRUCTURE ONLY (see oracle/lt_oracle.c).  Host pointers everywhere; the arena uses
+ * the same layout as the device arena (include/lt_layout.h) so a test can hand identical bytes to both.
+ */
+#ifndef LT_ORACLE_H
+#define LT_ORACLE_H
+
+#include <stdint.h>
+
+#include "../include/lt_env.h"
+#include "../include/lt_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_ORACLE_MODE_STEP 0
+#define LT_ORACLE_MODE_TERMS 1
+#define LT_ORACLE_MODE_RESET_ALL 2
+
+/* B3-style record of one env, as the reference's terms read it; [leg][link type]. */
+typedef struct lt_term_in {
+  float root_pos[3], root_quat[4], root_lin[3], root_ang[3];
+  float q[4][3], qd[4][3], qdd[4][3], tau[4][3];
+  float act_raw[4][3], act_prev[4][3];
+  float fhist[3][4][4]; /* [slot][type hip,thigh,calf,foot][leg] : |F| history, newest first */
+  float trunk_fhist[3];
+  float foot_pos[4][3], foot_vel[4][3];
+  float obj_pos[3], obj_quat[4], obj_lin[3], obj_ang[3];
+  float obj_timers[4]; /* cur_air, cur_contact, last_air, last_contact */
+  float cmd[3];
+  int32_t terminated;
+} lt_term_in;
+
+/* state + inputs of AdaptiveSymmetricGaitReward(withObject); arrays in the class's foot column order
+ * [FR, RL, FL, RR] (reference locotouch/mdp/rewards.py:89-92) */
+typedef struct lt_gait_io {
+  /* inputs */
+  float cur_air[4], cur_con[4], sensor_last_air[4];
+  float cmd[3];
+  float lin_err, ang_err;
+  float obj_xy_yaw[2];
+  int32_t any_nonzero_cmd;
+  /* state (rewards.py:96-105) */
+  float last_step_air[4], last_step_con[4], valid_last_air[4];
+  int32_t swinging_in_zero_cmd[4], valid_prev_contact[4];
+  float last_cmd[3];
+  float step_from_change;
+} lt_gait_io;
+
+int lt_oracle_obs_dim(const lt_cfg* cfg);
+int64_t lt_oracle_state_bytes(const lt_cfg* cfg);
+int lt_oracle_reset_all(const lt_cfg* cfg, void* arena);
+int lt_oracle_step(const lt_cfg* cfg, void* arena, const float* actions, int nthreads);
+int lt_oracle_eval_terms(const lt_cfg* cfg, void* arena);
+
+/* term-level entry points (golden-vector tests) */
+void lt_oracle_process_action(const lt_cfg* cfg, const float a[12], float raw[12], float prev[12], float prev2[12]);
+float lt_oracle_gait(const lt_cfg* cfg, lt_gait_io* G, float step_dt);
+void lt_oracle_rewards(const lt_cfg* cfg, const lt_term_in* in, lt_gait_io* G, float step_dt, float* terms);
+int lt_oracle_terminations(const lt_cfg* cfg, const lt_term_in* in, int64_t ep_len, int64_t max_len);
+void lt_oracle_object_state_obs(const lt_cfg* cfg, const lt_term_in* in, const float* noise16, float out[13]);
+void lt_oracle_command_update(int64_t ep_len, int zero_steps, const float buf[3], int standing, float cmd[3]);
+void lt_oracle_cmd_params_init(const lt_cfg* cfg, float* P);
+void lt_oracle_curriculum(const lt_cfg* cfg, float* P, int64_t n, const float* rec, float* trk);
+void lt_oracle_obs_push(const int* term_dims, int nterms, int hist, const float* frame, int fill, float* row);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
