@@ -271,6 +271,10 @@ int lt_env_step(lt_env* env, const float* actions, void* stream);
  * command update (parity-test hook: lets a test write a golden state into the views and read the terms).
  * `terminated_in` (uint8[N], device, may be NULL) feeds the `alive` term. */
 int lt_env_eval_terms(lt_env* env, void* stream);
+/* The curriculum / population-gate pass that lt_env_step runs after its step kernel, on the records currently in
+ * LT_F_CURRICULUM (does not advance the step counter).  For drivers that schedule the kernels themselves and for the
+ * parity test against the reference's curriculum sequence (mdp/curriculums.py:184-275). */
+int lt_env_curriculum_update(lt_env* env, void* stream);
 int lt_env_get_view(lt_env* env, int field, lt_view* view);
 /* Host-side override of the command block (what `set_ranges` does in the reference; resume workflows). */
 int lt_env_set_command_ranges(lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream);

@@ -60,15 +60,5 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags: list[str]
     return LIB
 
 
-def build_oracle(force: bool = False) -> str:
-    """The checker (oracle/) - building it is not using it; only tests / smoke / bench cpu_baseline load it."""
-    odir = os.path.join(REPO, "oracle")
-    if force:
-        subprocess.run(["make", "-C", odir, "clean"], check=True, stdout=subprocess.DEVNULL)
-    subprocess.run(["make", "-C", odir], check=True, stdout=subprocess.DEVNULL)
-    return os.path.join(odir, "_build", "liblt_oracle.so")
-
-
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
-    print(build_oracle())

@@ -1,8 +1,1476 @@
-// placeholder until the kernels land
+// lt_env.hip - the environment-step kernels for MI355X (gfx950 / CDNA4).
+//
+// One launch of lt_step_kernel = one ManagerBasedRLEnv.step() for every env on this GPU:
+//   action term -> 4 x (DC-motor PD -> ABA forward dynamics with implicit penalty contacts -> contact sensors)
+//   -> terminations -> 23 reward terms (incl. the adaptive symmetric-gait class) -> masked reset (events, RNG)
+//   -> command term -> interval pushes -> observation frame + 6-deep history -> outputs.
+// It is followed by the single-block lt_post_kernel (velocity curriculum, population gates, step counter).
+// Neither kernel synchronises with the host; the pair is hipGraph-capturable.
+//
+// Lane mapping: 4 lanes per env (lane&3 = leg FR/FL/RR/RL, each lane owns the hip-thigh-calf chain of its leg),
+// 16 envs per wave64, one wave per workgroup.  Tree-level coupling (floating base, carried cylinder) and all
+// per-env reductions go through DPP quad butterflies - no LDS, no barriers in the physics.  All persistent
+// state is SoA "quad arrays" float[N][4] (include/lt_layout.h), so every state access of a wave is one
+// coalesced 256-byte transaction.  The roofline that bounds the kernel is HBM: 6720 algorithmic bytes per
+// env-step; see DESIGN.md for the per-field breakdown.
+//
+// Reference citations use paths relative to the reference repo (locotouch/...).
 #include <hip/hip_runtime.h>
+
+#include "lt_device_math.h"
 #include "lt_internal.h"
-int lt_launch_reset_all(const lt_env*, void*) { return (int)hipErrorNotSupported; }
-int lt_launch_step(const lt_env*, const float*, void*) { return (int)hipErrorNotSupported; }
-int lt_launch_eval_terms(const lt_env*, void*) { return (int)hipErrorNotSupported; }
-int lt_launch_set_command_ranges(const lt_env*, const float*, int, float, void*) { return (int)hipErrorNotSupported; }
+#include "../../include/lt_go1_model.h"
+
+using namespace lt;
+
+namespace {
+
+constexpr int MODE_STEP = 0, MODE_TERMS = 1, MODE_RESET_ALL = 2;
+
+struct KArgs {
+  lt_cfg cfg;
+  lt_layout L;
+  char* arena;
+  const float* actions;
+};
+
+// ---- robot model (generated from the reference URDF by tools/compile_robot_model.py) ----------------
+__constant__ float k_link_mass[4][3] = LT_LINK_MASS_INIT;
+__constant__ float k_link_com[4][3][3] = LT_LINK_COM_INIT;
+__constant__ float k_link_icom[4][3][6] = LT_LINK_ICOM_INIT;
+__constant__ float k_joint_off[4][3][3] = LT_JOINT_OFFSET_INIT;
+__constant__ float k_joint_default[4][3] = LT_JOINT_DEFAULT_INIT;
+__constant__ float k_hip_cyl_y[4] = LT_HIP_CYL_Y_INIT;
+__device__ constexpr float k_joint_lo[3] = LT_JOINT_LOWER_INIT;
+__device__ constexpr float k_joint_hi[3] = LT_JOINT_UPPER_INIT;
+__device__ constexpr float k_trunk_com[3] = LT_TRUNK_COM_INIT;
+__device__ constexpr float k_trunk_icom[6] = LT_TRUNK_ICOM_INIT;
+__device__ constexpr float k_trunk_half[3] = LT_TRUNK_BOX_HALF_INIT;
+
+// RNG stream ids - shared spec with oracle/lt_oracle.c
+enum {
+  RS_NOISE_JPOS = 0x100, RS_NOISE_JVEL = 0x110, RS_NOISE_BASE = 0x120, RS_NOISE_OBJ = 0x130,
+  RS_RESET_ROOT = 0x200, RS_RESET_JOINT = 0x210, RS_RESET_MAT = 0x220, RS_RESET_OBJ = 0x221, RS_RESET_EVENT = 0x223,
+  RS_CMD_RESET = 0x230, RS_CMD_TIMER = 0x240, RS_PUSH_ROBOT = 0x250, RS_PUSH_OBJ = 0x260, RS_STARTUP = 0x300
+};
+
+// observation history tables: for output column `col` of a group row, where does the value come from?
+//   src[col] >= 0 : old row, column src[col] (one slot newer);  src[col] < 0 : newest frame, element -src-1
+//   frame[col]    : newest-frame element of that column's term (used when every slot is filled, i.e. after reset)
+struct ObsTable { short src[352]; short frame[352]; };
+constexpr ObsTable make_obs_table(int nterms) {
+  ObsTable t{};
+  const int dims[7] = {3, 3, 3, 12, 12, 12, 13};  // cmd, ang vel, gravity, joint pos, joint vel, last action, object state
+  int off = 0, fo = 0;
+  for (int i = 0; i < nterms; ++i) {
+    const int d = dims[i];
+    for (int s = 0; s < 6; ++s)
+      for (int k = 0; k < d; ++k) {
+        t.src[off + s * d + k] = (short)(s == 5 ? -(fo + k) - 1 : off + (s + 1) * d + k);
+        t.frame[off + s * d + k] = (short)(fo + k);
+      }
+    off += 6 * d;
+    fo += d;
+  }
+  return t;
+}
+__constant__ ObsTable k_obs_tab_loco = make_obs_table(6);
+__constant__ ObsTable k_obs_tab_teacher = make_obs_table(7);
+
+// ---- spatial algebra types ---------------------------------------------------------------------------
+struct I6 { M3 A, B, C; };  // [A B; B^T C], angular first
+struct S6 { V3 a, l; };
+struct LinkC { float m; V3 mc; M3 Io; V3 r; };  // mass, m*com, rotational inertia about the link origin, joint offset
+
+__device__ __forceinline__ M3 skew_of(V3 v) {
+  M3 o = m3_zero();
+  o.m[1] = -v.z; o.m[2] = v.y; o.m[3] = v.z; o.m[5] = -v.x; o.m[6] = -v.y; o.m[7] = v.x;
+  return o;
+}
+__device__ __forceinline__ M3 inertia_about_origin(float m, V3 c, const float ic[6], float scale) {
+  // Ic*scale - m c~ c~ = Ic*scale + m (|c|^2 1 - c c^T)
+  M3 o;
+  const float cc = dot(c, c);
+  o.m[0] = ic[0] * scale + m * (cc - c.x * c.x); o.m[1] = ic[1] * scale - m * c.x * c.y; o.m[2] = ic[2] * scale - m * c.x * c.z;
+  o.m[3] = o.m[1]; o.m[4] = ic[3] * scale + m * (cc - c.y * c.y); o.m[5] = ic[4] * scale - m * c.y * c.z;
+  o.m[6] = o.m[2]; o.m[7] = o.m[5]; o.m[8] = ic[5] * scale + m * (cc - c.z * c.z);
+  return o;
+}
+
+// ---- per-env (replicated in the quad) and per-leg (one lane) register state ---------------------------
+struct Base {
+  V3 p; Q4 q; V3 u, w;  // root pose, world linear / angular velocity
+};
+struct Obj {
+  V3 p; Q4 q; V3 u, w;
+  float cur_air, cur_con, last_air, last_con;
+  float rad, len, mass, mu;
+};
+struct Leg {
+  float q[3], qd[3], qdd[3], tau[3], raw[3], prev[3], prev2[3];
+  float fh[3][4];  // |F| history [slot][hip,thigh,calf,foot]
+  float cur_air, cur_con, last_air, last_con;
+  float mu;
+  V3 foot_p, foot_v;
+  float g_last_air, g_last_con, g_valid;
+  int g_flags;
+};
+struct Misc {
+  float trunk_mass_add, trunk_mu, trunk_rest, obj_rest;
+  float trunk_fh[3];
+  V3 cmd; float cmd_time_left; V3 cmd_buf; float cmd_standing;
+  float push_robot_left, push_obj_left;
+  V3 gait_cmd; float gait_step;
+  long long ep_len;
+};
+struct Report {  // contact forces of the last physics substep (world frame)
+  V3 body[4];    // hip, thigh, calf, foot of this lane's leg
+  V3 trunk_part; // this lane's share of the trunk force (corners + plate reactions)
+  V3 obj_part;   // this lane's share of the object force
+};
+
+// ---- contact law (DESIGN.md "contact model"; executable spec: oracle/lt_oracle.c contact_eval) ----------
+struct Law { bool active; float fx, fy, fn, cte, Bn; };
+__device__ __forceinline__ Law contact_law(float d, V3 vrel, float kn, float cn, float ct, float mu, float ramp_depth, float h) {
+  Law c;
+  c.active = false; c.fx = c.fy = c.fn = c.cte = c.Bn = 0.f;
+  if (!(d > 0.f)) return c;
+  float ramp = d / ramp_depth;
+  ramp = ramp > 1.f ? 1.f : ramp;
+  const float Bn = kn * h + cn * ramp;
+  const float f0n = kn * d - Bn * vrel.z;
+  if (!(f0n > 0.f)) return c;
+  const float vt = sqrtf(vrel.x * vrel.x + vrel.y * vrel.y);
+  float cte = mu * f0n / (vt > 1e-6f ? vt : 1e-6f);
+  cte = cte > ct ? ct : cte;
+  c.active = true;
+  c.fx = -cte * vrel.x; c.fy = -cte * vrel.y; c.fn = f0n; c.cte = cte; c.Bn = Bn;
+  return c;
+}
+// add h J^T B J (J = [-r~ 1]) with B = cte 1 + (Bn - cte) n n^T to a 6x6, n in the coords of the 6x6
+__device__ __forceinline__ void add_contact_inertia(I6& IA, V3 r, V3 n, float cte, float Bn, float h) {
+  M3 hB = m3_diag(h * cte);
+  hB += outer(h * (Bn - cte) * n, n);
+  const M3 T = skew_mul(r, hB);
+  IA.B += T;
+  IA.A -= mul_skew(T, r);
+  IA.C += hB;
+}
+
+// ---- kinematics of one joint: parent (w,v,Rw,pw) -> child, plus the velocity-product term c = v x S qd -----
+template <int AX>
+__device__ __forceinline__ void joint_fk(V3 wp, V3 vp, const M3& Rwp, V3 pwp, V3 r, float c, float s, float qd,
+                                         V3& om, V3& vl, M3& Rw, V3& pw, V3& ca, V3& cl) {
+  const V3 t = vp + cross(wp, r);
+  const V3 vj = axis_scaled<AX>(qd);
+  om = rot_inv<AX>(c, s, wp) + vj;
+  vl = rot_inv<AX>(c, s, t);
+  ca = cross(om, vj);
+  cl = cross(vl, vj);
+  Rw = mul_rot<AX>(Rwp, c, s);
+  pw = pwp + mul(Rwp, r);
+}
+// rigid-body bias force of a link: v x* (I v) - gravity wrench;  IA = I
+__device__ __forceinline__ void link_init(const LinkC& lc, V3 om, V3 vl, const M3& Rw, float g, I6& IA, S6& pA) {
+  IA.A = lc.Io; IA.B = skew_of(lc.mc); IA.C = m3_diag(lc.m);
+  const V3 n = mul(lc.Io, om) + cross(lc.mc, vl);
+  const V3 f = cross(om, lc.mc) + lc.m * vl;
+  pA.a = cross(om, n) + cross(vl, f);
+  pA.l = cross(om, f);
+  const V3 gb = (-g) * row(Rw, 2);  // Rw^T (0,0,-g)
+  pA.a -= cross(lc.mc, gb);
+  pA.l -= lc.m * gb;
+}
+struct RC { Law law; V3 f0w; };
+// ground contact of a sphere (centre r in the link frame, radius rho); accumulates into (IA, pA)
+__device__ __forceinline__ RC ground_contact(const lt_cfg& c, float h, V3 r, float rho, float mu, const M3& Rw, V3 pw, V3 om, V3 vl,
+                                             I6& IA, S6& pA) {
+  RC out;
+  const V3 zb = row(Rw, 2);
+  const V3 rc = r - rho * zb;
+  const V3 Pc = pw + mul(Rw, rc);
+  const V3 vw = mul(Rw, vl + cross(om, rc));
+  out.law = contact_law(-Pc.z, vw, c.ground_kn, c.ground_cn, c.ground_ct, mu, c.contact_ramp, h);
+  out.f0w = v3(out.law.fx, out.law.fy, out.law.fn);
+  if (out.law.active) {
+    add_contact_inertia(IA, rc, zb, out.law.cte, out.law.Bn, h);
+    const V3 f0b = tmul(Rw, out.f0w);
+    pA.a -= cross(rc, f0b);
+    pA.l -= f0b;
+  }
+  return out;
+}
+// final (post-solve) force of a ground contact on a link with spatial acceleration (aa, al)
+__device__ __forceinline__ V3 ground_force(const RC& rc_, float h, V3 r, float rho, const M3& Rw, V3 aa, V3 al) {
+  if (!rc_.law.active) return v3(0.f, 0.f, 0.f);
+  const V3 rc = r - rho * row(Rw, 2);
+  const V3 aw = mul(Rw, al + cross(aa, rc));
+  return v3(rc_.f0w.x - h * rc_.law.cte * aw.x, rc_.f0w.y - h * rc_.law.cte * aw.y, rc_.f0w.z - h * rc_.law.Bn * aw.z);
+}
+
+// ABA backward step of one link about axis AX: project the joint out, shift to the parent frame, accumulate
+template <int AX>
+__device__ __forceinline__ void link_backward(const I6& IA, const S6& pA, float tau, V3 ca, V3 cl, float c, float s, V3 r,
+                                              S6& U, float& D, float& u, I6& IAp, S6& pAp) {
+  U.a = col(IA.A, AX);
+  U.l = row(IA.B, AX);
+  D = comp<AX>(U.a);
+  u = tau - comp<AX>(pA.a);
+  const float iD = 1.f / D;
+  I6 Ia;
+  Ia.A = IA.A; Ia.A -= outer(iD * U.a, U.a);
+  Ia.B = IA.B; Ia.B -= outer(iD * U.a, U.l);
+  Ia.C = IA.C; Ia.C -= outer(iD * U.l, U.l);
+  const float k = u * iD;
+  const V3 pa_a = pA.a + mul(Ia.A, ca) + mul(Ia.B, cl) + k * U.a;
+  const V3 pa_l = pA.l + tmul(Ia.B, ca) + mul(Ia.C, cl) + k * U.l;
+  const M3 A1 = rot_sim<AX>(c, s, Ia.A), B1 = rot_sim<AX>(c, s, Ia.B), C1 = rot_sim<AX>(c, s, Ia.C);
+  const V3 n1 = rot_fwd<AX>(c, s, pa_a), f1 = rot_fwd<AX>(c, s, pa_l);
+  M3 B2 = B1;
+  B2 += skew_mul(r, C1);
+  const M3 K1 = mul_skew(B1, r), K2 = mul_skew(B2, r);
+  IAp.A += A1; IAp.A -= transpose(K1); IAp.A -= K2;
+  IAp.B += B2;
+  IAp.C += C1;
+  pAp.a += n1 + cross(r, f1);
+  pAp.l += f1;
+}
+// ABA forward (acceleration) step
+template <int AX>
+__device__ __forceinline__ void link_forward(V3 apa, V3 apl, float c, float s, V3 r, V3 ca, V3 cl, const S6& U, float D, float u,
+                                             V3& aa, V3& al, float& qdd) {
+  al = rot_inv<AX>(c, s, apl + cross(apa, r)) + cl;
+  aa = rot_inv<AX>(c, s, apa) + ca;
+  qdd = (u - dot(U.a, aa) - dot(U.l, al)) / D;
+  aa += axis_scaled<AX>(qdd);
+}
+
+// 6x6 SPD solve (Cholesky), fully unrolled into registers.  M = [A B; B^T C] (upper blocks), rhs (a, l)
+__device__ __forceinline__ void spd6_solve(const I6& M, V3 ba, V3 bl, V3& xa, V3& xl) {
+  float A[6][6];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      A[i][j] = M.A.m[i * 3 + j];
+      A[i][3 + j] = M.B.m[i * 3 + j];
+      A[3 + i][j] = M.B.m[j * 3 + i];
+      A[3 + i][3 + j] = M.C.m[i * 3 + j];
+    }
+  float Lm[6][6], inv[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      float sacc = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) sacc -= Lm[i][k] * Lm[j][k];
+      if (i == j) { Lm[i][i] = sqrtf(sacc); inv[i] = 1.f / Lm[i][i]; }
+      else Lm[i][j] = sacc * inv[j];
+    }
+  }
+  float b[6] = {ba.x, ba.y, ba.z, bl.x, bl.y, bl.z}, y[6], x[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float sacc = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) sacc -= Lm[i][k] * y[k];
+    y[i] = sacc * inv[i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float sacc = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) sacc -= Lm[k][i] * x[k];
+    x[i] = sacc * inv[i];
+  }
+  xa = v3(x[0], x[1], x[2]);
+  xl = v3(x[3], x[4], x[5]);
+}
+__device__ __forceinline__ M3 qsum_sym(const M3& a) {  // quad-sum of a symmetric 3x3 (6 butterflies)
+  M3 o;
+  o.m[0] = qsum(a.m[0]); o.m[1] = qsum(a.m[1]); o.m[2] = qsum(a.m[2]); o.m[4] = qsum(a.m[4]); o.m[5] = qsum(a.m[5]); o.m[8] = qsum(a.m[8]);
+  o.m[3] = o.m[1]; o.m[6] = o.m[2]; o.m[7] = o.m[5];
+  return o;
+}
+__device__ __forceinline__ M3 qsum_full(const M3& a) {
+  M3 o;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o.m[i] = qsum(a.m[i]);
+  return o;
+}
+
+// sphere table of this lane: 0 foot (calf), 1 calf mid (calf), 2 knee (thigh), 3 hip (hip), 4/5 trunk corners
+__device__ __forceinline__ V3 trunk_corner(int leg, bool hi) {
+  const float sx = leg < 2 ? 1.f : -1.f, sy = (leg & 1) ? 1.f : -1.f;
+  return hi ? v3(sx * k_trunk_half[0], sy * LT_BACK_HALF_Y, LT_BACK_TOP_Z) : v3(sx * k_trunk_half[0], sy * k_trunk_half[1], -k_trunk_half[2]);
+}
+
+// =====================================================================================================
+// K2 physics: one integrator substep of length h (torques held).  Reference: PhysX (closed source) - this is
+// the engine's own model, specified by oracle/lt_oracle.c physics_substep and DESIGN.md "Physics".
+// =====================================================================================================
+template <bool HAS_OBJ>
+__device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int leg, const LinkC (&LC)[3], Base& B, Leg& G, Obj& O,
+                                                const Misc& X, Report& rep) {
+  const float g = c.gravity;
+  float cq[3], sq[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) sincosf(G.q[k], &sq[k], &cq[k]);
+  const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
+  const V3 wb = tmul(R0, B.w), vb = tmul(R0, B.u);
+  // forward kinematics of this lane's chain
+  V3 om[3], vl[3], pw[3], ca[3], cl[3];
+  M3 Rw[3];
+  joint_fk<0>(wb, vb, R0, B.p, LC[0].r, cq[0], sq[0], G.qd[0], om[0], vl[0], Rw[0], pw[0], ca[0], cl[0]);
+  joint_fk<1>(om[0], vl[0], Rw[0], pw[0], LC[1].r, cq[1], sq[1], G.qd[1], om[1], vl[1], Rw[1], pw[1], ca[1], cl[1]);
+  joint_fk<1>(om[1], vl[1], Rw[1], pw[1], LC[2].r, cq[2], sq[2], G.qd[2], om[2], vl[2], Rw[2], pw[2], ca[2], cl[2]);
+
+  // this lane's share of the trunk's articulated inertia / bias force
+  I6 IA0; IA0.A = m3_zero(); IA0.B = m3_zero(); IA0.C = m3_zero();
+  S6 pA0; pA0.a = v3(0, 0, 0); pA0.l = v3(0, 0, 0);
+  rep.trunk_part = v3(0, 0, 0);
+  rep.obj_part = v3(0, 0, 0);
+
+  // ---- carried cylinder: free body, implicit contacts with the plate (sample = lane) and the ground ----
+  V3 obj_aa = v3(0, 0, 0), obj_al = v3(0, 0, 0);
+  if (HAS_OBJ) {
+    const M3 Ro = quat_to_mat(O.q.w, O.q.x, O.q.y, O.q.z);
+    const V3 ay = col(Ro, 1);
+    const float rad = O.rad, half = 0.5f * O.len;
+    const float mu_plate = 0.5f * (X.trunk_mu + O.mu);
+    const V3 ct = tmul(R0, O.p - B.p), at = tmul(R0, ay);
+    const float hx = LT_BACK_HALF_X, hy = LT_RAIL_Y + LT_RAIL_RADIUS, zp = LT_BACK_TOP_Z;
+    float s0 = -half, s1 = half;
+    bool ok = true;
+    {  // slab clipping of the axis segment against |x| <= hx, |y| <= hy (plate frame)
+      const float cc[2] = {ct.x, ct.y}, dd[2] = {at.x, at.y}, lim[2] = {hx, hy};
+#pragma unroll
+      for (int ax = 0; ax < 2; ++ax) {
+        if (ok) {
+          if (fabsf(dd[ax]) < 1e-9f) { if (fabsf(cc[ax]) > lim[ax]) ok = false; }
+          else {
+            float ta = (-lim[ax] - cc[ax]) / dd[ax], tb = (lim[ax] - cc[ax]) / dd[ax];
+            if (ta > tb) { const float t = ta; ta = tb; tb = t; }
+            s0 = ta > s0 ? ta : s0;
+            s1 = tb < s1 ? tb : s1;
+            if (s0 > s1) ok = false;
+          }
+        }
+      }
+    }
+    I6 Mo; Mo.A = m3_zero(); Mo.B = m3_zero(); Mo.C = m3_zero();
+    V3 rhs_a = v3(0, 0, 0), rhs_l = v3(0, 0, 0);
+    // plate sample of this lane
+    Law lp; lp.active = false; lp.fx = lp.fy = lp.fn = lp.cte = lp.Bn = 0.f;
+    V3 Pw_p = v3(0, 0, 0), rho_p = v3(0, 0, 0), F0_p = v3(0, 0, 0);
+    const V3 nw = col(R0, 2);  // plate normal in world
+    if (ok) {
+      const float nza = at.z;
+      const V3 up = v3(-nza * at.x, -nza * at.y, 1.f - nza * at.z);
+      const float un = norm(up);
+      const float inv = 1.f / (un > 1e-6f ? un : 1e-6f);
+      const float sk = s0 + (s1 - s0) * (float)leg / 3.f;
+      const V3 Pt = v3(ct.x + sk * at.x - rad * up.x * inv, ct.y + sk * at.y - rad * up.y * inv, ct.z + sk * at.z - rad * up.z * inv);
+      const float d = zp - Pt.z;
+      Pw_p = B.p + mul(R0, Pt);
+      rho_p = Pw_p - O.p;
+      const V3 vo = O.u + cross(O.w, rho_p);
+      const V3 vt = B.u + cross(B.w, Pw_p - B.p);
+      const V3 vrel = tmul(R0, vo - vt);
+      lp = contact_law(d, vrel, c.plate_kn / 4, c.plate_cn / 4, c.plate_ct / 4, mu_plate, c.contact_ramp, h);
+      if (lp.active) {
+        F0_p = mul(R0, v3(lp.fx, lp.fy, lp.fn));
+        add_contact_inertia(Mo, rho_p, nw, lp.cte, lp.Bn, h);
+        rhs_a += cross(rho_p, F0_p);
+        rhs_l += F0_p;
+      }
+    }
+    // ground rim point of this lane (lanes 0 and 1: the two axis ends)
+    Law lg; lg.active = false; lg.fx = lg.fy = lg.fn = lg.cte = lg.Bn = 0.f;
+    V3 rho_g = v3(0, 0, 0), F0_g = v3(0, 0, 0);
+    if (leg < 2) {
+      const float nza = ay.z;
+      const V3 up = v3(-nza * ay.x, -nza * ay.y, 1.f - nza * ay.z);
+      const float un = norm(up);
+      const float inv = 1.f / (un > 1e-6f ? un : 1e-6f);
+      const float sk = leg == 0 ? -half : half;
+      const V3 Pw = v3(O.p.x + sk * ay.x - rad * up.x * inv, O.p.y + sk * ay.y - rad * up.y * inv, O.p.z + sk * ay.z - rad * up.z * inv);
+      rho_g = Pw - O.p;
+      const V3 vo = O.u + cross(O.w, rho_g);
+      lg = contact_law(-Pw.z, vo, c.ground_kn, c.ground_cn, c.ground_ct, O.mu * c.ground_mu, c.contact_ramp, h);
+      if (lg.active) {
+        F0_g = v3(lg.fx, lg.fy, lg.fn);
+        add_contact_inertia(Mo, rho_g, v3(0, 0, 1), lg.cte, lg.Bn, h);
+        rhs_a += cross(rho_g, F0_g);
+        rhs_l += F0_g;
+      }
+    }
+    // assemble and solve (replicated in the quad): [I_w 0; 0 m] + sum_k h J^T B J
+    I6 M;
+    M.A = qsum_sym(Mo.A); M.B = qsum_full(Mo.B); M.C = qsum_sym(Mo.C);
+    rhs_a = qsum(rhs_a); rhs_l = qsum(rhs_l);
+    const float m = O.mass;
+    const float Iyy = 0.5f * m * rad * rad, Ixx = m * (3.f * rad * rad + O.len * O.len) / 12.f;
+    M3 Iw = m3_diag(Ixx);
+    Iw += outer((Iyy - Ixx) * ay, ay);
+    M.A += Iw;
+    M.C += m3_diag(m);
+    rhs_a -= cross(O.w, mul(Iw, O.w));
+    rhs_l.z -= m * g;
+    spd6_solve(M, rhs_a, rhs_l, obj_aa, obj_al);
+    // final contact forces of this lane's samples; reaction of the plate sample on the trunk (explicit)
+    if (lp.active) {
+      const V3 ap = obj_al + cross(obj_aa, rho_p);
+      const float an = dot(nw, ap);
+      // B_w ap = cte ap + (Bn - cte) (n.ap) n
+      const V3 F = F0_p - h * (lp.cte * ap + ((lp.Bn - lp.cte) * an) * nw);
+      rep.obj_part += F;
+      const V3 Fn = -F;
+      const V3 rb = tmul(R0, Pw_p - B.p), fb = tmul(R0, Fn);
+      pA0.a -= cross(rb, fb);
+      pA0.l -= fb;
+      rep.trunk_part += Fn;
+    }
+    if (lg.active) {
+      const V3 ap = obj_al + cross(obj_aa, rho_g);
+      rep.obj_part += v3(F0_g.x - h * lg.cte * ap.x, F0_g.y - h * lg.cte * ap.y, F0_g.z - h * lg.Bn * ap.z);
+    }
+  }
+
+  // ---- links of this leg: rigid-body terms + ground contacts ----
+  I6 IA[3];
+  S6 pA[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) link_init(LC[k], om[k], vl[k], Rw[k], g, IA[k], pA[k]);
+  const float mu_foot = G.mu * c.ground_mu, mu_body = c.ground_mu;
+  const V3 r_foot = v3(0.f, 0.f, -0.213f), r_calf = v3(0.f, 0.f, -0.1065f), r_knee = v3(0.f, 0.f, -0.213f);
+  const V3 r_hip = v3(0.f, k_hip_cyl_y[leg], 0.f);
+  const RC c_foot = ground_contact(c, h, r_foot, LT_FOOT_RADIUS, mu_foot, Rw[2], pw[2], om[2], vl[2], IA[2], pA[2]);
+  const RC c_calf = ground_contact(c, h, r_calf, 0.012f, mu_body, Rw[2], pw[2], om[2], vl[2], IA[2], pA[2]);
+  const RC c_knee = ground_contact(c, h, r_knee, 0.022f, mu_body, Rw[1], pw[1], om[1], vl[1], IA[1], pA[1]);
+  const RC c_hip = ground_contact(c, h, r_hip, LT_HIP_CYL_RADIUS, mu_body, Rw[0], pw[0], om[0], vl[0], IA[0], pA[0]);
+  const V3 r_tlo = trunk_corner(leg, false), r_thi = trunk_corner(leg, true);
+  const RC c_tlo = ground_contact(c, h, r_tlo, 0.f, mu_body, R0, B.p, wb, vb, IA0, pA0);
+  const RC c_thi = ground_contact(c, h, r_thi, 0.f, mu_body, R0, B.p, wb, vb, IA0, pA0);
+
+  // ---- ABA backward pass: calf -> thigh -> hip -> trunk share ----
+  S6 U[3];
+  float D[3], u[3];
+  link_backward<1>(IA[2], pA[2], G.tau[2], ca[2], cl[2], cq[2], sq[2], LC[2].r, U[2], D[2], u[2], IA[1], pA[1]);
+  link_backward<1>(IA[1], pA[1], G.tau[1], ca[1], cl[1], cq[1], sq[1], LC[1].r, U[1], D[1], u[1], IA[0], pA[0]);
+  link_backward<0>(IA[0], pA[0], G.tau[0], ca[0], cl[0], cq[0], sq[0], LC[0].r, U[0], D[0], u[0], IA0, pA0);
+
+  // ---- floating base: quad-sum the four shares, add the trunk's own rigid-body terms, solve 6x6 ----
+  I6 M;
+  M.A = qsum_sym(IA0.A); M.B = qsum_full(IA0.B); M.C = qsum_sym(IA0.C);
+  V3 p0a = qsum(pA0.a), p0l = qsum(pA0.l);
+  {
+    const float mt = LT_TRUNK_MASS + X.trunk_mass_add;
+    LinkC T;
+    T.m = mt;
+    const V3 ctr = v3(k_trunk_com[0], k_trunk_com[1], k_trunk_com[2]);
+    T.mc = mt * ctr;
+    T.Io = inertia_about_origin(mt, ctr, k_trunk_icom, mt / LT_TRUNK_MASS);
+    I6 I0;
+    S6 pT;
+    link_init(T, wb, vb, R0, g, I0, pT);
+    M.A += I0.A; M.B += I0.B; M.C += I0.C;
+    p0a += pT.a; p0l += pT.l;
+  }
+  V3 a0a, a0l;
+  spd6_solve(M, -p0a, -p0l, a0a, a0l);
+
+  // ---- forward pass + final contact forces ----
+  V3 aa[3], al[3];
+  float qdd[3];
+  link_forward<0>(a0a, a0l, cq[0], sq[0], LC[0].r, ca[0], cl[0], U[0], D[0], u[0], aa[0], al[0], qdd[0]);
+  link_forward<1>(aa[0], al[0], cq[1], sq[1], LC[1].r, ca[1], cl[1], U[1], D[1], u[1], aa[1], al[1], qdd[1]);
+  link_forward<1>(aa[1], al[1], cq[2], sq[2], LC[2].r, ca[2], cl[2], U[2], D[2], u[2], aa[2], al[2], qdd[2]);
+  rep.body[3] = ground_force(c_foot, h, r_foot, LT_FOOT_RADIUS, Rw[2], aa[2], al[2]);
+  rep.body[2] = ground_force(c_calf, h, r_calf, 0.012f, Rw[2], aa[2], al[2]);
+  rep.body[1] = ground_force(c_knee, h, r_knee, 0.022f, Rw[1], aa[1], al[1]);
+  rep.body[0] = ground_force(c_hip, h, r_hip, LT_HIP_CYL_RADIUS, Rw[0], aa[0], al[0]);
+  rep.trunk_part += ground_force(c_tlo, h, r_tlo, 0.f, R0, a0a, a0l);
+  rep.trunk_part += ground_force(c_thi, h, r_thi, 0.f, R0, a0a, a0l);
+
+  // ---- semi-implicit Euler ----
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float qd = G.qd[k] + h * qdd[k];
+    float q = G.q[k] + h * qd;
+    if (q < k_joint_lo[k]) { q = k_joint_lo[k]; if (qd < 0.f) qd = 0.f; }
+    if (q > k_joint_hi[k]) { q = k_joint_hi[k]; if (qd > 0.f) qd = 0.f; }
+    G.q[k] = q; G.qd[k] = qd;
+  }
+  {
+    const V3 acl = a0l + cross(wb, vb);  // classical acceleration of the base origin (body coords)
+    B.u += h * mul(R0, acl);
+    B.w += h * mul(R0, a0a);
+    B.p += h * B.u;
+    B.q = q_integrate(B.q, B.w, h);
+  }
+  if (HAS_OBJ) {
+    O.w += h * obj_aa;
+    O.u += h * obj_al;
+    O.p += h * O.u;
+    O.q = q_integrate(O.q, O.w, h);
+  }
+}
+
+// foot centre position / velocity (world) of this lane's leg for the current state
+__device__ __forceinline__ void foot_kinematics(const LinkC (&LC)[3], const Base& B, Leg& G) {
+  const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
+  V3 om[3], vl[3], pw[3], ca, cl;
+  M3 Rw[3];
+  float s, c;
+  sincosf(G.q[0], &s, &c);
+  joint_fk<0>(tmul(R0, B.w), tmul(R0, B.u), R0, B.p, LC[0].r, c, s, G.qd[0], om[0], vl[0], Rw[0], pw[0], ca, cl);
+  sincosf(G.q[1], &s, &c);
+  joint_fk<1>(om[0], vl[0], Rw[0], pw[0], LC[1].r, c, s, G.qd[1], om[1], vl[1], Rw[1], pw[1], ca, cl);
+  sincosf(G.q[2], &s, &c);
+  joint_fk<1>(om[1], vl[1], Rw[1], pw[1], LC[2].r, c, s, G.qd[2], om[2], vl[2], Rw[2], pw[2], ca, cl);
+  const V3 rf = v3(0.f, 0.f, -0.213f);
+  G.foot_p = pw[2] + mul(Rw[2], rf);
+  G.foot_v = mul(Rw[2], vl[2] + cross(om[2], rf));
+}
+
+// ---- K1: DC-motor PD (reference assets/go1.py:41-49 + IsaacLab DCMotor [DEP]) ----
+__device__ __forceinline__ float dc_motor(const lt_cfg& c, float q_des, float q, float qd) {
+  const float tau = c.kp * (q_des - q) + c.kd * (0.f - qd);
+  float hi = c.saturation_effort * (1.f - qd / c.velocity_limit);
+  hi = hi < 0.f ? 0.f : (hi > c.effort_limit ? c.effort_limit : hi);
+  float lo = c.saturation_effort * (-1.f - qd / c.velocity_limit);
+  lo = lo < -c.effort_limit ? -c.effort_limit : (lo > 0.f ? 0.f : lo);
+  return tau < lo ? lo : (tau > hi ? hi : tau);
+}
+
+// ---- K3: ContactSensor air/contact timers [DEP, SURVEY.md Appendix C] ----
+__device__ __forceinline__ void timers_update(float& cur_air, float& cur_con, float& last_air, float& last_con, bool contact, float dt) {
+  const bool first_contact = (cur_air > 0.f) && contact;
+  const bool first_detach = (cur_con > 0.f) && !contact;
+  if (first_contact) last_air = cur_air + dt;
+  if (first_detach) last_con = cur_con + dt;
+  cur_air = contact ? 0.f : cur_air + dt;
+  cur_con = contact ? cur_con + dt : 0.f;
+}
+
+// ---- K5: adaptive symmetric gait reward (reference locotouch/mdp/rewards.py:60-392) --------------------
+// Arrays are in the class's foot column order [FR, RL, FL, RR]; every lane of the quad evaluates the same code.
+struct Gait {
+  float cur_air[4], cur_con[4], sensor_last_air[4];
+  float last_air[4], last_con[4], valid[4];
+  int swing0[4], prevc[4];
+  V3 last_cmd; float step_from_change;
+};
+__device__ __forceinline__ float gait_swing_bonus(const lt_cfg& c, const Gait& G, int f0, int f1, float step_dt) {
+  const float judge = c.gait_judge_time, ub = c.gait_rwd_upper, lb = c.gait_rwd_lower, tol = c.gait_tolerance_proportion;
+  const float scale = ub / (1.0f / (c.gait_soft_min_frequency * 2.0f));                                     // :72,:78
+  const float tbar = (G.cur_air[f0] + G.cur_air[f1]) / 2.f;
+  const bool both_air = (G.cur_air[f0] > judge) && (G.cur_air[f1] > judge);                                 // :247
+  const int t0 = f0 < 2 ? 0 : 2, o0 = f0 < 2 ? 2 : 0;                                                        // :250-254
+  const float vt0 = G.valid[t0], vt1 = G.valid[t0 + 1], vo0 = G.valid[o0], vo1 = G.valid[o0 + 1];
+  const float mean_t = (vt0 + vt1) / 2.f, mean_o = (vo0 + vo1) / 2.f;
+  const bool valid_t = (vt0 > judge) && (vt1 > judge) && (vt0 > 2.f * step_dt) && (vt1 > 2.f * step_dt);   // :253,:260
+  const bool valid_o = (vo0 > judge) && (vo1 > judge) && (vo0 > 2.f * step_dt) && (vo1 > 2.f * step_dt);   // :257,:261
+  if (!(both_air && (valid_t || valid_o))) return 0.f;                                                      // :264-265,:341-344
+  const float Tref = mean_o, Ttol = Tref + tol * Tref, diff = mean_t - mean_o;                               // :266-276
+  const float Text = clampf(Ttol - diff, Tref, Ttol);                                                       // :277-278
+  float r_within = scale * tbar; r_within = r_within > ub ? ub : r_within;                                  // :289
+  float r_ref = scale * Tref; r_ref = r_ref > ub ? ub : r_ref;
+  float r_ext = scale * Text; r_ext = r_ext > ub ? ub : r_ext;
+  float r_tol = scale * Ttol; r_tol = r_tol > ub ? ub : r_tol;
+  if ((tbar <= Text) || (diff < 0.f)) return r_within;                                                      // :281,:285-286
+  const bool ext_lt_tol = Text < Ttol;                                                                      // :295
+  if ((tbar > Text) && (tbar <= Ttol)) {                                                                    // :282,:296-307
+    if (!ext_lt_tol) return r_ext;
+    const float a = -r_ext / (Ttol - Text);
+    return a * tbar + (-a * Ttol);
+  }
+  float lower = lb;                                                                                         // :319-325
+  if (valid_o) lower = clampf(ext_lt_tol ? (diff / (tol * Tref)) * lb : r_tol, lb, ub);
+  float beyond = lower;                                                                                     // :310-330
+  if (Text > Tref) {
+    const float a = -r_ref / (Text - Tref);
+    beyond = a * tbar + (-a * Ttol);
+  }
+  return beyond < lower ? lower : beyond;
+}
+__device__ __forceinline__ float gait_reward(const lt_cfg& c, Gait& G, V3 cmd, float lin_err, float ang_err, float ox, float oy,
+                                             bool any_nonzero_cmd, float step_dt) {
+  const float judge = c.gait_judge_time, ab = c.gait_air_bound, cb = c.gait_contact_bound;
+  const float async_judge = judge + c.gait_async_tolerance;
+  const bool nonzero = norm(cmd) > 0.f;
+  // _update_valid_last_air_contact_time :158-200
+  if (!nonzero) for (int f = 0; f < 4; ++f) G.valid[f] = 0.f;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const bool new_swing = (G.last_air[f] < judge) && (G.cur_air[f] > judge);
+    if (new_swing && nonzero) G.swing0[f] = 0;
+    if ((G.cur_air[f] > judge) && !nonzero) G.swing0[f] = 1;
+  }
+  G.step_from_change += 1.f;
+  const bool changing = (fabsf(cmd.x - G.last_cmd.x) > 1.0e-3f) || (fabsf(cmd.y - G.last_cmd.y) > 1.0e-3f) || (fabsf(cmd.z - G.last_cmd.z) > 1.0e-3f);
+  if (changing) {
+    G.last_cmd = cmd;
+    G.step_from_change = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { G.swing0[f] = 1; G.valid[f] = 0.f; }
+  }
+  if (any_nonzero_cmd) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const bool landing = (G.last_con[f] < judge) && (G.cur_con[f] > judge);
+      if (landing && G.prevc[f] && !G.swing0[f]) G.valid[f] = G.sensor_last_air[f];
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    G.last_air[f] = G.cur_air[f];
+    G.last_con[f] = G.cur_con[f];
+    if (G.cur_con[f] > judge) G.prevc[f] = 1;
+  }
+  // task performance score :202-213, :372-392
+  const float e_lin = nonzero ? lin_err : 0.f, e_ang = nonzero ? ang_err : 0.f;
+  const float vel_score = (expf(-(e_lin / c.gait_vel_sigma)) + expf(-(e_ang / c.gait_vel_sigma))) / 2.f;
+  float score = vel_score;
+  if (c.gait_with_object) {
+    const float sx = clampf(1.f - fabsf(ox) / c.danger_x_max, 0.f, 1.f);
+    const float sy = clampf(1.f - fabsf(oy) / c.danger_y_max, 0.f, 1.f);
+    score = clampf((vel_score * 2.f + (sx + sy) / 2.f) / 3.f, 0.f, 1.f);
+  }
+  float sync[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {                                                                             // :218-241
+    const int f0 = 2 * p, f1 = 2 * p + 1;
+    const bool both_air = (G.cur_air[f0] > judge && G.cur_air[f0] < ab) && (G.cur_air[f1] > judge && G.cur_air[f1] < ab);
+    const bool both_con = (G.cur_con[f0] > judge && G.cur_con[f0] < cb) && (G.cur_con[f1] > judge && G.cur_con[f1] < cb);
+    float bonus = gait_swing_bonus(c, G, f0, f1, step_dt);
+    const float rs = 1.f - c.gait_task_ratio + c.gait_task_ratio * score;
+    if (bonus > 0.f) bonus *= rs;
+    bonus += 1.f;
+    sync[p] = both_air ? bonus : (both_con ? 1.f : 0.f);
+  }
+  float asum = 0.f;
+  const int pf0[4] = {0, 1, 0, 2}, pf1[4] = {2, 3, 3, 1};                                                    // :144-147
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {                                                                             // :348-363
+    const int f0 = pf0[p], f1 = pf1[p];
+    const bool c0t = G.cur_con[f0] > judge && G.cur_con[f0] <= async_judge, c1t = G.cur_con[f1] > judge && G.cur_con[f1] <= async_judge;
+    const bool a0 = G.cur_air[f0] > judge && G.cur_air[f0] < ab, a1 = G.cur_air[f1] > judge && G.cur_air[f1] < ab;
+    const bool c0 = G.cur_con[f0] > judge && G.cur_con[f0] < cb, c1 = G.cur_con[f1] > judge && G.cur_con[f1] < cb;
+    asum += ((c0t && c1t) || (a0 && c1) || (c0 && a1)) ? 1.f : 0.f;
+  }
+  const float stepping = ((sync[0] + sync[1]) / 2.f + asum / 4.f) / 2.f;                                    // :141-151
+  bool all_stance = true;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) all_stance = all_stance && (G.cur_con[f] > judge);                            // :365-368
+  const float stance = (all_stance ? 1.f : 0.f) * c.gait_stance_scale;
+  return nonzero ? stepping : stance;                                                                       // :153-154
+}
+
+// object_state_in_robot_frame (reference locotouch/mdp/observations.py:38-91); u16 = 16 uniforms or nullptr-like flag
+__device__ __forceinline__ void object_state_obs(const lt_cfg& c, const Base& B, const Obj& O, bool noisy, const float* u16, float* out) {
+  float s[13];
+  const V3 pr = qapply_inv(B.q, O.p - B.p), lr = qapply_inv(B.q, O.u - B.u), ar = qapply_inv(B.q, O.w - B.w);
+  Q4 qr = qmul(qconj(B.q), O.q);
+  s[0] = pr.x; s[1] = pr.y; s[2] = pr.z; s[3] = lr.x; s[4] = lr.y; s[5] = lr.z;
+  s[10] = ar.x; s[11] = ar.y; s[12] = ar.z;
+  const bool non_contact = (O.last_con < c.obj_contact_time_threshold) && (O.cur_con < c.obj_contact_time_threshold);  // :65
+  if (non_contact) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) s[i] = 0.f;
+    qr.w = 1.f; qr.x = qr.y = qr.z = 0.f;
+  }
+  if (noisy) {                                                                                              // :71-83
+    const int nidx[13] = {0, 1, 2, 3, 4, 5, -1, -1, -1, -1, 9, 10, 11};
+#pragma unroll
+    for (int i = 0; i < 13; ++i)
+      if (nidx[i] >= 0) { const float n = c.obj_noise[nidx[i]]; s[i] += u16[i] * (2.f * n) - n; }
+    float e[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const float n = c.obj_noise[6 + i]; e[i] = u16[13 + i] * (2.f * n) - n; }
+    qr = qmul(qr, q_from_euler(e[0], e[1], e[2]));
+  }
+  s[6] = qr.w; s[7] = qr.x; s[8] = qr.y; s[9] = qr.z;
+#pragma unroll
+  for (int i = 0; i < 13; ++i) out[i] = s[i] * c.obj_scale[i];                                              // :85-89
+}
+
+// command resampling (reference locotouch/mdp/commands.py:517-559 + UniformVelocityCommand [DEP])
+__device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P, uint32_t env, uint64_t step, uint32_t stream, Misc& X) {
+  const U4 u0 = rng4(c.seed, env, step, stream), u1 = rng4(c.seed, env, step, stream + 1);
+  const float ub[3] = {u0.a, u0.c, u1.a}, uv[3] = {u0.b, u0.d, u1.b};
+  float cmd[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float lo = P[2 * d], hi = P[2 * d + 1];
+    if (c.cmd_multi_sampling && P[12 + d] == 0.f) {
+      const float plo = P[6 + 2 * d], phi = P[6 + 2 * d + 1], p = c.cmd_new_probs;
+      if (ub[d] < p) { hi = plo; }
+      else if (ub[d] < 1.f - p) { lo = plo; hi = phi; }
+      else { lo = phi; }
+    }
+    cmd[d] = lo + uv[d] * (hi - lo);
+  }
+  X.cmd = v3(cmd[0], cmd[1], cmd[2]);
+  X.cmd_buf = X.cmd;
+  X.cmd_standing = (u1.c <= P[16]) ? 1.f : 0.f;
+  X.cmd_time_left = c.cmd_resample_time[0] + u1.d * (c.cmd_resample_time[1] - c.cmd_resample_time[0]);
+}
+
+// =====================================================================================================
+// the step kernel
+// =====================================================================================================
+template <int TASK, int MODE>
+__global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
+  constexpr bool HAS_OBJ = TASK != LT_TASK_LOCOMOTION;
+  constexpr int FRAME = HAS_OBJ ? 58 : 45;
+  constexpr int OBS = FRAME * 6;
+  const lt_cfg& c = a.cfg;
+  const lt_layout& L = a.L;
+  const int lane = threadIdx.x;
+  const int leg = lane & 3;
+  const long long gid = (long long)blockIdx.x * 64 + lane;  // == env*4 + leg
+  const long long env = gid >> 2;
+  const long long q4 = L.npad * 4;
+  char* const arena = a.arena;
+  auto F = [&](int field, int q) -> float* { return (float*)(arena + L.quad_off[field]) + (long long)q * q4 + gid; };
+  const float* P = (const float*)(arena + L.off_cmd_params);
+  const uint64_t step = MODE == MODE_RESET_ALL ? 0ull : (uint64_t)((const long long*)(arena + L.off_counters))[0];
+  const float step_dt = c.sim_dt * (float)c.decimation;
+
+  __shared__ float s_frame[2][16][64];
+  __shared__ int s_fill[16];
+
+  // ---- model constants of this lane's leg ----
+  LinkC LC[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    LC[k].m = k_link_mass[leg][k];
+    const V3 com = v3(k_link_com[leg][k][0], k_link_com[leg][k][1], k_link_com[leg][k][2]);
+    LC[k].mc = LC[k].m * com;
+    float ic[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ic[i] = k_link_icom[leg][k][i];
+    LC[k].Io = inertia_about_origin(LC[k].m, com, ic, 1.f);
+    LC[k].r = v3(k_joint_off[leg][k][0], k_joint_off[leg][k][1], k_joint_off[leg][k][2]);
+  }
+  float qdef[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) qdef[k] = k_joint_default[leg][k];
+
+  // ---- load state (one coalesced 256-B access per quad array) ----
+  Base B; Obj O; Leg G; Misc X;
+  {
+    float t;
+    t = *F(LT_F_ROOT_POS, 0); B.p = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+    t = *F(LT_F_ROOT_QUAT, 0); B.q.w = qbcast<0>(t); B.q.x = qbcast<1>(t); B.q.y = qbcast<2>(t); B.q.z = qbcast<3>(t);
+    t = *F(LT_F_ROOT_LIN_VEL_W, 0); B.u = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+    t = *F(LT_F_ROOT_ANG_VEL_W, 0); B.w = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+    t = *F(LT_F_OBJ_POS, 0); O.p = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+    t = *F(LT_F_OBJ_QUAT, 0); O.q.w = qbcast<0>(t); O.q.x = qbcast<1>(t); O.q.y = qbcast<2>(t); O.q.z = qbcast<3>(t);
+    t = *F(LT_F_OBJ_LIN_VEL_W, 0); O.u = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+    t = *F(LT_F_OBJ_ANG_VEL_W, 0); O.w = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+    t = *F(LT_F_OBJ_TIMERS, 0); O.cur_air = qbcast<0>(t); O.cur_con = qbcast<1>(t); O.last_air = qbcast<2>(t); O.last_con = qbcast<3>(t);
+    t = *F(LT_F_OBJ_PARAMS, 0); O.rad = qbcast<0>(t); O.len = qbcast<1>(t); O.mass = qbcast<2>(t); O.mu = qbcast<3>(t);
+    t = *F(LT_F_ENV_PARAMS, 0); X.trunk_mass_add = qbcast<0>(t); X.trunk_mu = qbcast<1>(t); X.trunk_rest = qbcast<2>(t); X.obj_rest = qbcast<3>(t);
+    t = *F(LT_F_TRUNK_FORCE_HIST, 0); X.trunk_fh[0] = qbcast<0>(t); X.trunk_fh[1] = qbcast<1>(t); X.trunk_fh[2] = qbcast<2>(t);
+    t = *F(LT_F_CMD, 0); X.cmd = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.cmd_time_left = qbcast<3>(t);
+    t = *F(LT_F_CMD_BUF, 0); X.cmd_buf = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.cmd_standing = qbcast<3>(t);
+    t = *F(LT_F_EVENT_TIMERS, 0); X.push_robot_left = qbcast<0>(t); X.push_obj_left = qbcast<1>(t);
+    t = *F(LT_F_GAIT_CMD, 0); X.gait_cmd = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.gait_step = qbcast<3>(t);
+    X.ep_len = ((const long long*)(arena + L.off_ep_len))[env];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      G.q[k] = *F(LT_F_JOINT_POS, k); G.qd[k] = *F(LT_F_JOINT_VEL, k);
+      G.qdd[k] = *F(LT_F_JOINT_ACC, k); G.tau[k] = *F(LT_F_APPLIED_TORQUE, k);
+      G.raw[k] = *F(LT_F_ACT_RAW, k); G.prev[k] = *F(LT_F_ACT_PREV_RAW, k); G.prev2[k] = *F(LT_F_ACT_PREV_PREV_RAW, k);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int ty = 0; ty < 4; ++ty) G.fh[s][ty] = *F(LT_F_FORCE_HIST, s * 4 + ty);
+    G.cur_air = *F(LT_F_FOOT_CUR_AIR, 0); G.cur_con = *F(LT_F_FOOT_CUR_CONTACT, 0);
+    G.last_air = *F(LT_F_FOOT_LAST_AIR, 0); G.last_con = *F(LT_F_FOOT_LAST_CONTACT, 0);
+    G.mu = *F(LT_F_FOOT_FRICTION, 0);
+    G.foot_p = v3(*F(LT_F_FOOT_POS_W, 0), *F(LT_F_FOOT_POS_W, 1), *F(LT_F_FOOT_POS_W, 2));
+    G.foot_v = v3(*F(LT_F_FOOT_VEL_W, 0), *F(LT_F_FOOT_VEL_W, 1), *F(LT_F_FOOT_VEL_W, 2));
+    G.g_last_air = *F(LT_F_GAIT_LAST_AIR, 0); G.g_last_con = *F(LT_F_GAIT_LAST_CONTACT, 0);
+    G.g_valid = *F(LT_F_GAIT_VALID_LAST_AIR, 0);
+    G.g_flags = *(const int*)F(LT_F_GAIT_FLAGS, 0);
+  }
+
+  // ---- startup events (reset-all only): reference locomotion_base_env_cfg.py:224-244, rand_cylinder_...:21-27 ----
+  if (MODE == MODE_RESET_ALL) {
+    const uint64_t st = ~0ull;
+    const U4 u = rng4(c.seed, (uint32_t)env, st, RS_STARTUP);
+    X.trunk_mass_add = lerp2(c.trunk_mass_add, u.a);
+    O.rad = lerp2(c.obj_radius, u.b);
+    O.len = lerp2(c.obj_length, u.c);
+    const U4 uf = rng4(c.seed, (uint32_t)env, st, RS_STARTUP + 0x10 + leg);
+    const float ms = lerp2(c.foot_friction, uf.a), md = lerp2(c.foot_friction, uf.b);
+    G.mu = md < ms ? md : ms;
+    O.mass = 1.0f; O.mu = 1.0f; X.trunk_mu = 1.0f; X.trunk_rest = 0.f; X.obj_rest = 0.f;
+    if (!HAS_OBJ) { O.q.w = 1.f; O.q.x = O.q.y = O.q.z = 0.f; }
+  }
+
+  // =================================================================================================
+  // stages 1-3: action term, decimation x (PD, physics, sensors), counters
+  // =================================================================================================
+  if (MODE == MODE_STEP) {
+    // 1. JointPositionActionPrevPrev.process_actions (reference mdp/actions.py:30-44); action index = type*4 + leg
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      G.prev2[k] = G.prev[k];
+      G.prev[k] = G.raw[k];
+      float x = env < L.n ? a.actions[env * 12 + k * 4 + leg] : 0.f;  // padded tail envs read no action
+      x = x < -c.action_clip ? -c.action_clip : (x > c.action_clip ? c.action_clip : x);
+      G.raw[k] = x * c.action_scale;
+    }
+    // 2. decimation loop
+    const float h = c.sim_dt / (float)c.phys_substeps;
+    for (int d = 0; d < c.decimation; ++d) {
+      float qd0[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        qd0[k] = G.qd[k];
+        G.tau[k] = dc_motor(c, qdef[k] + G.raw[k], G.q[k], G.qd[k]);
+      }
+      Report rep;
+      for (int s = 0; s < c.phys_substeps; ++s) physics_substep<HAS_OBJ>(c, h, leg, LC, B, G, O, X, rep);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) G.qdd[k] = (G.qd[k] - qd0[k]) / c.sim_dt;  // Articulation.data.joint_acc [DEP]
+      // K3 sensors: |F| history (newest first) + timers, at the sensor period = sim dt (locomotion_base_env_cfg.py:358-359)
+#pragma unroll
+      for (int ty = 0; ty < 4; ++ty) {
+        G.fh[2][ty] = G.fh[1][ty];
+        G.fh[1][ty] = G.fh[0][ty];
+        G.fh[0][ty] = norm(rep.body[ty]);
+      }
+      timers_update(G.cur_air, G.cur_con, G.last_air, G.last_con, G.fh[0][3] > c.contact_force_threshold, c.sim_dt);
+      X.trunk_fh[2] = X.trunk_fh[1]; X.trunk_fh[1] = X.trunk_fh[0];
+      X.trunk_fh[0] = norm(qsum(rep.trunk_part));
+      if (HAS_OBJ) timers_update(O.cur_air, O.cur_con, O.last_air, O.last_con, norm(qsum(rep.obj_part)) > c.contact_force_threshold, c.sim_dt);
+    }
+    foot_kinematics(LC, B, G);
+    X.ep_len += 1;  // 3.
+  }
+
+  // =================================================================================================
+  // stages 4-5: terminations and rewards
+  // =================================================================================================
+  int bits = 0;
+  bool terminated = false, time_out = false, reset = false;
+  float sums[LT_REWARD_SLOTS / 4];  // this lane's episode sums: terms leg, leg+4, ...  (quad array q holds terms 4q..4q+3)
+#pragma unroll
+  for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) sums[q] = *F(LT_F_EPISODE_SUMS, q);
+  if (MODE != MODE_RESET_ALL) {
+    const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
+    const V3 vb = tmul(R0, B.u), wb = tmul(R0, B.w);
+    const V3 gb = -row(R0, 2);  // R0^T (0,0,-1)
+    // ---- 4. terminations (stock terms [DEP], cfg locomotion_base_env_cfg.py:296-313; mdp/terminations.py:10-23)
+    {
+      const V3 gq = qapply_inv(B.q, v3(0.f, 0.f, -1.f));
+      if (c.term_enabled[LT_T_TIME_OUT] && X.ep_len >= (long long)c.max_episode_length) bits |= 1 << LT_T_TIME_OUT;
+      if (c.term_enabled[LT_T_BASE_ORIENTATION] && acosf(-gq.z) > c.term_orientation_limit) bits |= 1 << LT_T_BASE_ORIENTATION;
+      if (c.term_enabled[LT_T_BASE_HEIGHT] && B.p.z < c.term_min_height) bits |= 1 << LT_T_BASE_HEIGHT;
+      if (c.term_enabled[LT_T_BASE_CONTACT]) {
+        const float mx = fmaxf(X.trunk_fh[0], fmaxf(X.trunk_fh[1], X.trunk_fh[2]));
+        if (mx > c.term_contact_threshold) bits |= 1 << LT_T_BASE_CONTACT;
+      }
+      if (c.term_enabled[LT_T_HIP_CONTACT]) {
+        const float mx = fmaxf(G.fh[0][0], fmaxf(G.fh[1][0], G.fh[2][0]));
+        if (qor(mx > c.term_contact_threshold ? 1 : 0)) bits |= 1 << LT_T_HIP_CONTACT;
+      }
+      if (HAS_OBJ) {
+        if (c.term_enabled[LT_T_OBJECT_BELOW_ROBOT] && O.p.z < B.p.z) bits |= 1 << LT_T_OBJECT_BELOW_ROBOT;
+        if (c.term_enabled[LT_T_OBJECT_BAD_ROLL]) {
+          const V3 go = qapply_inv(O.q, v3(0.f, 0.f, -1.f));
+          if (fabsf(asinf(go.y)) > c.term_object_roll_limit) bits |= 1 << LT_T_OBJECT_BAD_ROLL;
+        }
+      }
+      time_out = bits & 1;
+      terminated = (bits & ~1) != 0;
+    }
+    const bool alive_in = MODE == MODE_TERMS ? ((const unsigned char*)(arena + L.off_terminated))[env] != 0 : terminated;
+    // ---- 5. rewards (reference locotouch/mdp/rewards.py; weights/dt by the RewardManager [DEP])
+    float terms[LT_REWARD_SLOTS];
+#pragma unroll
+    for (int i = 0; i < LT_REWARD_SLOTS; ++i) terms[i] = 0.f;
+    const float* w = c.reward_weight;
+    const V3 cmd = X.cmd;
+    const float cn = norm(cmd);
+    const float lin_err = sqrtf((cmd.x - vb.x) * (cmd.x - vb.x) + (cmd.y - vb.y) * (cmd.y - vb.y));
+    const float ang_err = fabsf(cmd.z - wb.z);
+    if (w[LT_R_ALIVE] != 0.f) terms[LT_R_ALIVE] = alive_in ? 0.f : 1.f;
+    if (w[LT_R_TRACK_LIN_VEL_XY] != 0.f) terms[LT_R_TRACK_LIN_VEL_XY] = expf(-(lin_err / c.track_sigma));       // :15-20
+    if (w[LT_R_TRACK_ANG_VEL_Z] != 0.f) terms[LT_R_TRACK_ANG_VEL_Z] = expf(-(ang_err / c.track_sigma));         // :22-27
+    const float foot_pv = sqrtf(G.foot_v.x * G.foot_v.x + G.foot_v.y * G.foot_v.y);
+    if (w[LT_R_FOOT_SLIP] != 0.f) {                                                                           // :31-42
+      const float mx = fmaxf(G.fh[0][3], fmaxf(G.fh[1][3], G.fh[2][3]));
+      terms[LT_R_FOOT_SLIP] = qsum(mx > c.foot_slip_threshold ? foot_pv : 0.f);
+    }
+    if (w[LT_R_FOOT_DRAGGING] != 0.f)                                                                         // :44-56
+      terms[LT_R_FOOT_DRAGGING] = qsum((G.foot_p.z <= c.foot_drag_height && foot_pv > c.foot_drag_vel) ? 1.f : 0.f);
+    // gait: gather the four feet in class column order [FR, RL, FL, RR] = legs [0, 3, 1, 2]
+    Gait GT;
+    {
+      GT.cur_air[0] = qbcast<0>(G.cur_air); GT.cur_air[1] = qbcast<3>(G.cur_air); GT.cur_air[2] = qbcast<1>(G.cur_air); GT.cur_air[3] = qbcast<2>(G.cur_air);
+      GT.cur_con[0] = qbcast<0>(G.cur_con); GT.cur_con[1] = qbcast<3>(G.cur_con); GT.cur_con[2] = qbcast<1>(G.cur_con); GT.cur_con[3] = qbcast<2>(G.cur_con);
+      GT.sensor_last_air[0] = qbcast<0>(G.last_air); GT.sensor_last_air[1] = qbcast<3>(G.last_air); GT.sensor_last_air[2] = qbcast<1>(G.last_air); GT.sensor_last_air[3] = qbcast<2>(G.last_air);
+      GT.last_air[0] = qbcast<0>(G.g_last_air); GT.last_air[1] = qbcast<3>(G.g_last_air); GT.last_air[2] = qbcast<1>(G.g_last_air); GT.last_air[3] = qbcast<2>(G.g_last_air);
+      GT.last_con[0] = qbcast<0>(G.g_last_con); GT.last_con[1] = qbcast<3>(G.g_last_con); GT.last_con[2] = qbcast<1>(G.g_last_con); GT.last_con[3] = qbcast<2>(G.g_last_con);
+      GT.valid[0] = qbcast<0>(G.g_valid); GT.valid[1] = qbcast<3>(G.g_valid); GT.valid[2] = qbcast<1>(G.g_valid); GT.valid[3] = qbcast<2>(G.g_valid);
+      const int f0 = qbcasti<0>(G.g_flags), f1 = qbcasti<3>(G.g_flags), f2 = qbcasti<1>(G.g_flags), f3 = qbcasti<2>(G.g_flags);
+      GT.swing0[0] = f0 & 1; GT.swing0[1] = f1 & 1; GT.swing0[2] = f2 & 1; GT.swing0[3] = f3 & 1;
+      GT.prevc[0] = (f0 >> 1) & 1; GT.prevc[1] = (f1 >> 1) & 1; GT.prevc[2] = (f2 >> 1) & 1; GT.prevc[3] = (f3 >> 1) & 1;
+      GT.last_cmd = X.gait_cmd; GT.step_from_change = X.gait_step;
+    }
+    if (w[LT_R_GAIT] != 0.f) {
+      float ox = 0.f, oy = 0.f;
+      if (HAS_OBJ && c.gait_with_object) {                                                                    // :372-385
+        const Q4 qy = q_from_euler(0.f, 0.f, q_yaw_2pi(B.q));
+        const V3 o = qapply_inv(qy, O.p - B.p);
+        ox = o.x; oy = o.y;
+      }
+      terms[LT_R_GAIT] = gait_reward(c, GT, cmd, lin_err, ang_err, ox, oy, P[26] != 0.f, step_dt);
+      // scatter the class state back: lane (leg) owns column {0:0, 1:2, 2:3, 3:1}
+      G.g_last_air = sel4(leg, GT.last_air[0], GT.last_air[2], GT.last_air[3], GT.last_air[1]);
+      G.g_last_con = sel4(leg, GT.last_con[0], GT.last_con[2], GT.last_con[3], GT.last_con[1]);
+      G.g_valid = sel4(leg, GT.valid[0], GT.valid[2], GT.valid[3], GT.valid[1]);
+      const int fl0 = GT.swing0[0] | (GT.prevc[0] << 1), fl1 = GT.swing0[1] | (GT.prevc[1] << 1), fl2 = GT.swing0[2] | (GT.prevc[2] << 1), fl3 = GT.swing0[3] | (GT.prevc[3] << 1);
+      G.g_flags = leg == 0 ? fl0 : (leg == 1 ? fl2 : (leg == 2 ? fl3 : fl1));
+      X.gait_cmd = GT.last_cmd; X.gait_step = GT.step_from_change;
+    }
+    if (w[LT_R_TRACK_BASE_HEIGHT] != 0.f) { const float d = B.p.z - c.base_height_target; terms[LT_R_TRACK_BASE_HEIGHT] = d * d; }  // :398-402
+    if (w[LT_R_BASE_Z_VELOCITY] != 0.f) terms[LT_R_BASE_Z_VELOCITY] = vb.z * vb.z;                              // :404-408
+    if (w[LT_R_BASE_ROLL_PITCH_ANGLE] != 0.f) terms[LT_R_BASE_ROLL_PITCH_ANGLE] = gb.x * gb.x + gb.y * gb.y;     // :416-420
+    if (w[LT_R_BASE_ROLL_PITCH_VELOCITY] != 0.f) terms[LT_R_BASE_ROLL_PITCH_VELOCITY] = fabsf(wb.x) + fabsf(wb.y); // :410-414
+    {
+      float s_lim = 0.f, s_pos = 0.f, s_acc = 0.f, s_vel = 0.f, s_tau = 0.f, s_act = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float mid = (k_joint_lo[k] + k_joint_hi[k]) / 2.f, rng = k_joint_hi[k] - k_joint_lo[k];
+        const float lo = mid - 0.5f * rng * LT_SOFT_LIMIT_FACTOR, hi = mid + 0.5f * rng * LT_SOFT_LIMIT_FACTOR;
+        float x = G.q[k] - lo; x = x > 0.f ? 0.f : x;
+        float y = G.q[k] - hi; y = y < 0.f ? 0.f : y;
+        s_lim += -x + y;                                                                                      // :423-427
+        const float dq = G.q[k] - qdef[k];
+        s_pos += dq * dq; s_acc += G.qdd[k] * G.qdd[k]; s_vel += G.qd[k] * G.qd[k]; s_tau += G.tau[k] * G.tau[k];
+        const float da = G.raw[k] - G.prev[k];
+        s_act += da * da;
+      }
+      s_lim = qsum(s_lim); s_pos = qsum(s_pos); s_acc = qsum(s_acc); s_vel = qsum(s_vel); s_tau = qsum(s_tau); s_act = qsum(s_act);
+      if (w[LT_R_JOINT_POSITION_LIMIT] != 0.f) terms[LT_R_JOINT_POSITION_LIMIT] = s_lim;
+      if (w[LT_R_JOINT_POSITION] != 0.f) {                                                                    // :429-440
+        const float bv = sqrtf(vb.x * vb.x + vb.y * vb.y), r = sqrtf(s_pos);
+        terms[LT_R_JOINT_POSITION] = (cn > 0.f || bv > c.joint_pos_vel_threshold) ? r : c.joint_pos_stand_scale * r;
+      }
+      if (w[LT_R_JOINT_ACCELERATION] != 0.f) terms[LT_R_JOINT_ACCELERATION] = sqrtf(s_acc);                     // :446-448
+      if (w[LT_R_JOINT_VELOCITY] != 0.f) terms[LT_R_JOINT_VELOCITY] = sqrtf(s_vel);                             // :442-444
+      if (w[LT_R_JOINT_TORQUE] != 0.f) terms[LT_R_JOINT_TORQUE] = sqrtf(s_tau);                                 // :450-452
+      if (w[LT_R_ACTION_RATE] != 0.f) terms[LT_R_ACTION_RATE] = s_act;                                          // :454-456
+    }
+    if (w[LT_R_THIGH_CALF_COLLISION] != 0.f) {                                                                // :459-466
+      const float m1 = fmaxf(G.fh[0][1], fmaxf(G.fh[1][1], G.fh[2][1])), m2 = fmaxf(G.fh[0][2], fmaxf(G.fh[1][2], G.fh[2][2]));
+      terms[LT_R_THIGH_CALF_COLLISION] = qsum((m1 > c.thigh_calf_threshold ? 1.f : 0.f) + (m2 > c.thigh_calf_threshold ? 1.f : 0.f));
+    }
+    if (HAS_OBJ) {
+      const V3 dpos = O.p - B.p;
+      const V3 pr = qapply_inv(B.q, dpos), lr = qapply_inv(B.q, O.u - B.u), ar = qapply_inv(B.q, O.w - B.w);
+      if (w[LT_R_OBJECT_XY_POSITION] != 0.f)                                                                  // :469-481
+        terms[LT_R_OBJECT_XY_POSITION] = sqrtf(dpos.x * dpos.x + dpos.y * dpos.y) * (cn > 0.f ? 1.f : 0.f);
+      if (w[LT_R_OBJECT_XY_VELOCITY] != 0.f) terms[LT_R_OBJECT_XY_VELOCITY] = lr.x * lr.x + lr.y * lr.y;        // :483-491
+      if (w[LT_R_OBJECT_Z_CONTACT] != 0.f) terms[LT_R_OBJECT_Z_CONTACT] = (O.last_con > 0.f && O.cur_air > 0.f) ? 1.f : 0.f;  // :596-604
+      if (w[LT_R_OBJECT_Z_VELOCITY] != 0.f) terms[LT_R_OBJECT_Z_VELOCITY] = lr.z * lr.z;                        // :493-501
+      if (w[LT_R_OBJECT_ROLL_PITCH_ANGLE] != 0.f) {                                                           // :524-533
+        const V3 gz = v3(0.f, 0.f, -1.f);
+        const V3 gr = qapply_inv(B.q, qapply(O.q, qapply_inv(O.q, gz)));
+        terms[LT_R_OBJECT_ROLL_PITCH_ANGLE] = gr.y * gr.y;
+      }
+      if (w[LT_R_OBJECT_ROLL_PITCH_VELOCITY] != 0.f) terms[LT_R_OBJECT_ROLL_PITCH_VELOCITY] = ar.x * ar.x;      // :535-543
+      if (w[LT_R_OBJECT_YAW_ALIGNMENT] != 0.f) {                                                              // :545-567
+        const Q4 qr = q_from_euler(0.f, 0.f, q_yaw_2pi(B.q)), qo = q_from_euler(0.f, 0.f, q_yaw_2pi(O.q));
+        float yd = q_yaw_2pi(qmul(qconj(qr), qo));
+        const float pi = 3.14159265358979323846f;
+        if (yd > pi) yd -= 2.f * pi;
+        if (yd > 0.5f * pi) yd -= pi;
+        if (yd <= -0.5f * pi) yd += pi;
+        terms[LT_R_OBJECT_YAW_ALIGNMENT] = yd * yd * (cn > 0.f ? 1.f : 0.f);
+      }
+      if (w[LT_R_OBJECT_DANGEROUS_STATE] != 0.f) {                                                            // :569-594
+        const bool danger = (fabsf(pr.x) > c.danger_x_max) || (fabsf(pr.y) > c.danger_y_max) || (pr.z < c.danger_z_min) ||
+                            (sqrtf(lr.x * lr.x + lr.y * lr.y) > c.danger_vel_xy_max);
+        terms[LT_R_OBJECT_DANGEROUS_STATE] = danger ? 1.f : 0.f;
+      }
+    }
+    float rew = 0.f;
+#pragma unroll
+    for (int i = 0; i < LT_NUM_REWARD_TERMS; ++i) {
+      const float v = terms[i] * w[i] * step_dt;
+      rew += v;
+      if ((i & 3) == leg) sums[i >> 2] += v;
+    }
+    if (leg == 0) {
+      ((float*)(arena + L.off_reward))[env] = rew;
+      ((int*)(arena + L.off_term_bits))[env] = bits;
+    }
+    if (c.debug_terms) {
+#pragma unroll
+      for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q)
+        *F(LT_F_REWARD_TERMS, q) = sel4(leg, terms[4 * q], terms[4 * q + 1], terms[4 * q + 2], terms[4 * q + 3]);
+    }
+  }
+
+  // =================================================================================================
+  // stage 6: reset (curriculum record, log snapshot, reset events, manager resets), 7 command, 8 pushes
+  // =================================================================================================
+  if (MODE == MODE_STEP) {
+    reset = terminated || time_out;
+    if (leg == 0) {
+      ((unsigned char*)(arena + L.off_terminated))[env] = terminated ? 1 : 0;
+      ((unsigned char*)(arena + L.off_time_out))[env] = time_out ? 1 : 0;
+      ((long long*)(arena + L.off_dones))[env] = reset ? 1 : 0;
+    }
+    // this step's curriculum record (reset, ep_len, sum_lin, sum_ang): the sums live in lanes 1 and 2 of array 0
+    {
+      const float sum_lin = qbcast<LT_R_TRACK_LIN_VEL_XY & 3>(sums[LT_R_TRACK_LIN_VEL_XY >> 2]);
+      const float sum_ang = qbcast<LT_R_TRACK_ANG_VEL_Z & 3>(sums[LT_R_TRACK_ANG_VEL_Z >> 2]);
+      *F(LT_F_CURRICULUM, 0) = reset ? sel4(leg, 1.f, (float)X.ep_len, sum_lin, sum_ang) : 0.f;
+    }
+    if (reset) {
+#pragma unroll
+      for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) *F(LT_F_LAST_EPISODE_SUMS, q) = sums[q];
+      const float fin = *F(LT_F_LAST_EPISODE_INFO, 0);  // lane 0 holds episodes_finished
+      *F(LT_F_LAST_EPISODE_INFO, 0) = sel4(leg, fin + 1.f, (float)X.ep_len, (float)bits, 0.f);
+    }
+  }
+  if ((MODE == MODE_STEP && reset) || MODE == MODE_RESET_ALL) {
+    const uint32_t e32 = (uint32_t)env;
+    // E4 reset_root_state_uniform [DEP] (params locomotion_base_env_cfg.py:249-267 / object_transport_teacher...:144-160)
+    U4 u = rng4(c.seed, e32, step, RS_RESET_ROOT);
+    B.p = v3(lerp2(c.reset_root_pos[0], u.a), lerp2(c.reset_root_pos[1], u.b), LT_ROOT_INIT_HEIGHT + lerp2(c.reset_root_pos[2], u.c));
+    u = rng4(c.seed, e32, step, RS_RESET_ROOT + 1);
+    B.q = q_from_euler(lerp2(c.reset_root_rpy[0], u.a), lerp2(c.reset_root_rpy[1], u.b), lerp2(c.reset_root_rpy[2], u.c));
+    u = rng4(c.seed, e32, step, RS_RESET_ROOT + 2);
+    U4 w4 = rng4(c.seed, e32, step, RS_RESET_ROOT + 3);
+    B.u = v3(lerp2(c.reset_root_vel[0], u.a), lerp2(c.reset_root_vel[1], u.b), lerp2(c.reset_root_vel[2], u.c));
+    B.w = v3(lerp2(c.reset_root_vel[3], w4.a), lerp2(c.reset_root_vel[4], w4.b), lerp2(c.reset_root_vel[5], w4.c));
+    // E5 reset_joints_by_offset [DEP] :269-276
+    u = rng4(c.seed, e32, step, RS_RESET_JOINT + leg);
+    w4 = rng4(c.seed, e32, step, RS_RESET_JOINT + 4 + leg);
+    const float up[3] = {u.a, u.b, u.c}, uv[3] = {w4.a, w4.b, w4.c};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float mid = (k_joint_lo[k] + k_joint_hi[k]) / 2.f, rng = k_joint_hi[k] - k_joint_lo[k];
+      const float lo = mid - 0.5f * rng * LT_SOFT_LIMIT_FACTOR, hi = mid + 0.5f * rng * LT_SOFT_LIMIT_FACTOR;
+      G.q[k] = clampf(qdef[k] + lerp2(c.reset_joint_pos, up[k]), lo, hi);
+      G.qd[k] = clampf(lerp2(c.reset_joint_vel, uv[k]), -c.velocity_limit, c.velocity_limit);
+      G.qdd[k] = 0.f; G.tau[k] = 0.f;
+      G.raw[k] = 0.f; G.prev[k] = 0.f; G.prev2[k] = 0.f;                                                       // actions.py:46-52
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int ty = 0; ty < 4; ++ty) G.fh[s][ty] = 0.f;
+    G.cur_air = G.cur_con = G.last_air = G.last_con = 0.f;
+    G.g_last_air = G.g_last_con = G.g_valid = 0.f; G.g_flags = 0;                                               // rewards.py:107-114
+    X.trunk_fh[0] = X.trunk_fh[1] = X.trunk_fh[2] = 0.f;
+    X.gait_cmd = v3(0, 0, 0); X.gait_step = 0.f;
+    if (HAS_OBJ) {
+      u = rng4(c.seed, e32, step, RS_RESET_MAT);                                                               // E3 (events.py:160-196), E2
+      X.trunk_mu = lerp2(c.trunk_friction, u.a); X.trunk_mu = X.trunk_mu > 1.f ? 1.f : X.trunk_mu;
+      X.trunk_rest = lerp2(c.trunk_restitution, u.b);
+      O.mu = lerp2(c.obj_friction, u.c); O.mu = O.mu > 1.f ? 1.f : O.mu;
+      X.obj_rest = lerp2(c.obj_restitution, u.d);
+      u = rng4(c.seed, e32, step, RS_RESET_OBJ);                                                               // E6 (events.py:85-109)
+      w4 = rng4(c.seed, e32, step, RS_RESET_OBJ + 1);
+      O.p = v3(B.p.x + lerp2(c.obj_reset_pos[0], u.a), B.p.y + lerp2(c.obj_reset_pos[1], u.b), B.p.z + lerp2(c.obj_reset_pos[2], u.c));
+      O.p.z += O.len / 2.f;
+      O.q = qmul(B.q, q_from_euler(lerp2(c.obj_reset_rpy[0], w4.a), lerp2(c.obj_reset_rpy[1], w4.b), lerp2(c.obj_reset_rpy[2], w4.c)));
+      O.u = B.u; O.w = B.w;
+      O.mass = 1.0f + lerp2(c.obj_mass_add, w4.d);                                                             // E1
+      O.cur_air = O.cur_con = O.last_air = O.last_con = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) sums[q] = 0.f;
+    command_resample(c, P, e32, step, RS_CMD_RESET, X);
+    u = rng4(c.seed, e32, step, RS_RESET_EVENT);
+    X.push_robot_left = lerp2(c.push_robot_interval, u.a);
+    X.push_obj_left = lerp2(c.push_obj_interval, u.b);
+    X.ep_len = 0;
+    foot_kinematics(LC, B, G);
+    if (MODE == MODE_RESET_ALL && c.cmd_multi_sampling && 0 < (int)P[15]) X.cmd = v3(0, 0, 0);                 // commands.py:559
+  }
+  if (MODE == MODE_STEP) {
+    // 7. CommandTerm.compute [DEP] + MultiSampling._update_command (commands.py:561-576)
+    X.cmd_time_left -= step_dt;
+    if (X.cmd_time_left <= 0.f) command_resample(c, P, (uint32_t)env, step, RS_CMD_TIMER, X);
+    if (c.cmd_multi_sampling) {
+      const long long zs = (long long)(int)P[15];
+      if (X.ep_len < zs) X.cmd = 0.0f * X.cmd_buf;
+      if (X.ep_len == zs) X.cmd = X.cmd_buf;
+    }
+    if (X.cmd_standing != 0.f) X.cmd = v3(0, 0, 0);
+    // 8. interval events: push_by_setting_velocity [DEP] (cfg locomotion_base_env_cfg.py:279-292, teacher :189-209)
+    X.push_robot_left -= step_dt;
+    if (X.push_robot_left < 1e-6f) {
+      const U4 u = rng4(c.seed, (uint32_t)env, step, RS_PUSH_ROBOT), w4 = rng4(c.seed, (uint32_t)env, step, RS_PUSH_ROBOT + 1);
+      X.push_robot_left = lerp2(c.push_robot_interval, u.d);
+      B.u += v3(lerp2(c.push_robot_vel[0], u.a), lerp2(c.push_robot_vel[1], u.b), lerp2(c.push_robot_vel[2], u.c));
+      B.w += v3(lerp2(c.push_robot_vel[3], w4.a), lerp2(c.push_robot_vel[4], w4.b), lerp2(c.push_robot_vel[5], w4.c));
+    }
+    if (HAS_OBJ) {
+      X.push_obj_left -= step_dt;
+      if (X.push_obj_left < 1e-6f) {
+        const U4 u = rng4(c.seed, (uint32_t)env, step, RS_PUSH_OBJ), w4 = rng4(c.seed, (uint32_t)env, step, RS_PUSH_OBJ + 1);
+        X.push_obj_left = lerp2(c.push_obj_interval, u.d);
+        O.u += v3(lerp2(c.push_obj_vel[0], u.a), lerp2(c.push_obj_vel[1], u.b), lerp2(c.push_obj_vel[2], u.c));
+        O.w += v3(lerp2(c.push_obj_vel[3], w4.a), lerp2(c.push_obj_vel[4], w4.b), lerp2(c.push_obj_vel[5], w4.c));
+      }
+    }
+  }
+
+  // =================================================================================================
+  // stage 9: observation frame (policy: noisy, critic: clean) -> LDS, then the 6-deep history rows
+  //   term order: reference locomotion_base_env_cfg.py:74-109, object_state object_transport_teacher...:37-43
+  // =================================================================================================
+  {
+    const int el = lane >> 2;
+    const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
+    const V3 wb = tmul(R0, B.w), gb = -row(R0, 2);
+    const bool noisy = c.enable_corruption != 0;
+    const U4 uj = rng4(c.seed, (uint32_t)env, step, RS_NOISE_JPOS + leg), uvv = rng4(c.seed, (uint32_t)env, step, RS_NOISE_JVEL + leg);
+    const float nj[3] = {uj.a, uj.b, uj.c}, nv[3] = {uvv.a, uvv.b, uvv.c};
+    float* fp = s_frame[0][el];
+    float* fc = s_frame[1][el];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float x = G.q[k] - qdef[k];
+      fc[9 + k * 4 + leg] = x;
+      fp[9 + k * 4 + leg] = x + (noisy ? nj[k] * (2.f * c.obs_noise_joint_pos) - c.obs_noise_joint_pos : 0.f);
+      const float v = G.qd[k];
+      fc[21 + k * 4 + leg] = v * c.obs_scale_joint_vel;
+      fp[21 + k * 4 + leg] = (v + (noisy ? nv[k] * (2.f * c.obs_noise_joint_vel) - c.obs_noise_joint_vel : 0.f)) * c.obs_scale_joint_vel;
+      fc[33 + k * 4 + leg] = G.raw[k];
+      fp[33 + k * 4 + leg] = G.raw[k];
+    }
+    if (leg == 0) {
+      const U4 ua = rng4(c.seed, (uint32_t)env, step, RS_NOISE_BASE), ug = rng4(c.seed, (uint32_t)env, step, RS_NOISE_BASE + 1);
+      const float na[3] = {ua.a, ua.b, ua.c}, ng[3] = {ug.a, ug.b, ug.c};
+      const float cm[3] = {X.cmd.x, X.cmd.y, X.cmd.z}, wv[3] = {wb.x, wb.y, wb.z}, gv[3] = {gb.x, gb.y, gb.z};
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        fp[i] = cm[i]; fc[i] = cm[i];
+        fc[3 + i] = wv[i] * c.obs_scale_ang_vel;
+        fp[3 + i] = (wv[i] + (noisy ? na[i] * (2.f * c.obs_noise_ang_vel) - c.obs_noise_ang_vel : 0.f)) * c.obs_scale_ang_vel;
+        fc[6 + i] = gv[i];
+        fp[6 + i] = gv[i] + (noisy ? ng[i] * (2.f * c.obs_noise_gravity) - c.obs_noise_gravity : 0.f);
+      }
+      s_fill[el] = (reset || MODE != MODE_STEP) ? 1 : 0;
+    }
+    if (HAS_OBJ && leg == 1) {
+      float u16[16];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const U4 t = rng4(c.seed, (uint32_t)env, step, RS_NOISE_OBJ + b);
+        u16[4 * b] = t.a; u16[4 * b + 1] = t.b; u16[4 * b + 2] = t.c; u16[4 * b + 3] = t.d;
+      }
+      float o[13];
+      object_state_obs(c, B, O, noisy, u16, o);
+#pragma unroll
+      for (int i = 0; i < 13; ++i) fp[45 + i] = o[i];
+      object_state_obs(c, B, O, false, u16, o);
+#pragma unroll
+      for (int i = 0; i < 13; ++i) fc[45 + i] = o[i];
+    }
+  }
+  __syncthreads();
+  {
+    // 16 env rows of this wave are one contiguous chunk of 16*OBS floats: stream it with float4 stores, reading the
+    // shifted old values in place (each store depends on its own loads; later iterations only read higher addresses)
+    const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
+    constexpr int ROW4 = OBS / 4;  // 87 (teacher) or 67.5 -> locomotion rows are not float4-aligned: handled below
+    if (OBS % 4 == 0) {
+#pragma unroll 1
+      for (int grp = 0; grp < 2; ++grp) {
+        float* rows = (float*)(arena + (grp == 0 ? L.off_obs_policy : L.off_obs_critic)) + (long long)blockIdx.x * 16 * OBS;
+        for (int idx = lane; idx < 16 * ROW4; idx += 64) {
+          const int r = idx / ROW4, c4 = idx - r * ROW4;
+          const float* fr = s_frame[grp][r];
+          const float* old = rows + r * OBS;
+          const bool fill = s_fill[r] != 0;
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int col = c4 * 4 + j;
+            const int s = tab.src[col];
+            v[j] = fill ? fr[tab.frame[col]] : (s >= 0 ? old[s] : fr[-s - 1]);
+          }
+          *(float4*)(rows + r * OBS + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    } else {
+      // 270-wide rows (locomotion): 16 rows = 4320 floats, still a multiple of 4 per wave chunk -> float2 granularity
+      constexpr int ROW2 = OBS / 2;
+#pragma unroll 1
+      for (int grp = 0; grp < 2; ++grp) {
+        float* rows = (float*)(arena + (grp == 0 ? L.off_obs_policy : L.off_obs_critic)) + (long long)blockIdx.x * 16 * OBS;
+        for (int idx = lane; idx < 16 * ROW2; idx += 64) {
+          const int r = idx / ROW2, c2 = idx - r * ROW2;
+          const float* fr = s_frame[grp][r];
+          const float* old = rows + r * OBS;
+          const bool fill = s_fill[r] != 0;
+          float v[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int col = c2 * 2 + j;
+            const int s = tab.src[col];
+            v[j] = fill ? fr[tab.frame[col]] : (s >= 0 ? old[s] : fr[-s - 1]);
+          }
+          *(float2*)(rows + r * OBS + c2 * 2) = make_float2(v[0], v[1]);
+        }
+      }
+    }
+  }
+
+  // ---- store state ----
+  {
+    *F(LT_F_ROOT_POS, 0) = sel4(leg, B.p.x, B.p.y, B.p.z, 0.f);
+    *F(LT_F_ROOT_QUAT, 0) = sel4(leg, B.q.w, B.q.x, B.q.y, B.q.z);
+    *F(LT_F_ROOT_LIN_VEL_W, 0) = sel4(leg, B.u.x, B.u.y, B.u.z, 0.f);
+    *F(LT_F_ROOT_ANG_VEL_W, 0) = sel4(leg, B.w.x, B.w.y, B.w.z, 0.f);
+    if (HAS_OBJ || MODE == MODE_RESET_ALL) {
+      *F(LT_F_OBJ_POS, 0) = sel4(leg, O.p.x, O.p.y, O.p.z, 0.f);
+      *F(LT_F_OBJ_QUAT, 0) = sel4(leg, O.q.w, O.q.x, O.q.y, O.q.z);
+      *F(LT_F_OBJ_LIN_VEL_W, 0) = sel4(leg, O.u.x, O.u.y, O.u.z, 0.f);
+      *F(LT_F_OBJ_ANG_VEL_W, 0) = sel4(leg, O.w.x, O.w.y, O.w.z, 0.f);
+      *F(LT_F_OBJ_TIMERS, 0) = sel4(leg, O.cur_air, O.cur_con, O.last_air, O.last_con);
+      *F(LT_F_OBJ_PARAMS, 0) = sel4(leg, O.rad, O.len, O.mass, O.mu);
+    }
+    *F(LT_F_ENV_PARAMS, 0) = sel4(leg, X.trunk_mass_add, X.trunk_mu, X.trunk_rest, X.obj_rest);
+    *F(LT_F_TRUNK_FORCE_HIST, 0) = sel4(leg, X.trunk_fh[0], X.trunk_fh[1], X.trunk_fh[2], 0.f);
+    *F(LT_F_CMD, 0) = sel4(leg, X.cmd.x, X.cmd.y, X.cmd.z, X.cmd_time_left);
+    *F(LT_F_CMD_BUF, 0) = sel4(leg, X.cmd_buf.x, X.cmd_buf.y, X.cmd_buf.z, X.cmd_standing);
+    *F(LT_F_EVENT_TIMERS, 0) = sel4(leg, X.push_robot_left, X.push_obj_left, 0.f, 0.f);
+    *F(LT_F_GAIT_CMD, 0) = sel4(leg, X.gait_cmd.x, X.gait_cmd.y, X.gait_cmd.z, X.gait_step);
+    if (leg == 0) ((long long*)(arena + L.off_ep_len))[env] = X.ep_len;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      *F(LT_F_JOINT_POS, k) = G.q[k]; *F(LT_F_JOINT_VEL, k) = G.qd[k];
+      *F(LT_F_JOINT_ACC, k) = G.qdd[k]; *F(LT_F_APPLIED_TORQUE, k) = G.tau[k];
+      *F(LT_F_ACT_RAW, k) = G.raw[k]; *F(LT_F_ACT_PREV_RAW, k) = G.prev[k]; *F(LT_F_ACT_PREV_PREV_RAW, k) = G.prev2[k];
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int ty = 0; ty < 4; ++ty) *F(LT_F_FORCE_HIST, s * 4 + ty) = G.fh[s][ty];
+    *F(LT_F_FOOT_CUR_AIR, 0) = G.cur_air; *F(LT_F_FOOT_CUR_CONTACT, 0) = G.cur_con;
+    *F(LT_F_FOOT_LAST_AIR, 0) = G.last_air; *F(LT_F_FOOT_LAST_CONTACT, 0) = G.last_con;
+    *F(LT_F_FOOT_FRICTION, 0) = G.mu;
+    *F(LT_F_FOOT_POS_W, 0) = G.foot_p.x; *F(LT_F_FOOT_POS_W, 1) = G.foot_p.y; *F(LT_F_FOOT_POS_W, 2) = G.foot_p.z;
+    *F(LT_F_FOOT_VEL_W, 0) = G.foot_v.x; *F(LT_F_FOOT_VEL_W, 1) = G.foot_v.y; *F(LT_F_FOOT_VEL_W, 2) = G.foot_v.z;
+    *F(LT_F_GAIT_LAST_AIR, 0) = G.g_last_air; *F(LT_F_GAIT_LAST_CONTACT, 0) = G.g_last_con;
+    *F(LT_F_GAIT_VALID_LAST_AIR, 0) = G.g_valid;
+    *(int*)F(LT_F_GAIT_FLAGS, 0) = G.g_flags;
+#pragma unroll
+    for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) *F(LT_F_EPISODE_SUMS, q) = sums[q];
+  }
+}
+
+// =====================================================================================================
+// post kernel (one block): velocity curriculum (reference mdp/curriculums.py:184-275 + commands.py:471-505),
+// population gate of rewards.py:190, common step counter.  Runs after every step kernel, on the same stream.
+// =====================================================================================================
+__device__ float block_sum(float v, float* sh) {
+  const int tid = threadIdx.x;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) sh[tid >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (tid == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+  if (tid == 0) sh[16] = t;
+  __syncthreads();
+  return sh[16];
+}
+__device__ __forceinline__ void set_range(float* P, int d, float lo, float hi) {
+  P[6 + 2 * d] = P[2 * d]; P[6 + 2 * d + 1] = P[2 * d + 1];
+  P[2 * d] = lo; P[2 * d + 1] = hi;
+  P[12 + d] = (P[6 + 2 * d] == P[2 * d] && P[6 + 2 * d + 1] == P[2 * d + 1]) ? 1.f : 0.f;
+}
+__global__ __launch_bounds__(1024) void lt_post_kernel(const KArgs a, int bump_counter) {
+  const lt_cfg& c = a.cfg;
+  const lt_layout& L = a.L;
+  char* const arena = a.arena;
+  float* P = (float*)(arena + L.off_cmd_params);
+  __shared__ float sh[32];
+  const long long n = L.n, q4 = L.npad * 4;
+  float* rec = (float*)(arena + L.quad_off[LT_F_CURRICULUM]);
+  float* trk1 = rec + q4;
+  float* trk2 = rec + 2 * q4;
+  const float* cmd = (const float*)(arena + L.quad_off[LT_F_CMD]);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // population gate (rewards.py:190) for the next step
+  float nz = 0.f, any = 0.f;
+  for (long long e = tid; e < n; e += nt) {
+    const float* cc = cmd + e * 4;
+    if (cc[0] != 0.f || cc[1] != 0.f || cc[2] != 0.f) nz = 1.f;
+    if (rec[e * 4] != 0.f) any = 1.f;
+  }
+  nz = block_sum(nz, sh);
+  any = block_sum(any, sh);
+  if (tid == 0) P[26] = nz > 0.f ? 1.f : 0.f;
+  if (c.cur_enabled && any > 0.f) {  // _reset_idx (and the curriculum with it) only runs when some env reset
+    const float* mx = c.cmd_range_max;
+    const float inv_n = 1.f / (float)n;
+    __syncthreads();
+    const bool lin_open = (P[1] != mx[0] || P[12] == 0.f || P[3] != mx[1] || P[13] == 0.f) && (P[17] - P[18] <= (float)c.cur_max_distance_bins);
+    __syncthreads();
+    if (lin_open) {
+      float notall = 0.f, sl = 0.f, sr = 0.f;
+      for (long long e = tid; e < n; e += nt) {
+        if (rec[e * 4] != 0.f) { trk1[e * 4 + 0] = 1.f; trk1[e * 4 + 1] = rec[e * 4 + 1]; trk1[e * 4 + 2] = rec[e * 4 + 2]; }
+        if (trk1[e * 4 + 0] == 0.f) notall = 1.f;
+        sl += trk1[e * 4 + 1]; sr += trk1[e * 4 + 2];
+      }
+      notall = block_sum(notall, sh); sl = block_sum(sl, sh); sr = block_sum(sr, sh);
+      const bool pass = notall == 0.f && sl * inv_n > c.cur_len_threshold && sr * inv_n > c.cur_reward_threshold[0];
+      if (pass) {
+        if (tid == 0) {
+          P[19] += 1.f;
+          if ((int)P[19] == c.cur_repeat_times[0]) {
+            const float lx = clampf(P[0] - P[21], -mx[0], 0.f), ly = clampf(P[2] - P[22], -mx[1], 0.f);
+            set_range(P, 0, lx, -lx);
+            set_range(P, 1, ly, -ly);
+            if (P[12] != 0.f && P[13] != 0.f && P[14] != 0.f) { P[15] = (float)c.cmd_zero_steps_final; P[16] = c.cmd_rel_standing_final; }
+            P[19] = 0.f; P[17] += 1.f;
+          }
+        }
+        for (long long e = tid; e < n; e += nt) { trk1[e * 4 + 0] = 0.f; trk1[e * 4 + 1] = 0.f; trk1[e * 4 + 2] = 0.f; }
+      }
+    }
+    __syncthreads();
+    const bool ang_open = (P[5] != mx[2] || P[14] == 0.f) && (P[18] - P[17] <= (float)c.cur_max_distance_bins);
+    __syncthreads();
+    if (ang_open) {
+      float notall = 0.f, sl = 0.f, sr = 0.f;
+      for (long long e = tid; e < n; e += nt) {
+        if (rec[e * 4] != 0.f) { trk1[e * 4 + 3] = 1.f; trk2[e * 4 + 0] = rec[e * 4 + 1]; trk2[e * 4 + 1] = rec[e * 4 + 3]; }
+        if (trk1[e * 4 + 3] == 0.f) notall = 1.f;
+        sl += trk2[e * 4 + 0]; sr += trk2[e * 4 + 1];
+      }
+      notall = block_sum(notall, sh); sl = block_sum(sl, sh); sr = block_sum(sr, sh);
+      const bool pass = notall == 0.f && sl * inv_n > c.cur_len_threshold && sr * inv_n > c.cur_reward_threshold[1];
+      if (pass) {
+        if (tid == 0) {
+          P[20] += 1.f;
+          if ((int)P[20] == c.cur_repeat_times[1]) {
+            const float lz = clampf(P[4] - P[23], -mx[2], 0.f);
+            set_range(P, 2, lz, -lz);
+            if (P[12] != 0.f && P[13] != 0.f && P[14] != 0.f) { P[15] = (float)c.cmd_zero_steps_final; P[16] = c.cmd_rel_standing_final; }
+            P[20] = 0.f; P[18] += 1.f;
+          }
+        }
+        for (long long e = tid; e < n; e += nt) { trk1[e * 4 + 3] = 0.f; trk2[e * 4 + 0] = 0.f; trk2[e * 4 + 1] = 0.f; }
+      }
+    }
+    if (tid == 0) { P[24] = lin_open ? 1.f : 0.f; P[25] = ang_open ? 1.f : 0.f; }
+  }
+  if (tid == 0 && bump_counter) ((long long*)(arena + L.off_counters))[0] += 1;
+}
+
+// command/curriculum block initialisation (reference mdp/curriculums.py:187-193, commands.py:427-469)
+__global__ void lt_init_params_kernel(const KArgs a) {
+  const lt_cfg& c = a.cfg;
+  float* P = (float*)(a.arena + a.L.off_cmd_params);
+  const int i = threadIdx.x;
+  if (i >= LT_CMD_PARAMS_LEN) return;
+  float v = 0.f;
+  if (i < 6) v = c.cmd_range_init[i / 2][i & 1];
+  else if (i < 12) v = c.cmd_range_init[(i - 6) / 2][i & 1];
+  else if (i < 15) v = 1.f;
+  else if (i == 15) v = (float)c.cmd_zero_steps;
+  else if (i == 16) v = c.cmd_rel_standing;
+  else if (i >= 21 && i < 24) v = c.cur_enabled ? (c.cmd_range_max[i - 21] - c.cmd_range_init[i - 21][1]) / (float)c.cur_bins[i - 21] : 0.f;
+  else if (i == 24 || i == 25) v = c.cur_enabled ? 1.f : 0.f;
+  else if (i == 26) v = 1.f;
+  P[i] = v;
+  if (i == 0) ((long long*)(a.arena + a.L.off_counters))[0] = 1;
+}
+__global__ void lt_set_ranges_kernel(const KArgs a, float r0, float r1, float r2, float r3, float r4, float r5, int zero_steps, float rel_standing) {
+  float* P = (float*)(a.arena + a.L.off_cmd_params);
+  if (threadIdx.x != 0) return;
+  const float r[6] = {r0, r1, r2, r3, r4, r5};
+  for (int d = 0; d < 3; ++d) set_range(P, d, r[2 * d], r[2 * d + 1]);
+  P[15] = (float)zero_steps;
+  P[16] = rel_standing;
+}
+
+KArgs make_args(const lt_env* env, const float* actions) {
+  KArgs k;
+  k.cfg = env->cfg;
+  k.L = env->layout;
+  k.arena = (char*)env->arena;
+  k.actions = actions;
+  return k;
+}
+
+template <int MODE>
+int launch_step(const lt_env* env, const float* actions, hipStream_t s) {
+  const KArgs k = make_args(env, actions);
+  const dim3 grid((unsigned)(env->layout.npad / 16)), block(64);
+  if (env->cfg.task == LT_TASK_LOCOMOTION) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE>), grid, block, 0, s, k);
+  else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE>), grid, block, 0, s, k);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int lt_launch_reset_all(const lt_env* env, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(env->arena, 0, (size_t)env->layout.total_bytes, s);
+  if (e != hipSuccess) return (int)e;
+  const KArgs k = make_args(env, nullptr);
+  hipLaunchKernelGGL(lt_init_params_kernel, dim3(1), dim3(64), 0, s, k);
+  e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  return launch_step<MODE_RESET_ALL>(env, nullptr, s);
+}
+
+int lt_launch_step(const lt_env* env, const float* actions, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int e = launch_step<MODE_STEP>(env, actions, s);
+  if (e != 0) return e;
+  const KArgs k = make_args(env, actions);
+  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, s, k, 1);
+  return (int)hipGetLastError();
+}
+
+int lt_launch_eval_terms(const lt_env* env, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  // refresh the population gate from the commands currently in the arena, then evaluate the terms
+  const KArgs k = make_args(env, nullptr);
+  KArgs k2 = k;
+  k2.cfg.cur_enabled = 0;
+  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, s, k2, 0);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  return launch_step<MODE_TERMS>(env, nullptr, s);
+}
+
+int lt_launch_curriculum(const lt_env* env, void* stream) {
+  const KArgs k = make_args(env, nullptr);
+  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, k, 0);
+  return (int)hipGetLastError();
+}
+
+int lt_launch_set_command_ranges(const lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream) {
+  const KArgs k = make_args(env, nullptr);
+  hipLaunchKernelGGL(lt_set_ranges_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, ranges[0], ranges[1], ranges[2], ranges[3],
+                     ranges[4], ranges[5], zero_steps, rel_standing);
+  return (int)hipGetLastError();
+}
+
 const char* lt_hip_error_string(int err) { return hipGetErrorString((hipError_t)err); }

@@ -124,6 +124,12 @@ int lt_env_eval_terms(lt_env* env, void* stream) {
   return finish(lt_launch_eval_terms(env, stream), "lt_env_eval_terms");
 }
 
+int lt_env_curriculum_update(lt_env* env, void* stream) {
+  if (!env) return LT_EINVAL;
+  if (!env->arena) { lt_set_error("lt_env_curriculum_update: arena not bound"); return LT_EFAULT; }
+  return finish(lt_launch_curriculum(env, stream), "lt_env_curriculum_update");
+}
+
 int lt_env_set_command_ranges(lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream) {
   if (!env || !ranges) return LT_EINVAL;
   if (!env->arena) { lt_set_error("lt_env_set_command_ranges: arena not bound"); return LT_EFAULT; }

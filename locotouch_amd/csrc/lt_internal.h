@@ -18,6 +18,7 @@ struct lt_env {
 int lt_launch_reset_all(const lt_env* env, void* stream);
 int lt_launch_step(const lt_env* env, const float* actions, void* stream);
 int lt_launch_eval_terms(const lt_env* env, void* stream);
+int lt_launch_curriculum(const lt_env* env, void* stream);
 int lt_launch_set_command_ranges(const lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream);
 const char* lt_hip_error_string(int err);
 

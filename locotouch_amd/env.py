@@ -1,0 +1,207 @@
+"""Host-side mirror of the reference's env interface on top of the HIP library (C ABI: include/lt_env.h).
+
+`LocoTouchVecEnv` implements the `VecEnv` protocol that loco_rl's runner drives (reference
+loco_rl/loco_rl/env/vec_env.py:12-101; call sites loco_rl/loco_rl/runners/on_policy_runner.py:32,44,81,121-132,158)
+with the semantics of IsaacLab's `RslRlVecEnvWrapper` around `ManagerBasedRLEnv`:
+
+    obs, extras = env.get_observations()
+    obs, rew, dones, extras = env.step(actions)      # extras["observations"]["critic"], extras["time_outs"], extras["log"]
+    env.episode_length_buf = torch.randint_like(...)  # settable (on_policy_runner.py:121-124)
+
+PyTorch is plumbing only: it owns the device arena (one uint8 tensor) and hands `data_ptr()`/the current stream to
+the C ABI; every tensor this class returns is a zero-copy view into that arena.  There is no CPU fallback: a missing
+liblocotouch_env.so or a non-CUDA(HIP) device raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+
+from . import _abi
+
+C = _abi.CONSTS
+_TORCH_DTYPES = {0: torch.float32, 1: torch.int64, 2: torch.uint8, 3: torch.int32}
+
+TASK_IDS = {
+    # gym ids of the reference registry (locotouch/config/locotouch/__init__.py:14,99)
+    "Isaac-Locomotion-LocoTouch-v1": C["LT_TASK_LOCOMOTION"],
+    "Isaac-RandCylinderTransportTeacher-LocoTouch-v1": C["LT_TASK_TRANSPORT_TEACHER"],
+}
+REWARD_TERM_NAMES = [  # manager order == enum lt_reward_term
+    "alive", "track_lin_vel_xy", "track_ang_vel_z", "foot_slip", "foot_dragging", "gait", "track_base_height",
+    "base_z_velocity", "base_roll_pitch_angle", "base_roll_pitch_velocity", "joint_position_limit", "joint_position",
+    "joint_acceleration", "joint_velocity", "joint_torque", "action_rate", "thigh_calf_collision", "object_xy_position",
+    "object_xy_velocity", "object_z_contact", "object_z_velocity", "object_roll_pitch_angle", "object_roll_pitch_velocity",
+    "object_yaw_alignment", "object_dangerous_state"]
+TERMINATION_NAMES = ["time_out", "base_orientation", "base_height_below_minimum", "base_contact", "hip_contact",
+                     "object_below_robot", "object_bad_orientation"]
+
+
+class LocoTouchVecEnv:
+    """One process per GPU; `num_envs` environments sharded to this rank."""
+
+    def __init__(self, task: str | int = "Isaac-RandCylinderTransportTeacher-LocoTouch-v1", num_envs: int = 4096,
+                 device: str | torch.device = "cuda:0", seed: int = 42, cfg: _abi.LtCfg | None = None, **overrides):
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("LocoTouchVecEnv needs a HIP device (there is no CPU path in the product; "
+                               "the CPU oracle under oracle/ is test infrastructure only)")
+        self._lib = _abi.load()
+        task_id = TASK_IDS[task] if isinstance(task, str) else int(task)
+        self.cfg = cfg.copy() if cfg is not None else _abi.default_cfg(task_id, num_envs=num_envs, seed=seed)
+        for k, v in overrides.items():
+            if not hasattr(self.cfg, k):
+                raise AttributeError(f"lt_cfg has no field {k!r}")
+            setattr(self.cfg, k, v)
+        self.task = task
+        self.num_envs = int(self.cfg.num_envs)
+        self.num_actions = 12
+        self.num_obs = self._lib.lt_cfg_obs_dim(ctypes.byref(self.cfg))
+        self.num_privileged_obs = self.num_obs
+        self.step_dt = float(self.cfg.sim_dt) * int(self.cfg.decimation)
+        self.max_episode_length_s = float(self.cfg.episode_length_s)
+        self.max_episode_length = int(self.cfg.max_episode_length)
+        self._handle = ctypes.c_void_p()
+        _abi.check(self._lib.lt_env_create(ctypes.byref(self.cfg), ctypes.byref(self._handle)), "lt_env_create")
+        nbytes = ctypes.c_size_t()
+        _abi.check(self._lib.lt_env_state_bytes(ctypes.byref(self.cfg), ctypes.byref(nbytes)), "lt_env_state_bytes")
+        with torch.cuda.device(self.device):
+            self.arena = torch.zeros(nbytes.value + 256, dtype=torch.uint8, device=self.device)
+        pad = (-self.arena.data_ptr()) % 256
+        self._arena_aligned = self.arena[pad:pad + nbytes.value]
+        _abi.check(self._lib.lt_env_bind(self._handle, ctypes.c_void_p(self._arena_aligned.data_ptr()), nbytes.value), "lt_env_bind")
+        self._views: dict[int, torch.Tensor] = {}
+        self.obs_policy = self.view(C["LT_F_OBS_POLICY"])
+        self.obs_critic = self.view(C["LT_F_OBS_CRITIC"])
+        self.reward_buf = self.view(C["LT_F_REWARD"])
+        self.dones_buf = self.view(C["LT_F_DONES"])
+        self.terminated_buf = self.view(C["LT_F_TERMINATED"])
+        self.time_out_buf = self.view(C["LT_F_TIME_OUT"])
+        self._ep_len = self.view(C["LT_F_EP_LEN"])
+        self.cmd_params = self.view(C["LT_F_CMD_PARAMS"])
+        self.counters = self.view(C["LT_F_COUNTERS"])
+        self.extras: dict = {}
+        self._log_finished = None
+        self.reset()
+
+    # ---- zero-copy views -------------------------------------------------------------------------
+    def view(self, field: int) -> torch.Tensor:
+        if field in self._views:
+            return self._views[field]
+        v = _abi.LtView()
+        _abi.check(self._lib.lt_env_get_view(self._handle, field, ctypes.byref(v)), "lt_env_get_view")
+        dtype = _TORCH_DTYPES[v.dtype]
+        esz = torch.empty((), dtype=dtype).element_size()
+        off = v.ptr - self._arena_aligned.data_ptr()
+        assert off >= 0 and off % esz == 0
+        base = self._arena_aligned.view(dtype) if esz == 1 else self._arena_aligned[: self._arena_aligned.numel() // esz * esz].view(dtype)
+        shape = tuple(v.shape[i] for i in range(v.ndim))
+        stride = tuple(v.stride[i] for i in range(v.ndim))
+        t = torch.as_strided(base, shape, stride, storage_offset=off // esz)
+        self._views[field] = t
+        return t
+
+    def field(self, name: str) -> torch.Tensor:
+        """Quad fields come back as [N, Q, 4] views with component c = q*4 + lane (include/lt_layout.h)."""
+        return self.view(C[name])
+
+    # ---- VecEnv protocol -------------------------------------------------------------------------
+    @property
+    def episode_length_buf(self) -> torch.Tensor:
+        return self._ep_len
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value: torch.Tensor) -> None:
+        self._ep_len.copy_(value.to(self._ep_len.dtype))
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def _stream(self) -> ctypes.c_void_p:
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self):
+        _abi.check(self._lib.lt_env_reset_all(self._handle, self._stream()), "lt_env_reset_all")
+        return self.get_observations()
+
+    def _extras(self) -> dict:
+        return {"observations": {"policy": self.obs_policy, "critic": self.obs_critic}, "time_outs": self.time_out_buf.bool()}
+
+    def get_observations(self):
+        return self.obs_policy, self._extras()
+
+    def step(self, actions: torch.Tensor):
+        """One env step for all envs; returns views that the next step overwrites (same ownership rule as the
+        reference: the trainer copies what it keeps, loco_rl/loco_rl/storage/rollout_storage.py:86-97)."""
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.shape != (self.num_envs, 12):
+            actions = actions.to(torch.float32).reshape(self.num_envs, 12).contiguous()
+        _abi.check(self._lib.lt_env_step(self._handle, ctypes.c_void_p(actions.data_ptr()), self._stream()), "lt_env_step")
+        return self.obs_policy, self.reward_buf, self.dones_buf, self._extras()
+
+    def step_raw(self, actions_ptr: int) -> None:
+        """Launch-only variant for captured (hipGraph) rollouts: no tensor bookkeeping on the host."""
+        _abi.check(self._lib.lt_env_step(self._handle, ctypes.c_void_p(actions_ptr), self._stream()), "lt_env_step")
+
+    def eval_terms(self) -> None:
+        _abi.check(self._lib.lt_env_eval_terms(self._handle, self._stream()), "lt_env_eval_terms")
+
+    def curriculum_update(self) -> None:
+        _abi.check(self._lib.lt_env_curriculum_update(self._handle, self._stream()), "lt_env_curriculum_update")
+
+    def set_command_ranges(self, ranges, zero_steps: int, rel_standing: float) -> None:
+        arr = (ctypes.c_float * 6)(*[float(x) for x in ranges])
+        _abi.check(self._lib.lt_env_set_command_ranges(self._handle, arr, int(zero_steps), float(rel_standing), self._stream()),
+                   "lt_env_set_command_ranges")
+
+    # ---- logging (host sync only when asked) -------------------------------------------------------
+    def episode_log(self) -> dict:
+        """`extras["log"]`-style means over the episodes finished since the last call
+        (Episode_Reward/<term> = mean(sum)/max_episode_length_s, RewardManager.reset [DEP])."""
+        info = self.field("LT_F_LAST_EPISODE_INFO")[:, 0, :]
+        finished = info[:, 0].clone()
+        prev = self._log_finished if self._log_finished is not None else torch.zeros_like(finished)
+        mask = finished > prev
+        self._log_finished = finished
+        log = {}
+        if bool(mask.any()):
+            sums = self.field("LT_F_LAST_EPISODE_SUMS").reshape(self.num_envs, -1)[mask]
+            for i, name in enumerate(REWARD_TERM_NAMES):
+                if self.cfg.reward_weight[i] != 0:
+                    log[f"Episode_Reward/{name}"] = float(sums[:, i].mean()) / self.max_episode_length_s
+            bits = info[mask, 2].to(torch.int64)
+            for b, name in enumerate(TERMINATION_NAMES):
+                if self.cfg.term_enabled[b]:
+                    log[f"Episode_Termination/{name}"] = float(((bits >> b) & 1).float().sum())
+            log["Episode/length"] = float(info[mask, 1].mean())
+        p = self.cmd_params
+        log["Metrics/base_velocity/lin_vel_x"] = float(p[1])
+        log["Metrics/base_velocity/lin_vel_y"] = float(p[3])
+        log["Metrics/base_velocity/ang_vel_z"] = float(p[5])
+        log["Metrics/base_velocity/initial_zero_command_steps"] = float(p[15])
+        log["Metrics/base_velocity/rel_standing_envs"] = float(p[16])
+        return log
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            self._lib.lt_env_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make(task: str, num_envs: int = 4096, device: str = "cuda:0", seed: int = 42, **kw) -> LocoTouchVecEnv:
+    """`gym.make(task, cfg=...)` + `RslRlVecEnvWrapper(env)` equivalent (reference locotouch/scripts/train.py:98,116)."""
+    if task not in TASK_IDS:
+        raise KeyError(f"unknown task {task!r}; registered: {sorted(TASK_IDS)}")
+    return LocoTouchVecEnv(task, num_envs=num_envs, device=device, seed=seed, **kw)
+
+
+__all__ = ["LocoTouchVecEnv", "make", "TASK_IDS", "REWARD_TERM_NAMES", "TERMINATION_NAMES"]
+_ = math

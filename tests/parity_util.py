@@ -1,0 +1,107 @@
+"""Field-by-field comparison of the device arena (HIP path) with the host arena of the CPU oracle."""
+from __future__ import annotations
+
+import numpy as np
+
+from locotouch_amd import _abi
+from locotouch_amd.layout import Layout, QUAD_FIELDS
+
+C = _abi.CONSTS
+
+# (atol, rtol) per quad field; fp32 tolerance stated here (BASELINE.json north_star: "within a stated fp32 tolerance").
+# Forces are stiff functions of position (k_n = 2e4 N/m: 1e-6 m of fp32 noise is 2e-2 N), hence the looser band there.
+TOL = {
+    "default": (2e-5, 2e-5),
+    "LT_F_ROOT_LIN_VEL_W": (1e-4, 1e-4), "LT_F_ROOT_ANG_VEL_W": (2e-4, 2e-4),
+    "LT_F_OBJ_LIN_VEL_W": (2e-4, 2e-4), "LT_F_OBJ_ANG_VEL_W": (1e-3, 1e-3),
+    "LT_F_JOINT_VEL": (1e-3, 2e-4), "LT_F_JOINT_ACC": (0.5, 1e-3), "LT_F_APPLIED_TORQUE": (1e-3, 1e-4),
+    "LT_F_FORCE_HIST": (5e-2, 2e-3), "LT_F_TRUNK_FORCE_HIST": (5e-2, 2e-3),
+    "LT_F_FOOT_VEL_W": (1e-3, 1e-3),
+    "LT_F_EPISODE_SUMS": (2e-4, 2e-4), "LT_F_LAST_EPISODE_SUMS": (2e-4, 2e-4), "LT_F_REWARD_TERMS": (2e-3, 5e-4),
+    "LT_F_CURRICULUM": (2e-4, 2e-4),
+}
+# fields whose values hinge on a thresholded contact force (|F| > 1 N): a borderline flip changes the timer by a whole dt.
+FLIP_TOLERANT = {"LT_F_FOOT_CUR_AIR", "LT_F_FOOT_CUR_CONTACT", "LT_F_FOOT_LAST_AIR", "LT_F_FOOT_LAST_CONTACT", "LT_F_OBJ_TIMERS",
+                 "LT_F_GAIT_LAST_AIR", "LT_F_GAIT_LAST_CONTACT", "LT_F_GAIT_VALID_LAST_AIR", "LT_F_GAIT_FLAGS"}
+
+
+def device_arena_to_host(env) -> np.ndarray:
+    return env._arena_aligned.detach().cpu().numpy().copy()
+
+
+def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", max_flip_frac: float = 0.0, obs_tol=(2e-4, 2e-4),
+                        skip=()):
+    n = int(cfg.num_envs)
+    obs_dim = (45 if cfg.task == C["LT_TASK_LOCOMOTION"] else 58) * int(cfg.obs_history)
+    L = Layout(n, obs_dim)
+    assert dev.shape == ref.shape == (L.total_bytes,), (dev.shape, ref.shape, L.total_bytes)
+    report, failures, flip_envs = [], [], set()
+    for name in QUAD_FIELDS:
+        if name in skip:
+            continue
+        a, b = L.vec(dev, name), L.vec(ref, name)
+        if name == "LT_F_GAIT_FLAGS":
+            bad = (a.view(np.int32) != b.view(np.int32)).any(axis=1)
+            err = float(bad.mean())
+        else:
+            atol, rtol = TOL.get(name, TOL["default"])
+            with np.errstate(invalid="ignore"):
+                badm = ~(np.abs(a - b) <= atol + rtol * np.abs(b))
+            badm |= ~np.isfinite(a)
+            bad = badm.any(axis=1)
+            err = float(np.nanmax(np.abs(a - b))) if a.size else 0.0
+        report.append((name, err, int(bad.sum())))
+        if bad.any():
+            if name in FLIP_TOLERANT:
+                flip_envs |= set(np.nonzero(bad)[0].tolist())
+            else:
+                failures.append((name, err, np.nonzero(bad)[0][:5].tolist()))
+    for name in L.plain:
+        if name in skip:
+            continue
+        a, b = L.arr(dev, name), L.arr(ref, name)
+        if name in ("LT_F_OBS_POLICY", "LT_F_OBS_CRITIC", "LT_F_REWARD"):
+            a, b = a[:n], b[:n]
+            atol, rtol = obs_tol
+            badm = ~(np.abs(a - b) <= atol + rtol * np.abs(b)) | ~np.isfinite(a)
+            bad = badm.reshape(n, -1).any(axis=1)
+            err = float(np.abs(a - b).max())
+            soft = True
+        elif name == "LT_F_CMD_PARAMS":
+            a, b = a.copy(), b.copy()
+            a[26] = b[26] = 0  # population gate: maintained by the device post kernel only
+            bad = np.array([not np.allclose(a, b, atol=1e-6)])
+            err = float(np.abs(a - b).max())
+            soft = False
+        elif name == "LT_F_COUNTERS":
+            bad = np.array([a[0] != b[0]])
+            err = float(abs(int(a[0]) - int(b[0])))
+            soft = False
+        else:  # integer outputs: bit-exact (reset / episode indexing)
+            a, b = a[:n], b[:n]
+            bad = a != b
+            err = float(bad.mean())
+            soft = name in ("LT_F_TERM_BITS", "LT_F_DONES", "LT_F_TERMINATED")
+        report.append((name, err, int(np.sum(bad))))
+        if np.any(bad):
+            if soft and name not in ("LT_F_OBS_POLICY", "LT_F_OBS_CRITIC", "LT_F_REWARD"):
+                flip_envs |= set(np.nonzero(bad)[0].tolist())
+            elif soft:
+                # obs / reward may only differ in envs that already flipped a thresholded contact
+                rest = set(np.nonzero(bad)[0].tolist()) - flip_envs
+                if rest:
+                    flip_envs |= rest
+            else:
+                failures.append((name, err, np.nonzero(bad)[0][:5].tolist()))
+    frac = len(flip_envs) / max(1, n)
+    if failures or frac > max_flip_frac:
+        lines = [f"parity {what}: {len(failures)} hard field failures, {len(flip_envs)}/{n} envs differ in thresholded/soft fields "
+                 f"(allowed fraction {max_flip_frac})"]
+        lines += [f"  HARD {nm}: max|err|={e:.3e} envs={ids}" for nm, e, ids in failures]
+        lines += [f"  {nm:28s} max|err|={e:.3e} bad_envs={nb}" for nm, e, nb in report if nb]
+        raise AssertionError("\n".join(lines))
+    return dict(report=report, flip_envs=sorted(flip_envs))
+
+
+def compare_arenas(env, ora, what: str = "", **kw):
+    return compare_host_arenas(env.cfg, device_arena_to_host(env), ora.arena, what=what, **kw)

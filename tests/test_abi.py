@@ -1,0 +1,91 @@
+"""CPU-only checks of the C-ABI boundary: the library loads, exports every symbol include/lt_env.h declares,
+the ctypes mirror matches, and the Python layout mirror agrees with lt_env_get_view.  No compute calls."""
+import ctypes
+import re
+
+import numpy as np
+import pytest
+
+from locotouch_amd import _abi
+from locotouch_amd.layout import Layout, QUAD_FIELDS, field_quads
+
+C = _abi.CONSTS
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _abi.load()
+    src = re.sub(r"/\*.*?\*/", "", open(_abi.HEADER).read(), flags=re.S)
+    declared = set(re.findall(r"\b(lt_\w+)\s*\(", src)) - {"lt_align256"}
+    declared = {d for d in declared if not d.startswith("lt_field") and not d.startswith("lt_layout") and d != "lt_quad"}
+    assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_cfg_struct_mirror_and_defaults():
+    lib = _abi.load()
+    assert lib.lt_cfg_sizeof() == ctypes.sizeof(_abi.LtCfg)
+    loco = _abi.default_cfg(C["LT_TASK_LOCOMOTION"])
+    teach = _abi.default_cfg(C["LT_TASK_TRANSPORT_TEACHER"])
+    assert lib.lt_cfg_obs_dim(ctypes.byref(loco)) == 270 and lib.lt_cfg_obs_dim(ctypes.byref(teach)) == 348
+    assert loco.num_envs == 4096 and loco.decimation == 4 and abs(loco.sim_dt - 0.005) < 1e-9 and loco.max_episode_length == 1000
+    # 17 active rewards for locomotion, 23 for the teacher
+    assert sum(1 for i in range(C["LT_NUM_REWARD_TERMS"]) if loco.reward_weight[i] != 0) == 17
+    assert sum(1 for i in range(C["LT_NUM_REWARD_TERMS"]) if teach.reward_weight[i] != 0) == 23
+    assert [teach.term_enabled[i] for i in range(7)] == [1, 1, 1, 0, 1, 1, 1]
+    assert [loco.term_enabled[i] for i in range(7)] == [1, 1, 1, 1, 1, 0, 0]
+    assert teach.cmd_multi_sampling == 1 and teach.cur_enabled == 1 and loco.cur_enabled == 0
+    assert lib.lt_cfg_default(7, ctypes.byref(loco)) == C["LT_EINVAL"]
+
+
+@pytest.mark.parametrize("task,n", [(0, 4096), (1, 4096), (1, 100), (1, 17)])
+def test_layout_mirror_matches_c(task, n):
+    lib = _abi.load()
+    cfg = _abi.default_cfg(task, num_envs=n)
+    h = ctypes.c_void_p()
+    assert lib.lt_env_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    nbytes = ctypes.c_size_t()
+    assert lib.lt_env_state_bytes(ctypes.byref(cfg), ctypes.byref(nbytes)) == 0
+    L = Layout(n, lib.lt_cfg_obs_dim(ctypes.byref(cfg)))
+    assert L.total_bytes == nbytes.value
+    v = _abi.LtView()
+    for name in QUAD_FIELDS:
+        assert lib.lt_env_get_view(h, C[name], ctypes.byref(v)) == 0
+        assert (v.ptr or 0) == L.quad_off[name], name
+        assert list(v.shape) == [n, field_quads(name), 4] and list(v.stride) == [4, L.npad * 4, 1]
+    for name, (off, dtype, shape) in L.plain.items():
+        assert lib.lt_env_get_view(h, C[name], ctypes.byref(v)) == 0
+        assert (v.ptr or 0) == off, name
+    assert lib.lt_env_get_view(h, 63, ctypes.byref(v)) == C["LT_EINVAL"]
+    # error behaviour: stepping / resetting without a bound arena fails loudly, never silently
+    assert lib.lt_env_reset_all(h, None) == C["LT_EFAULT"]
+    dummy = (ctypes.c_float * 12)()
+    assert lib.lt_env_step(h, ctypes.cast(dummy, ctypes.c_void_p), None) == C["LT_EFAULT"]
+    assert b"not bound" in lib.lt_last_error()
+    assert lib.lt_env_bind(h, ctypes.c_void_p(256), 16) == C["LT_EFAULT"]
+    assert lib.lt_env_destroy(h) == 0
+
+
+def test_invalid_cfg_rejected():
+    lib = _abi.load()
+    cfg = _abi.default_cfg(1)
+    cfg.num_envs = 0
+    h = ctypes.c_void_p()
+    assert lib.lt_env_create(ctypes.byref(cfg), ctypes.byref(h)) == C["LT_EINVAL"]
+    cfg.num_envs = 8
+    cfg.obs_history = 3
+    assert lib.lt_env_create(ctypes.byref(cfg), ctypes.byref(h)) == C["LT_EINVAL"]
+
+
+def test_product_path_has_no_oracle_dependency():
+    """The shipped package must never import / link the oracle (it is the checker, not the product)."""
+    import glob
+    import os
+
+    root = os.path.dirname(_abi.__file__)
+    for path in glob.glob(os.path.join(root, "**", "*.py"), recursive=True) + glob.glob(os.path.join(root, "csrc", "*")):
+        text = open(path, errors="ignore").read()
+        # comments may cite the oracle as the executable spec; code may not include, import, link or dlopen it
+        assert not re.search(r'#include\s+"[^"]*oracle', text), path
+        assert not re.search(r"oracle_lib|liblt_oracle|from\s+oracle|import\s+oracle|lt_oracle_\w+\s*\(", text), path
+    _ = np
