@@ -14,7 +14,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
 HEADER = os.path.join(REPO, "include", "lt_env.h")
-LIB_PATH = os.path.join(_HERE, "_lib", "liblocotouch_env.so")
+LIB_PATH = os.environ.get("LOCOTOUCH_AMD_LIB", os.path.join(_HERE, "_lib", "liblocotouch_env.so"))
 
 _CTYPES = {"float": ctypes.c_float, "int32_t": ctypes.c_int32, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64}
 

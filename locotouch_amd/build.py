@@ -42,20 +42,31 @@ def up_to_date() -> bool:
 
 
 def build_lib(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
+    """Compile every source to an object (device code for gfx950 only), link, and verify the offload bundle."""
     if not force and up_to_date():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
-           "-Wall", "-Wno-unused-function", "-I", os.path.join(REPO, "include"), "-o", LIB + ".tmp"]
-    cmd += (extra_flags or [])
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function",
+              "-I", os.path.join(REPO, "include")] + (extra_flags or [])
+    objs = []
     for s in sources():
-        if s.endswith(".hip"):
-            cmd += ["-x", "hip", s]
-        else:
-            cmd += ["-x", "c++", s]
+        o = os.path.join(obj_dir, os.path.basename(s) + ".o")
+        # NOTE: one translation unit per hipcc call - mixing `-x hip` and `-x c++` inputs in one command makes
+        # the hipcc wrapper drop --offload-arch and emit gfx906 device code.
+        cmd = [hipcc(), f"--offload-arch={ARCH}"] + common + ["-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        objs.append(o)
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    blob = open(LIB + ".tmp", "rb").read()
+    if f"hipv4-amdgcn-amd-amdhsa--{ARCH}".encode() not in blob:
+        raise RuntimeError(f"{LIB}: offload bundle holds no {ARCH} code object")
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

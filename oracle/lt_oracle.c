@@ -1527,6 +1527,7 @@ static void post_step(const lt_cfg* cfg, void* arena, const lt_layout* L) {
       lt_quad(arena, L, LT_F_CURRICULUM, 2)[e * 4 + c] = trk[e * 8 + 4 + c];
     }
   free(rec); free(trk);
+  P[26] = any_nonzero(arena, L) ? 1.0f : 0.0f; /* population gate of rewards.py:190 for the next step */
   counters(arena, L)[0] += 1;
 }
 
@@ -1550,6 +1551,7 @@ int lt_oracle_reset_all(const lt_cfg* cfg, void* arena) {
     step_one(cfg, arena, &L, NULL, e, 0, 1, LT_ORACLE_MODE_RESET_ALL);
   }
   if (cfg->cur_enabled) { P[24] = 1; P[25] = 1; }
+  P[26] = 1;
   counters(arena, &L)[0] = 1;
   return 0;
 }
@@ -1558,7 +1560,7 @@ int lt_oracle_step(const lt_cfg* cfg, void* arena, const float* actions, int nth
   lt_layout L;
   lt_layout_init(&L, cfg->num_envs, lt_oracle_obs_dim(cfg));
   uint64_t step = (uint64_t)counters(arena, &L)[0];
-  int nz = any_nonzero(arena, &L);
+  int nz = ((const float*)((char*)arena + L.off_cmd_params))[26] != 0;
   int64_t n = L.n;
   (void)nthreads;
 #ifdef _OPENMP

@@ -12,14 +12,23 @@ C = _abi.CONSTS
 # Forces are stiff functions of position (k_n = 2e4 N/m: 1e-6 m of fp32 noise is 2e-2 N), hence the looser band there.
 TOL = {
     "default": (2e-5, 2e-5),
-    "LT_F_ROOT_LIN_VEL_W": (1e-4, 1e-4), "LT_F_ROOT_ANG_VEL_W": (2e-4, 2e-4),
+    # positions integrate the velocities below over 20 ms: 3e-3 rad/s * 0.02 s = 6e-5
+    "LT_F_JOINT_POS": (1.5e-4, 5e-5), "LT_F_ROOT_POS": (5e-5, 5e-5), "LT_F_ROOT_QUAT": (5e-5, 5e-5),
+    "LT_F_OBJ_POS": (5e-5, 5e-5), "LT_F_OBJ_QUAT": (1e-4, 1e-4), "LT_F_FOOT_POS_W": (1e-4, 1e-4),
+    "LT_F_ROOT_LIN_VEL_W": (2e-4, 2e-4), "LT_F_ROOT_ANG_VEL_W": (5e-4, 5e-4),
     "LT_F_OBJ_LIN_VEL_W": (2e-4, 2e-4), "LT_F_OBJ_ANG_VEL_W": (1e-3, 1e-3),
-    "LT_F_JOINT_VEL": (1e-3, 2e-4), "LT_F_JOINT_ACC": (0.5, 1e-3), "LT_F_APPLIED_TORQUE": (1e-3, 1e-4),
+    # one env step = 4 stiff contact solves: joint velocities (|qd| up to 30 rad/s) carry ~1e-4 relative fp32 noise,
+    # and joint_acc = d(qd)/dt at 200 Hz multiplies that by 200
+    "LT_F_JOINT_VEL": (3e-3, 5e-4), "LT_F_JOINT_ACC": (1.0, 2e-3), "LT_F_APPLIED_TORQUE": (2e-3, 2e-4),
     "LT_F_FORCE_HIST": (5e-2, 2e-3), "LT_F_TRUNK_FORCE_HIST": (5e-2, 2e-3),
-    "LT_F_FOOT_VEL_W": (1e-3, 1e-3),
+    "LT_F_FOOT_VEL_W": (2e-3, 1e-3),
     "LT_F_EPISODE_SUMS": (2e-4, 2e-4), "LT_F_LAST_EPISODE_SUMS": (2e-4, 2e-4), "LT_F_REWARD_TERMS": (2e-3, 5e-4),
     "LT_F_CURRICULUM": (2e-4, 2e-4),
 }
+# per-term overrides inside LT_F_REWARD_TERMS (unweighted terms): the L2 norms of joint acc / vel / torque inherit the
+# tolerance of their inputs
+TERM_TOL = {C["LT_R_JOINT_ACCELERATION"]: (2.0, 2e-3), C["LT_R_JOINT_VELOCITY"]: (5e-3, 5e-4), C["LT_R_JOINT_TORQUE"]: (5e-3, 5e-4),
+            C["LT_R_FOOT_SLIP"]: (4e-3, 1e-3)}
 # fields whose values hinge on a thresholded contact force (|F| > 1 N): a borderline flip changes the timer by a whole dt.
 FLIP_TOLERANT = {"LT_F_FOOT_CUR_AIR", "LT_F_FOOT_CUR_CONTACT", "LT_F_FOOT_LAST_AIR", "LT_F_FOOT_LAST_CONTACT", "LT_F_OBJ_TIMERS",
                  "LT_F_GAIT_LAST_AIR", "LT_F_GAIT_LAST_CONTACT", "LT_F_GAIT_VALID_LAST_AIR", "LT_F_GAIT_FLAGS"}
@@ -29,7 +38,7 @@ def device_arena_to_host(env) -> np.ndarray:
     return env._arena_aligned.detach().cpu().numpy().copy()
 
 
-def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", max_flip_frac: float = 0.0, obs_tol=(2e-4, 2e-4),
+def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", max_flip_frac: float = 0.0, obs_tol=(4e-4, 4e-4),
                         skip=()):
     n = int(cfg.num_envs)
     obs_dim = (45 if cfg.task == C["LT_TASK_LOCOMOTION"] else 58) * int(cfg.obs_history)
@@ -45,6 +54,11 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
             err = float(bad.mean())
         else:
             atol, rtol = TOL.get(name, TOL["default"])
+            if name == "LT_F_REWARD_TERMS":
+                atol = np.full(a.shape[1], atol, np.float32)
+                rtol = np.full(a.shape[1], rtol, np.float32)
+                for col, (ta, tr) in TERM_TOL.items():
+                    atol[col], rtol[col] = ta, tr
             with np.errstate(invalid="ignore"):
                 badm = ~(np.abs(a - b) <= atol + rtol * np.abs(b))
             badm |= ~np.isfinite(a)
@@ -68,8 +82,6 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
             err = float(np.abs(a - b).max())
             soft = True
         elif name == "LT_F_CMD_PARAMS":
-            a, b = a.copy(), b.copy()
-            a[26] = b[26] = 0  # population gate: maintained by the device post kernel only
             bad = np.array([not np.allclose(a, b, atol=1e-6)])
             err = float(np.abs(a - b).max())
             soft = False
