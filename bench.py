@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the synthetic rollout of Isaac-RandCylinderTransportTeacher-LocoTouch-v1
+at 4096 envs per GPU (BASELINE.json metric), one process per GPU.
+
+A "step" = one pass of the hot path over one batch: policy act (random-init 348->512->256->128->12 ActorCritic, fp32)
+-> lt_env_step (HIP kernels through the C ABI) -> PPO.process_env_step (time-out bootstrap + rollout-storage write).
+All inputs are HBM-resident; the 24-step rollout is replayed as one hipGraph when capture succeeds.
+
+    python bench.py --gpus 1 --steps 2400 --warmup 1000
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     - the dominant kernel (lt_step_kernel) timed live with HIP events (lt_env_step_profiled) against the
+                 HBM roofline: algorithmic bytes = 6720 B per env-step x envs per launch.
+  cpu_baseline - the CPU oracle (a port: oracle/lt_oracle.c, OpenMP over envs) timed on this box's host cores on a
+                 bounded sample of the same workload.  A reported baseline, not the optimisation target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+ALGO_BYTES_PER_ENV_STEP = {"teacher": 6720, "locomotion": 5344}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling is 6290 GB/s
+TASKS = {"teacher": "Isaac-RandCylinderTransportTeacher-LocoTouch-v1", "locomotion": "Isaac-Locomotion-LocoTouch-v1"}
+POLICY_CFG = dict(init_noise_std=1.0, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], activation="elu")
+PPO_CFG = dict(value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2, entropy_coef=0.01, num_learning_epochs=5,
+               num_mini_batches=4, learning_rate=1.0e-3, schedule="adaptive", gamma=0.99, lam=0.95, desired_kl=0.01,
+               max_grad_norm=1.0)
+ROLLOUT = 24  # num_steps_per_env (agents/rsl_rl_ppo_cfg.py:7)
+
+
+def cpu_baseline(task: str, num_envs: int, budget_s: float = 12.0) -> dict:
+    """The oracle timed on the host cores (bounded sample).  Only this leg of bench.py touches oracle/."""
+    import numpy as np
+
+    from locotouch_amd import _abi
+    from tests import oracle_lib
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cfg = _abi.default_cfg(_abi.CONSTS["LT_TASK_TRANSPORT_TEACHER" if task == "teacher" else "LT_TASK_LOCOMOTION"], num_envs=num_envs, seed=42)
+    env = oracle_lib.OracleEnv(cfg)
+    env.reset_all()
+    rng = np.random.default_rng(1234)
+    acts = (0.5 * rng.standard_normal((8, num_envs, 12))).astype(np.float32)
+    for i in range(2):
+        env.step(acts[i], nthreads=cores)
+    t0, steps = time.perf_counter(), 0
+    while True:
+        env.step(acts[steps % 8], nthreads=cores)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 400:
+            break
+    return {"value": num_envs * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps x {num_envs} envs of the same task, 0.5*N(0,1) actions, OpenMP over envs, {el:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2400)
+    ap.add_argument("--warmup", type=int, default=1000)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--task", default="teacher", choices=list(TASKS))
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-update", action="store_true", help="also report rollout + PPO update (+ all-reduce) throughput")
+    args = ap.parse_args()
+
+    import torch
+
+    from locotouch_amd.env import LocoTouchVecEnv
+    from locotouch_amd.rl import PPO, ActorCritic, Dist
+
+    dist = Dist.from_env()
+    if dist.world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={dist.world_size}: launch with torch.distributed.run for N>1")
+    dev = torch.device(f"cuda:{dist.local_rank}")
+    torch.cuda.set_device(dev)
+    n = args.envs
+    env = LocoTouchVecEnv(TASKS[args.task], num_envs=n, device=dev, seed=42 + dist.rank)
+    torch.manual_seed(1234)  # identical random-init policy on every rank
+    ac = ActorCritic(env.num_obs, env.num_obs, 12, **POLICY_CFG)
+    alg = PPO(ac, device=dev, dist=dist, **PPO_CFG)
+    alg.init_storage(n, ROLLOUT, [env.num_obs], [env.num_obs], [12])
+    obs, extras = env.get_observations()
+    critic_obs = extras["observations"]["critic"]
+
+    def rollout_steps(k: int) -> None:
+        """k consecutive rollout steps starting at storage slot 0 (k <= ROLLOUT)."""
+        alg.storage.clear()
+        with torch.inference_mode():
+            for _ in range(k):
+                actions = alg.act(obs, critic_obs)
+                _, rew, dones, infos = env.step(actions)
+                alg.process_env_step(rew, dones, infos)
+
+    graph = None
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                rollout_steps(ROLLOUT)  # warm every op / allocation before capture
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                rollout_steps(ROLLOUT)
+            torch.cuda.synchronize(dev)
+        except Exception as exc:  # capture is an optimisation, not a requirement
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize(dev)
+
+    def run(k: int) -> None:
+        full, rem = divmod(k, ROLLOUT)
+        for _ in range(full):
+            if graph is not None:
+                graph.replay()
+            else:
+                rollout_steps(ROLLOUT)
+        if rem:
+            rollout_steps(rem)
+
+    run(args.warmup)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce_max_(elapsed)
+    elapsed = float(elapsed)
+    value = n * args.gpus * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: live HIP-event timing of lt_step_kernel on the launch stream ----
+    with torch.inference_mode():
+        act = alg.act(obs, critic_obs).clone()
+    for _ in range(20):
+        env.step_profiled(act)
+    ms = [env.step_profiled(act) for _ in range(200)]
+    k_ms = sum(ms) / len(ms)
+    algo_bytes = ALGO_BYTES_PER_ENV_STEP[args.task] * n
+    achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(f"{args.task}_{n}", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "lt_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                "env_only_steps_per_s": n / (k_ms * 1e-3)}
+
+    extra = {}
+    if args.with_update:  # rollout + GAE + PPO update with the gradient all-reduce (Perf/total_fps of the reference)
+        iters = 3
+        dist.barrier(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            rollout_steps(ROLLOUT)
+            with torch.inference_mode():
+                alg.compute_returns(critic_obs)
+            alg.update()
+        torch.cuda.synchronize(dev); dist.barrier()
+        el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce_max_(el)
+        extra["train_total_fps"] = n * args.gpus * ROLLOUT * iters / float(el)
+
+    cpu = None
+    if dist.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.task, n)
+
+    if dist.rank == 0:
+        out = {"metric": "env-steps/sec (whole node), TransportTeacher 4096 envs/GPU", "value": value, "unit": "env-steps/s",
+               "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{TASKS[args.task]} rollout (policy act + env step + storage), {n} envs/GPU, "
+                                      f"random-init ActorCritic [512,256,128], seed 42+rank",
+                          "envs_per_gpu": n, "rollout_len": ROLLOUT, "hipgraph": graph is not None},
+               "roofline": roofline, "cpu_baseline": cpu}
+        out.update(extra)
+        print(json.dumps(out))
+    dist.shutdown()
+
+
+if __name__ == "__main__":
+    main()

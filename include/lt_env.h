@@ -267,6 +267,9 @@ int lt_env_reset_all(lt_env* env, void* stream);
 /* One ManagerBasedRLEnv.step(): actions float[N][12] (device).  Outputs live in the arena views
  * (OBS_POLICY, OBS_CRITIC, REWARD, DONES, TERMINATED, TIME_OUT). */
 int lt_env_step(lt_env* env, const float* actions, void* stream);
+/* Profiling variant of lt_env_step: HIP events bracket the step kernel on `stream`; the call WAITS for them (host
+ * sync - never use it inside a captured region) and returns the step kernel's duration in milliseconds. */
+int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float* step_kernel_ms);
 /* Reward / termination / observation terms on the CURRENT arena contents, without physics, reset or
  * command update (parity-test hook: lets a test write a golden state into the views and read the terms).
  * `terminated_in` (uint8[N], device, may be NULL) feeds the `alive` term. */

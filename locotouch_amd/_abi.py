@@ -98,6 +98,7 @@ def load() -> ctypes.CDLL:
     lib.lt_env_bind.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.lt_env_reset_all.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.lt_env_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.lt_env_step_profiled.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
     lib.lt_env_eval_terms.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.lt_env_curriculum_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.lt_env_get_view.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(LtView)]
@@ -114,7 +115,7 @@ def load() -> ctypes.CDLL:
 
 
 EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_obs_dim", "lt_env_create",
-           "lt_env_destroy", "lt_env_state_bytes", "lt_env_bind", "lt_env_reset_all", "lt_env_step", "lt_env_eval_terms",
+           "lt_env_destroy", "lt_env_state_bytes", "lt_env_bind", "lt_env_reset_all", "lt_env_step", "lt_env_step_profiled", "lt_env_eval_terms",
            "lt_env_curriculum_update", "lt_env_get_view", "lt_env_set_command_ranges", "lt_env_kernel_name"]
 
 

@@ -1448,6 +1448,31 @@ int lt_launch_step(const lt_env* env, const float* actions, void* stream) {
   return (int)hipGetLastError();
 }
 
+int lt_launch_step_profiled(lt_env* env, const float* actions, void* stream, float* ms) {
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e;
+  if (!env->ev_start) {
+    hipEvent_t a, b;
+    if ((e = hipEventCreate(&a)) != hipSuccess) return (int)e;
+    if ((e = hipEventCreate(&b)) != hipSuccess) return (int)e;
+    env->ev_start = a; env->ev_stop = b;
+  }
+  if ((e = hipEventRecord((hipEvent_t)env->ev_start, s)) != hipSuccess) return (int)e;
+  int rc = launch_step<MODE_STEP>(env, actions, s);
+  if (rc != 0) return rc;
+  if ((e = hipEventRecord((hipEvent_t)env->ev_stop, s)) != hipSuccess) return (int)e;
+  const KArgs k = make_args(env, actions);
+  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, s, k, 1);
+  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  if ((e = hipEventSynchronize((hipEvent_t)env->ev_stop)) != hipSuccess) return (int)e;
+  return (int)hipEventElapsedTime(ms, (hipEvent_t)env->ev_start, (hipEvent_t)env->ev_stop);
+}
+
+void lt_release_events(lt_env* env) {
+  if (env->ev_start) { (void)hipEventDestroy((hipEvent_t)env->ev_start); env->ev_start = nullptr; }
+  if (env->ev_stop) { (void)hipEventDestroy((hipEvent_t)env->ev_stop); env->ev_stop = nullptr; }
+}
+
 int lt_launch_eval_terms(const lt_env* env, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // refresh the population gate from the commands currently in the arena, then evaluate the terms

@@ -49,6 +49,7 @@ int lt_env_create(const lt_cfg* cfg, lt_env** out) {
 }
 
 int lt_env_destroy(lt_env* env) {
+  if (env) lt_release_events(env);
   delete env;
   return LT_OK;
 }
@@ -116,6 +117,12 @@ int lt_env_step(lt_env* env, const float* actions, void* stream) {
   if (!env || !actions) return LT_EINVAL;
   if (!env->arena) { lt_set_error("lt_env_step: arena not bound"); return LT_EFAULT; }
   return finish(lt_launch_step(env, actions, stream), "lt_env_step");
+}
+
+int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float* step_kernel_ms) {
+  if (!env || !actions || !step_kernel_ms) return LT_EINVAL;
+  if (!env->arena) { lt_set_error("lt_env_step_profiled: arena not bound"); return LT_EFAULT; }
+  return finish(lt_launch_step_profiled(env, actions, stream, step_kernel_ms), "lt_env_step_profiled");
 }
 
 int lt_env_eval_terms(lt_env* env, void* stream) {

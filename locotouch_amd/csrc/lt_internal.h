@@ -11,13 +11,17 @@ struct lt_env {
   lt_layout layout;
   void* arena = nullptr;   // caller-owned device memory
   size_t arena_bytes = 0;
+  void* ev_start = nullptr;  // hipEvent_t pair for lt_env_step_profiled (created lazily)
+  void* ev_stop = nullptr;
 };
 
 // implemented in lt_env.hip -------------------------------------------------------------------------
 // Every launcher enqueues on `stream` and returns a hipError_t value as int (0 = hipSuccess).
 int lt_launch_reset_all(const lt_env* env, void* stream);
 int lt_launch_step(const lt_env* env, const float* actions, void* stream);
+int lt_launch_step_profiled(lt_env* env, const float* actions, void* stream, float* ms);
 int lt_launch_eval_terms(const lt_env* env, void* stream);
+void lt_release_events(lt_env* env);
 int lt_launch_curriculum(const lt_env* env, void* stream);
 int lt_launch_set_command_ranges(const lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream);
 const char* lt_hip_error_string(int err);

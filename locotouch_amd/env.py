@@ -145,6 +145,13 @@ class LocoTouchVecEnv:
         """Launch-only variant for captured (hipGraph) rollouts: no tensor bookkeeping on the host."""
         _abi.check(self._lib.lt_env_step(self._handle, ctypes.c_void_p(actions_ptr), self._stream()), "lt_env_step")
 
+    def step_profiled(self, actions: torch.Tensor) -> float:
+        """lt_env_step with HIP events around the step kernel; returns its duration in ms (host-syncing)."""
+        ms = ctypes.c_float()
+        _abi.check(self._lib.lt_env_step_profiled(self._handle, ctypes.c_void_p(actions.data_ptr()), self._stream(), ctypes.byref(ms)),
+                   "lt_env_step_profiled")
+        return float(ms.value)
+
     def eval_terms(self) -> None:
         _abi.check(self._lib.lt_env_eval_terms(self._handle, self._stream()), "lt_env_eval_terms")
 

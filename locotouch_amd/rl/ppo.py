@@ -1,0 +1,146 @@
+"""PPO with clipped surrogate / clipped value loss and the adaptive-KL learning-rate schedule.
+
+Behavioural twin of the reference's `PPO` (loco_rl/loco_rl/algorithms/ppo.py:19-385) for the feed-forward
+ActorCritic path the LocoTouch agents use (agents/rsl_rl_ppo_cfg.py:11-30: clip 0.2, gamma 0.99, lam 0.95, lr 1e-3
+adaptive, desired KL 0.01, entropy 0.01, value coef 1.0, grad-norm 1.0, 5 epochs x 4 minibatches); the RND and
+symmetry branches of the reference are never enabled by those configs and are out of scope.
+
+Data parallelism (new): gradients live in one flat fp32 bucket that is all-reduced (mean) between
+`backward()` and the gradient clip, and the KL estimate is all-reduced before the learning-rate decision.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .dist import Dist
+from .modules import ActorCritic
+from .storage import RolloutStorage
+
+
+class PPO:
+    def __init__(self, actor_critic: ActorCritic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998,
+                 lam=0.95, value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0,
+                 use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01, device="cpu",
+                 normalize_advantage_per_mini_batch=False, dist: Dist | None = None, **unused):
+        self.device = device
+        self.dist = dist or Dist()
+        self.actor_critic = actor_critic.to(device)
+        self.optimizer = torch.optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
+        self.storage: RolloutStorage | None = None
+        self.learning_rate = learning_rate
+        self.schedule, self.desired_kl = schedule, desired_kl
+        self.clip_param, self.gamma, self.lam = clip_param, gamma, lam
+        self.num_learning_epochs, self.num_mini_batches = num_learning_epochs, num_mini_batches
+        self.value_loss_coef, self.entropy_coef, self.max_grad_norm = value_loss_coef, entropy_coef, max_grad_norm
+        self.use_clipped_value_loss = use_clipped_value_loss
+        self.normalize_advantage_per_mini_batch = normalize_advantage_per_mini_batch
+        self._t = {}
+        self._flat_grad: torch.Tensor | None = None
+        if self.dist.world_size > 1:
+            self._make_flat_grad_bucket()
+            self.broadcast_parameters()
+
+    # ---- data-parallel plumbing ------------------------------------------------------------------
+    def _make_flat_grad_bucket(self) -> None:
+        params = [p for p in self.actor_critic.parameters() if p.requires_grad]
+        total = sum(p.numel() for p in params)
+        self._flat_grad = torch.zeros(total, device=params[0].device, dtype=params[0].dtype)
+        off = 0
+        for p in params:
+            p.grad = self._flat_grad[off:off + p.numel()].view_as(p)  # gradients accumulate straight into the bucket
+            off += p.numel()
+
+    def broadcast_parameters(self) -> None:
+        for t in list(self.actor_critic.parameters()) + list(self.actor_critic.buffers()):
+            self.dist.broadcast_(t.data, src=0)
+
+    # ---- rollout -----------------------------------------------------------------------------------
+    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape) -> None:
+        self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape[0], critic_obs_shape[0],
+                                      action_shape[0], self.device)
+
+    def test_mode(self) -> None:
+        self.actor_critic.eval()
+
+    def train_mode(self) -> None:
+        self.actor_critic.train()
+
+    def act(self, obs: torch.Tensor, critic_obs: torch.Tensor) -> torch.Tensor:
+        ac, t = self.actor_critic, self._t
+        t["actions"] = ac.act(obs).detach()
+        t["values"] = ac.evaluate(critic_obs).detach()
+        t["log_prob"] = ac.get_actions_log_prob(t["actions"]).detach()
+        t["mu"] = ac.action_mean.detach()
+        t["sigma"] = ac.action_std.detach()
+        t["obs"], t["critic_obs"] = obs, critic_obs  # recorded before env.step() overwrites the env's buffers
+        return t["actions"]
+
+    def process_env_step(self, rewards: torch.Tensor, dones: torch.Tensor, infos: dict) -> None:
+        t = self._t
+        rew = rewards.clone()
+        if "time_outs" in infos:  # bootstrap the value through time-limit terminations (ppo.py:162-165)
+            rew += self.gamma * torch.squeeze(t["values"] * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+        self.storage.add(t["obs"], t["critic_obs"], t["actions"], rew, dones, t["values"], t["log_prob"], t["mu"], t["sigma"])
+        self._t = {}
+        self.actor_critic.reset(dones)
+
+    def compute_returns(self, last_critic_obs: torch.Tensor) -> None:
+        last_values = self.actor_critic.evaluate(last_critic_obs).detach()
+        self.storage.compute_returns(last_values, self.gamma, self.lam,
+                                     normalize_advantage=not self.normalize_advantage_per_mini_batch, dist=self.dist)
+
+    # ---- update ------------------------------------------------------------------------------------
+    def _adapt_learning_rate(self, mu, sigma, old_mu, old_sigma) -> None:
+        with torch.inference_mode():
+            kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5)
+                           + (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
+            kl_mean = torch.mean(kl)
+            if self.dist.world_size > 1:
+                kl_mean = self.dist.all_reduce_mean_(kl_mean.clone())
+            kl_mean = float(kl_mean)  # host decision, as in the reference (ppo.py:273-281)
+        if kl_mean > self.desired_kl * 2.0:
+            self.learning_rate = max(1e-5, self.learning_rate / 1.5)
+        elif self.desired_kl / 2.0 > kl_mean > 0.0:
+            self.learning_rate = min(1e-2, self.learning_rate * 1.5)
+        for group in self.optimizer.param_groups:
+            group["lr"] = self.learning_rate
+
+    def update(self):
+        ac = self.actor_critic
+        sum_value = sum_surr = sum_ent = 0.0
+        for b in self.storage.mini_batches(self.num_mini_batches, self.num_learning_epochs):
+            adv = b.advantages
+            if self.normalize_advantage_per_mini_batch:
+                with torch.no_grad():
+                    adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+            ac.act(b.obs)
+            log_prob = ac.get_actions_log_prob(b.actions)
+            value = ac.evaluate(b.critic_obs)
+            mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
+            if self.desired_kl is not None and self.schedule == "adaptive":
+                self._adapt_learning_rate(mu, sigma, b.mu, b.sigma)
+            ratio = torch.exp(log_prob - torch.squeeze(b.log_prob))
+            a = torch.squeeze(adv)
+            surrogate_loss = torch.max(-a * ratio, -a * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+            if self.use_clipped_value_loss:
+                clipped = b.values + (value - b.values).clamp(-self.clip_param, self.clip_param)
+                value_loss = torch.max((value - b.returns).pow(2), (clipped - b.returns).pow(2)).mean()
+            else:
+                value_loss = (b.returns - value).pow(2).mean()
+            loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
+            if self._flat_grad is not None:
+                self._flat_grad.zero_()
+            else:
+                self.optimizer.zero_grad()
+            loss.backward()
+            if self._flat_grad is not None:
+                self.dist.all_reduce_mean_(self._flat_grad)  # RCCL all-reduce of the policy gradients over xGMI
+            nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
+            self.optimizer.step()
+            sum_value += value_loss.item()
+            sum_surr += surrogate_loss.item()
+            sum_ent += entropy.mean().item()
+        n = self.num_learning_epochs * self.num_mini_batches
+        self.storage.clear()
+        return sum_value / n, sum_surr / n, sum_ent / n, None, None

@@ -1,0 +1,135 @@
+"""On-policy training loop: rollout (policy act -> env step -> storage) then PPO update, with checkpoints and logging.
+
+Interface of the reference's `OnPolicyRunner` (loco_rl/loco_rl/runners/on_policy_runner.py:21-489):
+`OnPolicyRunner(env, train_cfg: dict, log_dir, device)`, `.learn(n, init_at_random_ep_len)`, `.save/.load` with the
+checkpoint dict keys `model_state_dict, optimizer_state_dict, iter, infos` (:369-385), `.get_inference_policy`.
+Perf scalars keep the reference's names (`Perf/total_fps`, `Perf/collection time`, `Perf/learning_time`, :275,291-293).
+The per-step host syncs of the reference's bookkeeping (:197-199) are replaced by device-side accumulators that are
+read once per iteration.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from collections import deque
+
+import torch
+
+from .dist import Dist
+from .modules import ActorCritic
+from .ppo import PPO
+
+
+class OnPolicyRunner:
+    def __init__(self, env, train_cfg: dict, log_dir: str | None = None, device="cpu", dist: Dist | None = None):
+        self.cfg = dict(train_cfg)
+        self.alg_cfg = dict(train_cfg["algorithm"])
+        self.policy_cfg = dict(train_cfg["policy"])
+        self.device, self.env, self.dist = device, env, dist or Dist()
+        obs, extras = env.get_observations()
+        num_obs = obs.shape[1]
+        num_critic_obs = extras["observations"]["critic"].shape[1] if "critic" in extras["observations"] else num_obs
+        self.policy_cfg.pop("class_name", None)
+        self.alg_cfg.pop("class_name", None)
+        ac = ActorCritic(num_obs, num_critic_obs, env.num_actions, **self.policy_cfg).to(device)
+        self.alg = PPO(ac, device=device, dist=self.dist, **self.alg_cfg)
+        self.num_steps_per_env = int(self.cfg["num_steps_per_env"])
+        self.save_interval = int(self.cfg.get("save_interval", 50))
+        self.alg.init_storage(env.num_envs, self.num_steps_per_env, [num_obs], [num_critic_obs], [env.num_actions])
+        self.log_dir = log_dir if self.dist.is_main else None
+        self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0.0, 0
+        self.history: list[dict] = []
+
+    def learn(self, num_learning_iterations: int, init_at_random_ep_len: bool = False) -> None:
+        env, alg = self.env, self.alg
+        if init_at_random_ep_len:  # on_policy_runner.py:121-124
+            env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+        obs, extras = env.get_observations()
+        critic_obs = extras["observations"].get("critic", obs)
+        obs, critic_obs = obs.to(self.device), critic_obs.to(self.device)
+        alg.train_mode()
+        n = env.num_envs
+        rew_acc = torch.zeros(n, device=self.device)
+        len_acc = torch.zeros(n, device=self.device)
+        rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
+        start = self.current_learning_iteration
+        for it in range(start, start + num_learning_iterations):
+            t0 = time.time()
+            fin_rew, fin_len = [], []
+            with torch.inference_mode():
+                for _ in range(self.num_steps_per_env):
+                    actions = alg.act(obs, critic_obs)
+                    obs, rewards, dones, infos = env.step(actions.to(env.device))
+                    obs, rewards, dones = obs.to(self.device), rewards.to(self.device), dones.to(self.device)
+                    critic_obs = infos["observations"].get("critic", obs).to(self.device)
+                    alg.process_env_step(rewards, dones, infos)
+                    rew_acc += rewards
+                    len_acc += 1
+                    d = dones > 0
+                    fin_rew.append(torch.where(d, rew_acc, torch.full_like(rew_acc, float("nan"))))
+                    fin_len.append(torch.where(d, len_acc, torch.full_like(len_acc, float("nan"))))
+                    rew_acc = torch.where(d, torch.zeros_like(rew_acc), rew_acc)
+                    len_acc = torch.where(d, torch.zeros_like(len_acc), len_acc)
+                alg.compute_returns(critic_obs)
+            t1 = time.time()
+            value_loss, surrogate_loss, entropy, _, _ = alg.update()
+            t2 = time.time()
+            # one host read per iteration for the episode statistics
+            fr, fl = torch.stack(fin_rew).flatten(), torch.stack(fin_len).flatten()
+            keep = ~torch.isnan(fr)
+            rewbuffer.extend(fr[keep].tolist())
+            lenbuffer.extend(fl[keep].tolist())
+            self.current_learning_iteration = it
+            collect, learn = t1 - t0, t2 - t1
+            steps = self.num_steps_per_env * n * self.dist.world_size
+            self.tot_timesteps += steps
+            self.tot_time += collect + learn
+            rec = {"iter": it, "Perf/total_fps": steps / (collect + learn), "Perf/collection time": collect,
+                   "Perf/learning_time": learn, "Loss/value_function": value_loss, "Loss/surrogate": surrogate_loss,
+                   "Loss/entropy": entropy, "Loss/learning_rate": alg.learning_rate,
+                   "Policy/mean_noise_std": float(alg.actor_critic.action_std.mean()),
+                   "Train/mean_reward": (sum(rewbuffer) / len(rewbuffer)) if rewbuffer else None,
+                   "Train/mean_episode_length": (sum(lenbuffer) / len(lenbuffer)) if lenbuffer else None}
+            if hasattr(env, "episode_log"):
+                rec.update(env.episode_log())
+            self.history.append(rec)
+            if self.log_dir is not None:
+                os.makedirs(self.log_dir, exist_ok=True)
+                with open(os.path.join(self.log_dir, "progress.jsonl"), "a") as f:
+                    f.write(json.dumps(rec) + "\n")
+                if it % self.save_interval == 0:
+                    self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
+        self.current_learning_iteration = start + num_learning_iterations
+        if self.log_dir is not None:
+            self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+
+    # ---- checkpoints (reference on_policy_runner.py:369-422) -------------------------------------------
+    def save(self, path: str, infos=None) -> None:
+        if not self.dist.is_main:
+            return
+        torch.save({"model_state_dict": self.alg.actor_critic.state_dict(),
+                    "optimizer_state_dict": self.alg.optimizer.state_dict(),
+                    "iter": self.current_learning_iteration, "infos": infos}, path)
+
+    def load(self, path: str, load_optimizer: bool = True, pretrained: bool = False):
+        loaded = torch.load(path, map_location=self.device, weights_only=True)
+        sd = loaded["model_state_dict"]
+        if pretrained:  # actor only + reset exploration noise (reference :404-412)
+            actor_sd = {k[len("actor."):]: v for k, v in sd.items() if k.startswith("actor.")}
+            self.alg.actor_critic.actor.load_state_dict(actor_sd)
+            self.alg.actor_critic.reset_init_std()
+        else:
+            self.alg.actor_critic.load_state_dict(sd)
+            if load_optimizer:
+                self.alg.optimizer.load_state_dict(loaded["optimizer_state_dict"])
+            self.current_learning_iteration = loaded["iter"]
+        if self.dist.world_size > 1:
+            self.alg.broadcast_parameters()
+        return loaded.get("infos")
+
+    def get_inference_policy(self, device=None):
+        self.alg.test_mode()
+        if device is not None:
+            self.alg.actor_critic.to(device)
+        return self.alg.actor_critic.act_inference

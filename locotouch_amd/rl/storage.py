@@ -1,0 +1,105 @@
+"""Rollout buffer + GAE(lambda) + flat minibatch sampling for PPO.
+
+Same contract as the reference's `RolloutStorage` (loco_rl/loco_rl/storage/rollout_storage.py:13-243): (T, N, .)
+buffers, `compute_returns` = GAE with the global (unbiased-std) advantage normalisation, and a minibatch generator
+that draws ONE `randperm` per update and reuses it for every epoch (:189).  In a multi-GPU job each rank holds its own
+env shard; the advantage statistics are then all-reduced so they equal the single-process statistics over all shards
+(SURVEY.md §8(e) item 3).
+"""
+from __future__ import annotations
+
+from typing import Iterator, NamedTuple
+
+import torch
+
+from .dist import Dist
+
+
+class Batch(NamedTuple):
+    obs: torch.Tensor
+    critic_obs: torch.Tensor
+    actions: torch.Tensor
+    values: torch.Tensor
+    advantages: torch.Tensor
+    returns: torch.Tensor
+    log_prob: torch.Tensor
+    mu: torch.Tensor
+    sigma: torch.Tensor
+
+
+class RolloutStorage:
+    def __init__(self, num_envs: int, num_steps: int, obs_dim: int, critic_obs_dim: int, num_actions: int, device="cpu"):
+        self.num_envs, self.num_steps, self.device = num_envs, num_steps, device
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, device=device, dtype=dtype)  # noqa: E731
+        self.observations = z(num_steps, num_envs, obs_dim)
+        self.privileged_observations = z(num_steps, num_envs, critic_obs_dim)
+        self.actions = z(num_steps, num_envs, num_actions)
+        self.mu = z(num_steps, num_envs, num_actions)
+        self.sigma = z(num_steps, num_envs, num_actions)
+        self.rewards = z(num_steps, num_envs, 1)
+        self.dones = z(num_steps, num_envs, 1, dtype=torch.uint8)
+        self.values = z(num_steps, num_envs, 1)
+        self.returns = z(num_steps, num_envs, 1)
+        self.advantages = z(num_steps, num_envs, 1)
+        self.actions_log_prob = z(num_steps, num_envs, 1)
+        self.step = 0
+
+    def add(self, obs, critic_obs, actions, rewards, dones, values, log_prob, mu, sigma) -> None:
+        t = self.step
+        if t >= self.num_steps:
+            raise OverflowError("rollout buffer is full: call clear() before adding transitions")
+        self.observations[t].copy_(obs)
+        self.privileged_observations[t].copy_(critic_obs)
+        self.actions[t].copy_(actions)
+        self.rewards[t].copy_(rewards.view(-1, 1))
+        self.dones[t].copy_(dones.view(-1, 1))
+        self.values[t].copy_(values)
+        self.actions_log_prob[t].copy_(log_prob.view(-1, 1))
+        self.mu[t].copy_(mu)
+        self.sigma[t].copy_(sigma)
+        self.step = t + 1
+
+    def clear(self) -> None:
+        self.step = 0
+
+    def compute_returns(self, last_values: torch.Tensor, gamma: float, lam: float, normalize_advantage: bool = True,
+                        dist: Dist | None = None) -> None:
+        """GAE: delta_t = r_t + gamma (1-d_t) V_{t+1} - V_t ;  A_t = delta_t + gamma lam (1-d_t) A_{t+1} ; R_t = A_t + V_t."""
+        gae = 0
+        next_values = last_values
+        for t in range(self.num_steps - 1, -1, -1):
+            alive = 1.0 - self.dones[t].float()
+            delta = self.rewards[t] + alive * gamma * next_values - self.values[t]
+            gae = delta + alive * gamma * lam * gae
+            self.returns[t] = gae + self.values[t]
+            next_values = self.values[t]
+        self.advantages = self.returns - self.values
+        if normalize_advantage:
+            if dist is None or dist.world_size == 1:
+                self.advantages = (self.advantages - self.advantages.mean()) / (self.advantages.std() + 1e-8)
+            else:
+                a = self.advantages
+                stats = torch.stack([a.sum(), (a * a).sum(), torch.tensor(float(a.numel()), device=a.device)]).double()
+                dist.all_reduce_sum_(stats)
+                n = stats[2]
+                mean = stats[0] / n
+                var = (stats[1] - n * mean * mean) / (n - 1.0)  # unbiased, like torch.std
+                self.advantages = (a - mean.float()) / (var.clamp_min(0).sqrt().float() + 1e-8)
+
+    def mini_batches(self, num_mini_batches: int, num_epochs: int) -> Iterator[Batch]:
+        total = self.num_envs * self.num_steps
+        mb = total // num_mini_batches
+        perm = torch.randperm(num_mini_batches * mb, requires_grad=False, device=self.device)
+        flat = [x.flatten(0, 1) for x in (self.observations, self.privileged_observations, self.actions, self.values,
+                                          self.advantages, self.returns, self.actions_log_prob, self.mu, self.sigma)]
+        for _ in range(num_epochs):
+            for i in range(num_mini_batches):
+                idx = perm[i * mb:(i + 1) * mb]
+                yield Batch(*[x[idx] for x in flat])
+
+    def get_statistics(self):
+        done = self.dones.clone()
+        done[-1] = 1
+        flat = done.permute(1, 0, 2).reshape(-1, 1)
+        ends = torch.cat((flat.new_tensor([-1], dtype=torch.int64), flat.nonzero(as_tuple=False)[:, 0]))
+        return (ends[1:] - ends[:-1]).float().mean(), self.rewards.mean()
