@@ -49,6 +49,13 @@ def cpu_baseline(task: str, num_envs: int, budget_s: float = 12.0) -> dict:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:  # honour the container's CPU share (cgroup v2 quota), not just the affinity mask
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    cores = min(cores, int(os.environ.get("LT_CPU_BASELINE_THREADS", "64")))
     cfg = _abi.default_cfg(_abi.CONSTS["LT_TASK_TRANSPORT_TEACHER" if task == "teacher" else "LT_TASK_LOCOMOTION"], num_envs=num_envs, seed=42)
     env = oracle_lib.OracleEnv(cfg)
     env.reset_all()

@@ -71,7 +71,11 @@ class ActorCritic(nn.Module):
     # -- rollout / update API ------------------------------------------------------------------------
     def act(self, observations: torch.Tensor, **kwargs) -> torch.Tensor:
         self.update_distribution(observations)
-        return self.distribution.sample()
+        # == Normal.sample() draw for draw (same normal_(0,1) fill), but hipGraph-capturable: torch.normal(mean_t, std_t)
+        # refuses stream capture on ROCm, randn_like does not.
+        d = self.distribution
+        with torch.no_grad():
+            return d.mean + d.stddev * torch.randn_like(d.mean)
 
     def get_actions_log_prob(self, actions: torch.Tensor) -> torch.Tensor:
         return self.distribution.log_prob(actions).sum(dim=-1)
