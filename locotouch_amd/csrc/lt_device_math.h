@@ -55,6 +55,7 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.
 __device__ __forceinline__ float norm(V3 a) { return sqrtf(dot(a, a)); }
 __device__ __forceinline__ V3 qsum(V3 a) { return v3(qsum(a.x), qsum(a.y), qsum(a.z)); }
 
+struct S3 { float xx, xy, xz, yy, yz, zz; };  // symmetric 3x3
 struct M3 { float m[9]; };  // row-major
 __device__ __forceinline__ M3 m3_zero() { M3 r; for (int i = 0; i < 9; ++i) r.m[i] = 0.f; return r; }
 __device__ __forceinline__ M3 m3_diag(float d) { M3 r = m3_zero(); r.m[0] = r.m[4] = r.m[8] = d; return r; }

@@ -34,13 +34,18 @@ struct KArgs {
   const float* actions;
 };
 
-// ---- robot model (generated from the reference URDF by tools/compile_robot_model.py) ----------------
-__constant__ float k_link_mass[4][3] = LT_LINK_MASS_INIT;
-__constant__ float k_link_com[4][3][3] = LT_LINK_COM_INIT;
-__constant__ float k_link_icom[4][3][6] = LT_LINK_ICOM_INIT;
-__constant__ float k_joint_off[4][3][3] = LT_JOINT_OFFSET_INIT;
-__constant__ float k_joint_default[4][3] = LT_JOINT_DEFAULT_INIT;
-__constant__ float k_hip_cyl_y[4] = LT_HIP_CYL_Y_INIT;
+// ---- robot model (generated from the reference URDF by tools/compile_robot_model.py), mirror form: every per-leg
+// constant is (FL-leg literal) x sign[pattern], sign = {1, sx, sy, sx*sy} of the lane's leg -> no table loads, nothing
+// held in registers across the physics loop.
+__device__ constexpr float k_m_mass[3] = LT_MIRROR_LINK_MASS_INIT;
+__device__ constexpr float k_m_mc[3][3] = LT_MIRROR_LINK_MC_INIT;
+__device__ constexpr int k_m_mc_pat[3][3] = LT_MIRROR_LINK_MC_PAT;
+__device__ constexpr float k_m_io[3][6] = LT_MIRROR_LINK_IO_INIT;
+__device__ constexpr int k_m_io_pat[3][6] = LT_MIRROR_LINK_IO_PAT;
+__device__ constexpr float k_m_off[3][3] = LT_MIRROR_JOINT_OFFSET_INIT;
+__device__ constexpr int k_m_off_pat[3][3] = LT_MIRROR_JOINT_OFFSET_PAT;
+__device__ constexpr float k_m_dq[3] = LT_MIRROR_JOINT_DEFAULT_INIT;
+__device__ constexpr int k_m_dq_pat[3] = LT_MIRROR_JOINT_DEFAULT_PAT;
 __device__ constexpr float k_joint_lo[3] = LT_JOINT_LOWER_INIT;
 __device__ constexpr float k_joint_hi[3] = LT_JOINT_UPPER_INIT;
 __device__ constexpr float k_trunk_com[3] = LT_TRUNK_COM_INIT;
@@ -80,7 +85,18 @@ __constant__ ObsTable k_obs_tab_teacher = make_obs_table(7);
 // ---- spatial algebra types ---------------------------------------------------------------------------
 struct I6 { M3 A, B, C; };  // [A B; B^T C], angular first
 struct S6 { V3 a, l; };
-struct LinkC { float m; V3 mc; M3 Io; V3 r; };  // mass, m*com, rotational inertia about the link origin, joint offset
+struct LinkC { float m; V3 mc; S3 Io; V3 r; };  // mass, m*com, rotational inertia about the link origin, joint offset
+// constants of link K of the lane's leg: literal x sign (zero components stay literal zeros and fold away)
+template <int K>
+__device__ __forceinline__ LinkC make_link(const float (&sgn)[4]) {
+  LinkC L;
+  L.m = k_m_mass[K];
+  L.mc = v3(k_m_mc[K][0] * sgn[k_m_mc_pat[K][0]], k_m_mc[K][1] * sgn[k_m_mc_pat[K][1]], k_m_mc[K][2] * sgn[k_m_mc_pat[K][2]]);
+  L.Io.xx = k_m_io[K][0] * sgn[k_m_io_pat[K][0]]; L.Io.xy = k_m_io[K][1] * sgn[k_m_io_pat[K][1]]; L.Io.xz = k_m_io[K][2] * sgn[k_m_io_pat[K][2]];
+  L.Io.yy = k_m_io[K][3] * sgn[k_m_io_pat[K][3]]; L.Io.yz = k_m_io[K][4] * sgn[k_m_io_pat[K][4]]; L.Io.zz = k_m_io[K][5] * sgn[k_m_io_pat[K][5]];
+  L.r = v3(k_m_off[K][0] * sgn[k_m_off_pat[K][0]], k_m_off[K][1] * sgn[k_m_off_pat[K][1]], k_m_off[K][2] * sgn[k_m_off_pat[K][2]]);
+  return L;
+}
 
 __device__ __forceinline__ M3 skew_of(V3 v) {
   M3 o = m3_zero();
@@ -170,17 +186,6 @@ __device__ __forceinline__ void joint_fk(V3 wp, V3 vp, const M3& Rwp, V3 pwp, V3
   Rw = mul_rot<AX>(Rwp, c, s);
   pw = pwp + mul(Rwp, r);
 }
-// rigid-body bias force of a link: v x* (I v) - gravity wrench;  IA = I
-__device__ __forceinline__ void link_init(const LinkC& lc, V3 om, V3 vl, const M3& Rw, float g, I6& IA, S6& pA) {
-  IA.A = lc.Io; IA.B = skew_of(lc.mc); IA.C = m3_diag(lc.m);
-  const V3 n = mul(lc.Io, om) + cross(lc.mc, vl);
-  const V3 f = cross(om, lc.mc) + lc.m * vl;
-  pA.a = cross(om, n) + cross(vl, f);
-  pA.l = cross(om, f);
-  const V3 gb = (-g) * row(Rw, 2);  // Rw^T (0,0,-g)
-  pA.a -= cross(lc.mc, gb);
-  pA.l -= lc.m * gb;
-}
 struct RC { Law law; V3 f0w; };
 // ground contact of a sphere (centre r in the link frame, radius rho); accumulates into (IA, pA)
 __device__ __forceinline__ RC ground_contact(const lt_cfg& c, float h, V3 r, float rho, float mu, const M3& Rw, V3 pw, V3 om, V3 vl,
@@ -206,43 +211,6 @@ __device__ __forceinline__ V3 ground_force(const RC& rc_, float h, V3 r, float r
   const V3 rc = r - rho * row(Rw, 2);
   const V3 aw = mul(Rw, al + cross(aa, rc));
   return v3(rc_.f0w.x - h * rc_.law.cte * aw.x, rc_.f0w.y - h * rc_.law.cte * aw.y, rc_.f0w.z - h * rc_.law.Bn * aw.z);
-}
-
-// ABA backward step of one link about axis AX: project the joint out, shift to the parent frame, accumulate
-template <int AX>
-__device__ __forceinline__ void link_backward(const I6& IA, const S6& pA, float tau, V3 ca, V3 cl, float c, float s, V3 r,
-                                              S6& U, float& D, float& u, I6& IAp, S6& pAp) {
-  U.a = col(IA.A, AX);
-  U.l = row(IA.B, AX);
-  D = comp<AX>(U.a);
-  u = tau - comp<AX>(pA.a);
-  const float iD = 1.f / D;
-  I6 Ia;
-  Ia.A = IA.A; Ia.A -= outer(iD * U.a, U.a);
-  Ia.B = IA.B; Ia.B -= outer(iD * U.a, U.l);
-  Ia.C = IA.C; Ia.C -= outer(iD * U.l, U.l);
-  const float k = u * iD;
-  const V3 pa_a = pA.a + mul(Ia.A, ca) + mul(Ia.B, cl) + k * U.a;
-  const V3 pa_l = pA.l + tmul(Ia.B, ca) + mul(Ia.C, cl) + k * U.l;
-  const M3 A1 = rot_sim<AX>(c, s, Ia.A), B1 = rot_sim<AX>(c, s, Ia.B), C1 = rot_sim<AX>(c, s, Ia.C);
-  const V3 n1 = rot_fwd<AX>(c, s, pa_a), f1 = rot_fwd<AX>(c, s, pa_l);
-  M3 B2 = B1;
-  B2 += skew_mul(r, C1);
-  const M3 K1 = mul_skew(B1, r), K2 = mul_skew(B2, r);
-  IAp.A += A1; IAp.A -= transpose(K1); IAp.A -= K2;
-  IAp.B += B2;
-  IAp.C += C1;
-  pAp.a += n1 + cross(r, f1);
-  pAp.l += f1;
-}
-// ABA forward (acceleration) step
-template <int AX>
-__device__ __forceinline__ void link_forward(V3 apa, V3 apl, float c, float s, V3 r, V3 ca, V3 cl, const S6& U, float D, float u,
-                                             V3& aa, V3& al, float& qdd) {
-  al = rot_inv<AX>(c, s, apl + cross(apa, r)) + cl;
-  aa = rot_inv<AX>(c, s, apa) + ca;
-  qdd = (u - dot(U.a, aa) - dot(U.l, al)) / D;
-  aa += axis_scaled<AX>(qdd);
 }
 
 // 6x6 SPD solve (Cholesky), fully unrolled into registers.  M = [A B; B^T C] (upper blocks), rhs (a, l)
@@ -306,220 +274,11 @@ __device__ __forceinline__ V3 trunk_corner(int leg, bool hi) {
   return hi ? v3(sx * k_trunk_half[0], sy * LT_BACK_HALF_Y, LT_BACK_TOP_Z) : v3(sx * k_trunk_half[0], sy * k_trunk_half[1], -k_trunk_half[2]);
 }
 
-// =====================================================================================================
-// K2 physics: one integrator substep of length h (torques held).  Reference: PhysX (closed source) - this is
-// the engine's own model, specified by oracle/lt_oracle.c physics_substep and DESIGN.md "Physics".
-// =====================================================================================================
-template <bool HAS_OBJ>
-__device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int leg, const LinkC (&LC)[3], Base& B, Leg& G, Obj& O,
-                                                const Misc& X, Report& rep) {
-  const float g = c.gravity;
-  float cq[3], sq[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) sincosf(G.q[k], &sq[k], &cq[k]);
-  const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
-  const V3 wb = tmul(R0, B.w), vb = tmul(R0, B.u);
-  // forward kinematics of this lane's chain
-  V3 om[3], vl[3], pw[3], ca[3], cl[3];
-  M3 Rw[3];
-  joint_fk<0>(wb, vb, R0, B.p, LC[0].r, cq[0], sq[0], G.qd[0], om[0], vl[0], Rw[0], pw[0], ca[0], cl[0]);
-  joint_fk<1>(om[0], vl[0], Rw[0], pw[0], LC[1].r, cq[1], sq[1], G.qd[1], om[1], vl[1], Rw[1], pw[1], ca[1], cl[1]);
-  joint_fk<1>(om[1], vl[1], Rw[1], pw[1], LC[2].r, cq[2], sq[2], G.qd[2], om[2], vl[2], Rw[2], pw[2], ca[2], cl[2]);
-
-  // this lane's share of the trunk's articulated inertia / bias force
-  I6 IA0; IA0.A = m3_zero(); IA0.B = m3_zero(); IA0.C = m3_zero();
-  S6 pA0; pA0.a = v3(0, 0, 0); pA0.l = v3(0, 0, 0);
-  rep.trunk_part = v3(0, 0, 0);
-  rep.obj_part = v3(0, 0, 0);
-
-  // ---- carried cylinder: free body, implicit contacts with the plate (sample = lane) and the ground ----
-  V3 obj_aa = v3(0, 0, 0), obj_al = v3(0, 0, 0);
-  if (HAS_OBJ) {
-    const M3 Ro = quat_to_mat(O.q.w, O.q.x, O.q.y, O.q.z);
-    const V3 ay = col(Ro, 1);
-    const float rad = O.rad, half = 0.5f * O.len;
-    const float mu_plate = 0.5f * (X.trunk_mu + O.mu);
-    const V3 ct = tmul(R0, O.p - B.p), at = tmul(R0, ay);
-    const float hx = LT_BACK_HALF_X, hy = LT_RAIL_Y + LT_RAIL_RADIUS, zp = LT_BACK_TOP_Z;
-    float s0 = -half, s1 = half;
-    bool ok = true;
-    {  // slab clipping of the axis segment against |x| <= hx, |y| <= hy (plate frame)
-      const float cc[2] = {ct.x, ct.y}, dd[2] = {at.x, at.y}, lim[2] = {hx, hy};
-#pragma unroll
-      for (int ax = 0; ax < 2; ++ax) {
-        if (ok) {
-          if (fabsf(dd[ax]) < 1e-9f) { if (fabsf(cc[ax]) > lim[ax]) ok = false; }
-          else {
-            float ta = (-lim[ax] - cc[ax]) / dd[ax], tb = (lim[ax] - cc[ax]) / dd[ax];
-            if (ta > tb) { const float t = ta; ta = tb; tb = t; }
-            s0 = ta > s0 ? ta : s0;
-            s1 = tb < s1 ? tb : s1;
-            if (s0 > s1) ok = false;
-          }
-        }
-      }
-    }
-    I6 Mo; Mo.A = m3_zero(); Mo.B = m3_zero(); Mo.C = m3_zero();
-    V3 rhs_a = v3(0, 0, 0), rhs_l = v3(0, 0, 0);
-    // plate sample of this lane
-    Law lp; lp.active = false; lp.fx = lp.fy = lp.fn = lp.cte = lp.Bn = 0.f;
-    V3 Pw_p = v3(0, 0, 0), rho_p = v3(0, 0, 0), F0_p = v3(0, 0, 0);
-    const V3 nw = col(R0, 2);  // plate normal in world
-    if (ok) {
-      const float nza = at.z;
-      const V3 up = v3(-nza * at.x, -nza * at.y, 1.f - nza * at.z);
-      const float un = norm(up);
-      const float inv = 1.f / (un > 1e-6f ? un : 1e-6f);
-      const float sk = s0 + (s1 - s0) * (float)leg / 3.f;
-      const V3 Pt = v3(ct.x + sk * at.x - rad * up.x * inv, ct.y + sk * at.y - rad * up.y * inv, ct.z + sk * at.z - rad * up.z * inv);
-      const float d = zp - Pt.z;
-      Pw_p = B.p + mul(R0, Pt);
-      rho_p = Pw_p - O.p;
-      const V3 vo = O.u + cross(O.w, rho_p);
-      const V3 vt = B.u + cross(B.w, Pw_p - B.p);
-      const V3 vrel = tmul(R0, vo - vt);
-      lp = contact_law(d, vrel, c.plate_kn / 4, c.plate_cn / 4, c.plate_ct / 4, mu_plate, c.contact_ramp, h);
-      if (lp.active) {
-        F0_p = mul(R0, v3(lp.fx, lp.fy, lp.fn));
-        add_contact_inertia(Mo, rho_p, nw, lp.cte, lp.Bn, h);
-        rhs_a += cross(rho_p, F0_p);
-        rhs_l += F0_p;
-      }
-    }
-    // ground rim point of this lane (lanes 0 and 1: the two axis ends)
-    Law lg; lg.active = false; lg.fx = lg.fy = lg.fn = lg.cte = lg.Bn = 0.f;
-    V3 rho_g = v3(0, 0, 0), F0_g = v3(0, 0, 0);
-    if (leg < 2) {
-      const float nza = ay.z;
-      const V3 up = v3(-nza * ay.x, -nza * ay.y, 1.f - nza * ay.z);
-      const float un = norm(up);
-      const float inv = 1.f / (un > 1e-6f ? un : 1e-6f);
-      const float sk = leg == 0 ? -half : half;
-      const V3 Pw = v3(O.p.x + sk * ay.x - rad * up.x * inv, O.p.y + sk * ay.y - rad * up.y * inv, O.p.z + sk * ay.z - rad * up.z * inv);
-      rho_g = Pw - O.p;
-      const V3 vo = O.u + cross(O.w, rho_g);
-      lg = contact_law(-Pw.z, vo, c.ground_kn, c.ground_cn, c.ground_ct, O.mu * c.ground_mu, c.contact_ramp, h);
-      if (lg.active) {
-        F0_g = v3(lg.fx, lg.fy, lg.fn);
-        add_contact_inertia(Mo, rho_g, v3(0, 0, 1), lg.cte, lg.Bn, h);
-        rhs_a += cross(rho_g, F0_g);
-        rhs_l += F0_g;
-      }
-    }
-    // assemble and solve (replicated in the quad): [I_w 0; 0 m] + sum_k h J^T B J
-    I6 M;
-    M.A = qsum_sym(Mo.A); M.B = qsum_full(Mo.B); M.C = qsum_sym(Mo.C);
-    rhs_a = qsum(rhs_a); rhs_l = qsum(rhs_l);
-    const float m = O.mass;
-    const float Iyy = 0.5f * m * rad * rad, Ixx = m * (3.f * rad * rad + O.len * O.len) / 12.f;
-    M3 Iw = m3_diag(Ixx);
-    Iw += outer((Iyy - Ixx) * ay, ay);
-    M.A += Iw;
-    M.C += m3_diag(m);
-    rhs_a -= cross(O.w, mul(Iw, O.w));
-    rhs_l.z -= m * g;
-    spd6_solve(M, rhs_a, rhs_l, obj_aa, obj_al);
-    // final contact forces of this lane's samples; reaction of the plate sample on the trunk (explicit)
-    if (lp.active) {
-      const V3 ap = obj_al + cross(obj_aa, rho_p);
-      const float an = dot(nw, ap);
-      // B_w ap = cte ap + (Bn - cte) (n.ap) n
-      const V3 F = F0_p - h * (lp.cte * ap + ((lp.Bn - lp.cte) * an) * nw);
-      rep.obj_part += F;
-      const V3 Fn = -F;
-      const V3 rb = tmul(R0, Pw_p - B.p), fb = tmul(R0, Fn);
-      pA0.a -= cross(rb, fb);
-      pA0.l -= fb;
-      rep.trunk_part += Fn;
-    }
-    if (lg.active) {
-      const V3 ap = obj_al + cross(obj_aa, rho_g);
-      rep.obj_part += v3(F0_g.x - h * lg.cte * ap.x, F0_g.y - h * lg.cte * ap.y, F0_g.z - h * lg.Bn * ap.z);
-    }
-  }
-
-  // ---- links of this leg: rigid-body terms + ground contacts ----
-  I6 IA[3];
-  S6 pA[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) link_init(LC[k], om[k], vl[k], Rw[k], g, IA[k], pA[k]);
-  const float mu_foot = G.mu * c.ground_mu, mu_body = c.ground_mu;
-  const V3 r_foot = v3(0.f, 0.f, -0.213f), r_calf = v3(0.f, 0.f, -0.1065f), r_knee = v3(0.f, 0.f, -0.213f);
-  const V3 r_hip = v3(0.f, k_hip_cyl_y[leg], 0.f);
-  const RC c_foot = ground_contact(c, h, r_foot, LT_FOOT_RADIUS, mu_foot, Rw[2], pw[2], om[2], vl[2], IA[2], pA[2]);
-  const RC c_calf = ground_contact(c, h, r_calf, 0.012f, mu_body, Rw[2], pw[2], om[2], vl[2], IA[2], pA[2]);
-  const RC c_knee = ground_contact(c, h, r_knee, 0.022f, mu_body, Rw[1], pw[1], om[1], vl[1], IA[1], pA[1]);
-  const RC c_hip = ground_contact(c, h, r_hip, LT_HIP_CYL_RADIUS, mu_body, Rw[0], pw[0], om[0], vl[0], IA[0], pA[0]);
-  const V3 r_tlo = trunk_corner(leg, false), r_thi = trunk_corner(leg, true);
-  const RC c_tlo = ground_contact(c, h, r_tlo, 0.f, mu_body, R0, B.p, wb, vb, IA0, pA0);
-  const RC c_thi = ground_contact(c, h, r_thi, 0.f, mu_body, R0, B.p, wb, vb, IA0, pA0);
-
-  // ---- ABA backward pass: calf -> thigh -> hip -> trunk share ----
-  S6 U[3];
-  float D[3], u[3];
-  link_backward<1>(IA[2], pA[2], G.tau[2], ca[2], cl[2], cq[2], sq[2], LC[2].r, U[2], D[2], u[2], IA[1], pA[1]);
-  link_backward<1>(IA[1], pA[1], G.tau[1], ca[1], cl[1], cq[1], sq[1], LC[1].r, U[1], D[1], u[1], IA[0], pA[0]);
-  link_backward<0>(IA[0], pA[0], G.tau[0], ca[0], cl[0], cq[0], sq[0], LC[0].r, U[0], D[0], u[0], IA0, pA0);
-
-  // ---- floating base: quad-sum the four shares, add the trunk's own rigid-body terms, solve 6x6 ----
-  I6 M;
-  M.A = qsum_sym(IA0.A); M.B = qsum_full(IA0.B); M.C = qsum_sym(IA0.C);
-  V3 p0a = qsum(pA0.a), p0l = qsum(pA0.l);
-  {
-    const float mt = LT_TRUNK_MASS + X.trunk_mass_add;
-    LinkC T;
-    T.m = mt;
-    const V3 ctr = v3(k_trunk_com[0], k_trunk_com[1], k_trunk_com[2]);
-    T.mc = mt * ctr;
-    T.Io = inertia_about_origin(mt, ctr, k_trunk_icom, mt / LT_TRUNK_MASS);
-    I6 I0;
-    S6 pT;
-    link_init(T, wb, vb, R0, g, I0, pT);
-    M.A += I0.A; M.B += I0.B; M.C += I0.C;
-    p0a += pT.a; p0l += pT.l;
-  }
-  V3 a0a, a0l;
-  spd6_solve(M, -p0a, -p0l, a0a, a0l);
-
-  // ---- forward pass + final contact forces ----
-  V3 aa[3], al[3];
-  float qdd[3];
-  link_forward<0>(a0a, a0l, cq[0], sq[0], LC[0].r, ca[0], cl[0], U[0], D[0], u[0], aa[0], al[0], qdd[0]);
-  link_forward<1>(aa[0], al[0], cq[1], sq[1], LC[1].r, ca[1], cl[1], U[1], D[1], u[1], aa[1], al[1], qdd[1]);
-  link_forward<1>(aa[1], al[1], cq[2], sq[2], LC[2].r, ca[2], cl[2], U[2], D[2], u[2], aa[2], al[2], qdd[2]);
-  rep.body[3] = ground_force(c_foot, h, r_foot, LT_FOOT_RADIUS, Rw[2], aa[2], al[2]);
-  rep.body[2] = ground_force(c_calf, h, r_calf, 0.012f, Rw[2], aa[2], al[2]);
-  rep.body[1] = ground_force(c_knee, h, r_knee, 0.022f, Rw[1], aa[1], al[1]);
-  rep.body[0] = ground_force(c_hip, h, r_hip, LT_HIP_CYL_RADIUS, Rw[0], aa[0], al[0]);
-  rep.trunk_part += ground_force(c_tlo, h, r_tlo, 0.f, R0, a0a, a0l);
-  rep.trunk_part += ground_force(c_thi, h, r_thi, 0.f, R0, a0a, a0l);
-
-  // ---- semi-implicit Euler ----
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float qd = G.qd[k] + h * qdd[k];
-    float q = G.q[k] + h * qd;
-    if (q < k_joint_lo[k]) { q = k_joint_lo[k]; if (qd < 0.f) qd = 0.f; }
-    if (q > k_joint_hi[k]) { q = k_joint_hi[k]; if (qd > 0.f) qd = 0.f; }
-    G.q[k] = q; G.qd[k] = qd;
-  }
-  {
-    const V3 acl = a0l + cross(wb, vb);  // classical acceleration of the base origin (body coords)
-    B.u += h * mul(R0, acl);
-    B.w += h * mul(R0, a0a);
-    B.p += h * B.u;
-    B.q = q_integrate(B.q, B.w, h);
-  }
-  if (HAS_OBJ) {
-    O.w += h * obj_aa;
-    O.u += h * obj_al;
-    O.p += h * O.u;
-    O.q = q_integrate(O.q, O.w, h);
-  }
-}
+#include "lt_physics_crba.h"
 
 // foot centre position / velocity (world) of this lane's leg for the current state
-__device__ __forceinline__ void foot_kinematics(const LinkC (&LC)[3], const Base& B, Leg& G) {
+__device__ __forceinline__ void foot_kinematics(const float (&sgn)[4], const Base& B, Leg& G) {
+  const LinkC LC[3] = {make_link<0>(sgn), make_link<1>(sgn), make_link<2>(sgn)};
   const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
   V3 om[3], vl[3], pw[3], ca, cl;
   M3 Rw[3];
@@ -743,24 +502,15 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
   __shared__ float s_frame[2][16][64];
   __shared__ int s_fill[16];
 
-  // ---- model constants of this lane's leg ----
-  LinkC LC[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    LC[k].m = k_link_mass[leg][k];
-    const V3 com = v3(k_link_com[leg][k][0], k_link_com[leg][k][1], k_link_com[leg][k][2]);
-    LC[k].mc = LC[k].m * com;
-    float ic[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) ic[i] = k_link_icom[leg][k][i];
-    LC[k].Io = inertia_about_origin(LC[k].m, com, ic, 1.f);
-    LC[k].r = v3(k_joint_off[leg][k][0], k_joint_off[leg][k][1], k_joint_off[leg][k][2]);
-  }
+  // ---- sign pattern of this lane's leg (mirror form of the model constants) ----
+  const float sx = leg < 2 ? 1.f : -1.f, sy = (leg & 1) ? 1.f : -1.f;
+  const float sgn[4] = {1.f, sx, sy, sx * sy};
   float qdef[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) qdef[k] = k_joint_default[leg][k];
+  for (int k = 0; k < 3; ++k) qdef[k] = k_m_dq[k] * sgn[k_m_dq_pat[k]];
 
-  // ---- load state (one coalesced 256-B access per quad array) ----
+  // ---- load the state the physics needs (one coalesced 256-B access per quad array); everything else is loaded
+  //      after the decimation loop so that it does not occupy registers (or scratch) during the physics ----
   Base B; Obj O; Leg G; Misc X;
   {
     float t;
@@ -776,16 +526,11 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
     t = *F(LT_F_OBJ_PARAMS, 0); O.rad = qbcast<0>(t); O.len = qbcast<1>(t); O.mass = qbcast<2>(t); O.mu = qbcast<3>(t);
     t = *F(LT_F_ENV_PARAMS, 0); X.trunk_mass_add = qbcast<0>(t); X.trunk_mu = qbcast<1>(t); X.trunk_rest = qbcast<2>(t); X.obj_rest = qbcast<3>(t);
     t = *F(LT_F_TRUNK_FORCE_HIST, 0); X.trunk_fh[0] = qbcast<0>(t); X.trunk_fh[1] = qbcast<1>(t); X.trunk_fh[2] = qbcast<2>(t);
-    t = *F(LT_F_CMD, 0); X.cmd = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.cmd_time_left = qbcast<3>(t);
-    t = *F(LT_F_CMD_BUF, 0); X.cmd_buf = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.cmd_standing = qbcast<3>(t);
-    t = *F(LT_F_EVENT_TIMERS, 0); X.push_robot_left = qbcast<0>(t); X.push_obj_left = qbcast<1>(t);
-    t = *F(LT_F_GAIT_CMD, 0); X.gait_cmd = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.gait_step = qbcast<3>(t);
-    X.ep_len = ((const long long*)(arena + L.off_ep_len))[env];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       G.q[k] = *F(LT_F_JOINT_POS, k); G.qd[k] = *F(LT_F_JOINT_VEL, k);
-      G.qdd[k] = *F(LT_F_JOINT_ACC, k); G.tau[k] = *F(LT_F_APPLIED_TORQUE, k);
-      G.raw[k] = *F(LT_F_ACT_RAW, k); G.prev[k] = *F(LT_F_ACT_PREV_RAW, k); G.prev2[k] = *F(LT_F_ACT_PREV_PREV_RAW, k);
+      G.raw[k] = *F(LT_F_ACT_RAW, k);
+      G.qdd[k] = 0.f; G.tau[k] = 0.f; G.prev[k] = 0.f; G.prev2[k] = 0.f;
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -794,11 +539,6 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
     G.cur_air = *F(LT_F_FOOT_CUR_AIR, 0); G.cur_con = *F(LT_F_FOOT_CUR_CONTACT, 0);
     G.last_air = *F(LT_F_FOOT_LAST_AIR, 0); G.last_con = *F(LT_F_FOOT_LAST_CONTACT, 0);
     G.mu = *F(LT_F_FOOT_FRICTION, 0);
-    G.foot_p = v3(*F(LT_F_FOOT_POS_W, 0), *F(LT_F_FOOT_POS_W, 1), *F(LT_F_FOOT_POS_W, 2));
-    G.foot_v = v3(*F(LT_F_FOOT_VEL_W, 0), *F(LT_F_FOOT_VEL_W, 1), *F(LT_F_FOOT_VEL_W, 2));
-    G.g_last_air = *F(LT_F_GAIT_LAST_AIR, 0); G.g_last_con = *F(LT_F_GAIT_LAST_CONTACT, 0);
-    G.g_valid = *F(LT_F_GAIT_VALID_LAST_AIR, 0);
-    G.g_flags = *(const int*)F(LT_F_GAIT_FLAGS, 0);
   }
 
   // ---- startup events (reset-all only): reference locomotion_base_env_cfg.py:224-244, rand_cylinder_...:21-27 ----
@@ -822,8 +562,7 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
     // 1. JointPositionActionPrevPrev.process_actions (reference mdp/actions.py:30-44); action index = type*4 + leg
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      G.prev2[k] = G.prev[k];
-      G.prev[k] = G.raw[k];
+      G.prev[k] = G.raw[k];  // prev_prev <- prev happens with the late loads below
       float x = env < L.n ? a.actions[env * 12 + k * 4 + leg] : 0.f;  // padded tail envs read no action
       x = x < -c.action_clip ? -c.action_clip : (x > c.action_clip ? c.action_clip : x);
       G.raw[k] = x * c.action_scale;
@@ -838,7 +577,7 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
         G.tau[k] = dc_motor(c, qdef[k] + G.raw[k], G.q[k], G.qd[k]);
       }
       Report rep;
-      for (int s = 0; s < c.phys_substeps; ++s) physics_substep<HAS_OBJ>(c, h, leg, LC, B, G, O, X, rep);
+      for (int s = 0; s < c.phys_substeps; ++s) physics_substep<HAS_OBJ>(c, h, leg, sgn, B, G, O, X, rep);
 #pragma unroll
       for (int k = 0; k < 3; ++k) G.qdd[k] = (G.qd[k] - qd0[k]) / c.sim_dt;  // Articulation.data.joint_acc [DEP]
       // K3 sensors: |F| history (newest first) + timers, at the sensor period = sim dt (locomotion_base_env_cfg.py:358-359)
@@ -853,8 +592,35 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
       X.trunk_fh[0] = norm(qsum(rep.trunk_part));
       if (HAS_OBJ) timers_update(O.cur_air, O.cur_con, O.last_air, O.last_con, norm(qsum(rep.obj_part)) > c.contact_force_threshold, c.sim_dt);
     }
-    foot_kinematics(LC, B, G);
-    X.ep_len += 1;  // 3.
+    foot_kinematics(sgn, B, G);
+  }
+  // ---- late loads: state the physics never touches (compiler barrier: keep these below the decimation loop) ----
+  asm volatile("" ::: "memory");
+  {
+    float t;
+    t = *F(LT_F_CMD, 0); X.cmd = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.cmd_time_left = qbcast<3>(t);
+    t = *F(LT_F_CMD_BUF, 0); X.cmd_buf = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.cmd_standing = qbcast<3>(t);
+    t = *F(LT_F_EVENT_TIMERS, 0); X.push_robot_left = qbcast<0>(t); X.push_obj_left = qbcast<1>(t);
+    t = *F(LT_F_GAIT_CMD, 0); X.gait_cmd = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.gait_step = qbcast<3>(t);
+    X.ep_len = ((const long long*)(arena + L.off_ep_len))[env];
+    G.g_last_air = *F(LT_F_GAIT_LAST_AIR, 0); G.g_last_con = *F(LT_F_GAIT_LAST_CONTACT, 0);
+    G.g_valid = *F(LT_F_GAIT_VALID_LAST_AIR, 0);
+    G.g_flags = *(const int*)F(LT_F_GAIT_FLAGS, 0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (MODE == MODE_STEP) {
+        G.prev2[k] = *F(LT_F_ACT_PREV_RAW, k);  // old prev becomes prev_prev (mdp/actions.py:32-33)
+      } else {
+        G.prev[k] = *F(LT_F_ACT_PREV_RAW, k); G.prev2[k] = *F(LT_F_ACT_PREV_PREV_RAW, k);
+        G.qdd[k] = *F(LT_F_JOINT_ACC, k); G.tau[k] = *F(LT_F_APPLIED_TORQUE, k);
+      }
+    }
+    if (MODE != MODE_STEP) {
+      G.foot_p = v3(*F(LT_F_FOOT_POS_W, 0), *F(LT_F_FOOT_POS_W, 1), *F(LT_F_FOOT_POS_W, 2));
+      G.foot_v = v3(*F(LT_F_FOOT_VEL_W, 0), *F(LT_F_FOOT_VEL_W, 1), *F(LT_F_FOOT_VEL_W, 2));
+    } else {
+      X.ep_len += 1;  // 3.
+    }
   }
 
   // =================================================================================================
@@ -1100,7 +866,7 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
     X.push_robot_left = lerp2(c.push_robot_interval, u.a);
     X.push_obj_left = lerp2(c.push_obj_interval, u.b);
     X.ep_len = 0;
-    foot_kinematics(LC, B, G);
+    foot_kinematics(sgn, B, G);
     if (MODE == MODE_RESET_ALL && c.cmd_multi_sampling && 0 < (int)P[15]) X.cmd = v3(0, 0, 0);                 // commands.py:559
   }
   if (MODE == MODE_STEP) {

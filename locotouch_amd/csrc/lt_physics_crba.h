@@ -1,0 +1,462 @@
+// Forward dynamics of one env (floating base + 4 x 3-link legs + carried cylinder) for lt_env.hip.
+//
+// Formulation (kernel side; the oracle uses a generic ABA - the two must agree to fp32 tolerance):
+//   (M + h Jc^T B Jc) a = tau - C + Jc^T F0'      with a = (base spatial accel, 12 joint accels)
+// * C by RNEA with zero accelerations (velocity products, gravity as explicit link wrenches, explicit contact parts),
+// * M by CRBA on rigid 10-parameter composites (mass, first moment, rotational inertia about the frame origin),
+// * the implicit penalty contacts (DESIGN.md "Physics model") enter through the contact Jacobian columns,
+// * per-leg Schur complement: each lane eliminates its 3 joints (3x3 Cholesky), the 4 lanes of the quad butterfly-sum
+//   their 6x6 base shares, every lane solves the same 6x6 and back-substitutes its own joints.
+// Lane = leg.  Everything lives in registers; no LDS, no barriers.
+#pragma once
+
+__device__ __forceinline__ V3 mul(const S3& s, V3 v) {
+  return v3(s.xx * v.x + s.xy * v.y + s.xz * v.z, s.xy * v.x + s.yy * v.y + s.yz * v.z, s.xz * v.x + s.yz * v.y + s.zz * v.z);
+}
+__device__ __forceinline__ S3 s3_from(const M3& a) { S3 s; s.xx = a.m[0]; s.xy = a.m[1]; s.xz = a.m[2]; s.yy = a.m[4]; s.yz = a.m[5]; s.zz = a.m[8]; return s; }
+template <int AX>
+__device__ __forceinline__ V3 s3_col(const S3& s) { return AX == 0 ? v3(s.xx, s.xy, s.xz) : (AX == 1 ? v3(s.xy, s.yy, s.yz) : v3(s.xz, s.yz, s.zz)); }
+// R S R^T for R = rot(AX, q)
+template <int AX>
+__device__ __forceinline__ S3 rot_sym(float c, float s, const S3& a) {
+  S3 o;
+  const float cc = c * c, ss = s * s, cs = c * s;
+  if (AX == 0) {
+    o.xx = a.xx; o.xy = c * a.xy - s * a.xz; o.xz = s * a.xy + c * a.xz;
+    o.yy = cc * a.yy - 2.f * cs * a.yz + ss * a.zz;
+    o.zz = ss * a.yy + 2.f * cs * a.yz + cc * a.zz;
+    o.yz = cs * (a.yy - a.zz) + (cc - ss) * a.yz;
+  } else {
+    o.yy = a.yy; o.xy = c * a.xy + s * a.yz; o.yz = -s * a.xy + c * a.yz;
+    o.xx = cc * a.xx + 2.f * cs * a.xz + ss * a.zz;
+    o.zz = ss * a.xx - 2.f * cs * a.xz + cc * a.zz;
+    o.xz = cs * (a.zz - a.xx) + (cc - ss) * a.xz;
+  }
+  return o;
+}
+
+struct Rigid { float m; V3 mc; S3 Io; };  // rigid (or composite) inertia about the frame origin
+struct F6 { V3 n, f; };                   // spatial force: moment about the frame origin, force
+
+// composite inertia of a child subtree re-expressed in the parent frame (child origin at r, child->parent rotation R)
+template <int AX>
+__device__ __forceinline__ Rigid rigid_to_parent(const Rigid& ch, float c, float s, V3 r) {
+  Rigid o;
+  o.m = ch.m;
+  const V3 cp = rot_fwd<AX>(c, s, ch.mc);  // first moment in parent axes, still about the child origin
+  o.mc = cp + ch.m * r;
+  S3 I = rot_sym<AX>(c, s, ch.Io);
+  const float rr = dot(r, r), rc2 = 2.f * dot(r, cp);
+  // + m(|r|^2 1 - r r^T) + 2 (r.c') 1 - r c'^T - c' r^T
+  I.xx += ch.m * (rr - r.x * r.x) + rc2 - 2.f * r.x * cp.x;
+  I.yy += ch.m * (rr - r.y * r.y) + rc2 - 2.f * r.y * cp.y;
+  I.zz += ch.m * (rr - r.z * r.z) + rc2 - 2.f * r.z * cp.z;
+  I.xy += -ch.m * r.x * r.y - r.x * cp.y - cp.x * r.y;
+  I.xz += -ch.m * r.x * r.z - r.x * cp.z - cp.x * r.z;
+  I.yz += -ch.m * r.y * r.z - r.y * cp.z - cp.y * r.z;
+  o.Io = I;
+  return o;
+}
+__device__ __forceinline__ Rigid rigid_add(const Rigid& a, const Rigid& b) {
+  Rigid o;
+  o.m = a.m + b.m; o.mc = a.mc + b.mc;
+  o.Io.xx = a.Io.xx + b.Io.xx; o.Io.xy = a.Io.xy + b.Io.xy; o.Io.xz = a.Io.xz + b.Io.xz;
+  o.Io.yy = a.Io.yy + b.Io.yy; o.Io.yz = a.Io.yz + b.Io.yz; o.Io.zz = a.Io.zz + b.Io.zz;
+  return o;
+}
+template <int AX>
+__device__ __forceinline__ F6 force_to_parent(const F6& x, float c, float s, V3 r) {
+  F6 o;
+  o.f = rot_fwd<AX>(c, s, x.f);
+  o.n = rot_fwd<AX>(c, s, x.n) + cross(r, o.f);
+  return o;
+}
+// column AX of a rigid 6x6: I [e;0] = (Io e, e x mc)
+template <int AX>
+__device__ __forceinline__ F6 rigid_col(const Rigid& R) {
+  F6 o;
+  o.n = s3_col<AX>(R.Io);
+  o.f = cross(axis_scaled<AX>(1.f), R.mc);
+  return o;
+}
+// rigid-body wrench for spatial velocity (om, vl) and acceleration (aa, al): I a + v x* I v - gravity
+__device__ __forceinline__ F6 rigid_bias(const Rigid& R, V3 om, V3 vl, V3 aa, V3 al, V3 gb) {
+  const V3 n = mul(R.Io, om) + cross(R.mc, vl);
+  const V3 f = cross(om, R.mc) + R.m * vl;
+  F6 o;
+  o.n = mul(R.Io, aa) + cross(R.mc, al) + cross(om, n) + cross(vl, f) - cross(R.mc, gb);
+  o.f = cross(aa, R.mc) + R.m * al + cross(om, f) - R.m * gb;
+  return o;
+}
+
+struct LegSys {        // this lane's 3 joints: H (sym 3x3), coupling to the base (3 x 6), right-hand side
+  float h00, h01, h02, h11, h12, h22;
+  V3 bn[3], bl[3];     // row j of H_lb: (moment part, force part), base body coords
+  float rhs[3];
+};
+
+// ground contact of a sphere on link K (0 hip, 1 thigh, 2 calf) of this leg.
+//   (aa, al) = velocity-product spatial acceleration of the link (zero joint / base accelerations)
+template <int K>
+__device__ __forceinline__ RC leg_contact(const lt_cfg& c, float h, V3 r, float rho, float mu, const M3& Rw, V3 pwk, V3 om, V3 vl,
+                                          V3 aa, V3 al, const M3& R0, V3 p0, const V3 (&axw)[3], const V3 (&pw)[3],
+                                          F6& fk, LegSys& S, I6& Mbb) {
+  RC out;
+  out.law.active = false; out.law.fx = out.law.fy = out.law.fn = out.law.cte = out.law.Bn = 0.f;
+  out.f0w = v3(0, 0, 0);
+  const V3 zb = row(Rw, 2);
+  const V3 rc = r - rho * zb;
+  const float pz = pwk.z + dot(zb, rc);  // world height of the contact point
+  if (!(pz < 0.f)) return out;          // above the ground: nothing else to compute
+  const V3 Pc = pwk + mul(Rw, rc);
+  const V3 vw = mul(Rw, vl + cross(om, rc));
+  out.law = contact_law(-Pc.z, vw, c.ground_kn, c.ground_cn, c.ground_ct, mu, c.contact_ramp, h);
+  out.f0w = v3(out.law.fx, out.law.fy, out.law.fn);
+  if (!out.law.active) return out;
+  const float hct = h * out.law.cte, hbn = h * out.law.Bn;
+  // explicit part with the velocity-product acceleration of the point folded in
+  const V3 avp = mul(Rw, al + cross(aa, rc));
+  const V3 F0 = v3(out.f0w.x - hct * avp.x, out.f0w.y - hct * avp.y, out.f0w.z - hbn * avp.z);
+  const V3 f0b = tmul(Rw, F0);
+  fk.n -= cross(rc, f0b);
+  fk.f -= f0b;
+  // implicit part through the Jacobian columns (world frame; the ground contact frame is world-aligned => B diagonal)
+  const V3 rho_b = tmul(R0, Pc - p0);
+  V3 g[3];
+#pragma unroll
+  for (int j = 0; j <= K; ++j) {
+    const V3 w = cross(axw[j], Pc - pw[j]);
+    g[j] = v3(hct * w.x, hct * w.y, hbn * w.z);
+    const V3 gb = tmul(R0, g[j]);
+    S.bn[j] += cross(rho_b, gb);
+    S.bl[j] += gb;
+  }
+  {
+    const V3 w0 = cross(axw[0], Pc - pw[0]);
+    S.h00 += dot(w0, g[0]);
+    if (K >= 1) {
+      const V3 w1 = cross(axw[1], Pc - pw[1]);
+      S.h01 += dot(w0, g[1]);
+      S.h11 += dot(w1, g[1]);
+      if (K >= 2) {
+        const V3 w2 = cross(axw[2], Pc - pw[2]);
+        S.h02 += dot(w0, g[2]);
+        S.h12 += dot(w1, g[2]);
+        S.h22 += dot(w2, g[2]);
+      }
+    }
+  }
+  add_contact_inertia(Mbb, rho_b, row(R0, 2), out.law.cte, out.law.Bn, h);
+  return out;
+}
+
+// =====================================================================================================
+// K2 physics: one integrator substep of length h (torques held).  Reference: PhysX (closed source) - this is the
+// engine's own model; executable spec: oracle/lt_oracle.c physics_substep; description: DESIGN.md "Physics model".
+// =====================================================================================================
+template <bool HAS_OBJ>
+__device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int leg, const float (&sgn)[4], Base& B, Leg& G, Obj& O,
+                                                const Misc& X, Report& rep) {
+  const float g = c.gravity;
+  const LinkC LC[3] = {make_link<0>(sgn), make_link<1>(sgn), make_link<2>(sgn)};
+  float cq[3], sq[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) sincosf(G.q[k], &sq[k], &cq[k]);
+  const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
+  const V3 wb = tmul(R0, B.w), vb = tmul(R0, B.u);
+  V3 om[3], vl[3], pw[3], ca[3], cl[3];
+  M3 Rw[3];
+  joint_fk<0>(wb, vb, R0, B.p, LC[0].r, cq[0], sq[0], G.qd[0], om[0], vl[0], Rw[0], pw[0], ca[0], cl[0]);
+  joint_fk<1>(om[0], vl[0], Rw[0], pw[0], LC[1].r, cq[1], sq[1], G.qd[1], om[1], vl[1], Rw[1], pw[1], ca[1], cl[1]);
+  joint_fk<1>(om[1], vl[1], Rw[1], pw[1], LC[2].r, cq[2], sq[2], G.qd[2], om[2], vl[2], Rw[2], pw[2], ca[2], cl[2]);
+  // velocity-product spatial accelerations (base and joint accelerations zero)
+  V3 aa[3], al[3];
+  aa[0] = ca[0]; al[0] = cl[0];
+  aa[1] = rot_inv<1>(cq[1], sq[1], aa[0]) + ca[1];
+  al[1] = rot_inv<1>(cq[1], sq[1], al[0] + cross(aa[0], LC[1].r)) + cl[1];
+  aa[2] = rot_inv<1>(cq[2], sq[2], aa[1]) + ca[2];
+  al[2] = rot_inv<1>(cq[2], sq[2], al[1] + cross(aa[1], LC[2].r)) + cl[2];
+  const V3 axw[3] = {col(Rw[0], 0), col(Rw[1], 1), col(Rw[2], 1)};  // joint axes in world
+
+  // this lane's share of the base block / base bias wrench
+  I6 Mbb; Mbb.A = m3_zero(); Mbb.B = m3_zero(); Mbb.C = m3_zero();
+  F6 pb; pb.n = v3(0, 0, 0); pb.f = v3(0, 0, 0);
+  rep.trunk_part = v3(0, 0, 0);
+  rep.obj_part = v3(0, 0, 0);
+
+  // ---- carried cylinder: free body, implicit contacts with the plate (sample = lane) and the ground ----
+  V3 obj_aa = v3(0, 0, 0), obj_al = v3(0, 0, 0);
+  if (HAS_OBJ) {
+    const M3 Ro = quat_to_mat(O.q.w, O.q.x, O.q.y, O.q.z);
+    const V3 ay = col(Ro, 1);
+    const float rad = O.rad, half = 0.5f * O.len;
+    const float mu_plate = 0.5f * (X.trunk_mu + O.mu);
+    const V3 ct = tmul(R0, O.p - B.p), at = tmul(R0, ay);
+    const float hx = LT_BACK_HALF_X, hy = LT_RAIL_Y + LT_RAIL_RADIUS, zp = LT_BACK_TOP_Z;
+    float s0 = -half, s1 = half;
+    bool ok = true;
+    {
+      const float cc[2] = {ct.x, ct.y}, dd[2] = {at.x, at.y}, lim[2] = {hx, hy};
+#pragma unroll
+      for (int ax = 0; ax < 2; ++ax) {
+        if (ok) {
+          if (fabsf(dd[ax]) < 1e-9f) { if (fabsf(cc[ax]) > lim[ax]) ok = false; }
+          else {
+            float ta = (-lim[ax] - cc[ax]) / dd[ax], tb = (lim[ax] - cc[ax]) / dd[ax];
+            if (ta > tb) { const float t = ta; ta = tb; tb = t; }
+            s0 = ta > s0 ? ta : s0;
+            s1 = tb < s1 ? tb : s1;
+            if (s0 > s1) ok = false;
+          }
+        }
+      }
+    }
+    I6 Mo; Mo.A = m3_zero(); Mo.B = m3_zero(); Mo.C = m3_zero();
+    V3 rhs_a = v3(0, 0, 0), rhs_l = v3(0, 0, 0);
+    Law lp; lp.active = false; lp.fx = lp.fy = lp.fn = lp.cte = lp.Bn = 0.f;
+    V3 Pw_p = v3(0, 0, 0), rho_p = v3(0, 0, 0), F0_p = v3(0, 0, 0);
+    const V3 nw = col(R0, 2);
+    if (ok) {
+      const float nza = at.z;
+      const V3 up = v3(-nza * at.x, -nza * at.y, 1.f - nza * at.z);
+      const float un = norm(up);
+      const float inv = 1.f / (un > 1e-6f ? un : 1e-6f);
+      const float sk = s0 + (s1 - s0) * (float)leg / 3.f;
+      const V3 Pt = v3(ct.x + sk * at.x - rad * up.x * inv, ct.y + sk * at.y - rad * up.y * inv, ct.z + sk * at.z - rad * up.z * inv);
+      const float d = zp - Pt.z;
+      if (d > 0.f) {
+        Pw_p = B.p + mul(R0, Pt);
+        rho_p = Pw_p - O.p;
+        const V3 vo = O.u + cross(O.w, rho_p);
+        const V3 vt = B.u + cross(B.w, Pw_p - B.p);
+        const V3 vrel = tmul(R0, vo - vt);
+        lp = contact_law(d, vrel, c.plate_kn / 4, c.plate_cn / 4, c.plate_ct / 4, mu_plate, c.contact_ramp, h);
+        if (lp.active) {
+          F0_p = mul(R0, v3(lp.fx, lp.fy, lp.fn));
+          add_contact_inertia(Mo, rho_p, nw, lp.cte, lp.Bn, h);
+          rhs_a += cross(rho_p, F0_p);
+          rhs_l += F0_p;
+        }
+      }
+    }
+    Law lg; lg.active = false; lg.fx = lg.fy = lg.fn = lg.cte = lg.Bn = 0.f;
+    V3 rho_g = v3(0, 0, 0), F0_g = v3(0, 0, 0);
+    if (leg < 2) {
+      const float nza = ay.z;
+      const V3 up = v3(-nza * ay.x, -nza * ay.y, 1.f - nza * ay.z);
+      const float un = norm(up);
+      const float inv = 1.f / (un > 1e-6f ? un : 1e-6f);
+      const float sk = leg == 0 ? -half : half;
+      const V3 Pw = v3(O.p.x + sk * ay.x - rad * up.x * inv, O.p.y + sk * ay.y - rad * up.y * inv, O.p.z + sk * ay.z - rad * up.z * inv);
+      if (Pw.z < 0.f) {
+        rho_g = Pw - O.p;
+        const V3 vo = O.u + cross(O.w, rho_g);
+        lg = contact_law(-Pw.z, vo, c.ground_kn, c.ground_cn, c.ground_ct, O.mu * c.ground_mu, c.contact_ramp, h);
+        if (lg.active) {
+          F0_g = v3(lg.fx, lg.fy, lg.fn);
+          add_contact_inertia(Mo, rho_g, v3(0, 0, 1), lg.cte, lg.Bn, h);
+          rhs_a += cross(rho_g, F0_g);
+          rhs_l += F0_g;
+        }
+      }
+    }
+    I6 M;
+    M.A = qsum_sym(Mo.A); M.B = qsum_full(Mo.B); M.C = qsum_sym(Mo.C);
+    rhs_a = qsum(rhs_a); rhs_l = qsum(rhs_l);
+    const float m = O.mass;
+    const float Iyy = 0.5f * m * rad * rad, Ixx = m * (3.f * rad * rad + O.len * O.len) / 12.f;
+    M3 Iw = m3_diag(Ixx);
+    Iw += outer((Iyy - Ixx) * ay, ay);
+    M.A += Iw;
+    M.C += m3_diag(m);
+    rhs_a -= cross(O.w, mul(Iw, O.w));
+    rhs_l.z -= m * g;
+    spd6_solve(M, rhs_a, rhs_l, obj_aa, obj_al);
+    if (lp.active) {
+      const V3 ap = obj_al + cross(obj_aa, rho_p);
+      const float an = dot(nw, ap);
+      const V3 F = F0_p - h * (lp.cte * ap + ((lp.Bn - lp.cte) * an) * nw);
+      rep.obj_part += F;
+      const V3 Fn = -F;
+      const V3 rb = tmul(R0, Pw_p - B.p), fb = tmul(R0, Fn);
+      pb.n -= cross(rb, fb);
+      pb.f -= fb;
+      rep.trunk_part += Fn;
+    }
+    if (lg.active) {
+      const V3 ap = obj_al + cross(obj_aa, rho_g);
+      rep.obj_part += v3(F0_g.x - h * lg.cte * ap.x, F0_g.y - h * lg.cte * ap.y, F0_g.z - h * lg.Bn * ap.z);
+    }
+  }
+
+  // ---- RNEA forces of this leg's links (zero accelerations) + contacts ----
+  Rigid RB[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { RB[k].m = LC[k].m; RB[k].mc = LC[k].mc; RB[k].Io = LC[k].Io; }
+  F6 f[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) f[k] = rigid_bias(RB[k], om[k], vl[k], aa[k], al[k], (-g) * row(Rw[k], 2));
+  LegSys S;
+  S.h00 = S.h01 = S.h02 = S.h11 = S.h12 = S.h22 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { S.bn[j] = v3(0, 0, 0); S.bl[j] = v3(0, 0, 0); }
+  const float mu_foot = G.mu * c.ground_mu, mu_body = c.ground_mu;
+  const V3 r_foot = v3(0.f, 0.f, -0.213f), r_calf = v3(0.f, 0.f, -0.1065f), r_knee = v3(0.f, 0.f, -0.213f);
+  const V3 r_hip = v3(0.f, LT_MIRROR_HIP_CYL_Y * sgn[LT_MIRROR_HIP_CYL_Y_PAT], 0.f);
+  const RC c_foot = leg_contact<2>(c, h, r_foot, LT_FOOT_RADIUS, mu_foot, Rw[2], pw[2], om[2], vl[2], aa[2], al[2], R0, B.p, axw, pw, f[2], S, Mbb);
+  const RC c_calf = leg_contact<2>(c, h, r_calf, 0.012f, mu_body, Rw[2], pw[2], om[2], vl[2], aa[2], al[2], R0, B.p, axw, pw, f[2], S, Mbb);
+  const RC c_knee = leg_contact<1>(c, h, r_knee, 0.022f, mu_body, Rw[1], pw[1], om[1], vl[1], aa[1], al[1], R0, B.p, axw, pw, f[1], S, Mbb);
+  const RC c_hip = leg_contact<0>(c, h, r_hip, LT_HIP_CYL_RADIUS, mu_body, Rw[0], pw[0], om[0], vl[0], aa[0], al[0], R0, B.p, axw, pw, f[0], S, Mbb);
+  // trunk corners of this lane (base accelerations are the unknowns: no velocity-product part)
+  const V3 r_tlo = trunk_corner(leg, false), r_thi = trunk_corner(leg, true);
+  RC c_tlo, c_thi;
+  {
+    I6 dummyI = Mbb;
+    S6 pA; pA.a = pb.n; pA.l = pb.f;
+    c_tlo = ground_contact(c, h, r_tlo, 0.f, mu_body, R0, B.p, wb, vb, dummyI, pA);
+    c_thi = ground_contact(c, h, r_thi, 0.f, mu_body, R0, B.p, wb, vb, dummyI, pA);
+    Mbb = dummyI; pb.n = pA.a; pb.f = pA.l;
+  }
+  // backward force pass
+  {
+    const F6 t2 = force_to_parent<1>(f[2], cq[2], sq[2], LC[2].r);
+    f[1].n += t2.n; f[1].f += t2.f;
+    const F6 t1 = force_to_parent<1>(f[1], cq[1], sq[1], LC[1].r);
+    f[0].n += t1.n; f[0].f += t1.f;
+    const F6 t0 = force_to_parent<0>(f[0], cq[0], sq[0], LC[0].r);
+    pb.n += t0.n; pb.f += t0.f;
+  }
+  S.rhs[0] = G.tau[0] - f[0].n.x;
+  S.rhs[1] = G.tau[1] - f[1].n.y;
+  S.rhs[2] = G.tau[2] - f[2].n.y;
+
+  // ---- CRBA on rigid composites ----
+  {
+    const Rigid C3 = RB[2];
+    const Rigid C2 = rigid_add(RB[1], rigid_to_parent<1>(C3, cq[2], sq[2], LC[2].r));
+    const Rigid C1 = rigid_add(RB[0], rigid_to_parent<1>(C2, cq[1], sq[1], LC[1].r));
+    const Rigid Cb = rigid_to_parent<0>(C1, cq[0], sq[0], LC[0].r);
+    // joint 2 (calf, axis y)
+    const F6 F3 = rigid_col<1>(C3);
+    S.h22 += C3.Io.yy;
+    const F6 F32 = force_to_parent<1>(F3, cq[2], sq[2], LC[2].r);
+    S.h12 += F32.n.y;
+    const F6 F31 = force_to_parent<1>(F32, cq[1], sq[1], LC[1].r);
+    S.h02 += F31.n.x;
+    const F6 F30 = force_to_parent<0>(F31, cq[0], sq[0], LC[0].r);
+    S.bn[2] += F30.n; S.bl[2] += F30.f;
+    // joint 1 (thigh, axis y)
+    const F6 F2 = rigid_col<1>(C2);
+    S.h11 += C2.Io.yy;
+    const F6 F21 = force_to_parent<1>(F2, cq[1], sq[1], LC[1].r);
+    S.h01 += F21.n.x;
+    const F6 F20 = force_to_parent<0>(F21, cq[0], sq[0], LC[0].r);
+    S.bn[1] += F20.n; S.bl[1] += F20.f;
+    // joint 0 (hip, axis x)
+    const F6 F1 = rigid_col<0>(C1);
+    S.h00 += C1.Io.xx;
+    const F6 F10 = force_to_parent<0>(F1, cq[0], sq[0], LC[0].r);
+    S.bn[0] += F10.n; S.bl[0] += F10.f;
+    // rigid share of the base block
+    Mbb.A.m[0] += Cb.Io.xx; Mbb.A.m[1] += Cb.Io.xy; Mbb.A.m[2] += Cb.Io.xz;
+    Mbb.A.m[3] += Cb.Io.xy; Mbb.A.m[4] += Cb.Io.yy; Mbb.A.m[5] += Cb.Io.yz;
+    Mbb.A.m[6] += Cb.Io.xz; Mbb.A.m[7] += Cb.Io.yz; Mbb.A.m[8] += Cb.Io.zz;
+    Mbb.B += skew_of(Cb.mc);
+    Mbb.C.m[0] += Cb.m; Mbb.C.m[4] += Cb.m; Mbb.C.m[8] += Cb.m;
+  }
+
+  // ---- eliminate this leg's joints: H = L L^T (3x3), Y = L^-1 H_lb, z = L^-1 rhs ----
+  float l00, l10, l11, l20, l21, l22, i0, i1, i2;
+  {
+    l00 = sqrtf(S.h00); i0 = 1.f / l00;
+    l10 = S.h01 * i0; l20 = S.h02 * i0;
+    l11 = sqrtf(S.h11 - l10 * l10); i1 = 1.f / l11;
+    l21 = (S.h12 - l20 * l10) * i1;
+    l22 = sqrtf(S.h22 - l20 * l20 - l21 * l21); i2 = 1.f / l22;
+  }
+  V3 yn[3], yl[3];
+  float z[3];
+  yn[0] = i0 * S.bn[0]; yl[0] = i0 * S.bl[0]; z[0] = S.rhs[0] * i0;
+  yn[1] = i1 * (S.bn[1] - l10 * yn[0]); yl[1] = i1 * (S.bl[1] - l10 * yl[0]); z[1] = (S.rhs[1] - l10 * z[0]) * i1;
+  yn[2] = i2 * (S.bn[2] - l20 * yn[0] - l21 * yn[1]); yl[2] = i2 * (S.bl[2] - l20 * yl[0] - l21 * yl[1]);
+  z[2] = (S.rhs[2] - l20 * z[0] - l21 * z[1]) * i2;
+  V3 rb_n = -pb.n, rb_f = -pb.f;  // base rhs share: -(bias wrench) - Y^T z
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    Mbb.A -= outer(yn[j], yn[j]);
+    Mbb.B -= outer(yn[j], yl[j]);
+    Mbb.C -= outer(yl[j], yl[j]);
+    rb_n -= z[j] * yn[j];
+    rb_f -= z[j] * yl[j];
+  }
+
+  // ---- floating base: quad-sum the four shares, add the trunk's own rigid-body terms, solve 6x6 ----
+  I6 M;
+  M.A = qsum_sym(Mbb.A); M.B = qsum_full(Mbb.B); M.C = qsum_sym(Mbb.C);
+  V3 r0a = qsum(rb_n), r0l = qsum(rb_f);
+  {
+    const float mt = LT_TRUNK_MASS + X.trunk_mass_add;
+    Rigid T;
+    T.m = mt;
+    const V3 ctr = v3(k_trunk_com[0], k_trunk_com[1], k_trunk_com[2]);
+    T.mc = mt * ctr;
+    T.Io = s3_from(inertia_about_origin(mt, ctr, k_trunk_icom, mt / LT_TRUNK_MASS));
+    const F6 ft = rigid_bias(T, wb, vb, v3(0, 0, 0), v3(0, 0, 0), (-g) * row(R0, 2));
+    r0a -= ft.n; r0l -= ft.f;
+    M.A.m[0] += T.Io.xx; M.A.m[1] += T.Io.xy; M.A.m[2] += T.Io.xz;
+    M.A.m[3] += T.Io.xy; M.A.m[4] += T.Io.yy; M.A.m[5] += T.Io.yz;
+    M.A.m[6] += T.Io.xz; M.A.m[7] += T.Io.yz; M.A.m[8] += T.Io.zz;
+    M.B += skew_of(T.mc);
+    M.C.m[0] += mt; M.C.m[4] += mt; M.C.m[8] += mt;
+  }
+  V3 a0a, a0l;
+  spd6_solve(M, r0a, r0l, a0a, a0l);
+
+  // ---- back-substitute the joints: qdd = L^-T (z - Y a_b) ----
+  float qdd[3];
+  {
+    const float t0 = z[0] - dot(yn[0], a0a) - dot(yl[0], a0l);
+    const float t1 = z[1] - dot(yn[1], a0a) - dot(yl[1], a0l);
+    const float t2 = z[2] - dot(yn[2], a0a) - dot(yl[2], a0l);
+    qdd[2] = t2 * i2;
+    qdd[1] = (t1 - l21 * qdd[2]) * i1;
+    qdd[0] = (t0 - l10 * qdd[1] - l20 * qdd[2]) * i0;
+  }
+  // total link accelerations (for the final contact forces)
+  V3 ta[3], tl[3];
+  ta[0] = rot_inv<0>(cq[0], sq[0], a0a) + ca[0] + axis_scaled<0>(qdd[0]);
+  tl[0] = rot_inv<0>(cq[0], sq[0], a0l + cross(a0a, LC[0].r)) + cl[0];
+  ta[1] = rot_inv<1>(cq[1], sq[1], ta[0]) + ca[1] + axis_scaled<1>(qdd[1]);
+  tl[1] = rot_inv<1>(cq[1], sq[1], tl[0] + cross(ta[0], LC[1].r)) + cl[1];
+  ta[2] = rot_inv<1>(cq[2], sq[2], ta[1]) + ca[2] + axis_scaled<1>(qdd[2]);
+  tl[2] = rot_inv<1>(cq[2], sq[2], tl[1] + cross(ta[1], LC[2].r)) + cl[2];
+  rep.body[3] = ground_force(c_foot, h, r_foot, LT_FOOT_RADIUS, Rw[2], ta[2], tl[2]);
+  rep.body[2] = ground_force(c_calf, h, r_calf, 0.012f, Rw[2], ta[2], tl[2]);
+  rep.body[1] = ground_force(c_knee, h, r_knee, 0.022f, Rw[1], ta[1], tl[1]);
+  rep.body[0] = ground_force(c_hip, h, r_hip, LT_HIP_CYL_RADIUS, Rw[0], ta[0], tl[0]);
+  rep.trunk_part += ground_force(c_tlo, h, r_tlo, 0.f, R0, a0a, a0l);
+  rep.trunk_part += ground_force(c_thi, h, r_thi, 0.f, R0, a0a, a0l);
+
+  // ---- semi-implicit Euler ----
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float qd = G.qd[k] + h * qdd[k];
+    float q = G.q[k] + h * qd;
+    if (q < k_joint_lo[k]) { q = k_joint_lo[k]; if (qd < 0.f) qd = 0.f; }
+    if (q > k_joint_hi[k]) { q = k_joint_hi[k]; if (qd > 0.f) qd = 0.f; }
+    G.q[k] = q; G.qd[k] = qd;
+  }
+  {
+    const V3 acl = a0l + cross(wb, vb);
+    B.u += h * mul(R0, acl);
+    B.w += h * mul(R0, a0a);
+    B.p += h * B.u;
+    B.q = q_integrate(B.q, B.w, h);
+  }
+  if (HAS_OBJ) {
+    O.w += h * obj_aa;
+    O.u += h * obj_al;
+    O.p += h * O.u;
+    O.q = q_integrate(O.q, O.w, h);
+  }
+}

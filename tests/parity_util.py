@@ -39,12 +39,16 @@ def device_arena_to_host(env) -> np.ndarray:
 
 
 def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", max_flip_frac: float = 0.0, obs_tol=(4e-4, 4e-4),
-                        skip=()):
+                        skip=(), max_event_frac: float = 0.0):
+    """`max_flip_frac`: envs allowed to differ in thresholded contact booleans / timers (force within fp32 noise of 1 N).
+    `max_event_frac`: envs allowed to diverge beyond the fp32 band in continuous fields this step - a discontinuous event
+    (joint-limit clamp zeroing a velocity, contact (de)activation) taken on one side and not on the other because the
+    deciding quantity sat within rounding of its threshold.  Callers bound the total over a run as well."""
     n = int(cfg.num_envs)
     obs_dim = (45 if cfg.task == C["LT_TASK_LOCOMOTION"] else 58) * int(cfg.obs_history)
     L = Layout(n, obs_dim)
     assert dev.shape == ref.shape == (L.total_bytes,), (dev.shape, ref.shape, L.total_bytes)
-    report, failures, flip_envs = [], [], set()
+    report, failures, flip_envs, event_envs = [], [], set(), set()
     for name in QUAD_FIELDS:
         if name in skip:
             continue
@@ -70,6 +74,7 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
                 flip_envs |= set(np.nonzero(bad)[0].tolist())
             else:
                 failures.append((name, err, np.nonzero(bad)[0][:5].tolist()))
+                event_envs |= set(np.nonzero(bad)[0].tolist())
     for name in L.plain:
         if name in skip:
             continue
@@ -106,13 +111,18 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
             else:
                 failures.append((name, err, np.nonzero(bad)[0][:5].tolist()))
     frac = len(flip_envs) / max(1, n)
-    if failures or frac > max_flip_frac:
+    only_env_fields = all(nm.startswith("LT_F_") and nm not in ("LT_F_CMD_PARAMS", "LT_F_COUNTERS") for nm, _, _ in failures)
+    events_ok = only_env_fields and len(event_envs) / max(1, n) <= max_event_frac
+    if events_ok:
+        flip_envs -= event_envs
+        frac = len(flip_envs) / max(1, n)
+    if (failures and not events_ok) or frac > max_flip_frac:
         lines = [f"parity {what}: {len(failures)} hard field failures, {len(flip_envs)}/{n} envs differ in thresholded/soft fields "
                  f"(allowed fraction {max_flip_frac})"]
         lines += [f"  HARD {nm}: max|err|={e:.3e} envs={ids}" for nm, e, ids in failures]
         lines += [f"  {nm:28s} max|err|={e:.3e} bad_envs={nb}" for nm, e, nb in report if nb]
         raise AssertionError("\n".join(lines))
-    return dict(report=report, flip_envs=sorted(flip_envs))
+    return dict(report=report, flip_envs=sorted(flip_envs), event_envs=sorted(event_envs) if failures else [])
 
 
 def compare_arenas(env, ora, what: str = "", **kw):

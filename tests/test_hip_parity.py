@@ -59,6 +59,7 @@ def test_step_parity_resynced(task, n, steps, phys):
     g = torch.Generator().manual_seed(3)
     n_reset = 0
     flips = 0
+    events = 0
     L = Layout(n, env.num_obs)
     for t in range(steps):
         scale = 0.0 if t < 10 else (0.3 if t < steps // 2 else 1.0)
@@ -69,11 +70,13 @@ def test_step_parity_resynced(task, n, steps, phys):
         env.step(act.cuda())
         ora.step(act.numpy())
         torch.cuda.synchronize()
-        res = compare_arenas(env, ora, what=f"{task} step {t}", max_flip_frac=0.05)
+        res = compare_arenas(env, ora, what=f"{task} step {t}", max_flip_frac=0.05, max_event_frac=2.0 / n)
         flips += len(res["flip_envs"])
+        events += len(res["event_envs"])
         n_reset += int(L.arr(ora.arena, "LT_F_DONES")[:n].sum())
     assert n_reset > 0, "the sequence must include resets"
     assert flips <= 0.01 * n * steps, f"too many thresholded-contact flips: {flips}"
+    assert events <= 0.003 * n * steps, f"too many discontinuous-event divergences: {events}"
 
 
 def test_free_running_statistics_teacher():
