@@ -501,6 +501,11 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
 
   __shared__ float s_frame[2][16][64];
   __shared__ int s_fill[16];
+  __shared__ short s_tab[704];  // observation history tables (src[352] | frame[352]) staged once per wave
+  {
+    const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
+    for (int i = lane; i < 352; i += 64) { s_tab[i] = tab.src[i]; s_tab[352 + i] = tab.frame[i]; }
+  }
 
   // ---- sign pattern of this lane's leg (mirror form of the model constants) ----
   const float sx = leg < 2 ? 1.f : -1.f, sy = (leg & 1) ? 1.f : -1.f;
@@ -954,48 +959,49 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
   }
   __syncthreads();
   {
-    // 16 env rows of this wave are one contiguous chunk of 16*OBS floats: stream it with float4 stores, reading the
-    // shifted old values in place (each store depends on its own loads; later iterations only read higher addresses)
-    const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
-    constexpr int ROW4 = OBS / 4;  // 87 (teacher) or 67.5 -> locomotion rows are not float4-aligned: handled below
-    if (OBS % 4 == 0) {
-#pragma unroll 1
-      for (int grp = 0; grp < 2; ++grp) {
-        float* rows = (float*)(arena + (grp == 0 ? L.off_obs_policy : L.off_obs_critic)) + (long long)blockIdx.x * 16 * OBS;
-        for (int idx = lane; idx < 16 * ROW4; idx += 64) {
-          const int r = idx / ROW4, c4 = idx - r * ROW4;
-          const float* fr = s_frame[grp][r];
-          const float* old = rows + r * OBS;
-          const bool fill = s_fill[r] != 0;
-          float v[4];
+    // History rows.  The 16 env rows of this wave are one contiguous chunk of 16*OBS floats per group.  Row(t) is built in
+    // place from row(t-1): every term block shifts left by one frame and takes the newest frame from LDS.  Work is
+    // batched so that many loads are in flight per wait (a lone wave per SIMD has nothing else to hide latency with):
+    // a batch loads BATCH float4-columns per lane for BOTH groups, then stores them.  In-place safety: a column only
+    // reads higher addresses of its own row, all loads of a batch precede its stores, later batches only read above.
+    constexpr int VEC = (OBS % 4 == 0) ? 4 : 2;     // 348 = 87 float4 ; 270 = 135 float2
+    constexpr int ROWV = OBS / VEC;
+    constexpr int TOTAL = 16 * ROWV;
+    constexpr int BATCH = 6;
+    float* const rows_p = (float*)(arena + L.off_obs_policy) + (long long)blockIdx.x * 16 * OBS;
+    float* const rows_c = (float*)(arena + L.off_obs_critic) + (long long)blockIdx.x * 16 * OBS;
+    for (int base = 0; base < TOTAL; base += 64 * BATCH) {
+      float vp[BATCH][VEC], vc[BATCH][VEC];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int col = c4 * 4 + j;
-            const int s = tab.src[col];
-            v[j] = fill ? fr[tab.frame[col]] : (s >= 0 ? old[s] : fr[-s - 1]);
+      for (int j = 0; j < BATCH; ++j) {
+        const int idx = base + j * 64 + lane;
+        if (idx < TOTAL) {
+          const int r = idx / ROWV, cv = idx - r * ROWV;
+          const bool fill = s_fill[r] != 0;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const int col = cv * VEC + e;
+            const int sidx = s_tab[col];         // >= 0: old column (one slot newer); < 0: newest frame element -sidx-1
+            const int fidx = s_tab[352 + col];   // newest-frame element of this column's term
+            const bool from_frame = fill || sidx < 0;
+            const int fi = fill ? fidx : (-sidx - 1);
+            vp[j][e] = from_frame ? s_frame[0][r][fi & 63] : rows_p[r * OBS + sidx];
+            vc[j][e] = from_frame ? s_frame[1][r][fi & 63] : rows_c[r * OBS + sidx];
           }
-          *(float4*)(rows + r * OBS + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
-    } else {
-      // 270-wide rows (locomotion): 16 rows = 4320 floats, still a multiple of 4 per wave chunk -> float2 granularity
-      constexpr int ROW2 = OBS / 2;
-#pragma unroll 1
-      for (int grp = 0; grp < 2; ++grp) {
-        float* rows = (float*)(arena + (grp == 0 ? L.off_obs_policy : L.off_obs_critic)) + (long long)blockIdx.x * 16 * OBS;
-        for (int idx = lane; idx < 16 * ROW2; idx += 64) {
-          const int r = idx / ROW2, c2 = idx - r * ROW2;
-          const float* fr = s_frame[grp][r];
-          const float* old = rows + r * OBS;
-          const bool fill = s_fill[r] != 0;
-          float v[2];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int col = c2 * 2 + j;
-            const int s = tab.src[col];
-            v[j] = fill ? fr[tab.frame[col]] : (s >= 0 ? old[s] : fr[-s - 1]);
+      for (int j = 0; j < BATCH; ++j) {
+        const int idx = base + j * 64 + lane;
+        if (idx < TOTAL) {
+          const int r = idx / ROWV, cv = idx - r * ROWV;
+          if (VEC == 4) {
+            *(float4*)(rows_p + r * OBS + cv * 4) = make_float4(vp[j][0], vp[j][1], vp[j][2], vp[j][VEC - 1]);
+            *(float4*)(rows_c + r * OBS + cv * 4) = make_float4(vc[j][0], vc[j][1], vc[j][2], vc[j][VEC - 1]);
+          } else {
+            *(float2*)(rows_p + r * OBS + cv * 2) = make_float2(vp[j][0], vp[j][1]);
+            *(float2*)(rows_c + r * OBS + cv * 2) = make_float2(vc[j][0], vc[j][1]);
           }
-          *(float2*)(rows + r * OBS + c2 * 2) = make_float2(v[0], v[1]);
         }
       }
     }
