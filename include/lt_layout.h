@@ -33,13 +33,18 @@ static inline int lt_field_quads(int f) {
   }
 }
 
+/* Device-resident copy of (lt_cfg, lt_layout) at the arena tail: the kernels read their configuration from HBM/L2
+ * through one pointer instead of a ~1.7 KB kernarg block (kernargs live in host-visible memory: every scalar-cache
+ * miss on them is a fabric round trip - measured 20 us of s_waitcnt per launch). */
+#define LT_DEV_ARGS_BYTES 4096
+
 typedef struct lt_layout {
   int64_t n;                         /* envs (padded to a multiple of 16 for the arena) */
   int64_t npad;
   int32_t obs_dim;
   int64_t quad_off[LT_NUM_QUAD_FIELDS]; /* byte offsets */
   int64_t off_ep_len, off_obs_policy, off_obs_critic, off_reward, off_dones, off_terminated, off_time_out,
-      off_term_bits, off_cmd_params, off_counters;
+      off_term_bits, off_cmd_params, off_counters, off_dev_args;
   int64_t total_bytes;
 } lt_layout;
 
@@ -64,6 +69,7 @@ static inline void lt_layout_init(lt_layout* L, int64_t num_envs, int32_t obs_di
   L->off_term_bits = off;   off = lt_align256(off + L->npad * 4);
   L->off_cmd_params = off;  off = lt_align256(off + LT_CMD_PARAMS_LEN * 4);
   L->off_counters = off;    off = lt_align256(off + 4 * 8);
+  L->off_dev_args = off;    off = lt_align256(off + LT_DEV_ARGS_BYTES);
   L->total_bytes = off;
 }
 
@@ -71,6 +77,11 @@ static inline void lt_layout_init(lt_layout* L, int64_t num_envs, int32_t obs_di
 static inline float* lt_quad(void* arena, const lt_layout* L, int f, int q) {
   return (float*)((char*)arena + L->quad_off[f]) + (int64_t)q * L->npad * 4;
 }
+
+typedef struct lt_dev_args {
+  lt_cfg cfg;
+  lt_layout layout;
+} lt_dev_args;
 
 #ifdef __cplusplus
 }

@@ -27,12 +27,14 @@ namespace {
 
 constexpr int MODE_STEP = 0, MODE_TERMS = 1, MODE_RESET_ALL = 2;
 
+// Kernel arguments: two pointers.  Configuration + layout are read from the device-resident lt_dev_args block at the
+// arena tail (include/lt_layout.h) - a 1.7 KB by-value kernarg cost ~20 us of scalar-load stalls per launch.
 struct KArgs {
-  lt_cfg cfg;
-  lt_layout L;
+  const lt_dev_args* __restrict__ d;
   char* arena;
   const float* actions;
 };
+static_assert(sizeof(lt_dev_args) <= LT_DEV_ARGS_BYTES, "lt_dev_args outgrew its arena slot");
 
 // ---- robot model (generated from the reference URDF by tools/compile_robot_model.py), mirror form: every per-leg
 // constant is (FL-leg literal) x sign[pattern], sign = {1, sx, sy, sx*sy} of the lane's leg -> no table loads, nothing
@@ -481,13 +483,38 @@ __device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P
 // =====================================================================================================
 // the step kernel
 // =====================================================================================================
-template <int TASK, int MODE>
+#ifdef LT_STAMPS
+#define LT_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps_[i] = t_; } while (0)
+#else
+#define LT_STAMP(i) do { } while (0)
+#endif
+
+// PREFETCH (small grids, <= 2 waves per CU): the previous observation rows of the wave (2 x 16 x OBS floats, 44.5 KB) are
+// fetched by LDS-DMA (global_load_lds_dwordx4, no VGPRs) at kernel start and land while the physics runs, so the
+// history pass at the tail has no global-load latency left - a lone wave per SIMD has nothing else to hide it behind.
+// Large grids keep the register path: 57 KB of LDS per wave would cap occupancy at 2 waves per CU.
+template <int TASK, int MODE, bool PREFETCH>
 __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
+#ifdef LT_STAMPS
+  unsigned long long stamps_[8];
+  for (int i = 0; i < 8; ++i) stamps_[i] = 0;
+#endif
+  LT_STAMP(0);
   constexpr bool HAS_OBJ = TASK != LT_TASK_LOCOMOTION;
   constexpr int FRAME = HAS_OBJ ? 58 : 45;
   constexpr int OBS = FRAME * 6;
-  const lt_cfg& c = a.cfg;
-  const lt_layout& L = a.L;
+  // Stage the (cfg, layout) block into LDS with one coalesced burst: ~130 scattered scalar loads (each its own L2 round
+  // trip + s_waitcnt for a lone wave) become two vector loads and cheap ds_reads.
+  __shared__ lt_dev_args s_d;
+  {
+    static_assert(sizeof(lt_dev_args) % 16 == 0, "lt_dev_args must be a multiple of 16 bytes");
+    const uint4* src = (const uint4*)a.d;
+    uint4* dst = (uint4*)&s_d;
+    for (int i = threadIdx.x; i < (int)(sizeof(lt_dev_args) / 16); i += 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  const lt_cfg& c = s_d.cfg;
+  const lt_layout& L = s_d.layout;
   const int lane = threadIdx.x;
   const int leg = lane & 3;
   const long long gid = (long long)blockIdx.x * 64 + lane;  // == env*4 + leg
@@ -502,6 +529,21 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
   __shared__ float s_frame[2][16][64];
   __shared__ int s_fill[16];
   __shared__ short s_tab[704];  // observation history tables (src[352] | frame[352]) staged once per wave
+  __shared__ __attribute__((aligned(16))) float s_old[PREFETCH ? 2 * 16 * OBS : 4];
+  if (PREFETCH) {
+    // 16*OBS floats per group = one contiguous chunk; each wave-instruction moves 64 lanes x 16 B = 1 KiB, lane-linear in LDS
+    constexpr int CHUNK16 = 16 * OBS / 4;  // float4 count per group (OBS*16 is a multiple of 4 for both tasks)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float* gsrc = (const float*)(a.arena + (g == 0 ? a.d->layout.off_obs_policy : a.d->layout.off_obs_critic)) + (long long)blockIdx.x * 16 * OBS;
+      for (int i = 0; i < (CHUNK16 + 63) / 64; ++i) {
+        const int v = i * 64 + threadIdx.x;
+        if (v < CHUNK16)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + v * 4),
+                                           (__attribute__((address_space(3))) void*)(s_old + g * 16 * OBS + i * 256), 16, 0, 0);
+      }
+    }
+  }
   {
     const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
     for (int i = lane; i < 352; i += 64) { s_tab[i] = tab.src[i]; s_tab[352 + i] = tab.frame[i]; }
@@ -546,6 +588,7 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
     G.mu = *F(LT_F_FOOT_FRICTION, 0);
   }
 
+  LT_STAMP(1);
   // ---- startup events (reset-all only): reference locomotion_base_env_cfg.py:224-244, rand_cylinder_...:21-27 ----
   if (MODE == MODE_RESET_ALL) {
     const uint64_t st = ~0ull;
@@ -599,6 +642,7 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
     }
     foot_kinematics(sgn, B, G);
   }
+  LT_STAMP(2);
   // ---- late loads: state the physics never touches (compiler barrier: keep these below the decimation loop) ----
   asm volatile("" ::: "memory");
   {
@@ -794,6 +838,7 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
     }
   }
 
+  LT_STAMP(3);
   // =================================================================================================
   // stage 6: reset (curriculum record, log snapshot, reset events, manager resets), 7 command, 8 pushes
   // =================================================================================================
@@ -903,6 +948,7 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
     }
   }
 
+  LT_STAMP(4);
   // =================================================================================================
   // stage 9: observation frame (policy: noisy, critic: clean) -> LDS, then the 6-deep history rows
   //   term order: reference locomotion_base_env_cfg.py:74-109, object_state object_transport_teacher...:37-43
@@ -958,6 +1004,57 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
     }
   }
   __syncthreads();
+  LT_STAMP(5);
+  if (PREFETCH) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of the old rows has long landed
+    __syncthreads();
+  }
+  if (PREFETCH)
+  {
+    // History rows (PREFETCH path: the old rows were DMA-ed into LDS at kernel start, behind the physics).
+    // The 16 env rows of this wave are one contiguous chunk of 16*OBS floats per group.  Row(t) is built in
+    // place from row(t-1): every term block shifts left by one frame and takes the newest frame from LDS.
+    // Lane l owns columns l, l+64, ... of EVERY row, so the per-column routing (table lookups) is done once per lane and
+    // reused for all 16 rows x 2 groups; each row is then NCH coalesced dword loads + NCH coalesced dword stores per group.
+    // In-place safety: a column only reads higher columns of its own row, and all loads of a row precede its stores.
+    constexpr int NCH = (OBS + 63) / 64;
+    int src[NCH], frm[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int col = i * 64 + lane;
+      const int cc = col < OBS ? col : OBS - 1;
+      src[i] = s_tab[cc];         // >= 0: old column (one slot newer); < 0: newest frame element -src-1
+      frm[i] = s_tab[352 + cc];   // newest-frame element of this column's term (rows that were just reset)
+    }
+    float* const rows_p = (float*)(arena + L.off_obs_policy) + (long long)blockIdx.x * 16 * OBS;
+    float* const rows_c = (float*)(arena + L.off_obs_critic) + (long long)blockIdx.x * 16 * OBS;
+    constexpr int RB = 4;  // rows per batch: only LDS reads and fire-and-forget stores, no global load in this tail
+    for (int r0 = 0; r0 < 16; r0 += RB) {
+      float vp[RB][NCH], vc[RB][NCH];
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) {
+        const int r = r0 + rr;
+        const bool fill = s_fill[r] != 0;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const bool from_frame = fill || src[i] < 0;
+          const int fi = fill ? frm[i] : (-src[i] - 1);
+          if (from_frame) { vp[rr][i] = s_frame[0][r][fi & 63]; vc[rr][i] = s_frame[1][r][fi & 63]; }
+          else { vp[rr][i] = s_old[r * OBS + src[i]]; vc[rr][i] = s_old[16 * OBS + r * OBS + src[i]]; }
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) {
+        const int r = r0 + rr;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int col = i * 64 + lane;
+          if (col < OBS) { rows_p[r * OBS + col] = vp[rr][i]; rows_c[r * OBS + col] = vc[rr][i]; }
+        }
+      }
+    }
+  }
+  else
   {
     // History rows.  The 16 env rows of this wave are one contiguous chunk of 16*OBS floats per group.  Row(t) is built in
     // place from row(t-1): every term block shifts left by one frame and takes the newest frame from LDS.  Work is
@@ -1007,6 +1104,7 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
     }
   }
 
+  LT_STAMP(6);
   // ---- store state ----
   {
     *F(LT_F_ROOT_POS, 0) = sel4(leg, B.p.x, B.p.y, B.p.z, 0.f);
@@ -1049,114 +1147,147 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
 #pragma unroll
     for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) *F(LT_F_EPISODE_SUMS, q) = sums[q];
   }
+#ifdef LT_STAMPS
+  LT_STAMP(7);
+  if (lane == 0)
+    for (int q = 0; q < 7; ++q) *F(LT_F_LAST_EPISODE_SUMS, q) = (float)(long long)(stamps_[q + 1] - stamps_[q]);
+#endif
 }
 
 // =====================================================================================================
 // post kernel (one block): velocity curriculum (reference mdp/curriculums.py:184-275 + commands.py:471-505),
 // population gate of rewards.py:190, common step counter.  Runs after every step kernel, on the same stream.
 // =====================================================================================================
-__device__ float block_sum(float v, float* sh) {
-  const int tid = threadIdx.x;
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+// block-wide sum of K values at once (one LDS round, two barriers); result replicated in every thread
+template <int K>
+__device__ __forceinline__ void block_sum(float (&v)[K], float* sh) {
+  const int tid = threadIdx.x, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+  __syncthreads();  // protect sh against the previous use
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < K; ++k) sh[(tid >> 6) * K + k] = v[k];
   __syncthreads();
-  if ((tid & 63) == 0) sh[tid >> 6] = v;
-  __syncthreads();
-  float t = 0.f;
-  if (tid == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
-  if (tid == 0) sh[16] = t;
-  __syncthreads();
-  return sh[16];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float t = 0.f;
+    for (int w = 0; w < nw; ++w) t += sh[w * K + k];
+    v[k] = t;
+  }
 }
 __device__ __forceinline__ void set_range(float* P, int d, float lo, float hi) {
   P[6 + 2 * d] = P[2 * d]; P[6 + 2 * d + 1] = P[2 * d + 1];
   P[2 * d] = lo; P[2 * d + 1] = hi;
   P[12 + d] = (P[6 + 2 * d] == P[2 * d] && P[6 + 2 * d + 1] == P[2 * d + 1]) ? 1.f : 0.f;
 }
-__global__ __launch_bounds__(1024) void lt_post_kernel(const KArgs a, int bump_counter) {
-  const lt_cfg& c = a.cfg;
-  const lt_layout& L = a.L;
+// Every thread keeps the per-env trackers of its envs in registers for the whole kernel (<= 8 envs per thread at
+// N = 8192; larger N strides further) and replays the reference's call order: lin gate -> maybe widen -> ang gate.
+__global__ __launch_bounds__(1024) void lt_post_kernel(const KArgs a, int bump_counter, int gates_only) {
+  const lt_cfg& c = a.d->cfg;
+  const lt_layout& L = a.d->layout;
   char* const arena = a.arena;
   float* P = (float*)(arena + L.off_cmd_params);
-  __shared__ float sh[32];
+  __shared__ float sh[16 * 8];
   const long long n = L.n, q4 = L.npad * 4;
-  float* rec = (float*)(arena + L.quad_off[LT_F_CURRICULUM]);
-  float* trk1 = rec + q4;
-  float* trk2 = rec + 2 * q4;
-  const float* cmd = (const float*)(arena + L.quad_off[LT_F_CMD]);
+  const float4* rec = (const float4*)(arena + L.quad_off[LT_F_CURRICULUM]);
+  float4* trk1 = (float4*)((float*)(arena + L.quad_off[LT_F_CURRICULUM]) + q4);
+  float4* trk2 = (float4*)((float*)(arena + L.quad_off[LT_F_CURRICULUM]) + 2 * q4);
+  const float4* cmd = (const float4*)(arena + L.quad_off[LT_F_CMD]);
   const int tid = threadIdx.x, nt = blockDim.x;
-  // population gate (rewards.py:190) for the next step
-  float nz = 0.f, any = 0.f;
+  // command block snapshot (uniform; thread 0 is the only writer, at the very end)
+  float Pl[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) Pl[i] = P[i];
+  const float* mx = c.cmd_range_max;
+  const bool cur = c.cur_enabled != 0 && !gates_only;
+  const bool lin_open = cur && (Pl[1] != mx[0] || Pl[12] == 0.f || Pl[3] != mx[1] || Pl[13] == 0.f) && (Pl[17] - Pl[18] <= (float)c.cur_max_distance_bins);
+  // pass 1: population gate, any-reset flag, lin statistics with this step's records merged in
+  float r1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // nz, any, not-all-reset(lin), sum len, sum reward
   for (long long e = tid; e < n; e += nt) {
-    const float* cc = cmd + e * 4;
-    if (cc[0] != 0.f || cc[1] != 0.f || cc[2] != 0.f) nz = 1.f;
-    if (rec[e * 4] != 0.f) any = 1.f;
-  }
-  nz = block_sum(nz, sh);
-  any = block_sum(any, sh);
-  if (tid == 0) P[26] = nz > 0.f ? 1.f : 0.f;
-  if (c.cur_enabled && any > 0.f) {  // _reset_idx (and the curriculum with it) only runs when some env reset
-    const float* mx = c.cmd_range_max;
-    const float inv_n = 1.f / (float)n;
-    __syncthreads();
-    const bool lin_open = (P[1] != mx[0] || P[12] == 0.f || P[3] != mx[1] || P[13] == 0.f) && (P[17] - P[18] <= (float)c.cur_max_distance_bins);
-    __syncthreads();
+    const float4 cc = cmd[e];
+    const float4 rc = rec[e];
+    if (cc.x != 0.f || cc.y != 0.f || cc.z != 0.f) r1[0] = 1.f;
+    if (rc.x != 0.f) r1[1] = 1.f;
     if (lin_open) {
-      float notall = 0.f, sl = 0.f, sr = 0.f;
-      for (long long e = tid; e < n; e += nt) {
-        if (rec[e * 4] != 0.f) { trk1[e * 4 + 0] = 1.f; trk1[e * 4 + 1] = rec[e * 4 + 1]; trk1[e * 4 + 2] = rec[e * 4 + 2]; }
-        if (trk1[e * 4 + 0] == 0.f) notall = 1.f;
-        sl += trk1[e * 4 + 1]; sr += trk1[e * 4 + 2];
-      }
-      notall = block_sum(notall, sh); sl = block_sum(sl, sh); sr = block_sum(sr, sh);
-      const bool pass = notall == 0.f && sl * inv_n > c.cur_len_threshold && sr * inv_n > c.cur_reward_threshold[0];
-      if (pass) {
-        if (tid == 0) {
-          P[19] += 1.f;
-          if ((int)P[19] == c.cur_repeat_times[0]) {
-            const float lx = clampf(P[0] - P[21], -mx[0], 0.f), ly = clampf(P[2] - P[22], -mx[1], 0.f);
-            set_range(P, 0, lx, -lx);
-            set_range(P, 1, ly, -ly);
-            if (P[12] != 0.f && P[13] != 0.f && P[14] != 0.f) { P[15] = (float)c.cmd_zero_steps_final; P[16] = c.cmd_rel_standing_final; }
-            P[19] = 0.f; P[17] += 1.f;
-          }
-        }
-        for (long long e = tid; e < n; e += nt) { trk1[e * 4 + 0] = 0.f; trk1[e * 4 + 1] = 0.f; trk1[e * 4 + 2] = 0.f; }
-      }
+      float4 t = trk1[e];
+      if (rc.x != 0.f) { t.x = 1.f; t.y = rc.y; t.z = rc.z; }
+      if (t.x == 0.f) r1[2] = 1.f;
+      r1[3] += t.y; r1[4] += t.z;
     }
-    __syncthreads();
-    const bool ang_open = (P[5] != mx[2] || P[14] == 0.f) && (P[18] - P[17] <= (float)c.cur_max_distance_bins);
-    __syncthreads();
-    if (ang_open) {
-      float notall = 0.f, sl = 0.f, sr = 0.f;
-      for (long long e = tid; e < n; e += nt) {
-        if (rec[e * 4] != 0.f) { trk1[e * 4 + 3] = 1.f; trk2[e * 4 + 0] = rec[e * 4 + 1]; trk2[e * 4 + 1] = rec[e * 4 + 3]; }
-        if (trk1[e * 4 + 3] == 0.f) notall = 1.f;
-        sl += trk2[e * 4 + 0]; sr += trk2[e * 4 + 1];
-      }
-      notall = block_sum(notall, sh); sl = block_sum(sl, sh); sr = block_sum(sr, sh);
-      const bool pass = notall == 0.f && sl * inv_n > c.cur_len_threshold && sr * inv_n > c.cur_reward_threshold[1];
-      if (pass) {
-        if (tid == 0) {
-          P[20] += 1.f;
-          if ((int)P[20] == c.cur_repeat_times[1]) {
-            const float lz = clampf(P[4] - P[23], -mx[2], 0.f);
-            set_range(P, 2, lz, -lz);
-            if (P[12] != 0.f && P[13] != 0.f && P[14] != 0.f) { P[15] = (float)c.cmd_zero_steps_final; P[16] = c.cmd_rel_standing_final; }
-            P[20] = 0.f; P[18] += 1.f;
-          }
-        }
-        for (long long e = tid; e < n; e += nt) { trk1[e * 4 + 3] = 0.f; trk2[e * 4 + 0] = 0.f; trk2[e * 4 + 1] = 0.f; }
-      }
-    }
-    if (tid == 0) { P[24] = lin_open ? 1.f : 0.f; P[25] = ang_open ? 1.f : 0.f; }
   }
-  if (tid == 0 && bump_counter) ((long long*)(arena + L.off_counters))[0] += 1;
+  block_sum<5>(r1, sh);
+  const bool any = r1[1] > 0.f;
+  const float inv_n = 1.f / (float)n;
+  const bool run = cur && any;  // _reset_idx (and the curriculum with it) only runs when some env reset this step
+  bool lin_pass = false, lin_widen = false;
+  if (run && lin_open) {
+    lin_pass = r1[2] == 0.f && r1[3] * inv_n > c.cur_len_threshold && r1[4] * inv_n > c.cur_reward_threshold[0];
+    if (lin_pass) {
+      Pl[19] += 1.f;
+      if ((int)Pl[19] == c.cur_repeat_times[0]) {
+        lin_widen = true;
+        const float lx = clampf(Pl[0] - Pl[21], -mx[0], 0.f), ly = clampf(Pl[2] - Pl[22], -mx[1], 0.f);
+        set_range(Pl, 0, lx, -lx);
+        set_range(Pl, 1, ly, -ly);
+        if (Pl[12] != 0.f && Pl[13] != 0.f && Pl[14] != 0.f) { Pl[15] = (float)c.cmd_zero_steps_final; Pl[16] = c.cmd_rel_standing_final; }
+        Pl[19] = 0.f; Pl[17] += 1.f;
+      }
+    }
+  }
+  const bool ang_open = run && (Pl[5] != mx[2] || Pl[14] == 0.f) && (Pl[18] - Pl[17] <= (float)c.cur_max_distance_bins);
+  // pass 2: ang statistics (gate evaluated after the lin update, as in the reference's call order) + tracker write-back
+  float r2[3] = {0.f, 0.f, 0.f};
+  if (run) {
+    for (long long e = tid; e < n; e += nt) {
+      const float4 rc = rec[e];
+      float4 t1 = trk1[e], t2 = trk2[e];
+      if (lin_open) {
+        if (rc.x != 0.f) { t1.x = 1.f; t1.y = rc.y; t1.z = rc.z; }
+        if (lin_pass) { t1.x = 0.f; t1.y = 0.f; t1.z = 0.f; }
+      }
+      if (ang_open) {
+        if (rc.x != 0.f) { t1.w = 1.f; t2.x = rc.y; t2.y = rc.w; }
+        if (t1.w == 0.f) r2[0] = 1.f;
+        r2[1] += t2.x; r2[2] += t2.y;
+      }
+      trk1[e] = t1; trk2[e] = t2;
+    }
+    if (ang_open) {
+      block_sum<3>(r2, sh);
+      const bool ang_pass = r2[0] == 0.f && r2[1] * inv_n > c.cur_len_threshold && r2[2] * inv_n > c.cur_reward_threshold[1];
+      if (ang_pass) {
+        Pl[20] += 1.f;
+        if ((int)Pl[20] == c.cur_repeat_times[1]) {
+          const float lz = clampf(Pl[4] - Pl[23], -mx[2], 0.f);
+          set_range(Pl, 2, lz, -lz);
+          if (Pl[12] != 0.f && Pl[13] != 0.f && Pl[14] != 0.f) { Pl[15] = (float)c.cmd_zero_steps_final; Pl[16] = c.cmd_rel_standing_final; }
+          Pl[20] = 0.f; Pl[18] += 1.f;
+        }
+        for (long long e = tid; e < n; e += nt) {  // each thread clears the rows it wrote itself just above
+          float4 t1 = trk1[e];
+          t1.w = 0.f;
+          trk1[e] = t1;
+          trk2[e] = make_float4(0.f, 0.f, trk2[e].z, trk2[e].w);
+        }
+      }
+    }
+    Pl[24] = lin_open ? 1.f : 0.f; Pl[25] = ang_open ? 1.f : 0.f;
+  }
+  Pl[26] = r1[0] > 0.f ? 1.f : 0.f;
+  (void)lin_widen;
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 27; ++i) P[i] = Pl[i];
+    if (bump_counter) ((long long*)(arena + L.off_counters))[0] += 1;
+  }
 }
 
 // command/curriculum block initialisation (reference mdp/curriculums.py:187-193, commands.py:427-469)
 __global__ void lt_init_params_kernel(const KArgs a) {
-  const lt_cfg& c = a.cfg;
-  float* P = (float*)(a.arena + a.L.off_cmd_params);
+  const lt_cfg& c = a.d->cfg;
+  float* P = (float*)(a.arena + a.d->layout.off_cmd_params);
   const int i = threadIdx.x;
   if (i >= LT_CMD_PARAMS_LEN) return;
   float v = 0.f;
@@ -1169,10 +1300,10 @@ __global__ void lt_init_params_kernel(const KArgs a) {
   else if (i == 24 || i == 25) v = c.cur_enabled ? 1.f : 0.f;
   else if (i == 26) v = 1.f;
   P[i] = v;
-  if (i == 0) ((long long*)(a.arena + a.L.off_counters))[0] = 1;
+  if (i == 0) ((long long*)(a.arena + a.d->layout.off_counters))[0] = 1;
 }
 __global__ void lt_set_ranges_kernel(const KArgs a, float r0, float r1, float r2, float r3, float r4, float r5, int zero_steps, float rel_standing) {
-  float* P = (float*)(a.arena + a.L.off_cmd_params);
+  float* P = (float*)(a.arena + a.d->layout.off_cmd_params);
   if (threadIdx.x != 0) return;
   const float r[6] = {r0, r1, r2, r3, r4, r5};
   for (int d = 0; d < 3; ++d) set_range(P, d, r[2 * d], r[2 * d + 1]);
@@ -1182,8 +1313,7 @@ __global__ void lt_set_ranges_kernel(const KArgs a, float r0, float r1, float r2
 
 KArgs make_args(const lt_env* env, const float* actions) {
   KArgs k;
-  k.cfg = env->cfg;
-  k.L = env->layout;
+  k.d = (const lt_dev_args*)((const char*)env->arena + env->layout.off_dev_args);
   k.arena = (char*)env->arena;
   k.actions = actions;
   return k;
@@ -1193,8 +1323,15 @@ template <int MODE>
 int launch_step(const lt_env* env, const float* actions, hipStream_t s) {
   const KArgs k = make_args(env, actions);
   const dim3 grid((unsigned)(env->layout.npad / 16)), block(64);
-  if (env->cfg.task == LT_TASK_LOCOMOTION) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE>), grid, block, 0, s, k);
-  else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE>), grid, block, 0, s, k);
+  // LDS-DMA prefetch of the history rows only where the grid is small enough that LDS does not cap occupancy
+  const bool prefetch = MODE == MODE_STEP && grid.x <= 2 * 256;
+  if (env->cfg.task == LT_TASK_LOCOMOTION) {
+    if (prefetch) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, MODE == MODE_STEP>), grid, block, 0, s, k);
+    else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, false>), grid, block, 0, s, k);
+  } else {
+    if (prefetch) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE, MODE == MODE_STEP>), grid, block, 0, s, k);
+    else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE, false>), grid, block, 0, s, k);
+  }
   return (int)hipGetLastError();
 }
 
@@ -1203,6 +1340,8 @@ int launch_step(const lt_env* env, const float* actions, hipStream_t s) {
 int lt_launch_reset_all(const lt_env* env, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(env->arena, 0, (size_t)env->layout.total_bytes, s);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemcpyAsync((char*)env->arena + env->layout.off_dev_args, &env->dev_args, sizeof(lt_dev_args), hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return (int)e;
   const KArgs k = make_args(env, nullptr);
   hipLaunchKernelGGL(lt_init_params_kernel, dim3(1), dim3(64), 0, s, k);
@@ -1216,7 +1355,7 @@ int lt_launch_step(const lt_env* env, const float* actions, void* stream) {
   int e = launch_step<MODE_STEP>(env, actions, s);
   if (e != 0) return e;
   const KArgs k = make_args(env, actions);
-  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, s, k, 1);
+  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, s, k, 1, 0);
   return (int)hipGetLastError();
 }
 
@@ -1234,7 +1373,7 @@ int lt_launch_step_profiled(lt_env* env, const float* actions, void* stream, flo
   if (rc != 0) return rc;
   if ((e = hipEventRecord((hipEvent_t)env->ev_stop, s)) != hipSuccess) return (int)e;
   const KArgs k = make_args(env, actions);
-  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, s, k, 1);
+  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, s, k, 1, 0);
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   if ((e = hipEventSynchronize((hipEvent_t)env->ev_stop)) != hipSuccess) return (int)e;
   return (int)hipEventElapsedTime(ms, (hipEvent_t)env->ev_start, (hipEvent_t)env->ev_stop);
@@ -1249,9 +1388,7 @@ int lt_launch_eval_terms(const lt_env* env, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // refresh the population gate from the commands currently in the arena, then evaluate the terms
   const KArgs k = make_args(env, nullptr);
-  KArgs k2 = k;
-  k2.cfg.cur_enabled = 0;
-  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, s, k2, 0);
+  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, s, k, 0, 1);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return launch_step<MODE_TERMS>(env, nullptr, s);
@@ -1259,7 +1396,7 @@ int lt_launch_eval_terms(const lt_env* env, void* stream) {
 
 int lt_launch_curriculum(const lt_env* env, void* stream) {
   const KArgs k = make_args(env, nullptr);
-  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, k, 0);
+  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, k, 0, 0);
   return (int)hipGetLastError();
 }
 

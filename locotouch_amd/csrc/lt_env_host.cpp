@@ -44,6 +44,9 @@ int lt_env_create(const lt_cfg* cfg, lt_env** out) {
   if (!e) return LT_ENOMEM;
   e->cfg = *cfg;
   lt_layout_init(&e->layout, cfg->num_envs, lt_cfg_obs_dim(cfg));
+  std::memset(&e->dev_args, 0, sizeof(e->dev_args));
+  e->dev_args.cfg = e->cfg;
+  e->dev_args.layout = e->layout;
   *out = e;
   return LT_OK;
 }

@@ -9,6 +9,7 @@
 struct lt_env {
   lt_cfg cfg;
   lt_layout layout;
+  lt_dev_args dev_args;  // host image of the device-resident (cfg, layout) block
   void* arena = nullptr;   // caller-owned device memory
   size_t arena_bytes = 0;
   void* ev_start = nullptr;  // hipEvent_t pair for lt_env_step_profiled (created lazily)

@@ -1553,6 +1553,13 @@ int lt_oracle_reset_all(const lt_cfg* cfg, void* arena) {
   if (cfg->cur_enabled) { P[24] = 1; P[25] = 1; }
   P[26] = 1;
   counters(arena, &L)[0] = 1;
+  {
+    lt_dev_args da;  /* byte-identical to what the HIP library uploads (tests copy whole arenas between the two) */
+    memset(&da, 0, sizeof(da));
+    da.cfg = *cfg;
+    da.layout = L;
+    memcpy((char*)arena + L.off_dev_args, &da, sizeof(da));
+  }
   return 0;
 }
 

@@ -76,7 +76,7 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
                 failures.append((name, err, np.nonzero(bad)[0][:5].tolist()))
                 event_envs |= set(np.nonzero(bad)[0].tolist())
     for name in L.plain:
-        if name in skip:
+        if name in skip or name.startswith("_"):
             continue
         a, b = L.arr(dev, name), L.arr(ref, name)
         if name in ("LT_F_OBS_POLICY", "LT_F_OBS_CRITIC", "LT_F_REWARD"):
