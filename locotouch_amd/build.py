@@ -52,8 +52,10 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags: list[str]
     #   register moves per physics substep plus 1.3 KB/lane of scratch; scalar f32 code has neither (measured: -35 %).
     # -ffinite-math-only -fno-signed-zeros: lets literal-zero components of the joint offsets fold away; no NaN/Inf
     #   is ever produced on the path (divisions are guarded), and +-0 never changes a result we keep.
+    # -freciprocal-math -fno-math-errno: x/y -> x*rcp(y) and bare v_sqrt (the IEEE division / sqrt expansions were 15 %
+    #   of the physics phase); the ~1 ulp differences sit far inside the stated parity tolerances.
     common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize", "-ffinite-math-only",
-              "-fno-signed-zeros", "-Wall", "-Wno-unused-function",
+              "-fno-signed-zeros", "-freciprocal-math", "-fno-math-errno", "-Wall", "-Wno-unused-function",
               "-I", os.path.join(REPO, "include")] + (extra_flags or [])
     objs = []
     for s in sources():

@@ -161,7 +161,7 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
   const LinkC LC[3] = {make_link<0>(sgn), make_link<1>(sgn), make_link<2>(sgn)};
   float cq[3], sq[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) sincosf(G.q[k], &sq[k], &cq[k]);
+  for (int k = 0; k < 3; ++k) { sq[k] = __sinf(G.q[k]); cq[k] = __cosf(G.q[k]); }  // v_sin/v_cos: |err| ~1e-6 on |q| < 4.6 rad
   const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
   const V3 wb = tmul(R0, B.w), vb = tmul(R0, B.u);
   V3 om[3], vl[3], pw[3], ca[3], cl[3];
