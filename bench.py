@@ -83,13 +83,14 @@ def main() -> None:
     ap.add_argument("--task", default="teacher", choices=list(TASKS))
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager-torch", action="store_true", help="reference-shaped rollout (torch elementwise ops) instead of the fused kernels")
     ap.add_argument("--with-update", action="store_true", help="also report rollout + PPO update (+ all-reduce) throughput")
     args = ap.parse_args()
 
     import torch
 
     from locotouch_amd.env import LocoTouchVecEnv
-    from locotouch_amd.rl import PPO, ActorCritic, Dist
+    from locotouch_amd.rl import PPO, ActorCritic, Dist, FusedRollout
 
     dist = Dist.from_env()
     if dist.world_size != args.gpus:
@@ -105,9 +106,14 @@ def main() -> None:
     obs, extras = env.get_observations()
     critic_obs = extras["observations"]["critic"]
 
+    fused = None if args.eager_torch else FusedRollout(env, alg)
+
     def rollout_steps(k: int) -> None:
         """k consecutive rollout steps starting at storage slot 0 (k <= ROLLOUT)."""
-        alg.storage.clear()
+        if fused is not None:  # policy GEMMs -> lt_rollout_act -> lt_env_step -> lt_rollout_record
+            fused.rollout(k)
+            return
+        alg.storage.clear()  # reference-shaped eager path (every elementwise op its own launch)
         with torch.inference_mode():
             for _ in range(k):
                 actions = alg.act(obs, critic_obs)
@@ -199,7 +205,7 @@ def main() -> None:
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{TASKS[args.task]} rollout (policy act + env step + storage), {n} envs/GPU, "
                                       f"random-init ActorCritic [512,256,128], seed 42+rank",
-                          "envs_per_gpu": n, "rollout_len": ROLLOUT, "hipgraph": graph is not None},
+                          "envs_per_gpu": n, "rollout_len": ROLLOUT, "hipgraph": graph is not None, "fused_rollout": fused is not None},
                "roofline": roofline, "cpu_baseline": cpu}
         out.update(extra)
         print(json.dumps(out))

@@ -281,6 +281,17 @@ int lt_env_curriculum_update(lt_env* env, void* stream);
 int lt_env_get_view(lt_env* env, int field, lt_view* view);
 /* Host-side override of the command block (what `set_ranges` does in the reference; resume workflows). */
 int lt_env_set_command_ranges(lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream);
+/* ---- rollout-side fused kernels (trainer boundary; reference loco_rl/loco_rl/algorithms/ppo.py:129-170 and
+ * loco_rl/loco_rl/storage/rollout_storage.py:79-107).  All pointers are device pointers; stream-ordered, no host sync. ----
+ * lt_rollout_act: a = mu + sigma * N(0,1) (Philox keyed by (seed, env, *step_counter)), log_prob = sum_k log N(a_k; mu_k, sigma_k),
+ * and the storage-slot writes: observation rows [n][obs_dim] (policy and critic), actions / mu / sigma [n][12], values / log_prob [n].
+ * `actions_out` [n][12] is the buffer handed to lt_env_step.  `step_counter` is the env's LT_F_COUNTERS view. */
+int lt_rollout_act(int64_t n, int obs_dim, uint64_t seed, const int64_t* step_counter, const float* mu, const float* std12,
+                   const float* value, const float* obs, const float* critic_obs, float* st_obs, float* st_critic_obs,
+                   float* st_actions, float* st_mu, float* st_sigma, float* st_values, float* st_logp, float* actions_out, void* stream);
+/* lt_rollout_record: st_rewards = reward + gamma * values * time_out (time-limit bootstrap, ppo.py:162-165); st_dones = dones != 0. */
+int lt_rollout_record(int64_t n, float gamma, const float* reward, const int64_t* dones, const uint8_t* time_out, const float* values,
+                      float* st_rewards, uint8_t* st_dones, void* stream);
 /* Device kernel names and static resource usage, for profiling scripts. */
 const char* lt_env_kernel_name(int which);
 

@@ -280,3 +280,54 @@ def test_velocity_curriculum_kernel_matches_reference_golden():
         assert int(p[15]) == int(g["zero_steps"][c]) and abs(p[16] - float(g["rel_standing"][c])) < 1e-7
         assert int(p[17]) == int(g["lin_bins"][c]) and int(p[18]) == int(g["ang_bins"][c]), f"call {c}"
     assert int(p[17]) > 5 and int(p[18]) > 5
+
+
+def test_fused_rollout_kernels_match_torch():
+    """lt_rollout_act / lt_rollout_record against the torch formulas they replace (ppo.py:129-170, rollout_storage.py:79-107)."""
+    import torch
+    from locotouch_amd.rl import PPO, ActorCritic, FusedRollout
+    from tests.rl_synth import POLICY_CFG, PPO_CFG
+
+    n = 4096
+    env = make_env("teacher", n)
+    torch.manual_seed(3)
+    alg = PPO(ActorCritic(348, 348, 12, **POLICY_CFG), device="cuda:0", **PPO_CFG)
+    with torch.no_grad():
+        alg.actor_critic.std.copy_(torch.linspace(0.3, 1.4, 12))
+    alg.init_storage(n, 4, [348], [348], [12])
+    fr = FusedRollout(env, alg)
+    obs0, cobs0 = env.obs_policy.clone(), env.obs_critic.clone()
+    with torch.inference_mode():
+        mu_ref = alg.actor_critic.actor(obs0)
+        v_ref = alg.actor_critic.critic(cobs0)
+    fr.rollout(2)
+    torch.cuda.synchronize()
+    st = alg.storage
+    assert torch.equal(st.observations[0], obs0) and torch.equal(st.privileged_observations[0], cobs0)
+    torch.testing.assert_close(st.mu[0], mu_ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(st.values[0], v_ref, rtol=1e-5, atol=1e-5)
+    std = alg.actor_critic.std.detach()
+    assert torch.equal(st.sigma[0], std.expand(n, 12))
+    z = (st.actions[0] - st.mu[0]) / std
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02 and abs(float((z ** 4).mean()) - 3.0) < 0.15
+    lp = torch.distributions.Normal(st.mu[0], std.expand(n, 12)).log_prob(st.actions[0]).sum(-1, keepdim=True)
+    torch.testing.assert_close(st.actions_log_prob[0], lp, rtol=1e-4, atol=1e-4)
+    assert not torch.equal(st.actions[0], st.actions[1])  # fresh noise every step (device-resident step counter)
+    # record kernel: slot 1 holds the transition of the last env step
+    exp_rew = env.reward_buf + alg.gamma * st.values[1].squeeze(1) * env.time_out_buf.float()
+    torch.testing.assert_close(st.rewards[1].squeeze(1), exp_rew, rtol=1e-6, atol=1e-6)
+    assert torch.equal(st.dones[1].squeeze(1), env.dones_buf.to(torch.uint8))
+    # the fused rollout is hipGraph-capturable and the update consumes its storage unchanged
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fr.rollout(4)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        fr.rollout(4)
+    g.replay()
+    torch.cuda.synchronize()
+    alg.compute_returns(env.obs_critic)
+    losses = alg.update()
+    assert all(np.isfinite(x) for x in losses[:3])
