@@ -183,6 +183,7 @@ class LocoTouchVecEnv:
                 if self.cfg.term_enabled[b]:
                     log[f"Episode_Termination/{name}"] = float(((bits >> b) & 1).float().sum())
             log["Episode/length"] = float(info[mask, 1].mean())
+            log["Episode/reward"] = float(sums[:, : len(REWARD_TERM_NAMES)].sum(1).mean())
         p = self.cmd_params
         log["Metrics/base_velocity/lin_vel_x"] = float(p[1])
         log["Metrics/base_velocity/lin_vel_y"] = float(p[3])

@@ -50,6 +50,7 @@ class OnPolicyRunner:
         obs, critic_obs = obs.to(self.device), critic_obs.to(self.device)
         alg.train_mode()
         n = env.num_envs
+        fused = self._make_fused()
         rew_acc = torch.zeros(n, device=self.device)
         len_acc = torch.zeros(n, device=self.device)
         rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
@@ -57,7 +58,13 @@ class OnPolicyRunner:
         for it in range(start, start + num_learning_iterations):
             t0 = time.time()
             fin_rew, fin_len = [], []
-            with torch.inference_mode():
+            if fused is not None:
+                # GPU path: GEMMs + fused kernels, episode statistics from the env's device-side accumulators
+                fused.rollout(self.num_steps_per_env)
+                with torch.inference_mode():
+                    alg.compute_returns(env.obs_critic)
+            else:
+              with torch.inference_mode():
                 for _ in range(self.num_steps_per_env):
                     actions = alg.act(obs, critic_obs)
                     obs, rewards, dones, infos = env.step(actions.to(env.device))
@@ -76,10 +83,11 @@ class OnPolicyRunner:
             value_loss, surrogate_loss, entropy, _, _ = alg.update()
             t2 = time.time()
             # one host read per iteration for the episode statistics
-            fr, fl = torch.stack(fin_rew).flatten(), torch.stack(fin_len).flatten()
-            keep = ~torch.isnan(fr)
-            rewbuffer.extend(fr[keep].tolist())
-            lenbuffer.extend(fl[keep].tolist())
+            if fin_rew:
+                fr, fl = torch.stack(fin_rew).flatten(), torch.stack(fin_len).flatten()
+                keep = ~torch.isnan(fr)
+                rewbuffer.extend(fr[keep].tolist())
+                lenbuffer.extend(fl[keep].tolist())
             self.current_learning_iteration = it
             collect, learn = t1 - t0, t2 - t1
             steps = self.num_steps_per_env * n * self.dist.world_size
@@ -88,11 +96,14 @@ class OnPolicyRunner:
             rec = {"iter": it, "Perf/total_fps": steps / (collect + learn), "Perf/collection time": collect,
                    "Perf/learning_time": learn, "Loss/value_function": value_loss, "Loss/surrogate": surrogate_loss,
                    "Loss/entropy": entropy, "Loss/learning_rate": alg.learning_rate,
-                   "Policy/mean_noise_std": float(alg.actor_critic.action_std.mean()),
+                   "Policy/mean_noise_std": float(alg.actor_critic.action_std.detach().mean()),
                    "Train/mean_reward": (sum(rewbuffer) / len(rewbuffer)) if rewbuffer else None,
                    "Train/mean_episode_length": (sum(lenbuffer) / len(lenbuffer)) if lenbuffer else None}
             if hasattr(env, "episode_log"):
                 rec.update(env.episode_log())
+                if fused is not None:  # the env's own per-episode accumulators stand in for rewbuffer / lenbuffer
+                    rec["Train/mean_reward"] = rec.get("Episode/reward")
+                    rec["Train/mean_episode_length"] = rec.get("Episode/length")
             self.history.append(rec)
             if self.log_dir is not None:
                 os.makedirs(self.log_dir, exist_ok=True)
@@ -103,6 +114,19 @@ class OnPolicyRunner:
         self.current_learning_iteration = start + num_learning_iterations
         if self.log_dir is not None:
             self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+
+    def _make_fused(self):
+        """FusedRollout when the env is the HIP env on a GPU and the policy is the plain feed-forward ActorCritic."""
+        try:
+            from ..env import LocoTouchVecEnv
+            from .fused import FusedRollout
+        except Exception:
+            return None
+        if not isinstance(self.env, LocoTouchVecEnv) or self.cfg.get("fused_rollout", True) is False:
+            return None
+        if getattr(self.alg.actor_critic, "noise_std_type", "scalar") != "scalar":
+            return None
+        return FusedRollout(self.env, self.alg)
 
     # ---- checkpoints (reference on_policy_runner.py:369-422) -------------------------------------------
     def save(self, path: str, infos=None) -> None:

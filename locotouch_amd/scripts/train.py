@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Train a teacher policy: the reference's `locotouch/scripts/train.py` flow on the MI355X-native env.
+
+    python -m locotouch_amd.scripts.train --task Isaac-RandCylinderTransportTeacher-LocoTouch-v1 --num_envs 4096 --headless
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m locotouch_amd.scripts.train --task ... (one rank per GPU)
+
+Flags follow the reference CLI (locotouch/scripts/cli_args.py:11-33, train.py:17-29); `--headless` / `--video` are accepted
+and ignored (there is no renderer).  Logs: logs/rsl_rl/<experiment>/<timestamp>/{progress.jsonl, model_<it>.pt, params/agent.yaml}.
+"""
+from __future__ import annotations
+
+import argparse
+import datetime
+import os
+
+import torch
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--task", default="Isaac-RandCylinderTransportTeacher-LocoTouch-v1")
+    ap.add_argument("--num_envs", type=int, default=4096)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--max_iterations", type=int, default=None)
+    ap.add_argument("--headless", action="store_true")
+    ap.add_argument("--video", action="store_true")
+    ap.add_argument("--resume", action="store_true")
+    ap.add_argument("--load_run", default=None)
+    ap.add_argument("--checkpoint", default=None)
+    ap.add_argument("--logger", default="tensorboard")
+    ap.add_argument("--log_root", default="logs/rsl_rl")
+    args, _unknown = ap.parse_known_args()  # hydra-style overrides of the reference CLI are tolerated and ignored
+
+    from locotouch_amd.agents import train_cfg
+    from locotouch_amd.env import make
+    from locotouch_amd.rl import Dist, OnPolicyRunner
+
+    dist = Dist.from_env()
+    cfg = train_cfg(args.task)
+    if args.seed is not None:
+        cfg["seed"] = args.seed
+    if args.max_iterations is not None:
+        cfg["max_iterations"] = args.max_iterations
+    device = f"cuda:{dist.local_rank}"
+    torch.cuda.set_device(device)
+    torch.manual_seed(cfg["seed"])
+    env = make(args.task, num_envs=args.num_envs, device=device, seed=cfg["seed"] + dist.rank)
+    log_dir = os.path.join(args.log_root, cfg["experiment_name"], datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S"))
+    runner = OnPolicyRunner(env, cfg, log_dir=log_dir, device=device, dist=dist)
+    if args.resume and args.checkpoint:
+        runner.load(args.checkpoint)
+    if dist.is_main:
+        os.makedirs(os.path.join(log_dir, "params"), exist_ok=True)
+        import yaml
+
+        with open(os.path.join(log_dir, "params", "agent.yaml"), "w") as f:
+            yaml.safe_dump(cfg, f)
+    runner.learn(cfg["max_iterations"], init_at_random_ep_len=True)
+    if dist.is_main and runner.history:
+        last = runner.history[-1]
+        print({k: last[k] for k in ("iter", "Perf/total_fps", "Loss/value_function", "Loss/surrogate", "Loss/learning_rate")})
+    dist.shutdown()
+
+
+if __name__ == "__main__":
+    main()
