@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 1
+#define LT_ABI_VERSION 2
 
 /* error codes */
 #define LT_OK 0
@@ -267,6 +267,15 @@ int lt_env_reset_all(lt_env* env, void* stream);
 /* One ManagerBasedRLEnv.step(): actions float[N][12] (device).  Outputs live in the arena views
  * (OBS_POLICY, OBS_CRITIC, REWARD, DONES, TERMINATED, TIME_OUT). */
 int lt_env_step(lt_env* env, const float* actions, void* stream);
+/* Rollout form of lt_env_step for drivers that keep the observation rows in their own rollout storage
+ * (loco_rl/loco_rl/storage/rollout_storage.py:79-107 copies obs / critic obs into slot t every step): the step kernel reads the previous
+ * rows from (prev_policy, prev_critic) and writes the new ones to (next_policy, next_critic), each float[npad][obs_dim], 16-byte aligned,
+ * e.g. storage slots t and t+1.  NULL = the arena's rows.  Only the step kernel is launched: follow it with lt_env_post_step on any
+ * stream ordered after it and before the next step (curriculum + step counter), which lets the caller overlap that pass. */
+int lt_env_step_rows(lt_env* env, const float* actions, const float* prev_policy, const float* prev_critic, float* next_policy,
+                     float* next_critic, void* stream);
+/* Second half of lt_env_step: curriculum / population gate on this step's records + step-counter increment. */
+int lt_env_post_step(lt_env* env, void* stream);
 /* Profiling variant of lt_env_step: HIP events bracket the step kernel on `stream`; the call WAITS for them (host
  * sync - never use it inside a captured region) and returns the step kernel's duration in milliseconds. */
 int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float* step_kernel_ms);
@@ -284,14 +293,18 @@ int lt_env_set_command_ranges(lt_env* env, const float ranges[6], int zero_steps
 /* ---- rollout-side fused kernels (trainer boundary; reference loco_rl/loco_rl/algorithms/ppo.py:129-170 and
  * loco_rl/loco_rl/storage/rollout_storage.py:79-107).  All pointers are device pointers; stream-ordered, no host sync. ----
  * lt_rollout_act: a = mu + sigma * N(0,1) (Philox keyed by (seed, env, *step_counter)), log_prob = sum_k log N(a_k; mu_k, sigma_k),
- * and the storage-slot writes: observation rows [n][obs_dim] (policy and critic), actions / mu / sigma [n][12], values / log_prob [n].
- * `actions_out` [n][12] is the buffer handed to lt_env_step.  `step_counter` is the env's LT_F_COUNTERS view. */
+ * and the storage-slot writes: actions / mu / sigma [n][12], log_prob [n]; when `obs` is non-NULL also the observation rows
+ * [n][obs_dim] (policy and critic) into (st_obs, st_critic_obs), and when `value` is non-NULL values [n] into st_values (drivers
+ * that use lt_env_step_rows already have the rows in the slot and hand the values to lt_rollout_record instead).
+ * `actions_out` [n][12] is the buffer handed to lt_env_step.  `step_counter`: int64 device scalar (the env's LT_F_COUNTERS view, or
+ * a caller-owned copy of it that lt_rollout_record advances). */
 int lt_rollout_act(int64_t n, int obs_dim, uint64_t seed, const int64_t* step_counter, const float* mu, const float* std12,
                    const float* value, const float* obs, const float* critic_obs, float* st_obs, float* st_critic_obs,
                    float* st_actions, float* st_mu, float* st_sigma, float* st_values, float* st_logp, float* actions_out, void* stream);
-/* lt_rollout_record: st_rewards = reward + gamma * values * time_out (time-limit bootstrap, ppo.py:162-165); st_dones = dones != 0. */
+/* lt_rollout_record: st_rewards = reward + gamma * values * time_out (time-limit bootstrap, ppo.py:162-165); st_dones = dones != 0;
+ * optional: st_values = values (NULL: skip), *bump_counter += 1 (NULL: skip). */
 int lt_rollout_record(int64_t n, float gamma, const float* reward, const int64_t* dones, const uint8_t* time_out, const float* values,
-                      float* st_rewards, uint8_t* st_dones, void* stream);
+                      float* st_rewards, uint8_t* st_dones, float* st_values, int64_t* bump_counter, void* stream);
 /* Device kernel names and static resource usage, for profiling scripts. */
 const char* lt_env_kernel_name(int which);
 

@@ -106,7 +106,9 @@ def load() -> ctypes.CDLL:
                                               ctypes.c_float, ctypes.c_void_p]
     vp = ctypes.c_void_p
     lib.lt_rollout_act.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_uint64] + [vp] * 15
-    lib.lt_rollout_record.argtypes = [ctypes.c_int64, ctypes.c_float] + [vp] * 7
+    lib.lt_rollout_record.argtypes = [ctypes.c_int64, ctypes.c_float] + [vp] * 9
+    lib.lt_env_step_rows.argtypes = [ctypes.c_void_p] + [vp] * 6
+    lib.lt_env_post_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.lt_env_kernel_name.argtypes = [ctypes.c_int]
     lib.lt_env_kernel_name.restype = ctypes.c_char_p
     if lib.lt_cfg_sizeof() != ctypes.sizeof(LtCfg):
@@ -119,7 +121,7 @@ def load() -> ctypes.CDLL:
 
 EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_obs_dim", "lt_env_create",
            "lt_env_destroy", "lt_env_state_bytes", "lt_env_bind", "lt_env_reset_all", "lt_env_step", "lt_env_step_profiled", "lt_env_eval_terms",
-           "lt_env_curriculum_update", "lt_env_get_view", "lt_env_set_command_ranges", "lt_rollout_act", "lt_rollout_record", "lt_env_kernel_name"]
+           "lt_env_curriculum_update", "lt_env_step_rows", "lt_env_post_step", "lt_env_get_view", "lt_env_set_command_ranges", "lt_rollout_act", "lt_rollout_record", "lt_env_kernel_name"]
 
 
 def default_cfg(task: int, num_envs: int | None = None, seed: int | None = None) -> LtCfg:

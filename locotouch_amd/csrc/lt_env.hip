@@ -33,6 +33,10 @@ struct KArgs {
   const lt_dev_args* __restrict__ d;
   char* arena;
   const float* actions;
+  // observation rows [npad][OBS] of the two groups: previous rows (read) and new rows (written).  Equal pointers =
+  // in-place update of the arena rows (lt_env_step); distinct = rollout-storage slots t / t+1 (lt_env_step_rows).
+  const float* obs_prev[2];
+  float* obs_next[2];
 };
 static_assert(sizeof(lt_dev_args) <= LT_DEV_ARGS_BYTES, "lt_dev_args outgrew its arena slot");
 
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
     constexpr int CHUNK16 = 16 * OBS / 4;  // float4 count per group (OBS*16 is a multiple of 4 for both tasks)
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      const float* gsrc = (const float*)(a.arena + (g == 0 ? a.d->layout.off_obs_policy : a.d->layout.off_obs_critic)) + (long long)blockIdx.x * 16 * OBS;
+      const float* gsrc = a.obs_prev[g] + (long long)blockIdx.x * 16 * OBS;
       for (int i = 0; i < (CHUNK16 + 63) / 64; ++i) {
         const int v = i * 64 + threadIdx.x;
         if (v < CHUNK16)
@@ -1026,8 +1030,8 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
       src[i] = s_tab[cc];         // >= 0: old column (one slot newer); < 0: newest frame element -src-1
       frm[i] = s_tab[352 + cc];   // newest-frame element of this column's term (rows that were just reset)
     }
-    float* const rows_p = (float*)(arena + L.off_obs_policy) + (long long)blockIdx.x * 16 * OBS;
-    float* const rows_c = (float*)(arena + L.off_obs_critic) + (long long)blockIdx.x * 16 * OBS;
+    float* const rows_p = a.obs_next[0] + (long long)blockIdx.x * 16 * OBS;
+    float* const rows_c = a.obs_next[1] + (long long)blockIdx.x * 16 * OBS;
     constexpr int RB = 4;  // rows per batch: only LDS reads and fire-and-forget stores, no global load in this tail
     for (int r0 = 0; r0 < 16; r0 += RB) {
       float vp[RB][NCH], vc[RB][NCH];
@@ -1065,8 +1069,10 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
     constexpr int ROWV = OBS / VEC;
     constexpr int TOTAL = 16 * ROWV;
     constexpr int BATCH = 6;
-    float* const rows_p = (float*)(arena + L.off_obs_policy) + (long long)blockIdx.x * 16 * OBS;
-    float* const rows_c = (float*)(arena + L.off_obs_critic) + (long long)blockIdx.x * 16 * OBS;
+    float* const rows_p = a.obs_next[0] + (long long)blockIdx.x * 16 * OBS;
+    float* const rows_c = a.obs_next[1] + (long long)blockIdx.x * 16 * OBS;
+    const float* const old_p = a.obs_prev[0] + (long long)blockIdx.x * 16 * OBS;
+    const float* const old_c = a.obs_prev[1] + (long long)blockIdx.x * 16 * OBS;
     for (int base = 0; base < TOTAL; base += 64 * BATCH) {
       float vp[BATCH][VEC], vc[BATCH][VEC];
 #pragma unroll
@@ -1082,8 +1088,8 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
             const int fidx = s_tab[352 + col];   // newest-frame element of this column's term
             const bool from_frame = fill || sidx < 0;
             const int fi = fill ? fidx : (-sidx - 1);
-            vp[j][e] = from_frame ? s_frame[0][r][fi & 63] : rows_p[r * OBS + sidx];
-            vc[j][e] = from_frame ? s_frame[1][r][fi & 63] : rows_c[r * OBS + sidx];
+            vp[j][e] = from_frame ? s_frame[0][r][fi & 63] : old_p[r * OBS + sidx];
+            vc[j][e] = from_frame ? s_frame[1][r][fi & 63] : old_c[r * OBS + sidx];
           }
         }
       }
@@ -1316,12 +1322,20 @@ KArgs make_args(const lt_env* env, const float* actions) {
   k.d = (const lt_dev_args*)((const char*)env->arena + env->layout.off_dev_args);
   k.arena = (char*)env->arena;
   k.actions = actions;
+  float* const rp = (float*)((char*)env->arena + env->layout.off_obs_policy);
+  float* const rc = (float*)((char*)env->arena + env->layout.off_obs_critic);
+  k.obs_prev[0] = rp; k.obs_prev[1] = rc;
+  k.obs_next[0] = rp; k.obs_next[1] = rc;
   return k;
 }
 
 template <int MODE>
-int launch_step(const lt_env* env, const float* actions, hipStream_t s) {
-  const KArgs k = make_args(env, actions);
+int launch_step(const lt_env* env, const float* actions, hipStream_t s, const float* const* prev = nullptr, float* const* next = nullptr) {
+  KArgs k = make_args(env, actions);
+  for (int g = 0; g < 2; ++g) {
+    if (prev && prev[g]) k.obs_prev[g] = prev[g];
+    if (next && next[g]) k.obs_next[g] = next[g];
+  }
   const dim3 grid((unsigned)(env->layout.npad / 16)), block(64);
   // LDS-DMA prefetch of the history rows only where the grid is small enough that LDS does not cap occupancy
   const bool prefetch = MODE == MODE_STEP && grid.x <= 2 * 256;
@@ -1356,6 +1370,16 @@ int lt_launch_step(const lt_env* env, const float* actions, void* stream) {
   if (e != 0) return e;
   const KArgs k = make_args(env, actions);
   hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, s, k, 1, 0);
+  return (int)hipGetLastError();
+}
+
+int lt_launch_step_rows(const lt_env* env, const float* actions, const float* const prev[2], float* const next[2], void* stream) {
+  return launch_step<MODE_STEP>(env, actions, (hipStream_t)stream, prev, next);
+}
+
+int lt_launch_post_step(const lt_env* env, void* stream) {
+  const KArgs k = make_args(env, nullptr);
+  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, k, 1, 0);
   return (int)hipGetLastError();
 }
 

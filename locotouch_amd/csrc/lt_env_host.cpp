@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <cstdint>
 #include <string>
 
 #include "lt_internal.h"
@@ -120,6 +121,25 @@ int lt_env_step(lt_env* env, const float* actions, void* stream) {
   if (!env || !actions) return LT_EINVAL;
   if (!env->arena) { lt_set_error("lt_env_step: arena not bound"); return LT_EFAULT; }
   return finish(lt_launch_step(env, actions, stream), "lt_env_step");
+}
+
+int lt_env_step_rows(lt_env* env, const float* actions, const float* prev_policy, const float* prev_critic, float* next_policy,
+                     float* next_critic, void* stream) {
+  if (!env || !actions) return LT_EINVAL;
+  if (!env->arena) { lt_set_error("lt_env_step_rows: arena not bound"); return LT_EFAULT; }
+  if (((uintptr_t)prev_policy | (uintptr_t)prev_critic | (uintptr_t)next_policy | (uintptr_t)next_critic) & 15) {
+    lt_set_error("lt_env_step_rows: observation rows must be 16-byte aligned");
+    return LT_EINVAL;
+  }
+  const float* prev[2] = {prev_policy, prev_critic};
+  float* next[2] = {next_policy, next_critic};
+  return finish(lt_launch_step_rows(env, actions, prev, next, stream), "lt_env_step_rows");
+}
+
+int lt_env_post_step(lt_env* env, void* stream) {
+  if (!env) return LT_EINVAL;
+  if (!env->arena) { lt_set_error("lt_env_post_step: arena not bound"); return LT_EFAULT; }
+  return finish(lt_launch_post_step(env, stream), "lt_env_post_step");
 }
 
 int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float* step_kernel_ms) {

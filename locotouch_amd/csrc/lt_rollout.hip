@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void lt_rollout_act_kernel(const ActArgs a) {
   const long long e0 = (long long)blockIdx.x * ENVS_PER_BLOCK;
   const int tid = threadIdx.x;
   // ---- observation rows -> storage slot (coalesced VEC-wide copies; the block's rows are contiguous) ----
-  {
+  if (a.obs) {
     const long long nrows = (a.n - e0) < ENVS_PER_BLOCK ? (a.n - e0) : ENVS_PER_BLOCK;
     const long long nvec = nrows * a.obs_dim / VEC;
     const long long base = e0 * a.obs_dim;
@@ -79,16 +79,20 @@ __global__ __launch_bounds__(256) void lt_rollout_act_kernel(const ActArgs a) {
     lp += __shfl_xor(lp, 8, 64); lp += __shfl_xor(lp, 4, 64); lp += __shfl_xor(lp, 2, 64); lp += __shfl_xor(lp, 1, 64);
     if (k == 0 && e < a.n) {
       a.st_logp[e] = lp;
-      a.st_values[e] = a.value[e];
+      if (a.value) a.st_values[e] = a.value[e];
     }
   }
 }
 
 __global__ void lt_rollout_record_kernel(long long n, float gamma, const float* reward, const long long* dones, const unsigned char* time_out,
-                                         const float* values, float* st_rewards, unsigned char* st_dones) {
+                                         const float* values, float* st_rewards, unsigned char* st_dones, float* st_values,
+                                         long long* bump_counter) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0 && bump_counter) bump_counter[0] += 1;  // the only writer; every reader is a later launch on the same stream
   if (e >= n) return;
-  st_rewards[e] = reward[e] + (time_out[e] ? gamma * values[e] : 0.f);
+  const float v = values[e];
+  if (st_values) st_values[e] = v;
+  st_rewards[e] = reward[e] + (time_out[e] ? gamma * v : 0.f);
   st_dones[e] = dones[e] != 0 ? 1 : 0;
 }
 
@@ -99,8 +103,10 @@ extern "C" {
 int lt_rollout_act(int64_t n, int obs_dim, uint64_t seed, const int64_t* step_counter, const float* mu, const float* std12,
                    const float* value, const float* obs, const float* critic_obs, float* st_obs, float* st_critic_obs, float* st_actions,
                    float* st_mu, float* st_sigma, float* st_values, float* st_logp, float* actions_out, void* stream) {
-  if (n <= 0 || obs_dim <= 0 || (obs_dim & 1) || !step_counter || !mu || !std12 || !value || !obs || !critic_obs || !st_obs ||
-      !st_critic_obs || !st_actions || !st_mu || !st_sigma || !st_values || !st_logp || !actions_out) {
+  const bool rows_ok = !obs || (critic_obs && st_obs && st_critic_obs);
+  const bool value_ok = !value || st_values;
+  if (n <= 0 || obs_dim <= 0 || (obs_dim & 1) || !step_counter || !mu || !std12 || !rows_ok || !value_ok || !st_actions || !st_mu ||
+      !st_sigma || !st_logp || !actions_out) {
     lt_set_error("lt_rollout_act: invalid argument");
     return LT_EINVAL;
   }
@@ -118,13 +124,13 @@ int lt_rollout_act(int64_t n, int obs_dim, uint64_t seed, const int64_t* step_co
 }
 
 int lt_rollout_record(int64_t n, float gamma, const float* reward, const int64_t* dones, const uint8_t* time_out, const float* values,
-                      float* st_rewards, uint8_t* st_dones, void* stream) {
+                      float* st_rewards, uint8_t* st_dones, float* st_values, int64_t* bump_counter, void* stream) {
   if (n <= 0 || !reward || !dones || !time_out || !values || !st_rewards || !st_dones) {
     lt_set_error("lt_rollout_record: invalid argument");
     return LT_EINVAL;
   }
   hipLaunchKernelGGL(lt_rollout_record_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n, gamma,
-                     reward, (const long long*)dones, time_out, values, st_rewards, st_dones);
+                     reward, (const long long*)dones, time_out, values, st_rewards, st_dones, st_values, (long long*)bump_counter);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;

@@ -145,6 +145,16 @@ class LocoTouchVecEnv:
         """Launch-only variant for captured (hipGraph) rollouts: no tensor bookkeeping on the host."""
         _abi.check(self._lib.lt_env_step(self._handle, ctypes.c_void_p(actions_ptr), self._stream()), "lt_env_step")
 
+    def step_rows_raw(self, actions_ptr: int, prev_policy: int, prev_critic: int, next_policy: int, next_critic: int) -> None:
+        """lt_env_step_rows: step kernel only, observation rows read from / written to caller storage (0 = arena rows)."""
+        vp = ctypes.c_void_p
+        _abi.check(self._lib.lt_env_step_rows(self._handle, vp(actions_ptr), vp(prev_policy or None), vp(prev_critic or None),
+                                              vp(next_policy or None), vp(next_critic or None), self._stream()), "lt_env_step_rows")
+
+    def post_step_raw(self) -> None:
+        """lt_env_post_step on the current stream (curriculum + step counter); pairs with step_rows_raw."""
+        _abi.check(self._lib.lt_env_post_step(self._handle, self._stream()), "lt_env_post_step")
+
     def step_profiled(self, actions: torch.Tensor) -> float:
         """lt_env_step with HIP events around the step kernel; returns its duration in ms (host-syncing)."""
         ms = ctypes.c_float()

@@ -16,6 +16,17 @@ from .. import _abi
 
 
 class FusedRollout:
+    """Stream plan of one step t (main = the caller's current stream, all joins by events, so the rollout captures):
+
+        main : actor(obs[t]) -> lt_rollout_act -> [join post(t-1)] lt_env_step_rows(obs[t] -> obs[t+1]) -> [join critic] lt_rollout_record
+        side : critic(obs_c[t])                                  (beside the actor GEMMs and the env step kernel)
+        post :                                                   lt_env_post_step(t)   (beside record and the next actor GEMMs)
+
+    The env writes observation rows straight into the storage slots (slot t+1 from slot t; the last step writes the arena
+    rows), so nothing copies observations.  The lone-wave-per-CU step kernel leaves 3 of 4 SIMDs idle at 4096 envs - the
+    critic GEMMs run there.
+    """
+
     def __init__(self, env, alg):
         from ..env import LocoTouchVecEnv
 
@@ -28,36 +39,69 @@ class FusedRollout:
         self.device = env.device
         self.actions = torch.zeros(env.num_envs, 12, device=self.device)
         self.side = torch.cuda.Stream(device=self.device)
-        self._step_counter = env.counters  # int64[4] view; [0] = common step counter (device-resident RNG key)
+        self.post = torch.cuda.Stream(device=self.device)
+        # policy-noise RNG key: a copy of the env's common step counter (refreshed at every rollout start, advanced by
+        # lt_rollout_record) so that lt_rollout_act never has to wait for the overlapped post kernel
+        self._act_counter = env.counters[:1].clone()
+        # rows written in place into the storage need whole 16-env wave tiles (npad == n)
+        self.rows_in_storage = env.num_envs % 16 == 0
 
     @staticmethod
     def _p(t: torch.Tensor) -> ctypes.c_void_p:
         return ctypes.c_void_p(t.data_ptr())
 
-    def step(self, t: int) -> None:
+    def step(self, t: int, last: bool) -> None:
         env, alg, st, p = self.env, self.alg, self.alg.storage, self._p
         ac = alg.actor_critic
         main = torch.cuda.current_stream(self.device)
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            value = ac.critic(env.obs_critic)
-        mu = ac.actor(env.obs_policy)
-        main.wait_stream(self.side)
-        value.record_stream(main)
         stream = ctypes.c_void_p(main.cuda_stream)
         n = env.num_envs
-        _abi.check(self.lib.lt_rollout_act(n, env.num_obs, int(env.cfg.seed), p(self._step_counter), p(mu), p(ac.std.data), p(value),
-                                           p(env.obs_policy), p(env.obs_critic), p(st.observations[t]), p(st.privileged_observations[t]),
-                                           p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), p(st.values[t]), p(st.actions_log_prob[t]),
-                                           p(self.actions), stream), "lt_rollout_act")
-        env.step_raw(self.actions.data_ptr())
-        _abi.check(self.lib.lt_rollout_record(n, float(alg.gamma), p(env.reward_buf), p(env.dones_buf), p(env.time_out_buf), p(st.values[t]),
-                                              p(st.rewards[t]), p(st.dones[t]), stream), "lt_rollout_record")
+        null = ctypes.c_void_p(None)
+        if self.rows_in_storage:
+            obs, cobs = st.observations[t], st.privileged_observations[t]
+        else:
+            obs, cobs = env.obs_policy, env.obs_critic
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            value = ac.critic(cobs)
+        mu = ac.actor(obs)
+        if self.rows_in_storage:
+            _abi.check(self.lib.lt_rollout_act(n, env.num_obs, int(env.cfg.seed), p(self._act_counter), p(mu), p(ac.std.data), null,
+                                               null, null, null, null, p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), null,
+                                               p(st.actions_log_prob[t]), p(self.actions), stream), "lt_rollout_act")
+        else:
+            _abi.check(self.lib.lt_rollout_act(n, env.num_obs, int(env.cfg.seed), p(self._act_counter), p(mu), p(ac.std.data), null,
+                                               p(obs), p(cobs), p(st.observations[t]), p(st.privileged_observations[t]),
+                                               p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), null, p(st.actions_log_prob[t]),
+                                               p(self.actions), stream), "lt_rollout_act")
+        main.wait_stream(self.post)  # previous step's curriculum pass / counter increment
+        if self.rows_in_storage and not last:
+            env.step_rows_raw(self.actions.data_ptr(), obs.data_ptr(), cobs.data_ptr(), st.observations[t + 1].data_ptr(),
+                              st.privileged_observations[t + 1].data_ptr())
+        elif self.rows_in_storage:
+            env.step_rows_raw(self.actions.data_ptr(), obs.data_ptr(), cobs.data_ptr(), 0, 0)
+        else:
+            env.step_rows_raw(self.actions.data_ptr(), 0, 0, 0, 0)
+        self.post.wait_stream(main)
+        with torch.cuda.stream(self.post):
+            env.post_step_raw()
+        main.wait_stream(self.side)
+        value.record_stream(main)
+        _abi.check(self.lib.lt_rollout_record(n, float(alg.gamma), p(env.reward_buf), p(env.dones_buf), p(env.time_out_buf), p(value),
+                                              p(st.rewards[t]), p(st.dones[t]), p(st.values[t]), p(self._act_counter), stream),
+                   "lt_rollout_record")
         st.step = t + 1
 
     def rollout(self, num_steps: int) -> None:
         """`num_steps` consecutive steps into storage slots 0.. (inference mode, capturable)."""
-        self.alg.storage.clear()
+        env, st = self.env, self.alg.storage
+        st.clear()
+        main = torch.cuda.current_stream(self.device)
         with torch.inference_mode():
+            self._act_counter.copy_(env.counters[:1])
+            if self.rows_in_storage:
+                st.observations[0].copy_(env.obs_policy)
+                st.privileged_observations[0].copy_(env.obs_critic)
             for t in range(num_steps):
-                self.step(t)
+                self.step(t, last=t == num_steps - 1)
+            main.wait_stream(self.post)  # joins the forked streams (required at the end of a capture)

@@ -300,9 +300,18 @@ def test_fused_rollout_kernels_match_torch():
     with torch.inference_mode():
         mu_ref = alg.actor_critic.actor(obs0)
         v_ref = alg.actor_critic.critic(cobs0)
-    fr.rollout(2)
+    fr.rollout(3)
     torch.cuda.synchronize()
     st = alg.storage
+    # rows written straight into the storage slots == the in-place path of lt_env_step on a twin env, bit for bit
+    twin = make_env("teacher", n)
+    for t in range(3):
+        o, r, d, _ = twin.step(st.actions[t].clone())
+        nxt_p = st.observations[t + 1] if t < 2 else env.obs_policy
+        nxt_c = st.privileged_observations[t + 1] if t < 2 else env.obs_critic
+        assert torch.equal(o, nxt_p) and torch.equal(twin.obs_critic, nxt_c), f"step {t}"
+        assert torch.equal(d.to(torch.uint8), st.dones[t].squeeze(1))
+    assert torch.equal(twin.counters, env.counters) and torch.equal(twin.cmd_params, env.cmd_params)
     assert torch.equal(st.observations[0], obs0) and torch.equal(st.privileged_observations[0], cobs0)
     torch.testing.assert_close(st.mu[0], mu_ref, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(st.values[0], v_ref, rtol=1e-5, atol=1e-5)
@@ -313,10 +322,10 @@ def test_fused_rollout_kernels_match_torch():
     lp = torch.distributions.Normal(st.mu[0], std.expand(n, 12)).log_prob(st.actions[0]).sum(-1, keepdim=True)
     torch.testing.assert_close(st.actions_log_prob[0], lp, rtol=1e-4, atol=1e-4)
     assert not torch.equal(st.actions[0], st.actions[1])  # fresh noise every step (device-resident step counter)
-    # record kernel: slot 1 holds the transition of the last env step
-    exp_rew = env.reward_buf + alg.gamma * st.values[1].squeeze(1) * env.time_out_buf.float()
-    torch.testing.assert_close(st.rewards[1].squeeze(1), exp_rew, rtol=1e-6, atol=1e-6)
-    assert torch.equal(st.dones[1].squeeze(1), env.dones_buf.to(torch.uint8))
+    # record kernel: slot 2 holds the transition of the last env step
+    exp_rew = env.reward_buf + alg.gamma * st.values[2].squeeze(1) * env.time_out_buf.float()
+    torch.testing.assert_close(st.rewards[2].squeeze(1), exp_rew, rtol=1e-6, atol=1e-6)
+    assert torch.equal(st.dones[2].squeeze(1), env.dones_buf.to(torch.uint8))
     # the fused rollout is hipGraph-capturable and the update consumes its storage unchanged
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
