@@ -305,6 +305,28 @@ int lt_rollout_act(int64_t n, int obs_dim, uint64_t seed, const int64_t* step_co
  * optional: st_values = values (NULL: skip), *bump_counter += 1 (NULL: skip). */
 int lt_rollout_record(int64_t n, float gamma, const float* reward, const int64_t* dones, const uint8_t* time_out, const float* values,
                       float* st_rewards, uint8_t* st_dones, float* st_values, int64_t* bump_counter, void* stream);
+/* ---- fused fp32 MLP inference (actor / critic evaluation inside the rollout loop; reference
+ * loco_rl/loco_rl/modules/actor_critic.py:113-131: self.actor(obs), self.critic(critic_obs) - Linear layers with one activation between).
+ * One launch per network on the f32-input MFMA; weights are re-packed from the torch.nn.Linear layout once per policy update. ---- */
+#define LT_MLP_MAX_LAYERS 6
+#define LT_MLP_MAX_WIDTH 1008
+enum lt_activation { LT_ACT_NONE = 0, LT_ACT_ELU = 1, LT_ACT_RELU = 2, LT_ACT_TANH = 3 };
+typedef struct lt_mlp_desc {
+  int32_t num_layers;                   /* Linear layers */
+  int32_t dims[LT_MLP_MAX_LAYERS + 1];  /* dims[0] = input width (<= LT_MLP_MAX_WIDTH), dims[l+1] = outputs of layer l (<= 512) */
+  int32_t activation;                   /* lt_activation between layers (none after the last) */
+} lt_mlp_desc;
+/* Floats of the packed parameter buffer of a network. */
+int lt_mlp_packed_floats(const lt_mlp_desc* desc, size_t* floats);
+/* weights[l]: float[dims[l+1]][dims[l]] (row-major, torch.nn.Linear.weight), biases[l]: float[dims[l+1]]; device pointers in a HOST array. */
+int lt_mlp_pack(const lt_mlp_desc* desc, const float* const* weights, const float* const* biases, float* packed, void* stream);
+/* y[m][dims[L]] = MLP(x[m][dims[0]]). */
+int lt_mlp_forward(const lt_mlp_desc* desc, const float* packed, const float* x, int64_t m, float* y, void* stream);
+/* Actor forward + the sampling / log-prob / storage-slot writes of lt_rollout_act in one launch (the policy head must have 12 outputs).
+ * Philox key step = *step_counter + step_offset. */
+int lt_rollout_policy(const lt_mlp_desc* actor, const float* packed, const float* obs, int64_t n, uint64_t seed, const int64_t* step_counter,
+                      int64_t step_offset, const float* std12, float* st_actions, float* st_mu, float* st_sigma, float* st_logp,
+                      float* actions_out, void* stream);
 /* Device kernel names and static resource usage, for profiling scripts. */
 const char* lt_env_kernel_name(int which);
 

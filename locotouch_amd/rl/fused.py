@@ -27,7 +27,7 @@ class FusedRollout:
     critic GEMMs run there.
     """
 
-    def __init__(self, env, alg):
+    def __init__(self, env, alg, use_packed_mlp: bool = True):
         from ..env import LocoTouchVecEnv
 
         if not isinstance(env, LocoTouchVecEnv):
@@ -45,6 +45,13 @@ class FusedRollout:
         self._act_counter = env.counters[:1].clone()
         # rows written in place into the storage need whole 16-env wave tiles (npad == n)
         self.rows_in_storage = env.num_envs % 16 == 0
+        # single-launch MLPs (lt_mlp.hip) when the stacks fit its shape limits, else the torch modules
+        self.actor_mlp = self.critic_mlp = None
+        if use_packed_mlp:
+            from .mlp import PackedMLP, describe
+
+            if describe(ac.actor) is not None and describe(ac.critic) is not None and env.num_actions == 12:
+                self.actor_mlp, self.critic_mlp = PackedMLP(ac.actor), PackedMLP(ac.critic)
 
     @staticmethod
     def _p(t: torch.Tensor) -> ctypes.c_void_p:
@@ -61,19 +68,27 @@ class FusedRollout:
             obs, cobs = st.observations[t], st.privileged_observations[t]
         else:
             obs, cobs = env.obs_policy, env.obs_critic
+        if self.actor_mlp is not None:
+            # actor MLP + sampling + log-prob + storage writes: one launch
+            if not self.rows_in_storage:
+                st.observations[t].copy_(obs)
+                st.privileged_observations[t].copy_(cobs)
+            _abi.check(self.lib.lt_rollout_policy(ctypes.byref(self.actor_mlp.desc), p(self.actor_mlp.packed), p(obs), n, int(env.cfg.seed),
+                                                  p(self._act_counter), t, p(ac.std.data), p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]),
+                                                  p(st.actions_log_prob[t]), p(self.actions), stream), "lt_rollout_policy")
+        else:
+            mu = ac.actor(obs)
+            rows = (null, null, null, null) if self.rows_in_storage else (p(obs), p(cobs), p(st.observations[t]), p(st.privileged_observations[t]))
+            _abi.check(self.lib.lt_rollout_act(n, env.num_obs, int(env.cfg.seed), p(self._act_counter), p(mu), p(ac.std.data), null,
+                                               *rows, p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), null,
+                                               p(st.actions_log_prob[t]), p(self.actions), stream), "lt_rollout_act")
+        # the critic runs beside the env step kernel (a lone wave per CU leaves 3 of 4 SIMDs idle at 4096 envs)
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
-            value = ac.critic(cobs)
-        mu = ac.actor(obs)
-        if self.rows_in_storage:
-            _abi.check(self.lib.lt_rollout_act(n, env.num_obs, int(env.cfg.seed), p(self._act_counter), p(mu), p(ac.std.data), null,
-                                               null, null, null, null, p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), null,
-                                               p(st.actions_log_prob[t]), p(self.actions), stream), "lt_rollout_act")
-        else:
-            _abi.check(self.lib.lt_rollout_act(n, env.num_obs, int(env.cfg.seed), p(self._act_counter), p(mu), p(ac.std.data), null,
-                                               p(obs), p(cobs), p(st.observations[t]), p(st.privileged_observations[t]),
-                                               p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), null, p(st.actions_log_prob[t]),
-                                               p(self.actions), stream), "lt_rollout_act")
+            if self.critic_mlp is not None:
+                value = self.critic_mlp(cobs)
+            else:
+                value = ac.critic(cobs)
         main.wait_stream(self.post)  # previous step's curriculum pass / counter increment
         if self.rows_in_storage and not last:
             env.step_rows_raw(self.actions.data_ptr(), obs.data_ptr(), cobs.data_ptr(), st.observations[t + 1].data_ptr(),
@@ -88,7 +103,7 @@ class FusedRollout:
         main.wait_stream(self.side)
         value.record_stream(main)
         _abi.check(self.lib.lt_rollout_record(n, float(alg.gamma), p(env.reward_buf), p(env.dones_buf), p(env.time_out_buf), p(value),
-                                              p(st.rewards[t]), p(st.dones[t]), p(st.values[t]), p(self._act_counter), stream),
+                                              p(st.rewards[t]), p(st.dones[t]), p(st.values[t]), null if self.actor_mlp is not None else p(self._act_counter), stream),
                    "lt_rollout_record")
         st.step = t + 1
 
@@ -99,6 +114,9 @@ class FusedRollout:
         main = torch.cuda.current_stream(self.device)
         with torch.inference_mode():
             self._act_counter.copy_(env.counters[:1])
+            if self.actor_mlp is not None:  # the optimizer has stepped since the last rollout
+                self.actor_mlp.pack()
+                self.critic_mlp.pack()
             if self.rows_in_storage:
                 st.observations[0].copy_(env.obs_policy)
                 st.privileged_observations[0].copy_(env.obs_critic)

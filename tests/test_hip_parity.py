@@ -365,3 +365,69 @@ def test_training_loop_runs_and_checkpoints(tmp_path):
     runner2.load(ck)
     for a, b in zip(runner.alg.actor_critic.parameters(), runner2.alg.actor_critic.parameters()):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dims,act,m", [((348, 512, 256, 128, 12), "elu", 4096), ((348, 512, 256, 128, 1), "elu", 1000),
+                                        ((45, 64, 64, 7), "relu", 37), ((270, 256, 128, 128, 12), "tanh", 50), ((33, 20), "elu", 16)])
+def test_fused_mlp_matches_torch(dims, act, m):
+    """lt_mlp_forward (f32-input MFMA, one launch) against the torch fp32 modules it replaces; tolerance 2e-5 * scale
+    (both are fp32 accumulations, only the summation order differs)."""
+    import torch
+    from locotouch_amd.rl.mlp import PackedMLP
+    from locotouch_amd.rl.modules import build_mlp
+
+    torch.manual_seed(5)
+    seq = build_mlp(dims[0], list(dims[1:-1]), dims[-1], act).to("cuda:0")
+    with torch.no_grad():
+        for p in seq.parameters():
+            p.mul_(2.0)  # livelier activations than the default init
+    x = torch.randn(m, dims[0], device="cuda:0") * 1.5
+    with torch.inference_mode():
+        ref = seq(x)
+        ref64 = seq.double()(x.double())
+    seq.float()
+    net = PackedMLP(seq)
+    y = net(x)
+    torch.cuda.synchronize()
+    scale = float(ref64.abs().max()) + 1.0
+    err = float((y.double() - ref64).abs().max())
+    err_torch = float((ref.double() - ref64).abs().max())
+    assert err < 2e-5 * scale, (err, err_torch)
+    assert err < 4 * err_torch + 1e-6 * scale  # no worse than torch's own fp32 error by more than a small factor
+    # parameters change -> pack() picks them up
+    with torch.no_grad():
+        for p in seq.parameters():
+            p.add_(0.01)
+    net.pack()
+    with torch.inference_mode():
+        torch.testing.assert_close(net(x), seq(x), rtol=2e-5, atol=2e-5 * scale)
+
+
+def test_fused_policy_kernel_matches_act_kernel():
+    """lt_rollout_policy (actor MLP + sampling in one launch) against actor GEMMs + lt_rollout_act on a twin env."""
+    import torch
+    from locotouch_amd.rl import PPO, ActorCritic, FusedRollout
+    from tests.rl_synth import POLICY_CFG, PPO_CFG
+
+    n = 1024
+    outs = []
+    for packed in (True, False):
+        env = make_env("teacher", n)
+        torch.manual_seed(3)
+        alg = PPO(ActorCritic(348, 348, 12, **POLICY_CFG), device="cuda:0", **PPO_CFG)
+        alg.init_storage(n, 3, [348], [348], [12])
+        fr = FusedRollout(env, alg, use_packed_mlp=packed)
+        assert (fr.actor_mlp is not None) == packed
+        fr.rollout(3)
+        torch.cuda.synchronize()
+        outs.append(alg.storage)
+    a, b = outs
+    # step 0 sees identical observations; later steps diverge only through ~1e-6 action differences
+    torch.testing.assert_close(a.mu[0], b.mu[0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a.actions[0], b.actions[0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a.actions_log_prob[0], b.actions_log_prob[0], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(a.values[0], b.values[0], rtol=1e-5, atol=1e-5)
+    assert torch.equal(a.sigma[0], b.sigma[0])
+    assert not torch.equal(a.actions[1] - a.mu[1], a.actions[0] - a.mu[0])  # fresh noise per step (counter + t keying)
+    z_a, z_b = (a.actions[2] - a.mu[2]), (b.actions[2] - b.mu[2])
+    torch.testing.assert_close(z_a, z_b, rtol=1e-4, atol=1e-5)  # same Philox draws at step 2 in both paths
