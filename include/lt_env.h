@@ -327,6 +327,12 @@ int lt_mlp_forward(const lt_mlp_desc* desc, const float* packed, const float* x,
 int lt_rollout_policy(const lt_mlp_desc* actor, const float* packed, const float* obs, int64_t n, uint64_t seed, const int64_t* step_counter,
                       int64_t step_offset, const float* std12, float* st_actions, float* st_mu, float* st_sigma, float* st_logp,
                       float* actions_out, void* stream);
+/* lt_rollout_policy plus the critic forward (values[n] = critic(critic_obs)) in the SAME launch: the two networks' workgroups share
+ * the chip, which hides each other's pipeline bubbles and leaves the env step kernel alone on the GPU afterwards. */
+int lt_rollout_policy_value(const lt_mlp_desc* actor, const float* actor_packed, const float* obs, const lt_mlp_desc* critic,
+                            const float* critic_packed, const float* critic_obs, float* values, int64_t n, uint64_t seed,
+                            const int64_t* step_counter, int64_t step_offset, const float* std12, float* st_actions, float* st_mu,
+                            float* st_sigma, float* st_logp, float* actions_out, void* stream);
 /* Device kernel names and static resource usage, for profiling scripts. */
 const char* lt_env_kernel_name(int which);
 

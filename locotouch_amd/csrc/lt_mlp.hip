@@ -2,7 +2,8 @@
 //
 // Reference: the policy evaluation inside the rollout loop, loco_rl/loco_rl/modules/actor_critic.py:113-131
 // (`act` -> update_distribution -> self.actor(obs); `evaluate` -> self.critic(obs)) - four Linear layers with ELU between,
-// which PyTorch runs as 4 GEMM launches + 3 activation launches per network and step.  Here the whole network is ONE launch:
+// which PyTorch runs as 4 GEMM launches + 3 activation launches per network and step.  Here a whole network - or the actor
+// and the critic side by side - is ONE launch:
 //
 //   * a workgroup (4 waves) owns 16 batch rows; their activations live in LDS ([16][S] floats, S = widest layer + 4 so that
 //     the 16 rows of a ds_read_b128 / ds_write_b128 phase fall on distinct banks) and never visit HBM between layers;
@@ -10,15 +11,17 @@
 //     tile is the A operand (16 output features x 4 k), the activations are the B operand (4 k x 16 rows), so a lane ends
 //     up with 4 CONSECUTIVE output features of ONE row -> the next layer's input is written back with one ds_write_b128;
 //   * each wave owns T = N/64 output tiles (independent accumulators -> the 40-cycle dependent MFMA latency never shows);
-//   * weights are pre-packed once per policy update (lt_mlp_pack) into the exact per-lane operand order
-//     [tile][k-group of 16][lane][4], so every wave-instruction of the weight stream is one fully coalesced 1-KiB
-//     global_load_dwordx4 that feeds 4 MFMAs; PF groups are kept in flight per wave (register ring) to cover L2 latency.
-//     All workgroups stream the same 1.4 MB, which stays L2-resident.
 //   * k inside a 16-group is permuted (lane quarter q takes k = 16g + 4q + i for MFMA i) - a summation-index relabelling
-//     applied to both operands - which is what makes both operand fetches 16-byte vectors.
+//     applied to both operands - which is what makes both operand fetches 16-byte vectors;
+//   * the parameters are pre-packed once per policy update (lt_mlp_pack) into ONE LINEAR STREAM PER WAVE of 1-KiB chunks
+//     (64 lanes x float4) in exactly the order the wave consumes them, across layers: [bias chunks of layer 0][weight
+//     chunks g-major, tile-minor][pad to 16]...[layer 1]...  The kernel keeps a 16-chunk register ring per wave and refills
+//     a slot right after its MFMAs, so 16 KiB per wave are always in flight and the first weights of layer l+1 are already
+//     on their way while layer l finishes - no pipeline restart at layer boundaries.  Every wave-instruction of the stream
+//     is one fully coalesced global_load_dwordx4; all workgroups stream the same ~1.4 MB, which stays L2-resident.
 //
-// MODE_POLICY adds the sampling epilogue of lt_rollout_act (a = mu + sigma N(0,1), log-prob, storage-slot writes) to the
-// last layer, so the actor side of a rollout step is a single launch.
+// The policy network's last layer carries the sampling epilogue of lt_rollout_act (a = mu + sigma N(0,1), log-prob,
+// storage-slot writes), so the actor side of a rollout step needs no further launch.
 #include <hip/hip_runtime.h>
 
 #include "lt_device_math.h"
@@ -31,18 +34,33 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROWS = 16;
+constexpr int RING = 16;               // chunks in flight per wave
 constexpr unsigned RS_POLICY = 0x400;  // same Philox stream id as lt_rollout_act
 constexpr int MODE_FORWARD = 0, MODE_POLICY = 1;
 
 __host__ __device__ inline int pad16(int x) { return (x + 15) & ~15; }
+// Tiles per wave of a layer with `ntiles` 16-feature output tiles: the smallest of {1, 2, 4, 8} that covers ntiles with 4 waves.
+__host__ __device__ inline int tiles_per_wave(int ntiles) {
+  const int per = (ntiles + 3) >> 2;
+  return per > 4 ? 8 : (per > 2 ? 4 : (per > 1 ? 2 : 1));
+}
+// chunks of one layer in the stream of an ACTIVE wave: T bias chunks + G*T weight chunks, padded to whole rings
+__host__ __device__ inline int layer_chunks(int K, int N) {
+  const int T = tiles_per_wave(pad16(N) / 16), G = pad16(K) / 16;
+  return (T * (G + 1) + RING - 1) / RING * RING;
+}
+__host__ __device__ inline int active_waves(int N) {
+  const int nt = pad16(N) / 16, T = tiles_per_wave(nt);
+  return (nt + T - 1) / T;
+}
 
 struct MlpArgs {
   int L;
   int dims[LT_MLP_MAX_LAYERS + 1];
   int activation;
-  long long woff[LT_MLP_MAX_LAYERS];  // float offsets into `packed`
-  long long boff[LT_MLP_MAX_LAYERS];
-  int stride;                         // LDS row stride in floats
+  int mode;
+  int stride;                 // LDS row stride in floats
+  long long wave_base[4];     // chunk offset of each wave's stream inside `packed`
   const float* packed;
   const float* x;
   long long m;
@@ -54,133 +72,110 @@ struct MlpArgs {
   const float* std12;
   float* st_actions; float* st_mu; float* st_sigma; float* st_logp; float* actions_out;
 };
+struct DualArgs {
+  MlpArgs net[2];
+  int split;  // blocks [0, split) run net[0], the rest net[1]
+};
 
-__device__ __forceinline__ float activate(float x, int kind) {
-  if (kind == LT_ACT_ELU) return x > 0.f ? x : expf(x) - 1.f;
-  if (kind == LT_ACT_RELU) return x > 0.f ? x : 0.f;
-  if (kind == LT_ACT_TANH) return tanhf(x);
+template <int KIND>
+__device__ __forceinline__ float activate(float x) {
+  if (KIND == LT_ACT_ELU) return x > 0.f ? x : __expf(x) - 1.f;  // |abs err| ~1e-7 (v_exp_f32), far inside the parity tolerance
+  if (KIND == LT_ACT_RELU) return x > 0.f ? x : 0.f;
+  if (KIND == LT_ACT_TANH) return tanhf(x);
   return x;
 }
-
-// Tiles per wave of a layer with `ntiles` 16-feature output tiles: the smallest of {1, 2, 4, 8} that covers ntiles with 4 waves.
-__host__ __device__ inline int tiles_per_wave(int ntiles) {
-  const int per = (ntiles + 3) >> 2;
-  return per > 4 ? 8 : (per > 2 ? 4 : (per > 1 ? 2 : 1));
+// activation + write-back of a wave's T output tiles as the next layer's input (KIND is a compile-time constant per call
+// site: a runtime `kind` inside the loop gets if-converted into computing EVERY activation for every element)
+template <int KIND, int T>
+__device__ __forceinline__ void write_activated(const f32x4 (&acc)[T], float* dst, int tile0, int npad) {
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float4 o;
+    o.x = activate<KIND>(acc[t][0]); o.y = activate<KIND>(acc[t][1]); o.z = activate<KIND>(acc[t][2]); o.w = activate<KIND>(acc[t][3]);
+    if (16 * (tile0 + t) < npad) *(float4*)(dst + 16 * t) = o;  // zero-pad tiles stay out of LDS
+  }
 }
-// The packed weights hold whole waves' worth of tiles (zero rows pad the last wave), so the inner loops carry no per-tile guards.
-__host__ __device__ inline int padded_tiles(int ntiles) {
-  const int T = tiles_per_wave(ntiles);
-  return (ntiles + T - 1) / T * T;
-}
 
-// One layer for this wave: T output tiles starting at tile0 = wave * T, G k-groups.
-template <int T, int MODE>
-__device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, float* s_act, int wave, int lane) {
-#ifdef LT_MLP_PF8
-  constexpr int PF = T == 8 ? LT_MLP_PF8 : (T == 4 ? 2 * LT_MLP_PF8 : 8);
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the 16 weight
+// chunks every wave keeps in flight - twice per layer - and undo the streaming across layer boundaries.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#ifdef LT_MLP_STAMPS
+__device__ unsigned long long g_mlp_stamps[1024 * 32];
+#define MLP_STAMP(i) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_mlp_stamps[blockIdx.x * 32 + (threadIdx.x >> 6) * 8 + (i)] = t_; } while (0)
 #else
-  constexpr int PF = T == 8 ? 2 : (T == 4 ? 4 : 8);
-#endif  // k-groups of weights in flight per wave (16 x dwordx4 per lane)
+#define MLP_STAMP(i) do { } while (0)
+#endif
+
+// One layer for this wave.  `ring` slot s holds chunk c0 + s of the wave's stream; the layer consumes its chunks in order
+// (item 0 = the T bias chunks, item i = k-group i-1) and leaves the ring positioned on the next layer's first chunk.
+template <int T>
+__device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, float* s_act, int wave, int lane, long long row_block,
+                                          float4 (&ring)[RING], const float4* __restrict__ stream, long long& c0) {
+  constexpr int R = RING / T;  // items per ring round
   const int r = lane & 15, q = lane >> 4;
   const int S = a.stride;
   const int G = pad16(a.dims[l]) / 16;
   const int N = a.dims[l + 1];
-  const int ntiles = padded_tiles(pad16(N) / 16);
   const int tile0 = wave * T;
-  const bool active = tile0 < ntiles;
-  const float4* __restrict__ wp = (const float4*)(a.packed + a.woff[l]) + (long long)tile0 * G * 64 + lane;
-  const float* __restrict__ bias = a.packed + a.boff[l];
+  const bool active = wave < active_waves(N);
   const float* const xrow = s_act + r * S + 4 * q;
   f32x4 acc[T];
   if (active) {
-    float4 w[PF][T];
+    float4 xa = *(const float4*)xrow, xb = xa;
+    for (int i0 = 0; i0 <= G; i0 += R) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const float4 b = *(const float4*)(bias + 16 * (tile0 + t) + 4 * q);
-      acc[t] = f32x4{b.x, b.y, b.z, b.w};
-    }
-    const int glast = G - 1;
+      for (int j = 0; j < R; ++j) {
+        const int i = i0 + j;  // item: 0 = bias, 1..G = k-group i-1
+        // the activations of the NEXT item are fetched before this item's MFMAs (two alternating registers)
+        const int gx = i < G ? i : G - 1;
+        if ((j & 1) == 0) xb = *(const float4*)(xrow + 16 * gx);
+        else xa = *(const float4*)(xrow + 16 * gx);
+        const float4 x = (j & 1) == 0 ? xa : xb;
+        if (i == 0) {
 #pragma unroll
-    for (int p = 0; p < PF; ++p) {
-      const int g = p < glast ? p : glast;
+          for (int t = 0; t < T; ++t) acc[t] = f32x4{ring[j * T + t].x, ring[j * T + t].y, ring[j * T + t].z, ring[j * T + t].w};
+        } else if (i <= G) {
 #pragma unroll
-      for (int t = 0; t < T; ++t) w[p][t] = wp[(t * G + g) * 64];
-    }
-    float4 x = *(const float4*)xrow;
-    const int gmain = G - G % PF;
-    for (int g0 = 0; g0 < gmain; g0 += PF) {
+          for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].x, x.x, acc[t], 0, 0, 0);
 #pragma unroll
-      for (int p = 0; p < PF; ++p) {
-        const int g = g0 + p;
-        const int gx = g + 1 < glast ? g + 1 : glast;
-#ifdef LT_MLP_EXP_NOLDS
-        const float4 xn = x;
-#else
-        const float4 xn = *(const float4*)(xrow + 16 * gx);
-#endif
-#ifdef LT_MLP_EXP_NOMFMA
+          for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].y, x.y, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc[t][0] += w[p][t].x * x.x + w[p][t].y * x.y + w[p][t].z * x.z + w[p][t].w * x.w;
-#else
+          for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].z, x.z, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p][t].x, x.x, acc[t], 0, 0, 0);
+          for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].w, x.w, acc[t], 0, 0, 0);
+        }
+        // refill the slots just consumed (pad chunks of a partial last round included: the ring invariant must hold)
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p][t].y, x.y, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p][t].z, x.z, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p][t].w, x.w, acc[t], 0, 0, 0);
-#endif
-#ifdef LT_MLP_EXP_SAMEGROUP
-        const int gn = 0;
-#else
-        const int gn = g + PF < glast ? g + PF : glast;  // past the end: a redundant re-load instead of a branch
-#endif
-#ifndef LT_MLP_EXP_NOLOAD
-#pragma unroll
-        for (int t = 0; t < T; ++t) w[p][t] = wp[(t * G + gn) * 64];
-#endif
-        // keep the refill HERE: left alone, the scheduler sinks it behind the next slot's MFMAs to save registers, which
+        for (int t = 0; t < T; ++t) ring[j * T + t] = stream[(c0 + RING + j * T + t) * 64];
+        // keep the refill HERE: left alone, the scheduler sinks it behind the next item's MFMAs to save registers, which
         // collapses the ring to one group in flight
         __builtin_amdgcn_sched_barrier(0);
-        x = xn;
       }
-    }
-    // tail (G not a multiple of PF): ring slots 0.. hold groups gmain..
-#pragma unroll
-    for (int p = 0; p < PF - 1; ++p) {
-      const int g = gmain + p;
-      if (g < G) {
-        const int gx = g + 1 < glast ? g + 1 : glast;
-        const float4 xn = *(const float4*)(xrow + 16 * gx);
-#pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p][t].x, x.x, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p][t].y, x.y, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p][t].z, x.z, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p][t].w, x.w, acc[t], 0, 0, 0);
-        x = xn;
-      }
+      c0 += RING;
+#ifdef LT_MLP_STAMPS
+      if (l == 0 && i0 == 0) MLP_STAMP(7);
+#endif
     }
   }
-  __syncthreads();  // every wave is done reading this layer's input
-  const long long e = (long long)blockIdx.x * ROWS + r;
+#ifdef LT_MLP_STAMPS
+  if (l == 0) MLP_STAMP(6);
+#endif
+  lds_barrier();  // every wave is done reading this layer's input
+  const long long e = row_block * ROWS + r;
   if (!last) {
     if (active) {
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        float4 o;
-        o.x = activate(acc[t][0], a.activation); o.y = activate(acc[t][1], a.activation);
-        o.z = activate(acc[t][2], a.activation); o.w = activate(acc[t][3], a.activation);
-        if (16 * (tile0 + t) < pad16(N)) *(float4*)(s_act + r * S + 16 * (tile0 + t) + 4 * q) = o;  // zero-pad tiles stay out of LDS
-      }
+      float* const dst = s_act + r * S + 16 * tile0 + 4 * q;
+      if (a.activation == LT_ACT_ELU) write_activated<LT_ACT_ELU, T>(acc, dst, tile0, pad16(N));
+      else if (a.activation == LT_ACT_RELU) write_activated<LT_ACT_RELU, T>(acc, dst, tile0, pad16(N));
+      else if (a.activation == LT_ACT_TANH) write_activated<LT_ACT_TANH, T>(acc, dst, tile0, pad16(N));
+      else write_activated<LT_ACT_NONE, T>(acc, dst, tile0, pad16(N));
     }
-    __syncthreads();
+    lds_barrier();
     return;
   }
-  if (MODE == MODE_FORWARD) {
+  if (a.mode == MODE_FORWARD) {
     if (active && e < a.m) {
 #pragma unroll
       for (int t = 0; t < T; ++t) {
@@ -225,20 +220,20 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
   }
 }
 
-#ifdef LT_MLP_STAMPS
-__device__ unsigned long long g_mlp_stamps[1024 * 8];
-#define MLP_STAMP(i) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-  if (threadIdx.x == 0 && blockIdx.x < 1024) g_mlp_stamps[blockIdx.x * 8 + (i)] = t_; } while (0)
-#else
-#define MLP_STAMP(i) do { } while (0)
-#endif
-
-template <int MODE>
-__global__ __launch_bounds__(256) void lt_mlp_kernel(const MlpArgs a) {
+__global__ __launch_bounds__(256) void lt_mlp_kernel(const DualArgs d) {
   extern __shared__ __attribute__((aligned(16))) float s_act[];
+  const bool second = (int)blockIdx.x >= d.split;
+  const MlpArgs& a = second ? d.net[1] : d.net[0];
+  const long long row_block = second ? (long long)blockIdx.x - d.split : (long long)blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   MLP_STAMP(0);
-  const long long row0 = (long long)blockIdx.x * ROWS;
+  // weight stream: 16 chunks in flight before anything else
+  const float4* __restrict__ stream = (const float4*)a.packed + a.wave_base[wave] * 64 + lane;
+  float4 ring[RING];
+#pragma unroll
+  for (int s = 0; s < RING; ++s) ring[s] = stream[s * 64];
+  long long c0 = 0;
+  const long long row0 = row_block * ROWS;
   const int S = a.stride;
   {
     const int K0 = a.dims[0], K0p = pad16(K0);
@@ -263,31 +258,43 @@ __global__ __launch_bounds__(256) void lt_mlp_kernel(const MlpArgs a) {
   for (int l = 0; l < a.L; ++l) {
     const int T = tiles_per_wave(pad16(a.dims[l + 1]) / 16);
     const bool last = l == a.L - 1;
-    if (T == 8) mlp_layer<8, MODE>(a, l, last, s_act, wave, lane);
-    else if (T == 4) mlp_layer<4, MODE>(a, l, last, s_act, wave, lane);
-    else if (T == 2) mlp_layer<2, MODE>(a, l, last, s_act, wave, lane);
-    else mlp_layer<1, MODE>(a, l, last, s_act, wave, lane);
+    if (T == 8) mlp_layer<8>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
+    else if (T == 4) mlp_layer<4>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
+    else if (T == 2) mlp_layer<2>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
+    else mlp_layer<1>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
     MLP_STAMP(2 + l);
   }
 }
 
-// weights [N][K] (torch.nn.Linear layout) + bias [N] -> packed operand order, zero padded
-__global__ void lt_mlp_pack_kernel(const float* __restrict__ w, const float* __restrict__ b, int K, int N, float* __restrict__ wdst,
-                                   float* __restrict__ bdst) {
-  const int G = pad16(K) / 16, ntiles = padded_tiles(pad16(N) / 16);
-  const long long total = (long long)ntiles * G * 64;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < total) {
-    const int lane = (int)(idx & 63);
-    const long long tg = idx >> 6;
-    const int g = (int)(tg % G), tile = (int)(tg / G);
-    const int n = 16 * tile + (lane & 15), k0 = 16 * g + 4 * (lane >> 4);
-    float v[4];
+// One layer of one network: weights [N][K] (torch.nn.Linear layout) + bias [N] -> the per-wave chunk streams.
+struct PackArgs {
+  const float* w; const float* b;
+  int K, N;
+  long long chunk_off[4];  // first chunk of this layer in each wave's stream (absolute, in chunks)
+  float* packed;
+};
+__global__ void lt_mlp_pack_kernel(const PackArgs p) {
+  const int T = tiles_per_wave(pad16(p.N) / 16), G = pad16(p.K) / 16;
+  const int chunks = layer_chunks(p.K, p.N), nact = active_waves(p.N);
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (wave, chunk, lane)
+  if (idx >= (long long)nact * chunks * 64) return;
+  const int lane = (int)(idx & 63);
+  const int c = (int)((idx >> 6) % chunks), wv = (int)((idx >> 6) / chunks);
+  const int r = lane & 15, q = lane >> 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < T) {  // bias chunk of tile wv*T + c: lane (r, q) starts its accumulator with features 4q..4q+3
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (n < N && k0 + i < K) ? w[(long long)n * K + k0 + i] : 0.f;
-    *(float4*)(wdst + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    for (int i = 0; i < 4; ++i) {
+      const int n = 16 * (wv * T + c) + 4 * q + i;
+      v[i] = n < p.N ? p.b[n] : 0.f;
+    }
+  } else if (c < T * (G + 1)) {
+    const int cc = c - T, g = cc / T, t = cc - g * T;
+    const int n = 16 * (wv * T + t) + r, k0 = 16 * g + 4 * q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (n < p.N && k0 + i < p.K) ? p.w[(long long)n * p.K + k0 + i] : 0.f;
   }
-  if (idx < ntiles * 16) bdst[idx] = idx < N ? b[idx] : 0.f;
+  *(float4*)(p.packed + ((p.chunk_off[wv] + c) * 64 + lane) * 4) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 bool desc_ok(const lt_mlp_desc* d) {
@@ -300,42 +307,67 @@ bool desc_ok(const lt_mlp_desc* d) {
   return true;
 }
 
+// stream geometry: per-wave totals (with one ring of zero chunks behind each stream: the refill runs one ring ahead)
+struct Geometry {
+  long long wave_base[4];
+  long long layer_off[LT_MLP_MAX_LAYERS][4];
+  long long total_chunks;
+};
+Geometry geometry(const lt_mlp_desc* d) {
+  Geometry g;
+  long long base = 0;
+  for (int w = 0; w < 4; ++w) {
+    g.wave_base[w] = base;
+    long long off = 0;
+    for (int l = 0; l < d->num_layers; ++l) {
+      g.layer_off[l][w] = base + off;
+      if (w < active_waves(d->dims[l + 1])) off += layer_chunks(d->dims[l], d->dims[l + 1]);
+    }
+    base += off + RING;
+  }
+  g.total_chunks = base;
+  return g;
+}
+
 void fill_args(const lt_mlp_desc* d, MlpArgs& a) {
   a.L = d->num_layers;
   a.activation = d->activation;
-  long long off = 0;
   int widest = 0;
   for (int l = 0; l <= d->num_layers; ++l) {
     a.dims[l] = d->dims[l];
     widest = pad16(d->dims[l]) > widest ? pad16(d->dims[l]) : widest;
   }
-  for (int l = 0; l < d->num_layers; ++l) {
-    a.woff[l] = off;
-    const int np = 16 * padded_tiles(pad16(d->dims[l + 1]) / 16);
-    off += (long long)pad16(d->dims[l]) * np;
-    a.boff[l] = off;
-    off += np;
-  }
+  const Geometry g = geometry(d);
+  for (int w = 0; w < 4; ++w) a.wave_base[w] = g.wave_base[w];
   a.stride = widest + 4;
 }
 
-int launch(const lt_mlp_desc* d, MlpArgs& a, int mode, hipStream_t s) {
-  size_t lds = (size_t)ROWS * a.stride * sizeof(float);
-#ifdef LT_MLP_EXP_LDS
-  lds = LT_MLP_EXP_LDS;
-  static bool once = false;
-  if (!once) {
-    once = true;
-    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<MODE_POLICY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<MODE_FORWARD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
-#endif
-  const dim3 grid((unsigned)((a.m + ROWS - 1) / ROWS)), block(256);
-  if (mode == MODE_POLICY) hipLaunchKernelGGL(lt_mlp_kernel<MODE_POLICY>, grid, block, lds, s, a);
-  else hipLaunchKernelGGL(lt_mlp_kernel<MODE_FORWARD>, grid, block, lds, s, a);
+int launch(DualArgs& d, int nets, hipStream_t s) {
+  int stride = d.net[0].stride;
+  if (nets == 2 && d.net[1].stride > stride) stride = d.net[1].stride;
+  const size_t lds = (size_t)ROWS * stride * sizeof(float);
+  const long long b0 = (d.net[0].m + ROWS - 1) / ROWS, b1 = nets == 2 ? (d.net[1].m + ROWS - 1) / ROWS : 0;
+  d.split = (int)b0;
+  hipLaunchKernelGGL(lt_mlp_kernel, dim3((unsigned)(b0 + b1)), dim3(256), lds, s, d);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;
+}
+
+bool policy_args_ok(const lt_mlp_desc* actor, const float* packed, const float* obs, int64_t n, const int64_t* step_counter, const float* std12,
+                    float* st_actions, float* st_mu, float* st_sigma, float* st_logp, float* actions_out) {
+  return desc_ok(actor) && actor->dims[actor->num_layers] == 12 && packed && obs && n > 0 && step_counter && std12 && st_actions && st_mu &&
+         st_sigma && st_logp && actions_out;
+}
+
+void fill_policy(const lt_mlp_desc* actor, const float* packed, const float* obs, int64_t n, uint64_t seed, const int64_t* step_counter,
+                 int64_t step_offset, const float* std12, float* st_actions, float* st_mu, float* st_sigma, float* st_logp, float* actions_out,
+                 MlpArgs& a) {
+  fill_args(actor, a);
+  a.mode = MODE_POLICY;
+  a.packed = packed; a.x = obs; a.m = n; a.y = nullptr;
+  a.seed = seed; a.step_counter = (const long long*)step_counter; a.step_offset = step_offset; a.std12 = std12;
+  a.st_actions = st_actions; a.st_mu = st_mu; a.st_sigma = st_sigma; a.st_logp = st_logp; a.actions_out = actions_out;
 }
 
 }  // namespace
@@ -344,29 +376,26 @@ extern "C" {
 
 #ifdef LT_MLP_STAMPS
 int lt_debug_mlp_stamps(unsigned long long* host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 1024 * 8);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 1024 * 32);
 }
 #endif
 
 int lt_mlp_packed_floats(const lt_mlp_desc* desc, size_t* floats) {
   if (!desc_ok(desc) || !floats) { lt_set_error("lt_mlp_packed_floats: unsupported network shape"); return LT_EINVAL; }
-  MlpArgs a;
-  fill_args(desc, a);
-  const int L = desc->num_layers;
-  *floats = (size_t)(a.boff[L - 1] + 16 * padded_tiles(pad16(desc->dims[L]) / 16));
+  *floats = (size_t)geometry(desc).total_chunks * 256;
   return LT_OK;
 }
 
 int lt_mlp_pack(const lt_mlp_desc* desc, const float* const* weights, const float* const* biases, float* packed, void* stream) {
   if (!desc_ok(desc) || !weights || !biases || !packed) { lt_set_error("lt_mlp_pack: invalid argument"); return LT_EINVAL; }
-  MlpArgs a;
-  fill_args(desc, a);
+  const Geometry g = geometry(desc);
   for (int l = 0; l < desc->num_layers; ++l) {
     if (!weights[l] || !biases[l]) { lt_set_error("lt_mlp_pack: null layer pointer"); return LT_EINVAL; }
-    const int K = desc->dims[l], N = desc->dims[l + 1];
-    const long long total = (long long)pad16(K) / 16 * padded_tiles(pad16(N) / 16) * 64;
-    hipLaunchKernelGGL(lt_mlp_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weights[l], biases[l], K, N,
-                       packed + a.woff[l], packed + a.boff[l]);
+    PackArgs p;
+    p.w = weights[l]; p.b = biases[l]; p.K = desc->dims[l]; p.N = desc->dims[l + 1]; p.packed = packed;
+    for (int w = 0; w < 4; ++w) p.chunk_off[w] = g.layer_off[l][w];
+    const long long total = (long long)active_waves(p.N) * layer_chunks(p.K, p.N) * 64;
+    hipLaunchKernelGGL(lt_mlp_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   }
@@ -375,26 +404,40 @@ int lt_mlp_pack(const lt_mlp_desc* desc, const float* const* weights, const floa
 
 int lt_mlp_forward(const lt_mlp_desc* desc, const float* packed, const float* x, int64_t m, float* y, void* stream) {
   if (!desc_ok(desc) || !packed || !x || !y || m <= 0) { lt_set_error("lt_mlp_forward: invalid argument"); return LT_EINVAL; }
-  MlpArgs a = {};
-  fill_args(desc, a);
-  a.packed = packed; a.x = x; a.m = m; a.y = y;
-  return launch(desc, a, MODE_FORWARD, (hipStream_t)stream);
+  DualArgs d = {};
+  fill_args(desc, d.net[0]);
+  d.net[0].mode = MODE_FORWARD;
+  d.net[0].packed = packed; d.net[0].x = x; d.net[0].m = m; d.net[0].y = y;
+  return launch(d, 1, (hipStream_t)stream);
 }
 
 int lt_rollout_policy(const lt_mlp_desc* actor, const float* packed, const float* obs, int64_t n, uint64_t seed, const int64_t* step_counter,
                       int64_t step_offset, const float* std12, float* st_actions, float* st_mu, float* st_sigma, float* st_logp,
                       float* actions_out, void* stream) {
-  if (!desc_ok(actor) || actor->dims[actor->num_layers] != 12 || !packed || !obs || n <= 0 || !step_counter || !std12 || !st_actions ||
-      !st_mu || !st_sigma || !st_logp || !actions_out) {
+  if (!policy_args_ok(actor, packed, obs, n, step_counter, std12, st_actions, st_mu, st_sigma, st_logp, actions_out)) {
     lt_set_error("lt_rollout_policy: invalid argument (the policy head must have 12 outputs)");
     return LT_EINVAL;
   }
-  MlpArgs a = {};
-  fill_args(actor, a);
-  a.packed = packed; a.x = obs; a.m = n; a.y = nullptr;
-  a.seed = seed; a.step_counter = (const long long*)step_counter; a.step_offset = step_offset; a.std12 = std12;
-  a.st_actions = st_actions; a.st_mu = st_mu; a.st_sigma = st_sigma; a.st_logp = st_logp; a.actions_out = actions_out;
-  return launch(actor, a, MODE_POLICY, (hipStream_t)stream);
+  DualArgs d = {};
+  fill_policy(actor, packed, obs, n, seed, step_counter, step_offset, std12, st_actions, st_mu, st_sigma, st_logp, actions_out, d.net[0]);
+  return launch(d, 1, (hipStream_t)stream);
+}
+
+int lt_rollout_policy_value(const lt_mlp_desc* actor, const float* actor_packed, const float* obs, const lt_mlp_desc* critic,
+                            const float* critic_packed, const float* critic_obs, float* values, int64_t n, uint64_t seed,
+                            const int64_t* step_counter, int64_t step_offset, const float* std12, float* st_actions, float* st_mu,
+                            float* st_sigma, float* st_logp, float* actions_out, void* stream) {
+  if (!policy_args_ok(actor, actor_packed, obs, n, step_counter, std12, st_actions, st_mu, st_sigma, st_logp, actions_out) || !desc_ok(critic) ||
+      !critic_packed || !critic_obs || !values) {
+    lt_set_error("lt_rollout_policy_value: invalid argument");
+    return LT_EINVAL;
+  }
+  DualArgs d = {};
+  fill_policy(actor, actor_packed, obs, n, seed, step_counter, step_offset, std12, st_actions, st_mu, st_sigma, st_logp, actions_out, d.net[0]);
+  fill_args(critic, d.net[1]);
+  d.net[1].mode = MODE_FORWARD;
+  d.net[1].packed = critic_packed; d.net[1].x = critic_obs; d.net[1].m = n; d.net[1].y = values;
+  return launch(d, 2, (hipStream_t)stream);
 }
 
 }  // extern "C"

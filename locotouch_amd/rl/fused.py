@@ -68,26 +68,25 @@ class FusedRollout:
             obs, cobs = st.observations[t], st.privileged_observations[t]
         else:
             obs, cobs = env.obs_policy, env.obs_critic
+        value = None
         if self.actor_mlp is not None:
-            # actor MLP + sampling + log-prob + storage writes: one launch
+            # actor MLP + sampling + log-prob + storage writes, and the critic MLP beside it: one launch
             if not self.rows_in_storage:
                 st.observations[t].copy_(obs)
                 st.privileged_observations[t].copy_(cobs)
-            _abi.check(self.lib.lt_rollout_policy(ctypes.byref(self.actor_mlp.desc), p(self.actor_mlp.packed), p(obs), n, int(env.cfg.seed),
-                                                  p(self._act_counter), t, p(ac.std.data), p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]),
-                                                  p(st.actions_log_prob[t]), p(self.actions), stream), "lt_rollout_policy")
+            _abi.check(self.lib.lt_rollout_policy_value(
+                ctypes.byref(self.actor_mlp.desc), p(self.actor_mlp.packed), p(obs), ctypes.byref(self.critic_mlp.desc),
+                p(self.critic_mlp.packed), p(cobs), p(st.values[t]), n, int(env.cfg.seed), p(self._act_counter), t, p(ac.std.data),
+                p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), p(st.actions_log_prob[t]), p(self.actions), stream), "lt_rollout_policy_value")
         else:
             mu = ac.actor(obs)
             rows = (null, null, null, null) if self.rows_in_storage else (p(obs), p(cobs), p(st.observations[t]), p(st.privileged_observations[t]))
             _abi.check(self.lib.lt_rollout_act(n, env.num_obs, int(env.cfg.seed), p(self._act_counter), p(mu), p(ac.std.data), null,
                                                *rows, p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), null,
                                                p(st.actions_log_prob[t]), p(self.actions), stream), "lt_rollout_act")
-        # the critic runs beside the env step kernel (a lone wave per CU leaves 3 of 4 SIMDs idle at 4096 envs)
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            if self.critic_mlp is not None:
-                value = self.critic_mlp(cobs)
-            else:
+            # torch critic beside the env step kernel
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
                 value = ac.critic(cobs)
         main.wait_stream(self.post)  # previous step's curriculum pass / counter increment
         if self.rows_in_storage and not last:
@@ -100,11 +99,15 @@ class FusedRollout:
         self.post.wait_stream(main)
         with torch.cuda.stream(self.post):
             env.post_step_raw()
-        main.wait_stream(self.side)
-        value.record_stream(main)
-        _abi.check(self.lib.lt_rollout_record(n, float(alg.gamma), p(env.reward_buf), p(env.dones_buf), p(env.time_out_buf), p(value),
-                                              p(st.rewards[t]), p(st.dones[t]), p(st.values[t]), null if self.actor_mlp is not None else p(self._act_counter), stream),
-                   "lt_rollout_record")
+        if value is not None:
+            main.wait_stream(self.side)
+            value.record_stream(main)
+            _abi.check(self.lib.lt_rollout_record(n, float(alg.gamma), p(env.reward_buf), p(env.dones_buf), p(env.time_out_buf), p(value),
+                                                  p(st.rewards[t]), p(st.dones[t]), p(st.values[t]), p(self._act_counter), stream),
+                       "lt_rollout_record")
+        else:  # values already sit in the storage slot; the policy kernel keys its noise on counter + t
+            _abi.check(self.lib.lt_rollout_record(n, float(alg.gamma), p(env.reward_buf), p(env.dones_buf), p(env.time_out_buf),
+                                                  p(st.values[t]), p(st.rewards[t]), p(st.dones[t]), null, null, stream), "lt_rollout_record")
         st.step = t + 1
 
     def rollout(self, num_steps: int) -> None:

@@ -30,14 +30,16 @@ for m in [int(a) for a in sys.argv[1:]] or [4096]:
     if hasattr(lib, "lt_debug_mlp_stamps"):
         import ctypes, numpy as np
         net(x, out); torch.cuda.synchronize()
-        buf = (ctypes.c_uint64 * (1024 * 8))()
+        buf = (ctypes.c_uint64 * (1024 * 32))()
         lib.lt_debug_mlp_stamps(buf)
-        st = np.array(buf, dtype=np.uint64).reshape(1024, 8)[: min(1024, (m + 15) // 16)].astype(np.int64)
+        nb = min(1024, (m + 15) // 16)
+        st = np.array(buf, dtype=np.uint64).reshape(1024, 4, 8)[:nb].astype(np.int64)
         L = len(dims) - 1
-        t0 = st[:, 0].min()
-        print("stamp ticks (100 MHz => 10 ns): block start spread", (st[:, 0] - t0).max(), " per-phase mean/max:")
-        names = ["stage input"] + [f"layer {l}" for l in range(L)]
+        t0 = st[:, :, 0].min()
+        print("stamps (10 ns ticks -> ns), mean over blocks, per wave 0..3; times since kernel start")
+        names = ["start", "input staged"] + [f"layer {l} done" for l in range(L)]
         for i, nm in enumerate(names):
-            d = st[:, i + 1] - st[:, i]
-            print(f"   {nm:12s} {d.mean() * 10:8.0f} ns  max {d.max() * 10:6d} ns")
-        print("   last block end - first start:", (st[:, L + 1].max() - t0) * 10, "ns")
+            print(f"   {nm:16s}", " ".join(f"{(st[:, w, i] - t0).mean() * 10:8.0f}" for w in range(4)))
+        print(f"   {'L0 round 0 done':16s}", " ".join(f"{(st[:, w, 7] - t0).mean() * 10:8.0f}" for w in range(4)))
+        print(f"   {'L0 loop done':16s}", " ".join(f"{(st[:, w, 6] - t0).mean() * 10:8.0f}" for w in range(4)))
+        print("   last block end - first start:", (st[:, :, L + 1].max() - t0) * 10, "ns")
