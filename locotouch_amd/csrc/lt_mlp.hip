@@ -24,6 +24,8 @@
 // storage-slot writes), so the actor side of a rollout step needs no further launch.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "lt_device_math.h"
 #include "lt_internal.h"
 
@@ -33,7 +35,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int ROWS = 16;
 constexpr int RING = 16;               // chunks in flight per wave
 constexpr unsigned RS_POLICY = 0x400;  // same Philox stream id as lt_rollout_act
 constexpr int MODE_FORWARD = 0, MODE_POLICY = 1;
@@ -110,7 +111,8 @@ __device__ unsigned long long g_mlp_stamps[1024 * 32];
 
 // One layer for this wave.  `ring` slot s holds chunk c0 + s of the wave's stream; the layer consumes its chunks in order
 // (item 0 = the T bias chunks, item i = k-group i-1) and leaves the ring positioned on the next layer's first chunk.
-template <int T>
+// RT row tiles (16 rows each) share every weight chunk: RT x the MFMA work per byte streamed from L2.
+template <int T, int RT>
 __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, float* s_act, int wave, int lane, long long row_block,
                                           float4 (&ring)[RING], const float4* __restrict__ stream, long long& c0) {
   constexpr int R = RING / T;  // items per ring round
@@ -120,31 +122,41 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
   const int N = a.dims[l + 1];
   const int tile0 = wave * T;
   const bool active = wave < active_waves(N);
-  const float* const xrow = s_act + r * S + 4 * q;
-  f32x4 acc[T];
+  const float* const xrow = s_act + r * S + 4 * q;  // row tile rt: + 16 * rt * S
+  f32x4 acc[RT][T];
   if (active) {
-    float4 xa = *(const float4*)xrow, xb = xa;
+    float4 xa[RT], xb[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { xa[rt] = *(const float4*)(xrow + 16 * rt * S); xb[rt] = xa[rt]; }
     for (int i0 = 0; i0 <= G; i0 += R) {
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         const int i = i0 + j;  // item: 0 = bias, 1..G = k-group i-1
-        // the activations of the NEXT item are fetched before this item's MFMAs (two alternating registers)
+        // the activations of the NEXT item are fetched before this item's MFMAs (two alternating register sets)
         const int gx = i < G ? i : G - 1;
-        if ((j & 1) == 0) xb = *(const float4*)(xrow + 16 * gx);
-        else xa = *(const float4*)(xrow + 16 * gx);
-        const float4 x = (j & 1) == 0 ? xa : xb;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          if ((j & 1) == 0) xb[rt] = *(const float4*)(xrow + 16 * rt * S + 16 * gx);
+          else xa[rt] = *(const float4*)(xrow + 16 * rt * S + 16 * gx);
+        }
         if (i == 0) {
 #pragma unroll
-          for (int t = 0; t < T; ++t) acc[t] = f32x4{ring[j * T + t].x, ring[j * T + t].y, ring[j * T + t].z, ring[j * T + t].w};
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[rt][t] = f32x4{ring[j * T + t].x, ring[j * T + t].y, ring[j * T + t].z, ring[j * T + t].w};
         } else if (i <= G) {
 #pragma unroll
-          for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].x, x.x, acc[t], 0, 0, 0);
+          for (int rt = 0; rt < RT; ++rt) {
+            const float4 x = (j & 1) == 0 ? xa[rt] : xb[rt];
 #pragma unroll
-          for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].y, x.y, acc[t], 0, 0, 0);
+            for (int t = 0; t < T; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].x, x.x, acc[rt][t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].z, x.z, acc[t], 0, 0, 0);
+            for (int t = 0; t < T; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].y, x.y, acc[rt][t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].w, x.w, acc[t], 0, 0, 0);
+            for (int t = 0; t < T; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].z, x.z, acc[rt][t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].w, x.w, acc[rt][t], 0, 0, 0);
+          }
         }
         // refill the slots just consumed (pad chunks of a partial last round included: the ring invariant must hold)
 #pragma unroll
@@ -163,65 +175,73 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
   if (l == 0) MLP_STAMP(6);
 #endif
   lds_barrier();  // every wave is done reading this layer's input
-  const long long e = row_block * ROWS + r;
   if (!last) {
     if (active) {
-      float* const dst = s_act + r * S + 16 * tile0 + 4 * q;
-      if (a.activation == LT_ACT_ELU) write_activated<LT_ACT_ELU, T>(acc, dst, tile0, pad16(N));
-      else if (a.activation == LT_ACT_RELU) write_activated<LT_ACT_RELU, T>(acc, dst, tile0, pad16(N));
-      else if (a.activation == LT_ACT_TANH) write_activated<LT_ACT_TANH, T>(acc, dst, tile0, pad16(N));
-      else write_activated<LT_ACT_NONE, T>(acc, dst, tile0, pad16(N));
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float* const dst = s_act + (r + 16 * rt) * S + 16 * tile0 + 4 * q;
+        if (a.activation == LT_ACT_ELU) write_activated<LT_ACT_ELU, T>(acc[rt], dst, tile0, pad16(N));
+        else if (a.activation == LT_ACT_RELU) write_activated<LT_ACT_RELU, T>(acc[rt], dst, tile0, pad16(N));
+        else if (a.activation == LT_ACT_TANH) write_activated<LT_ACT_TANH, T>(acc[rt], dst, tile0, pad16(N));
+        else write_activated<LT_ACT_NONE, T>(acc[rt], dst, tile0, pad16(N));
+      }
     }
     lds_barrier();
     return;
   }
-  if (a.mode == MODE_FORWARD) {
-    if (active && e < a.m) {
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
+  for (int rt = 0; rt < RT; ++rt) {
+    const long long e = row_block * (16 * RT) + 16 * rt + r;
+    if (a.mode == MODE_FORWARD) {
+      if (active && e < a.m) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int n = 16 * (tile0 + t) + 4 * q + i;
-          if (n < N) a.y[e * N + n] = acc[t][i];
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int n = 16 * (tile0 + t) + 4 * q + i;
+            if (n < N) a.y[e * N + n] = acc[rt][t][i];
+          }
         }
       }
-    }
-  } else {
-    // policy head: N == 12 -> one tile, held by wave 0; lane (r, q) owns actions 4q..4q+3 of env e (q == 3: padding)
-    if (wave == 0) {
-      float lp = 0.f;
-      if (q < 3 && e < a.m) {
-        const unsigned long long step = (unsigned long long)(a.step_counter[0] + a.step_offset);
-        const U4 u = rng4(a.seed, (unsigned)e, step, RS_POLICY + q);
-        const float ra = sqrtf(-2.f * __logf(1.f - u.a)), rb = sqrtf(-2.f * __logf(1.f - u.c));  // 1-u in (0,1]: never log(0)
-        float sa, ca, sb, cb;
-        __sincosf(6.28318530717958647692f * u.b, &sa, &ca);
-        __sincosf(6.28318530717958647692f * u.d, &sb, &cb);
-        const float z[4] = {ra * ca, ra * sa, rb * cb, rb * sb};
-        const float4 sg = *(const float4*)(a.std12 + 4 * q);
-        const float sgv[4] = {sg.x, sg.y, sg.z, sg.w};
-        float xv[4];
+    } else {
+      // policy head: N == 12 -> one tile, held by wave 0; lane (r, q) owns actions 4q..4q+3 of env e (q == 3: padding)
+      if (wave == 0) {
+        float lp = 0.f;
+        if (q < 3 && e < a.m) {
+          const unsigned long long step = (unsigned long long)(a.step_counter[0] + a.step_offset);
+          const U4 u = rng4(a.seed, (unsigned)e, step, RS_POLICY + q);
+          const float ra = sqrtf(-2.f * __logf(1.f - u.a)), rb = sqrtf(-2.f * __logf(1.f - u.c));  // 1-u in (0,1]: never log(0)
+          float sa, ca, sb, cb;
+          __sincosf(6.28318530717958647692f * u.b, &sa, &ca);
+          __sincosf(6.28318530717958647692f * u.d, &sb, &cb);
+          const float z[4] = {ra * ca, ra * sa, rb * cb, rb * sb};
+          const float4 sg = *(const float4*)(a.std12 + 4 * q);
+          const float sgv[4] = {sg.x, sg.y, sg.z, sg.w};
+          float xv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          xv[i] = acc[0][i] + sgv[i] * z[i];
-          lp += -(z[i] * z[i]) * 0.5f - __logf(sgv[i]) - 0.91893853320467274178f;  // Normal.log_prob
+          for (int i = 0; i < 4; ++i) {
+            xv[i] = acc[rt][0][i] + sgv[i] * z[i];
+            lp += -(z[i] * z[i]) * 0.5f - __logf(sgv[i]) - 0.91893853320467274178f;  // Normal.log_prob
+          }
+          const long long o = e * 12 + 4 * q;
+          const float4 xo = make_float4(xv[0], xv[1], xv[2], xv[3]);
+          *(float4*)(a.st_actions + o) = xo;
+          *(float4*)(a.actions_out + o) = xo;
+          *(float4*)(a.st_mu + o) = make_float4(acc[rt][0][0], acc[rt][0][1], acc[rt][0][2], acc[rt][0][3]);
+          *(float4*)(a.st_sigma + o) = sg;
         }
-        const long long o = e * 12 + 4 * q;
-        const float4 xa = make_float4(xv[0], xv[1], xv[2], xv[3]);
-        *(float4*)(a.st_actions + o) = xa;
-        *(float4*)(a.actions_out + o) = xa;
-        *(float4*)(a.st_mu + o) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-        *(float4*)(a.st_sigma + o) = sg;
+        lp += __shfl_xor(lp, 16, 64);
+        lp += __shfl_xor(lp, 32, 64);
+        if (q == 0 && e < a.m) a.st_logp[e] = lp;
       }
-      lp += __shfl_xor(lp, 16, 64);
-      lp += __shfl_xor(lp, 32, 64);
-      if (q == 0 && e < a.m) a.st_logp[e] = lp;
     }
   }
 }
 
+template <int RT>
 __global__ __launch_bounds__(256) void lt_mlp_kernel(const DualArgs d) {
   extern __shared__ __attribute__((aligned(16))) float s_act[];
+  constexpr int ROWS = 16 * RT;
   const bool second = (int)blockIdx.x >= d.split;
   const MlpArgs& a = second ? d.net[1] : d.net[0];
   const long long row_block = second ? (long long)blockIdx.x - d.split : (long long)blockIdx.x;
@@ -258,10 +278,10 @@ __global__ __launch_bounds__(256) void lt_mlp_kernel(const DualArgs d) {
   for (int l = 0; l < a.L; ++l) {
     const int T = tiles_per_wave(pad16(a.dims[l + 1]) / 16);
     const bool last = l == a.L - 1;
-    if (T == 8) mlp_layer<8>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
-    else if (T == 4) mlp_layer<4>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
-    else if (T == 2) mlp_layer<2>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
-    else mlp_layer<1>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
+    if (T == 8) mlp_layer<8, RT>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
+    else if (T == 4) mlp_layer<4, RT>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
+    else if (T == 2) mlp_layer<2, RT>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
+    else mlp_layer<1, RT>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
     MLP_STAMP(2 + l);
   }
 }
@@ -342,13 +362,34 @@ void fill_args(const lt_mlp_desc* d, MlpArgs& a) {
   a.stride = widest + 4;
 }
 
+// Row tiles per workgroup: the most (of 1, 2, 4) that still leaves every CU a workgroup - each doubling halves the bytes
+// streamed from L2 per FLOP, and at one 16-row tile per CU the kernel is bound by L2 -> CU bandwidth, not by the MFMA rate.
+int pick_row_tiles(long long rows_total_blocks16) {
+  int rt = 1;
+  while (rt < 4 && rows_total_blocks16 / (2 * rt) >= 256) rt *= 2;
+  return rt;
+}
+
 int launch(DualArgs& d, int nets, hipStream_t s) {
   int stride = d.net[0].stride;
   if (nets == 2 && d.net[1].stride > stride) stride = d.net[1].stride;
-  const size_t lds = (size_t)ROWS * stride * sizeof(float);
-  const long long b0 = (d.net[0].m + ROWS - 1) / ROWS, b1 = nets == 2 ? (d.net[1].m + ROWS - 1) / ROWS : 0;
+  const long long t0 = (d.net[0].m + 15) / 16, t1 = nets == 2 ? (d.net[1].m + 15) / 16 : 0;
+  int rt = pick_row_tiles(t0 + t1);
+  if (const char* o = getenv("LT_MLP_ROW_TILES")) rt = atoi(o) == 4 ? 4 : (atoi(o) == 2 ? 2 : 1);  // diagnostic override
+  while (rt > 1 && (size_t)16 * rt * stride * sizeof(float) > 160 * 1024) rt /= 2;  // one workgroup's activations must fit the LDS
+  const size_t lds = (size_t)16 * rt * stride * sizeof(float);
+  const long long b0 = (t0 + rt - 1) / rt, b1 = (t1 + rt - 1) / rt;
   d.split = (int)b0;
-  hipLaunchKernelGGL(lt_mlp_kernel, dim3((unsigned)(b0 + b1)), dim3(256), lds, s, d);
+  const dim3 grid((unsigned)(b0 + b1)), block(256);
+  static bool attr_set = false;
+  if (!attr_set) {  // more than the default 64 KB of dynamic LDS
+    attr_set = true;
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  if (rt == 4) hipLaunchKernelGGL(lt_mlp_kernel<4>, grid, block, lds, s, d);
+  else if (rt == 2) hipLaunchKernelGGL(lt_mlp_kernel<2>, grid, block, lds, s, d);
+  else hipLaunchKernelGGL(lt_mlp_kernel<1>, grid, block, lds, s, d);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;
