@@ -274,6 +274,10 @@ int lt_env_step(lt_env* env, const float* actions, void* stream);
  * stream ordered after it and before the next step (curriculum + step counter), which lets the caller overlap that pass. */
 int lt_env_step_rows(lt_env* env, const float* actions, const float* prev_policy, const float* prev_critic, float* next_policy,
                      float* next_critic, void* stream);
+/* lt_env_step_rows plus the rollout-storage writes of the transition (ppo.py:162-165, rollout_storage.py:79-107):
+ * st_rewards[n] = reward + gamma * values * time_out, st_dones[n] = dones != 0.  `values` = V(obs_t), float[n]. */
+int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_policy, const float* prev_critic, float* next_policy,
+                        float* next_critic, const float* values, float gamma, float* st_rewards, uint8_t* st_dones, void* stream);
 /* Second half of lt_env_step: curriculum / population gate on this step's records + step-counter increment. */
 int lt_env_post_step(lt_env* env, void* stream);
 /* Profiling variant of lt_env_step: HIP events bracket the step kernel on `stream`; the call WAITS for them (host

@@ -119,6 +119,7 @@ def load() -> ctypes.CDLL:
     lib.lt_mlp_forward.argtypes = [dp, vp, vp, ctypes.c_int64, vp, vp]
     lib.lt_rollout_policy.argtypes = [dp, vp, vp, ctypes.c_int64, ctypes.c_uint64, vp, ctypes.c_int64] + [vp] * 7
     lib.lt_rollout_policy_value.argtypes = [dp, vp, vp, dp, vp, vp, vp, ctypes.c_int64, ctypes.c_uint64, vp, ctypes.c_int64] + [vp] * 7
+    lib.lt_env_step_rollout.argtypes = [ctypes.c_void_p] + [vp] * 6 + [ctypes.c_float, vp, vp, vp]
     lib.lt_env_kernel_name.argtypes = [ctypes.c_int]
     lib.lt_env_kernel_name.restype = ctypes.c_char_p
     if lib.lt_cfg_sizeof() != ctypes.sizeof(LtCfg):
@@ -131,7 +132,7 @@ def load() -> ctypes.CDLL:
 
 EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_obs_dim", "lt_env_create",
            "lt_env_destroy", "lt_env_state_bytes", "lt_env_bind", "lt_env_reset_all", "lt_env_step", "lt_env_step_profiled", "lt_env_eval_terms",
-           "lt_env_curriculum_update", "lt_env_step_rows", "lt_env_post_step", "lt_env_get_view", "lt_env_set_command_ranges", "lt_rollout_act", "lt_rollout_record", "lt_mlp_packed_floats", "lt_mlp_pack", "lt_mlp_forward", "lt_rollout_policy", "lt_rollout_policy_value",
+           "lt_env_curriculum_update", "lt_env_step_rows", "lt_env_step_rollout", "lt_env_post_step", "lt_env_get_view", "lt_env_set_command_ranges", "lt_rollout_act", "lt_rollout_record", "lt_mlp_packed_floats", "lt_mlp_pack", "lt_mlp_forward", "lt_rollout_policy", "lt_rollout_policy_value",
            "lt_env_kernel_name"]
 
 

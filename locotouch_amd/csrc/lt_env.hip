@@ -19,6 +19,7 @@
 
 #include "lt_device_math.h"
 #include "lt_internal.h"
+#include "lt_post.h"
 #include "../../include/lt_go1_model.h"
 
 using namespace lt;
@@ -37,6 +38,11 @@ struct KArgs {
   // in-place update of the arena rows (lt_env_step); distinct = rollout-storage slots t / t+1 (lt_env_step_rows).
   const float* obs_prev[2];
   float* obs_next[2];
+  // optional rollout-storage writes of this transition (lt_env_step_rollout): rewards with the time-out bootstrap, dones
+  const float* rec_values;
+  float rec_gamma;
+  float* rec_rewards;
+  unsigned char* rec_dones;
 };
 static_assert(sizeof(lt_dev_args) <= LT_DEV_ARGS_BYTES, "lt_dev_args outgrew its arena slot");
 
@@ -834,6 +840,10 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
     if (leg == 0) {
       ((float*)(arena + L.off_reward))[env] = rew;
       ((int*)(arena + L.off_term_bits))[env] = bits;
+      if (MODE == MODE_STEP && a.rec_rewards && env < L.n) {  // ppo.py:162-165 + rollout_storage.py:79-107
+        a.rec_rewards[env] = rew + (time_out ? a.rec_gamma * a.rec_values[env] : 0.f);
+        a.rec_dones[env] = (terminated || time_out) ? 1 : 0;
+      }
     }
     if (c.debug_terms) {
 #pragma unroll
@@ -1164,130 +1174,9 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
 // post kernel (one block): velocity curriculum (reference mdp/curriculums.py:184-275 + commands.py:471-505),
 // population gate of rewards.py:190, common step counter.  Runs after every step kernel, on the same stream.
 // =====================================================================================================
-// block-wide sum of K values at once (one LDS round, two barriers); result replicated in every thread
-template <int K>
-__device__ __forceinline__ void block_sum(float (&v)[K], float* sh) {
-  const int tid = threadIdx.x, nw = blockDim.x >> 6;
-#pragma unroll
-  for (int k = 0; k < K; ++k)
-    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
-  __syncthreads();  // protect sh against the previous use
-  if ((tid & 63) == 0)
-#pragma unroll
-    for (int k = 0; k < K; ++k) sh[(tid >> 6) * K + k] = v[k];
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    float t = 0.f;
-    for (int w = 0; w < nw; ++w) t += sh[w * K + k];
-    v[k] = t;
-  }
-}
-__device__ __forceinline__ void set_range(float* P, int d, float lo, float hi) {
-  P[6 + 2 * d] = P[2 * d]; P[6 + 2 * d + 1] = P[2 * d + 1];
-  P[2 * d] = lo; P[2 * d + 1] = hi;
-  P[12 + d] = (P[6 + 2 * d] == P[2 * d] && P[6 + 2 * d + 1] == P[2 * d + 1]) ? 1.f : 0.f;
-}
-// Every thread keeps the per-env trackers of its envs in registers for the whole kernel (<= 8 envs per thread at
-// N = 8192; larger N strides further) and replays the reference's call order: lin gate -> maybe widen -> ang gate.
 __global__ __launch_bounds__(1024) void lt_post_kernel(const KArgs a, int bump_counter, int gates_only) {
-  const lt_cfg& c = a.d->cfg;
-  const lt_layout& L = a.d->layout;
-  char* const arena = a.arena;
-  float* P = (float*)(arena + L.off_cmd_params);
   __shared__ float sh[16 * 8];
-  const long long n = L.n, q4 = L.npad * 4;
-  const float4* rec = (const float4*)(arena + L.quad_off[LT_F_CURRICULUM]);
-  float4* trk1 = (float4*)((float*)(arena + L.quad_off[LT_F_CURRICULUM]) + q4);
-  float4* trk2 = (float4*)((float*)(arena + L.quad_off[LT_F_CURRICULUM]) + 2 * q4);
-  const float4* cmd = (const float4*)(arena + L.quad_off[LT_F_CMD]);
-  const int tid = threadIdx.x, nt = blockDim.x;
-  // command block snapshot (uniform; thread 0 is the only writer, at the very end)
-  float Pl[27];
-#pragma unroll
-  for (int i = 0; i < 27; ++i) Pl[i] = P[i];
-  const float* mx = c.cmd_range_max;
-  const bool cur = c.cur_enabled != 0 && !gates_only;
-  const bool lin_open = cur && (Pl[1] != mx[0] || Pl[12] == 0.f || Pl[3] != mx[1] || Pl[13] == 0.f) && (Pl[17] - Pl[18] <= (float)c.cur_max_distance_bins);
-  // pass 1: population gate, any-reset flag, lin statistics with this step's records merged in
-  float r1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // nz, any, not-all-reset(lin), sum len, sum reward
-  for (long long e = tid; e < n; e += nt) {
-    const float4 cc = cmd[e];
-    const float4 rc = rec[e];
-    if (cc.x != 0.f || cc.y != 0.f || cc.z != 0.f) r1[0] = 1.f;
-    if (rc.x != 0.f) r1[1] = 1.f;
-    if (lin_open) {
-      float4 t = trk1[e];
-      if (rc.x != 0.f) { t.x = 1.f; t.y = rc.y; t.z = rc.z; }
-      if (t.x == 0.f) r1[2] = 1.f;
-      r1[3] += t.y; r1[4] += t.z;
-    }
-  }
-  block_sum<5>(r1, sh);
-  const bool any = r1[1] > 0.f;
-  const float inv_n = 1.f / (float)n;
-  const bool run = cur && any;  // _reset_idx (and the curriculum with it) only runs when some env reset this step
-  bool lin_pass = false, lin_widen = false;
-  if (run && lin_open) {
-    lin_pass = r1[2] == 0.f && r1[3] * inv_n > c.cur_len_threshold && r1[4] * inv_n > c.cur_reward_threshold[0];
-    if (lin_pass) {
-      Pl[19] += 1.f;
-      if ((int)Pl[19] == c.cur_repeat_times[0]) {
-        lin_widen = true;
-        const float lx = clampf(Pl[0] - Pl[21], -mx[0], 0.f), ly = clampf(Pl[2] - Pl[22], -mx[1], 0.f);
-        set_range(Pl, 0, lx, -lx);
-        set_range(Pl, 1, ly, -ly);
-        if (Pl[12] != 0.f && Pl[13] != 0.f && Pl[14] != 0.f) { Pl[15] = (float)c.cmd_zero_steps_final; Pl[16] = c.cmd_rel_standing_final; }
-        Pl[19] = 0.f; Pl[17] += 1.f;
-      }
-    }
-  }
-  const bool ang_open = run && (Pl[5] != mx[2] || Pl[14] == 0.f) && (Pl[18] - Pl[17] <= (float)c.cur_max_distance_bins);
-  // pass 2: ang statistics (gate evaluated after the lin update, as in the reference's call order) + tracker write-back
-  float r2[3] = {0.f, 0.f, 0.f};
-  if (run) {
-    for (long long e = tid; e < n; e += nt) {
-      const float4 rc = rec[e];
-      float4 t1 = trk1[e], t2 = trk2[e];
-      if (lin_open) {
-        if (rc.x != 0.f) { t1.x = 1.f; t1.y = rc.y; t1.z = rc.z; }
-        if (lin_pass) { t1.x = 0.f; t1.y = 0.f; t1.z = 0.f; }
-      }
-      if (ang_open) {
-        if (rc.x != 0.f) { t1.w = 1.f; t2.x = rc.y; t2.y = rc.w; }
-        if (t1.w == 0.f) r2[0] = 1.f;
-        r2[1] += t2.x; r2[2] += t2.y;
-      }
-      trk1[e] = t1; trk2[e] = t2;
-    }
-    if (ang_open) {
-      block_sum<3>(r2, sh);
-      const bool ang_pass = r2[0] == 0.f && r2[1] * inv_n > c.cur_len_threshold && r2[2] * inv_n > c.cur_reward_threshold[1];
-      if (ang_pass) {
-        Pl[20] += 1.f;
-        if ((int)Pl[20] == c.cur_repeat_times[1]) {
-          const float lz = clampf(Pl[4] - Pl[23], -mx[2], 0.f);
-          set_range(Pl, 2, lz, -lz);
-          if (Pl[12] != 0.f && Pl[13] != 0.f && Pl[14] != 0.f) { Pl[15] = (float)c.cmd_zero_steps_final; Pl[16] = c.cmd_rel_standing_final; }
-          Pl[20] = 0.f; Pl[18] += 1.f;
-        }
-        for (long long e = tid; e < n; e += nt) {  // each thread clears the rows it wrote itself just above
-          float4 t1 = trk1[e];
-          t1.w = 0.f;
-          trk1[e] = t1;
-          trk2[e] = make_float4(0.f, 0.f, trk2[e].z, trk2[e].w);
-        }
-      }
-    }
-    Pl[24] = lin_open ? 1.f : 0.f; Pl[25] = ang_open ? 1.f : 0.f;
-  }
-  Pl[26] = r1[0] > 0.f ? 1.f : 0.f;
-  (void)lin_widen;
-  if (tid == 0) {
-#pragma unroll
-    for (int i = 0; i < 27; ++i) P[i] = Pl[i];
-    if (bump_counter) ((long long*)(arena + L.off_counters))[0] += 1;
-  }
+  post_body<4>(a.d, a.arena, bump_counter, gates_only, sh);
 }
 
 // command/curriculum block initialisation (reference mdp/curriculums.py:187-193, commands.py:427-469)
@@ -1326,12 +1215,17 @@ KArgs make_args(const lt_env* env, const float* actions) {
   float* const rc = (float*)((char*)env->arena + env->layout.off_obs_critic);
   k.obs_prev[0] = rp; k.obs_prev[1] = rc;
   k.obs_next[0] = rp; k.obs_next[1] = rc;
+  k.rec_values = nullptr; k.rec_gamma = 0.f; k.rec_rewards = nullptr; k.rec_dones = nullptr;
   return k;
 }
 
+struct RecordArgs { const float* values; float gamma; float* rewards; unsigned char* dones; };
+
 template <int MODE>
-int launch_step(const lt_env* env, const float* actions, hipStream_t s, const float* const* prev = nullptr, float* const* next = nullptr) {
+int launch_step(const lt_env* env, const float* actions, hipStream_t s, const float* const* prev = nullptr, float* const* next = nullptr,
+                const RecordArgs* rec = nullptr) {
   KArgs k = make_args(env, actions);
+  if (rec) { k.rec_values = rec->values; k.rec_gamma = rec->gamma; k.rec_rewards = rec->rewards; k.rec_dones = rec->dones; }
   for (int g = 0; g < 2; ++g) {
     if (prev && prev[g]) k.obs_prev[g] = prev[g];
     if (next && next[g]) k.obs_next[g] = next[g];
@@ -1373,8 +1267,10 @@ int lt_launch_step(const lt_env* env, const float* actions, void* stream) {
   return (int)hipGetLastError();
 }
 
-int lt_launch_step_rows(const lt_env* env, const float* actions, const float* const prev[2], float* const next[2], void* stream) {
-  return launch_step<MODE_STEP>(env, actions, (hipStream_t)stream, prev, next);
+int lt_launch_step_rows(const lt_env* env, const float* actions, const float* const prev[2], float* const next[2], const float* values,
+                        float gamma, float* st_rewards, unsigned char* st_dones, void* stream) {
+  const RecordArgs rec = {values, gamma, st_rewards, st_dones};
+  return launch_step<MODE_STEP>(env, actions, (hipStream_t)stream, prev, next, st_rewards ? &rec : nullptr);
 }
 
 int lt_launch_post_step(const lt_env* env, void* stream) {

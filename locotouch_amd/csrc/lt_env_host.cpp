@@ -133,7 +133,20 @@ int lt_env_step_rows(lt_env* env, const float* actions, const float* prev_policy
   }
   const float* prev[2] = {prev_policy, prev_critic};
   float* next[2] = {next_policy, next_critic};
-  return finish(lt_launch_step_rows(env, actions, prev, next, stream), "lt_env_step_rows");
+  return finish(lt_launch_step_rows(env, actions, prev, next, nullptr, 0.f, nullptr, nullptr, stream), "lt_env_step_rows");
+}
+
+int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_policy, const float* prev_critic, float* next_policy,
+                        float* next_critic, const float* values, float gamma, float* st_rewards, uint8_t* st_dones, void* stream) {
+  if (!env || !actions || !values || !st_rewards || !st_dones) return LT_EINVAL;
+  if (!env->arena) { lt_set_error("lt_env_step_rollout: arena not bound"); return LT_EFAULT; }
+  if (((uintptr_t)prev_policy | (uintptr_t)prev_critic | (uintptr_t)next_policy | (uintptr_t)next_critic) & 15) {
+    lt_set_error("lt_env_step_rollout: observation rows must be 16-byte aligned");
+    return LT_EINVAL;
+  }
+  const float* prev[2] = {prev_policy, prev_critic};
+  float* next[2] = {next_policy, next_critic};
+  return finish(lt_launch_step_rows(env, actions, prev, next, values, gamma, st_rewards, st_dones, stream), "lt_env_step_rollout");
 }
 
 int lt_env_post_step(lt_env* env, void* stream) {

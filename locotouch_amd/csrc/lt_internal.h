@@ -20,7 +20,8 @@ struct lt_env {
 // Every launcher enqueues on `stream` and returns a hipError_t value as int (0 = hipSuccess).
 int lt_launch_reset_all(const lt_env* env, void* stream);
 int lt_launch_step(const lt_env* env, const float* actions, void* stream);
-int lt_launch_step_rows(const lt_env* env, const float* actions, const float* const prev[2], float* const next[2], void* stream);
+int lt_launch_step_rows(const lt_env* env, const float* actions, const float* const prev[2], float* const next[2], const float* values,
+                        float gamma, float* st_rewards, unsigned char* st_dones, void* stream);
 int lt_launch_post_step(const lt_env* env, void* stream);
 int lt_launch_step_profiled(lt_env* env, const float* actions, void* stream, float* ms);
 int lt_launch_eval_terms(const lt_env* env, void* stream);

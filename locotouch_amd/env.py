@@ -151,6 +151,18 @@ class LocoTouchVecEnv:
         _abi.check(self._lib.lt_env_step_rows(self._handle, vp(actions_ptr), vp(prev_policy or None), vp(prev_critic or None),
                                               vp(next_policy or None), vp(next_critic or None), self._stream()), "lt_env_step_rows")
 
+    def step_rollout_raw(self, actions_ptr: int, prev_policy: int, prev_critic: int, next_policy: int, next_critic: int, values_ptr: int,
+                         gamma: float, st_rewards_ptr: int, st_dones_ptr: int) -> None:
+        """lt_env_step_rollout: step_rows_raw + the storage writes of the transition (bootstrapped reward, dones)."""
+        vp = ctypes.c_void_p
+        _abi.check(self._lib.lt_env_step_rollout(self._handle, vp(actions_ptr), vp(prev_policy or None), vp(prev_critic or None),
+                                                 vp(next_policy or None), vp(next_critic or None), vp(values_ptr), float(gamma),
+                                                 vp(st_rewards_ptr), vp(st_dones_ptr), self._stream()), "lt_env_step_rollout")
+
+    @property
+    def handle(self) -> ctypes.c_void_p:
+        return self._handle
+
     def post_step_raw(self) -> None:
         """lt_env_post_step on the current stream (curriculum + step counter); pairs with step_rows_raw."""
         _abi.check(self._lib.lt_env_post_step(self._handle, self._stream()), "lt_env_post_step")

@@ -58,57 +58,70 @@ class FusedRollout:
         return ctypes.c_void_p(t.data_ptr())
 
     def step(self, t: int, last: bool) -> None:
+        if self.actor_mlp is not None:
+            self._step_packed(t, last)
+        else:
+            self._step_torch(t, last)
+        self.alg.storage.step = t + 1
+
+    def _rows(self, t: int, last: bool):
+        """(obs, critic obs, next obs ptr, next critic obs ptr) of step t."""
+        env, st = self.env, self.alg.storage
+        if not self.rows_in_storage:
+            return env.obs_policy, env.obs_critic, 0, 0
+        nxt = (0, 0) if last else (st.observations[t + 1].data_ptr(), st.privileged_observations[t + 1].data_ptr())
+        return st.observations[t], st.privileged_observations[t], nxt[0], nxt[1]
+
+    def _step_packed(self, t: int, last: bool) -> None:
+        """Three launches on ONE stream (a linear graph: cross-queue edges of a forked graph cost ~10 us each on this stack):
+        [actor + critic MLPs + sampling] -> [env step + storage record] -> [curriculum pass]."""
+        env, alg, st, p = self.env, self.alg, self.alg.storage, self._p
+        ac = alg.actor_critic
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        n = env.num_envs
+        obs, cobs, nxt_p, nxt_c = self._rows(t, last)
+        if not self.rows_in_storage:
+            st.observations[t].copy_(obs)
+            st.privileged_observations[t].copy_(cobs)
+        _abi.check(self.lib.lt_rollout_policy_value(
+            ctypes.byref(self.actor_mlp.desc), p(self.actor_mlp.packed), p(obs), ctypes.byref(self.critic_mlp.desc),
+            p(self.critic_mlp.packed), p(cobs), p(st.values[t]), n, int(env.cfg.seed), p(self._act_counter), t, p(ac.std.data),
+            p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), p(st.actions_log_prob[t]), p(self.actions), stream),
+            "lt_rollout_policy_value")
+        prev = (obs.data_ptr(), cobs.data_ptr()) if self.rows_in_storage else (0, 0)
+        env.step_rollout_raw(self.actions.data_ptr(), prev[0], prev[1], nxt_p, nxt_c, st.values[t].data_ptr(), float(alg.gamma),
+                             st.rewards[t].data_ptr(), st.dones[t].data_ptr())
+        env.post_step_raw()
+
+    def _step_torch(self, t: int, last: bool) -> None:
+        """torch modules for the networks (shapes outside lt_mlp's limits): GEMMs -> lt_rollout_act -> env step -> record,
+        critic and post pass on forked streams."""
         env, alg, st, p = self.env, self.alg, self.alg.storage, self._p
         ac = alg.actor_critic
         main = torch.cuda.current_stream(self.device)
         stream = ctypes.c_void_p(main.cuda_stream)
         n = env.num_envs
         null = ctypes.c_void_p(None)
-        if self.rows_in_storage:
-            obs, cobs = st.observations[t], st.privileged_observations[t]
-        else:
-            obs, cobs = env.obs_policy, env.obs_critic
-        value = None
-        if self.actor_mlp is not None:
-            # actor MLP + sampling + log-prob + storage writes, and the critic MLP beside it: one launch
-            if not self.rows_in_storage:
-                st.observations[t].copy_(obs)
-                st.privileged_observations[t].copy_(cobs)
-            _abi.check(self.lib.lt_rollout_policy_value(
-                ctypes.byref(self.actor_mlp.desc), p(self.actor_mlp.packed), p(obs), ctypes.byref(self.critic_mlp.desc),
-                p(self.critic_mlp.packed), p(cobs), p(st.values[t]), n, int(env.cfg.seed), p(self._act_counter), t, p(ac.std.data),
-                p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), p(st.actions_log_prob[t]), p(self.actions), stream), "lt_rollout_policy_value")
-        else:
-            mu = ac.actor(obs)
-            rows = (null, null, null, null) if self.rows_in_storage else (p(obs), p(cobs), p(st.observations[t]), p(st.privileged_observations[t]))
-            _abi.check(self.lib.lt_rollout_act(n, env.num_obs, int(env.cfg.seed), p(self._act_counter), p(mu), p(ac.std.data), null,
-                                               *rows, p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), null,
-                                               p(st.actions_log_prob[t]), p(self.actions), stream), "lt_rollout_act")
-            # torch critic beside the env step kernel
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                value = ac.critic(cobs)
+        obs, cobs, nxt_p, nxt_c = self._rows(t, last)
+        mu = ac.actor(obs)
+        rows = (null, null, null, null) if self.rows_in_storage else (p(obs), p(cobs), p(st.observations[t]), p(st.privileged_observations[t]))
+        _abi.check(self.lib.lt_rollout_act(n, env.num_obs, int(env.cfg.seed), p(self._act_counter), p(mu), p(ac.std.data), null,
+                                           *rows, p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), null,
+                                           p(st.actions_log_prob[t]), p(self.actions), stream), "lt_rollout_act")
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            value = ac.critic(cobs)
         main.wait_stream(self.post)  # previous step's curriculum pass / counter increment
-        if self.rows_in_storage and not last:
-            env.step_rows_raw(self.actions.data_ptr(), obs.data_ptr(), cobs.data_ptr(), st.observations[t + 1].data_ptr(),
-                              st.privileged_observations[t + 1].data_ptr())
-        elif self.rows_in_storage:
-            env.step_rows_raw(self.actions.data_ptr(), obs.data_ptr(), cobs.data_ptr(), 0, 0)
-        else:
-            env.step_rows_raw(self.actions.data_ptr(), 0, 0, 0, 0)
+        prev = (obs.data_ptr(), cobs.data_ptr()) if self.rows_in_storage else (0, 0)
+        env.step_rows_raw(self.actions.data_ptr(), prev[0], prev[1], nxt_p, nxt_c)
         self.post.wait_stream(main)
         with torch.cuda.stream(self.post):
             env.post_step_raw()
-        if value is not None:
-            main.wait_stream(self.side)
-            value.record_stream(main)
-            _abi.check(self.lib.lt_rollout_record(n, float(alg.gamma), p(env.reward_buf), p(env.dones_buf), p(env.time_out_buf), p(value),
-                                                  p(st.rewards[t]), p(st.dones[t]), p(st.values[t]), p(self._act_counter), stream),
-                       "lt_rollout_record")
-        else:  # values already sit in the storage slot; the policy kernel keys its noise on counter + t
-            _abi.check(self.lib.lt_rollout_record(n, float(alg.gamma), p(env.reward_buf), p(env.dones_buf), p(env.time_out_buf),
-                                                  p(st.values[t]), p(st.rewards[t]), p(st.dones[t]), null, null, stream), "lt_rollout_record")
-        st.step = t + 1
+        main.wait_stream(self.side)
+        value.record_stream(main)
+        _abi.check(self.lib.lt_rollout_record(n, float(alg.gamma), p(env.reward_buf), p(env.dones_buf), p(env.time_out_buf), p(value),
+                                              p(st.rewards[t]), p(st.dones[t]), p(st.values[t]), p(self._act_counter), stream),
+                   "lt_rollout_record")
 
     def rollout(self, num_steps: int) -> None:
         """`num_steps` consecutive steps into storage slots 0.. (inference mode, capturable)."""
