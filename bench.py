@@ -68,7 +68,7 @@ def cpu_baseline(task: str, num_envs: int, budget_s: float = 12.0) -> dict:
         env.step(acts[steps % 8], nthreads=cores)
         steps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or steps >= 400:
+        if el > budget_s or steps >= 20000:
             break
     return {"value": num_envs * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{steps} steps x {num_envs} envs of the same task, 0.5*N(0,1) actions, OpenMP over envs, {el:.1f} s"}
@@ -200,7 +200,8 @@ def main() -> None:
         cpu = cpu_baseline(args.task, n)
 
     if dist.rank == 0:
-        out = {"metric": "env-steps/sec (whole node), TransportTeacher 4096 envs/GPU", "value": value, "unit": "env-steps/s",
+        task_name = "TransportTeacher" if args.task == "teacher" else "Locomotion"
+        out = {"metric": f"env-steps/sec (whole node), {task_name} {n} envs/GPU", "value": value, "unit": "env-steps/s",
                "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{TASKS[args.task]} rollout (policy act + env step + storage), {n} envs/GPU, "
