@@ -95,7 +95,7 @@ def main() -> None:
     dist = Dist.from_env()
     if dist.world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={dist.world_size}: launch with torch.distributed.run for N>1")
-    dev = torch.device(f"cuda:{dist.local_rank}")
+    dev = torch.device(f"cuda:{os.environ.get('LT_FORCE_DEVICE', dist.local_rank)}")  # LT_FORCE_DEVICE: multi-rank rehearsal on one GPU
     torch.cuda.set_device(dev)
     n = args.envs
     env = LocoTouchVecEnv(TASKS[args.task], num_envs=n, device=dev, seed=42 + dist.rank)

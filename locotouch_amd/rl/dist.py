@@ -17,9 +17,10 @@ import torch.distributed as td
 
 
 class Dist:
-    def __init__(self, rank: int = 0, world_size: int = 1, local_rank: int = 0, initialized_here: bool = False):
+    def __init__(self, rank: int = 0, world_size: int = 1, local_rank: int = 0, initialized_here: bool = False, backend: str = "nccl"):
         self.rank, self.world_size, self.local_rank = rank, world_size, local_rank
         self._initialized_here = initialized_here
+        self.backend = backend
 
     @staticmethod
     def from_env(backend: str | None = None) -> "Dist":
@@ -30,15 +31,15 @@ class Dist:
         rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # LT_DIST_BACKEND=gloo: rehearsal of the multi-rank path with several ranks on ONE GPU (RCCL refuses that)
+            backend = os.environ.get("LT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         here = False
         if not td.is_initialized():
             td.init_process_group(backend=backend, rank=rank, world_size=world)
             here = True
-        return Dist(rank, world, local, here)
+        return Dist(rank, world, local, here, backend)
 
     @property
     def is_main(self) -> bool:
@@ -48,25 +49,34 @@ class Dist:
         if self.world_size > 1:
             td.barrier()
 
+    def _collective(self, t: torch.Tensor, fn) -> torch.Tensor:
+        if self.backend == "gloo" and t.is_cuda:  # gloo rehearsal on a GPU box: stage through the host
+            h = t.detach().cpu()
+            fn(h)
+            t.copy_(h)
+        else:
+            fn(t)
+        return t
+
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1:
-            td.all_reduce(t, op=td.ReduceOp.SUM)
+            self._collective(t, lambda x: td.all_reduce(x, op=td.ReduceOp.SUM))
         return t
 
     def all_reduce_mean_(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1:
-            td.all_reduce(t, op=td.ReduceOp.SUM)
+            self._collective(t, lambda x: td.all_reduce(x, op=td.ReduceOp.SUM))
             t.div_(self.world_size)
         return t
 
     def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1:
-            td.all_reduce(t, op=td.ReduceOp.MAX)
+            self._collective(t, lambda x: td.all_reduce(x, op=td.ReduceOp.MAX))
         return t
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         if self.world_size > 1:
-            td.broadcast(t, src=src)
+            self._collective(t, lambda x: td.broadcast(x, src=src))
         return t
 
     def shutdown(self) -> None:
