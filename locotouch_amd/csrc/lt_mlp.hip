@@ -5,12 +5,12 @@
 // which PyTorch runs as 4 GEMM launches + 3 activation launches per network and step.  Here a whole network - or the actor
 // and the critic side by side - is ONE launch:
 //
-//   * a workgroup (4 waves) owns 16 batch rows; their activations live in LDS ([16][S] floats, S = widest layer + 4 so that
+//   * a workgroup (NW = 4 waves, one per SIMD) owns 16 * RT batch rows; their activations live in LDS ([16][S] floats, S = widest layer + 4 so that
 //     the 16 rows of a ds_read_b128 / ds_write_b128 phase fall on distinct banks) and never visit HBM between layers;
 //   * out^T = W . act^T on v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain, no reduced precision): the weight
 //     tile is the A operand (16 output features x 4 k), the activations are the B operand (4 k x 16 rows), so a lane ends
 //     up with 4 CONSECUTIVE output features of ONE row -> the next layer's input is written back with one ds_write_b128;
-//   * each wave owns T = N/64 output tiles (independent accumulators -> the 40-cycle dependent MFMA latency never shows);
+//   * each wave owns T = N/(16 NW) output tiles (independent accumulators -> the 40-cycle dependent MFMA latency never shows);
 //   * k inside a 16-group is permuted (lane quarter q takes k = 16g + 4q + i for MFMA i) - a summation-index relabelling
 //     applied to both operands - which is what makes both operand fetches 16-byte vectors;
 //   * the parameters are pre-packed once per policy update (lt_mlp_pack) into ONE LINEAR STREAM PER WAVE of 1-KiB chunks
@@ -36,13 +36,18 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int RING = 16;               // chunks in flight per wave
+#ifndef LT_MLP_WAVES
+#define LT_MLP_WAVES 4
+#endif
+constexpr int NW = LT_MLP_WAVES;       // waves per workgroup (4 or 8).  Measured: 8 (two per SIMD) buys nothing - the waves of a workgroup
+                                       // run in lockstep, so their epilogues and barriers coincide instead of hiding behind MFMAs
 constexpr unsigned RS_POLICY = 0x400;  // same Philox stream id as lt_rollout_act
 constexpr int MODE_FORWARD = 0, MODE_POLICY = 1;
 
 __host__ __device__ inline int pad16(int x) { return (x + 15) & ~15; }
-// Tiles per wave of a layer with `ntiles` 16-feature output tiles: the smallest of {1, 2, 4, 8} that covers ntiles with 4 waves.
+// Tiles per wave of a layer with `ntiles` 16-feature output tiles: the smallest of {1, 2, 4, 8} that covers ntiles with NW waves.
 __host__ __device__ inline int tiles_per_wave(int ntiles) {
-  const int per = (ntiles + 3) >> 2;
+  const int per = (ntiles + NW - 1) / NW;
   return per > 4 ? 8 : (per > 2 ? 4 : (per > 1 ? 2 : 1));
 }
 // chunks of one layer in the stream of an ACTIVE wave: T bias chunks + G*T weight chunks, padded to whole rings
@@ -61,7 +66,7 @@ struct MlpArgs {
   int activation;
   int mode;
   int stride;                 // LDS row stride in floats
-  long long wave_base[4];     // chunk offset of each wave's stream inside `packed`
+  long long wave_base[NW];    // chunk offset of each wave's stream inside `packed`
   const float* packed;
   const float* x;
   long long m;
@@ -102,9 +107,9 @@ __device__ __forceinline__ void write_activated(const f32x4 (&acc)[T], float* ds
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #ifdef LT_MLP_STAMPS
-__device__ unsigned long long g_mlp_stamps[1024 * 32];
+__device__ unsigned long long g_mlp_stamps[1024 * 8 * NW];
 #define MLP_STAMP(i) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-  if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_mlp_stamps[blockIdx.x * 32 + (threadIdx.x >> 6) * 8 + (i)] = t_; } while (0)
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_mlp_stamps[blockIdx.x * 8 * NW + (threadIdx.x >> 6) * 8 + (i)] = t_; } while (0)
 #else
 #define MLP_STAMP(i) do { } while (0)
 #endif
@@ -239,7 +244,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
 }
 
 template <int RT>
-__global__ __launch_bounds__(256) void lt_mlp_kernel(const DualArgs d) {
+__global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
   extern __shared__ __attribute__((aligned(16))) float s_act[];
   constexpr int ROWS = 16 * RT;
   const bool second = (int)blockIdx.x >= d.split;
@@ -259,14 +264,14 @@ __global__ __launch_bounds__(256) void lt_mlp_kernel(const DualArgs d) {
     const int K0 = a.dims[0], K0p = pad16(K0);
     if ((K0 & 3) == 0) {
       const int kv = K0p >> 2, k4 = K0 >> 2;
-      for (int idx = tid; idx < ROWS * kv; idx += 256) {
+      for (int idx = tid; idx < ROWS * kv; idx += 64 * NW) {
         const int rr = idx / kv, cc = idx - rr * kv;
         const long long e = row0 + rr;
         const float4 v = (cc < k4 && e < a.m) ? *(const float4*)(a.x + e * K0 + 4 * cc) : make_float4(0.f, 0.f, 0.f, 0.f);
         *(float4*)(s_act + rr * S + 4 * cc) = v;
       }
     } else {
-      for (int idx = tid; idx < ROWS * K0p; idx += 256) {
+      for (int idx = tid; idx < ROWS * K0p; idx += 64 * NW) {
         const int rr = idx / K0p, cc = idx - rr * K0p;
         const long long e = row0 + rr;
         s_act[rr * S + cc] = (cc < K0 && e < a.m) ? a.x[e * K0 + cc] : 0.f;
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(256) void lt_mlp_kernel(const DualArgs d) {
 struct PackArgs {
   const float* w; const float* b;
   int K, N;
-  long long chunk_off[4];  // first chunk of this layer in each wave's stream (absolute, in chunks)
+  long long chunk_off[NW];  // first chunk of this layer in each wave's stream (absolute, in chunks)
   float* packed;
 };
 __global__ void lt_mlp_pack_kernel(const PackArgs p) {
@@ -323,20 +328,20 @@ bool desc_ok(const lt_mlp_desc* d) {
   for (int l = 0; l <= d->num_layers; ++l)
     if (d->dims[l] < 1 || d->dims[l] > LT_MLP_MAX_WIDTH) return false;
   for (int l = 1; l <= d->num_layers; ++l)
-    if (d->dims[l] > 512) return false;  // 8 output tiles per wave at most
+    if (d->dims[l] > 512) return false;  // 8 output tiles per wave at most (NW = 4)
   return true;
 }
 
 // stream geometry: per-wave totals (with one ring of zero chunks behind each stream: the refill runs one ring ahead)
 struct Geometry {
-  long long wave_base[4];
-  long long layer_off[LT_MLP_MAX_LAYERS][4];
+  long long wave_base[NW];
+  long long layer_off[LT_MLP_MAX_LAYERS][NW];
   long long total_chunks;
 };
 Geometry geometry(const lt_mlp_desc* d) {
   Geometry g;
   long long base = 0;
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NW; ++w) {
     g.wave_base[w] = base;
     long long off = 0;
     for (int l = 0; l < d->num_layers; ++l) {
@@ -358,7 +363,7 @@ void fill_args(const lt_mlp_desc* d, MlpArgs& a) {
     widest = pad16(d->dims[l]) > widest ? pad16(d->dims[l]) : widest;
   }
   const Geometry g = geometry(d);
-  for (int w = 0; w < 4; ++w) a.wave_base[w] = g.wave_base[w];
+  for (int w = 0; w < NW; ++w) a.wave_base[w] = g.wave_base[w];
   a.stride = widest + 4;
 }
 
@@ -380,7 +385,7 @@ int launch(DualArgs& d, int nets, hipStream_t s) {
   const size_t lds = (size_t)16 * rt * stride * sizeof(float);
   const long long b0 = (t0 + rt - 1) / rt, b1 = (t1 + rt - 1) / rt;
   d.split = (int)b0;
-  const dim3 grid((unsigned)(b0 + b1)), block(256);
+  const dim3 grid((unsigned)(b0 + b1)), block(64 * NW);
   static bool attr_set = false;
   if (!attr_set) {  // more than the default 64 KB of dynamic LDS
     attr_set = true;
@@ -417,7 +422,7 @@ extern "C" {
 
 #ifdef LT_MLP_STAMPS
 int lt_debug_mlp_stamps(unsigned long long* host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 1024 * 32);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 1024 * 8 * NW);
 }
 #endif
 
@@ -434,7 +439,7 @@ int lt_mlp_pack(const lt_mlp_desc* desc, const float* const* weights, const floa
     if (!weights[l] || !biases[l]) { lt_set_error("lt_mlp_pack: null layer pointer"); return LT_EINVAL; }
     PackArgs p;
     p.w = weights[l]; p.b = biases[l]; p.K = desc->dims[l]; p.N = desc->dims[l + 1]; p.packed = packed;
-    for (int w = 0; w < 4; ++w) p.chunk_off[w] = g.layer_off[l][w];
+    for (int w = 0; w < NW; ++w) p.chunk_off[w] = g.layer_off[l][w];
     const long long total = (long long)active_waves(p.N) * layer_chunks(p.K, p.N) * 64;
     hipLaunchKernelGGL(lt_mlp_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     const hipError_t e = hipGetLastError();

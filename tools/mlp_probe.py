@@ -30,10 +30,11 @@ for m in [int(a) for a in sys.argv[1:]] or [4096]:
     if hasattr(lib, "lt_debug_mlp_stamps"):
         import ctypes, numpy as np
         net(x, out); torch.cuda.synchronize()
-        buf = (ctypes.c_uint64 * (1024 * 32))()
+        NWV = int(os.environ.get("NWV", "4"))
+        buf = (ctypes.c_uint64 * (1024 * 8 * NWV))()
         lib.lt_debug_mlp_stamps(buf)
-        nb = min(1024, (m + 15) // 16)
-        st = np.array(buf, dtype=np.uint64).reshape(1024, 4, 8)[:nb].astype(np.int64)
+        nb = min(1024, (m + 15) // 16 // int(os.environ.get("LT_MLP_ROW_TILES", "1")))
+        st = np.array(buf, dtype=np.uint64).reshape(1024, NWV, 8)[:nb].astype(np.int64)
         L = len(dims) - 1
         t0 = st[:, :, 0].min()
         print("stamps (10 ns ticks -> ns), mean over blocks, per wave 0..3; times since kernel start")
