@@ -38,6 +38,9 @@ def _to_dict(obj) -> Any:
         return {k: _to_dict(v) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)):
         return type(obj)(_to_dict(v) for v in obj) if not hasattr(obj, "_fields") else obj
+    if not isinstance(obj, type) and hasattr(obj, "__dict__") and callable(getattr(type(obj), "to_dict", None)):
+        # permissive records (isaaclab_shim._AnyCfg) and any other cfg-like object: plain dict of their attributes
+        return {k: _to_dict(v) for k, v in vars(obj).items() if not k.startswith("__")}
     if isinstance(obj, type) or callable(obj):
         mod = getattr(obj, "__module__", None)
         name = getattr(obj, "__qualname__", getattr(obj, "__name__", None))
@@ -120,6 +123,8 @@ def configclass(cls=None, **kwargs) -> Callable:
                         break
                 if inherited is MISSING:
                     setattr(c, name, field(default_factory=_missing))
+        if not any("__post_init__" in b.__dict__ for b in c.__mro__):
+            c.__post_init__ = lambda self: None  # so that `super().__post_init__()` chains terminate (isaaclab provides one)
         c = dataclasses.dataclass(c, eq=False, **kwargs)
         # kw-only style reordering is not needed: every field has a default by construction.
         c.to_dict = _to_dict

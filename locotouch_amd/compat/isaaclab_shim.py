@@ -320,7 +320,18 @@ class JointPositionActionCfg(JointActionCfg):
 # --------------------------------------------------------------------------------------------
 # generic cfg records: accept any keyword, keep them as attributes
 # --------------------------------------------------------------------------------------------
-class _AnyCfg:
+class _AnyMeta(type):
+    """Nested config classes of permissive records resolve on demand (`UrdfConverterCfg.JointDriveCfg.PDGainsCfg(...)`)."""
+
+    def __getattr__(cls, name):
+        if name.startswith("_") or not name[:1].isupper():
+            raise AttributeError(name)
+        nested = _anycfg(name)
+        setattr(cls, name, nested)
+        return nested
+
+
+class _AnyCfg(metaclass=_AnyMeta):
     """Permissive cfg record for spawn / physics-property classes the env engine only reads fields from."""
 
     def __init__(self, *args, **kwargs):
@@ -359,7 +370,7 @@ def _anycfg(name: str, **defaults):
             setattr(self, k, copy.deepcopy(v))
         _AnyCfg.__init__(self, *args, **kwargs)
 
-    return type(name, (_AnyCfg,), {"__init__": __init__})
+    return _AnyMeta(name, (_AnyCfg,), {"__init__": __init__})
 
 
 class _Placeholder:
@@ -525,20 +536,52 @@ def _env_cfg_classes():
 
 
 def _import_packages(package_name: str, blacklist_pkgs: list | None = None):
-    """Recursive import of sub-packages (triggers the `gym.register` calls in config/**/__init__.py)."""
+    """Recursive import of SUB-PACKAGES only (their `__init__` files hold the `gym.register` calls, config/**/__init__.py);
+    plain modules are reached through those `__init__` imports, never on their own - so `locotouch/scripts/*.py`, which parse
+    sys.argv at import, are not touched."""
     import importlib
     import pkgutil
 
     blacklist_pkgs = blacklist_pkgs or []
+
+    def walk(path, prefix):
+        for info in pkgutil.iter_modules(path, prefix):
+            if not info.ispkg or any(b in info.name for b in blacklist_pkgs):
+                continue
+            try:
+                mod = importlib.import_module(info.name)
+            except Exception as exc:  # task families this build does not implement (Go2W, ...) may lean on stock terms that are
+                if ".config.locotouch" in info.name or info.name.endswith(".mdp"):  # absent here; never hide a failure of the
+                    raise                                                           # LocoTouch tasks themselves
+                import warnings
+
+                warnings.warn(f"[compat] skipped {info.name}: {type(exc).__name__}: {exc}")
+                continue
+            walk(getattr(mod, "__path__", []), info.name + ".")
+
     package = importlib.import_module(package_name)
-    for info in pkgutil.walk_packages(package.__path__, package.__name__ + ".",
-                                      onerror=lambda name: None):
-        if any(b in info.name for b in blacklist_pkgs):
-            continue
-        importlib.import_module(info.name)
+    walk(package.__path__, package.__name__ + ".")
+
+
+def _plain(obj):
+    """Containers and scalars a safe YAML loader can read back: tuples -> lists, numpy / torch scalars -> python numbers,
+    anything else that is not a plain scalar -> its string form."""
+    if isinstance(obj, dict):
+        return {str(k) if not isinstance(k, (str, int, float, bool)) else k: _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple, set, frozenset)):
+        return [_plain(v) for v in obj]
+    if obj is None or isinstance(obj, (bool, int, float, str)):
+        return obj
+    if hasattr(obj, "item") and callable(obj.item) and getattr(obj, "ndim", 1) == 0:
+        return _plain(obj.item())
+    if hasattr(obj, "tolist") and callable(obj.tolist):
+        return _plain(obj.tolist())
+    return str(obj)
 
 
 def _dump_yaml(filename: str, data, sort_keys: bool = False):
+    """`dump_yaml(path, cfg)` of the launch scripts (train.py:150-151): the config's dict form, written with the SAFE dumper so
+    that `yaml.safe_load` reads it back (no python/tuple or python/object tags)."""
     import os
 
     import yaml
@@ -549,15 +592,20 @@ def _dump_yaml(filename: str, data, sort_keys: bool = False):
     if hasattr(data, "to_dict"):
         data = data.to_dict()
     with open(filename, "w") as f:
-        yaml.dump(data, f, default_flow_style=False, sort_keys=sort_keys)
+        yaml.safe_dump(_plain(data), f, default_flow_style=False, sort_keys=sort_keys)
 
 
 def _dump_pickle(filename: str, data):
+    """`dump_pickle(path, cfg)` of the launch scripts (train.py:152-153).  The stand-in config classes are built at install time
+    and are not importable by qualified name, so the live object cannot be pickled; what is written is the config's `to_dict()`
+    form (plain containers, classes / callables as "module:qualname" strings).  NOTE: that differs from the reference's file,
+    which holds the cfg object itself - a reader must treat `params/*.pkl` from this build as a dict."""
     import os
     import pickle
 
     if not filename.endswith("pkl"):
         filename += ".pkl"
     os.makedirs(os.path.dirname(filename), exist_ok=True)
+    payload = data.to_dict() if hasattr(data, "to_dict") else data
     with open(filename, "wb") as f:
-        pickle.dump(data, f)
+        pickle.dump(payload, f)

@@ -1,0 +1,404 @@
+"""Import surface that lets the reference's launch scripts run UNMODIFIED on top of this package.
+
+`install()` registers stand-ins for every third-party module `locotouch/scripts/{train,play}.py` import that is not in the
+image - `isaaclab*` (config classes, managers API: locotouch_amd/compat/isaaclab_shim.py), `isaaclab.app.AppLauncher`,
+`isaaclab_tasks.utils{,.hydra,.parse_cfg}`, `isaaclab_rl.rsl_rl`, `gymnasium` (registry + make) and `git` - and aliases
+`loco_rl` to the PyTorch-ROCm trainer (locotouch_amd/compat/loco_rl).  `gym.make(task, cfg=env_cfg)` then builds the HIP env
+(`LocoTouchVecEnv`) for the registered task ids this build implements; the reference's own config classes are imported and
+instantiated as they are (they only need the config-class machinery), and the values the scripts override on them
+(`scene.num_envs`, `seed`, `sim.device`) are honoured.
+
+    python -m locotouch_amd.compat.run_reference <path-to>/locotouch/scripts/train.py --task Isaac-...-v1 --num_envs 4096 --headless
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import os
+import re
+import sys
+import types
+
+import torch
+
+from . import isaaclab_shim
+from .configclass import MISSING, configclass
+
+SUPPORTED_TASKS = ("Isaac-Locomotion-LocoTouch-v1", "Isaac-RandCylinderTransportTeacher-LocoTouch-v1")
+_env_factory = None
+_INSTALLED = False
+
+
+def set_env_factory(fn) -> None:
+    """Override how `gym.make` builds the env: fn(task_id, env_cfg) -> VecEnv-protocol object (tests inject a CPU stand-in)."""
+    global _env_factory
+    _env_factory = fn
+
+
+def _module(name: str, **attrs) -> types.ModuleType:
+    m = sys.modules.get(name)
+    if m is None:
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        if "." in name:
+            parent, child = name.rsplit(".", 1)
+            setattr(_module(parent), child, m)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    return m
+
+
+# ---------------------------------------------------------------------------------------------------------
+# gymnasium: registry + make
+# ---------------------------------------------------------------------------------------------------------
+class EnvSpec:
+    def __init__(self, id, entry_point, kwargs):
+        self.id, self.entry_point, self.kwargs = id, entry_point, dict(kwargs or {})
+
+
+def _install_gym():
+    try:
+        import gymnasium  # noqa: F401  (a real gymnasium wins if the image has one)
+        return
+    except ImportError:
+        pass
+    registry: dict[str, EnvSpec] = {}
+
+    def register(id, entry_point=None, disable_env_checker=False, kwargs=None, **_unused):
+        registry[id] = EnvSpec(id, entry_point, kwargs)
+
+    def spec(id):
+        return registry[id]
+
+    def make(id, cfg=None, render_mode=None, **kwargs):
+        if id not in registry:
+            raise KeyError(f"gym.make: no registered env with id {id!r}")
+        return make_env(id, cfg)
+
+    class RecordVideo:  # there is no renderer: the wrapper is transparent
+        def __new__(cls, env, **kwargs):
+            return env
+
+    _module("gymnasium", register=register, make=make, spec=spec, registry=registry, Env=object)
+    _module("gymnasium.wrappers", RecordVideo=RecordVideo)
+
+
+class ManagedEnv:
+    """What `gym.make` returns: the HIP env behind the attribute surface the scripts and `RslRlVecEnvWrapper` touch
+    (`unwrapped`, `cfg`, `num_envs`, `device`, `step_dt`, `max_episode_length`, `episode_length_buf`, `close`)."""
+
+    def __init__(self, task_id: str, cfg, vec_env):
+        self.task_id, self.cfg, self.vec = task_id, cfg, vec_env
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def __getattr__(self, name):  # everything else is the VecEnv's
+        return getattr(self.vec, name)
+
+    @property
+    def episode_length_buf(self):
+        return self.vec.episode_length_buf
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):
+        self.vec.episode_length_buf = value
+
+    def close(self):
+        pass
+
+
+def make_env(task_id: str, cfg):
+    num_envs = int(cfg.scene.num_envs) if cfg is not None else 4096
+    seed = getattr(cfg, "seed", None) if cfg is not None else None
+    if _env_factory is not None:
+        return ManagedEnv(task_id, cfg, _env_factory(task_id, cfg))
+    if task_id not in SUPPORTED_TASKS:
+        raise NotImplementedError(f"task {task_id!r} is registered by the reference but not implemented by this build; "
+                                  f"implemented: {SUPPORTED_TASKS}")
+    from ..env import LocoTouchVecEnv
+
+    device = getattr(getattr(cfg, "sim", None), "device", None) or "cuda:0"
+    return ManagedEnv(task_id, cfg, LocoTouchVecEnv(task_id, num_envs=num_envs, device=device, seed=42 if seed is None else int(seed)))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# isaaclab.app, isaaclab_tasks.utils, isaaclab_rl.rsl_rl
+# ---------------------------------------------------------------------------------------------------------
+class _App:
+    def is_running(self) -> bool:
+        return True
+
+    def close(self) -> None:
+        pass
+
+
+class AppLauncher:
+    """No simulator application to launch; keeps the CLI surface (`--headless --device --enable_cameras ...`)."""
+
+    def __init__(self, launcher_args=None, **kwargs):
+        self.app = _App()
+
+    @staticmethod
+    def add_app_launcher_args(parser: argparse.ArgumentParser) -> None:
+        g = parser.add_argument_group("app_launcher", description="Arguments of the (absent) simulator application.")
+        g.add_argument("--headless", action="store_true", default=False)
+        g.add_argument("--livestream", type=int, default=-1)
+        g.add_argument("--enable_cameras", action="store_true", default=False)
+        g.add_argument("--device", type=str, default=None)
+        g.add_argument("--verbose", action="store_true", default=False)
+        g.add_argument("--experience", type=str, default="")
+        g.add_argument("--kit_args", type=str, default="")
+
+
+def load_cfg_from_registry(task_name: str, entry_point_key: str):
+    import gymnasium as gym
+
+    entry = gym.spec(task_name).kwargs.get(entry_point_key)
+    if entry is None:
+        raise ValueError(f"no entry point {entry_point_key!r} registered for {task_name!r}")
+    if isinstance(entry, str):
+        if entry.endswith(".yaml"):
+            import yaml
+
+            with open(entry) as f:
+                return yaml.safe_load(f)
+        mod, attr = entry.split(":")
+        entry = getattr(importlib.import_module(mod), attr)
+    return entry() if callable(entry) else entry
+
+
+def parse_env_cfg(task_name: str, device: str = "cuda:0", num_envs: int | None = None, use_fabric: bool | None = None):
+    cfg = load_cfg_from_registry(task_name, "env_cfg_entry_point")
+    cfg.sim.device = device
+    if num_envs is not None:
+        cfg.scene.num_envs = num_envs
+    return cfg
+
+
+def _apply_override(cfg, dotted: str, value: str) -> None:
+    import ast
+
+    obj = cfg
+    parts = dotted.split(".")
+    for p in parts[:-1]:
+        obj = getattr(obj, p)
+    try:
+        val = ast.literal_eval(value)
+    except Exception:
+        val = value
+    setattr(obj, parts[-1], val)
+
+
+def hydra_task_config(task_name: str, agent_cfg_entry_point: str):
+    """Decorator of the scripts' main(env_cfg, agent_cfg): loads both configs from the registry and applies
+    `env.<path>=<value>` / `agent.<path>=<value>` overrides left in sys.argv (the part of Hydra the scripts rely on)."""
+
+    def decorator(func):
+        def wrapper(*args, **kwargs):
+            env_cfg = load_cfg_from_registry(task_name, "env_cfg_entry_point")
+            agent_cfg = load_cfg_from_registry(task_name, agent_cfg_entry_point)
+            for tok in sys.argv[1:]:
+                m = re.match(r"^(env|agent)\.([\w.]+)=(.*)$", tok)
+                if m:
+                    _apply_override(env_cfg if m.group(1) == "env" else agent_cfg, m.group(2), m.group(3))
+            return func(env_cfg, agent_cfg, *args, **kwargs)
+
+        return wrapper
+
+    return decorator
+
+
+def get_checkpoint_path(log_path: str, run_dir: str = ".*", checkpoint: str = ".*", other_dirs=None, sort_alpha: bool = True) -> str:
+    """Latest run directory matching `run_dir` (regex) under `log_path`, latest file matching `checkpoint` inside it."""
+    try:
+        runs = [e.path for e in os.scandir(log_path) if e.is_dir() and re.match(run_dir, e.name)]
+    except FileNotFoundError:
+        runs = []
+    if not runs:
+        raise ValueError(f"no runs in {log_path!r} match {run_dir!r}")
+    runs.sort() if sort_alpha else runs.sort(key=os.path.getmtime)
+    run_path = os.path.join(runs[-1], *(other_dirs or []))
+    files = [f for f in os.listdir(run_path) if re.match(checkpoint, f)]
+    if not files:
+        raise ValueError(f"no checkpoints in {run_path!r} match {checkpoint!r}")
+    files.sort(key=lambda m: f"{m:0>15}")
+    return os.path.join(run_path, files[-1])
+
+
+def _rsl_rl_cfgs():
+    @configclass
+    class RslRlPpoActorCriticCfg:
+        class_name: str = "ActorCritic"
+        init_noise_std: float = MISSING
+        actor_hidden_dims: list = MISSING
+        critic_hidden_dims: list = MISSING
+        activation: str = MISSING
+
+    @configclass
+    class RslRlPpoAlgorithmCfg:
+        class_name: str = "PPO"
+        value_loss_coef: float = MISSING
+        use_clipped_value_loss: bool = MISSING
+        clip_param: float = MISSING
+        entropy_coef: float = MISSING
+        num_learning_epochs: int = MISSING
+        num_mini_batches: int = MISSING
+        learning_rate: float = MISSING
+        schedule: str = MISSING
+        gamma: float = MISSING
+        lam: float = MISSING
+        desired_kl: float = MISSING
+        max_grad_norm: float = MISSING
+
+    @configclass
+    class RslRlOnPolicyRunnerCfg:
+        seed: int = 42
+        device: str = "cuda:0"
+        num_steps_per_env: int = MISSING
+        max_iterations: int = MISSING
+        empirical_normalization: bool = MISSING
+        policy: object = MISSING
+        algorithm: object = MISSING
+        save_interval: int = MISSING
+        experiment_name: str = MISSING
+        run_name: str = ""
+        logger: str = "tensorboard"
+        neptune_project: str = "isaaclab"
+        wandb_project: str = "isaaclab"
+        resume: bool = False
+        load_run: str = ".*"
+        load_checkpoint: str = "model_.*.pt"
+
+    return RslRlPpoActorCriticCfg, RslRlPpoAlgorithmCfg, RslRlOnPolicyRunnerCfg
+
+
+class RslRlVecEnvWrapper:
+    """`RslRlVecEnvWrapper(env)`: the VecEnv protocol of loco_rl/loco_rl/env/vec_env.py:12-101 over what gym.make returned.
+    The HIP env already speaks that protocol, so this only forwards (and performs the reset the IsaacLab wrapper does)."""
+
+    def __init__(self, env, clip_actions=None):
+        self.env = env
+        self.clip_actions = clip_actions
+        vec = env.unwrapped
+        self.num_envs, self.num_actions, self.device = vec.num_envs, vec.num_actions, vec.device
+        self.max_episode_length = vec.max_episode_length
+        self.num_obs = vec.num_obs
+        self.num_privileged_obs = getattr(vec, "num_privileged_obs", vec.num_obs)
+
+    @property
+    def cfg(self):
+        return self.env.cfg
+
+    @property
+    def unwrapped(self):
+        return self.env.unwrapped
+
+    @property
+    def episode_length_buf(self):
+        return self.env.unwrapped.episode_length_buf
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):
+        self.env.unwrapped.episode_length_buf = value
+
+    def get_observations(self):
+        return self.env.unwrapped.get_observations()
+
+    def reset(self):
+        return self.env.unwrapped.reset()
+
+    def step(self, actions: torch.Tensor):
+        if self.clip_actions is not None:
+            actions = torch.clamp(actions, -self.clip_actions, self.clip_actions)
+        return self.env.unwrapped.step(actions)
+
+    def seed(self, seed: int = -1) -> int:
+        return seed
+
+    def close(self):
+        return self.env.close()
+
+    def __getattr__(self, name):
+        return getattr(self.env.unwrapped, name)
+
+
+def _export_unavailable(*args, **kwargs):
+    raise NotImplementedError("policy export (jit/onnx) is outside this build's scope; torch.save the ActorCritic instead")
+
+
+_STOCK_MDP = ["generated_commands", "base_ang_vel", "base_lin_vel", "projected_gravity", "joint_pos_rel", "joint_vel_rel", "last_action",
+              "is_alive", "time_out", "bad_orientation", "root_height_below_minimum", "illegal_contact", "randomize_rigid_body_mass",
+              "randomize_rigid_body_material", "reset_root_state_uniform", "reset_joints_by_offset", "reset_joints_by_scale",
+              "push_by_setting_velocity", "height_scan", "joint_pos_out_of_limit", "is_terminated", "action_rate_l2", "joint_acc_l2",
+              "joint_torques_l2", "flat_orientation_l2", "lin_vel_z_l2", "ang_vel_xy_l2", "undesired_contacts", "reset_scene_to_default"]
+
+
+def _stock_mdp() -> dict:
+    """Names the reference configs reference as `mdp.<name>` (locomotion_base_env_cfg.py).  In this build the terms are part of
+    the fused step kernel; the functions exist so that the configs import, and say so when called."""
+
+    def make(name):
+        def term(env, *args, **kwargs):
+            raise RuntimeError(f"isaaclab.envs.mdp.{name} is evaluated inside lt_step_kernel; the Python term is a config-time placeholder")
+
+        term.__name__ = name
+        return term
+
+    return {n: make(n) for n in _STOCK_MDP}
+
+
+def _permissive(modname: str) -> None:
+    """Unknown attribute of a stand-in module: `...Cfg` -> a permissive config class, anything else -> a placeholder term.
+    (The reference registers Go2W / other-robot tasks from the same package tree; importing their configs must not fail just
+    because this build does not implement those tasks.)"""
+    mod = _module(modname)
+
+    def getattr_(name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        if name.endswith("Cfg"):
+            value = isaaclab_shim._anycfg(name)
+        elif name[:1].isupper():
+            value = type(name, (isaaclab_shim._Placeholder,), {})
+        else:
+            def value(*args, _n=name, **kwargs):
+                raise RuntimeError(f"{modname}.{_n} is a config-time placeholder in this build")
+            value.__name__ = name
+        setattr(mod, name, value)
+        return value
+
+    mod.__getattr__ = getattr_
+
+
+def install(env_factory=None) -> None:
+    global _INSTALLED
+    if env_factory is not None:
+        set_env_factory(env_factory)
+    if _INSTALLED:
+        return
+    _INSTALLED = True
+    _install_gym()
+    isaaclab_shim.install(extra_mdp=_stock_mdp(), import_subpackages=True)
+    for m in ("isaaclab.envs.mdp", "isaaclab.envs.mdp.actions", "isaaclab.envs.mdp.commands", "isaaclab.sim", "isaaclab.sensors",
+              "isaaclab.assets", "isaaclab.actuators", "isaaclab.terrains", "isaaclab.utils.noise", "isaaclab.managers", "isaaclab.envs",
+              "isaaclab.scene", "isaaclab.sim.spawners", "isaaclab.sim.schemas", "isaaclab.utils.assets", "isaaclab.markers",
+              "isaaclab.markers.config", "isaaclab.terrains.config.rough"):
+        _permissive(m)
+    _module("isaaclab.app", AppLauncher=AppLauncher)
+    tu = _module("isaaclab_tasks.utils")
+    tu.get_checkpoint_path, tu.parse_env_cfg, tu.load_cfg_from_registry = get_checkpoint_path, parse_env_cfg, load_cfg_from_registry
+    _module("isaaclab_tasks.utils.hydra", hydra_task_config=hydra_task_config)
+    _module("isaaclab_tasks.utils.parse_cfg", load_cfg_from_registry=load_cfg_from_registry, parse_env_cfg=parse_env_cfg,
+            get_checkpoint_path=get_checkpoint_path)
+    ac, alg, runner = _rsl_rl_cfgs()
+    _module("isaaclab_rl")
+    _module("isaaclab_rl.rsl_rl", RslRlVecEnvWrapper=RslRlVecEnvWrapper, RslRlOnPolicyRunnerCfg=runner, RslRlPpoActorCriticCfg=ac,
+            RslRlPpoAlgorithmCfg=alg, export_policy_as_jit=_export_unavailable, export_policy_as_onnx=_export_unavailable)
+    # loco_rl -> this package's trainer
+    from . import loco_rl as alias
+
+    sys.modules["loco_rl"] = alias
+    for sub in ("runners", "models", "algorithms", "modules", "storage", "env", "utils"):
+        sys.modules[f"loco_rl.{sub}"] = importlib.import_module(f"{alias.__name__}.{sub}")

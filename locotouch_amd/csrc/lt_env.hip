@@ -34,6 +34,7 @@ struct KArgs {
   const lt_dev_args* __restrict__ d;
   char* arena;
   const float* actions;
+  long long npad;  // == d->layout.npad: lets the state loads be issued before the (cfg, layout) block has been staged
   // observation rows [npad][OBS] of the two groups: previous rows (read) and new rows (written).  Equal pointers =
   // in-place update of the arena rows (lt_env_step); distinct = rollout-storage slots t / t+1 (lt_env_step_rows).
   const float* obs_prev[2];
@@ -45,6 +46,25 @@ struct KArgs {
   unsigned char* rec_dones;
 };
 static_assert(sizeof(lt_dev_args) <= LT_DEV_ARGS_BYTES, "lt_dev_args outgrew its arena slot");
+
+// Quad-array index of every quad field (prefix sum of lt_field_quads): npad * 16 B is a multiple of 256, so the 256-byte
+// alignment of lt_layout_init never pads and quad_off[f] == k_cumq.v[f] * npad * 16 (lt_check_layout verifies it on the
+// host).  Field addresses are then compile-time multiples of one runtime stride: no offset-table loads in the kernels.
+struct CumQ { int v[LT_NUM_QUAD_FIELDS + 1]; };
+constexpr int field_quads_c(int f) {
+  return (f == LT_F_JOINT_POS || f == LT_F_JOINT_VEL || f == LT_F_JOINT_ACC || f == LT_F_APPLIED_TORQUE || f == LT_F_ACT_RAW ||
+          f == LT_F_ACT_PREV_RAW || f == LT_F_ACT_PREV_PREV_RAW || f == LT_F_FOOT_POS_W || f == LT_F_FOOT_VEL_W || f == LT_F_CURRICULUM)
+             ? 3
+             : (f == LT_F_FORCE_HIST ? 12 : ((f == LT_F_EPISODE_SUMS || f == LT_F_LAST_EPISODE_SUMS || f == LT_F_REWARD_TERMS) ? 7 : 1));
+}
+constexpr CumQ make_cumq() {
+  CumQ c{};
+  int acc = 0;
+  for (int f = 0; f < LT_NUM_QUAD_FIELDS; ++f) { c.v[f] = acc; acc += field_quads_c(f); }
+  c.v[LT_NUM_QUAD_FIELDS] = acc;
+  return c;
+}
+__device__ constexpr CumQ k_cumq = make_cumq();
 
 // ---- robot model (generated from the reference URDF by tools/compile_robot_model.py), mirror form: every per-leg
 // constant is (FL-leg literal) x sign[pattern], sign = {1, sx, sy, sx*sy} of the lane's leg -> no table loads, nothing
@@ -513,25 +533,50 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
   constexpr bool HAS_OBJ = TASK != LT_TASK_LOCOMOTION;
   constexpr int FRAME = HAS_OBJ ? 58 : 45;
   constexpr int OBS = FRAME * 6;
-  // Stage the (cfg, layout) block into LDS with one coalesced burst: ~130 scattered scalar loads (each its own L2 round
-  // trip + s_waitcnt for a lone wave) become two vector loads and cheap ds_reads.
-  __shared__ lt_dev_args s_d;
-  {
-    static_assert(sizeof(lt_dev_args) % 16 == 0, "lt_dev_args must be a multiple of 16 bytes");
-    const uint4* src = (const uint4*)a.d;
-    uint4* dst = (uint4*)&s_d;
-    for (int i = threadIdx.x; i < (int)(sizeof(lt_dev_args) / 16); i += 64) dst[i] = src[i];
-  }
-  __syncthreads();
-  const lt_cfg& c = s_d.cfg;
-  const lt_layout& L = s_d.layout;
   const int lane = threadIdx.x;
   const int leg = lane & 3;
   const long long gid = (long long)blockIdx.x * 64 + lane;  // == env*4 + leg
   const long long env = gid >> 2;
-  const long long q4 = L.npad * 4;
+  const long long q4 = a.npad * 4;
   char* const arena = a.arena;
-  auto F = [&](int field, int q) -> float* { return (float*)(arena + L.quad_off[field]) + (long long)q * q4 + gid; };
+  auto F = [&](int field, int q) -> float* { return (float*)arena + (long long)(k_cumq.v[field] + q) * q4 + gid; };
+
+  // ---- prologue: ONE memory round trip.  The (cfg, layout) block (two 16-B loads per lane, staged into LDS: ~130 scattered
+  //      scalar loads - each its own L2 round trip for a lone wave - become cheap ds_reads) and the state the physics needs
+  //      (one coalesced 256-B access per quad array) are issued together; vmcnt retires in order, so the 44-KB LDS-DMA of the
+  //      old observation rows is issued only AFTER them - it then lands behind the physics instead of in front of it.
+  //      Everything the physics never touches is loaded after the decimation loop (registers). ----
+  __shared__ lt_dev_args s_d;
+  static_assert(sizeof(lt_dev_args) % 16 == 0, "lt_dev_args must be a multiple of 16 bytes");
+  constexpr int STG = (int)(sizeof(lt_dev_args) / 16);
+  static_assert(STG <= 128, "staging assumes at most two 16-byte pieces per lane");
+  const uint4* const stg_src = (const uint4*)a.d;
+  const uint4 stg0 = stg_src[lane < STG ? lane : 0], stg1 = stg_src[lane + 64 < STG ? lane + 64 : 0];
+  struct {
+    float root_pos, root_quat, root_lin, root_ang, obj_pos, obj_quat, obj_lin, obj_ang, obj_timers, obj_params, env_params, trunk_fh;
+    float q[3], qd[3], raw[3], fh[12], cur_air, cur_con, last_air, last_con, mu;
+  } hot;
+  hot.root_pos = *F(LT_F_ROOT_POS, 0); hot.root_quat = *F(LT_F_ROOT_QUAT, 0);
+  hot.root_lin = *F(LT_F_ROOT_LIN_VEL_W, 0); hot.root_ang = *F(LT_F_ROOT_ANG_VEL_W, 0);
+  hot.obj_pos = *F(LT_F_OBJ_POS, 0); hot.obj_quat = *F(LT_F_OBJ_QUAT, 0);
+  hot.obj_lin = *F(LT_F_OBJ_LIN_VEL_W, 0); hot.obj_ang = *F(LT_F_OBJ_ANG_VEL_W, 0);
+  hot.obj_timers = *F(LT_F_OBJ_TIMERS, 0); hot.obj_params = *F(LT_F_OBJ_PARAMS, 0);
+  hot.env_params = *F(LT_F_ENV_PARAMS, 0); hot.trunk_fh = *F(LT_F_TRUNK_FORCE_HIST, 0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { hot.q[k] = *F(LT_F_JOINT_POS, k); hot.qd[k] = *F(LT_F_JOINT_VEL, k); hot.raw[k] = *F(LT_F_ACT_RAW, k); }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) hot.fh[i] = *F(LT_F_FORCE_HIST, i);
+  hot.cur_air = *F(LT_F_FOOT_CUR_AIR, 0); hot.cur_con = *F(LT_F_FOOT_CUR_CONTACT, 0);
+  hot.last_air = *F(LT_F_FOOT_LAST_AIR, 0); hot.last_con = *F(LT_F_FOOT_LAST_CONTACT, 0);
+  hot.mu = *F(LT_F_FOOT_FRICTION, 0);
+  {
+    uint4* dst = (uint4*)&s_d;
+    if (lane < STG) dst[lane] = stg0;
+    if (lane + 64 < STG) dst[lane + 64] = stg1;
+  }
+  __syncthreads();
+  const lt_cfg& c = s_d.cfg;
+  const lt_layout& L = s_d.layout;
   const float* P = (const float*)(arena + L.off_cmd_params);
   const uint64_t step = MODE == MODE_RESET_ALL ? 0ull : (uint64_t)((const long long*)(arena + L.off_counters))[0];
   const float step_dt = c.sim_dt * (float)c.decimation;
@@ -566,36 +611,35 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) qdef[k] = k_m_dq[k] * sgn[k_m_dq_pat[k]];
 
-  // ---- load the state the physics needs (one coalesced 256-B access per quad array); everything else is loaded
-  //      after the decimation loop so that it does not occupy registers (or scratch) during the physics ----
+  // ---- unpack the hot state (per-env vectors are broadcast inside the quad) ----
   Base B; Obj O; Leg G; Misc X;
   {
     float t;
-    t = *F(LT_F_ROOT_POS, 0); B.p = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
-    t = *F(LT_F_ROOT_QUAT, 0); B.q.w = qbcast<0>(t); B.q.x = qbcast<1>(t); B.q.y = qbcast<2>(t); B.q.z = qbcast<3>(t);
-    t = *F(LT_F_ROOT_LIN_VEL_W, 0); B.u = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
-    t = *F(LT_F_ROOT_ANG_VEL_W, 0); B.w = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
-    t = *F(LT_F_OBJ_POS, 0); O.p = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
-    t = *F(LT_F_OBJ_QUAT, 0); O.q.w = qbcast<0>(t); O.q.x = qbcast<1>(t); O.q.y = qbcast<2>(t); O.q.z = qbcast<3>(t);
-    t = *F(LT_F_OBJ_LIN_VEL_W, 0); O.u = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
-    t = *F(LT_F_OBJ_ANG_VEL_W, 0); O.w = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
-    t = *F(LT_F_OBJ_TIMERS, 0); O.cur_air = qbcast<0>(t); O.cur_con = qbcast<1>(t); O.last_air = qbcast<2>(t); O.last_con = qbcast<3>(t);
-    t = *F(LT_F_OBJ_PARAMS, 0); O.rad = qbcast<0>(t); O.len = qbcast<1>(t); O.mass = qbcast<2>(t); O.mu = qbcast<3>(t);
-    t = *F(LT_F_ENV_PARAMS, 0); X.trunk_mass_add = qbcast<0>(t); X.trunk_mu = qbcast<1>(t); X.trunk_rest = qbcast<2>(t); X.obj_rest = qbcast<3>(t);
-    t = *F(LT_F_TRUNK_FORCE_HIST, 0); X.trunk_fh[0] = qbcast<0>(t); X.trunk_fh[1] = qbcast<1>(t); X.trunk_fh[2] = qbcast<2>(t);
+    t = hot.root_pos; B.p = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+    t = hot.root_quat; B.q.w = qbcast<0>(t); B.q.x = qbcast<1>(t); B.q.y = qbcast<2>(t); B.q.z = qbcast<3>(t);
+    t = hot.root_lin; B.u = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+    t = hot.root_ang; B.w = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+    t = hot.obj_pos; O.p = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+    t = hot.obj_quat; O.q.w = qbcast<0>(t); O.q.x = qbcast<1>(t); O.q.y = qbcast<2>(t); O.q.z = qbcast<3>(t);
+    t = hot.obj_lin; O.u = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+    t = hot.obj_ang; O.w = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+    t = hot.obj_timers; O.cur_air = qbcast<0>(t); O.cur_con = qbcast<1>(t); O.last_air = qbcast<2>(t); O.last_con = qbcast<3>(t);
+    t = hot.obj_params; O.rad = qbcast<0>(t); O.len = qbcast<1>(t); O.mass = qbcast<2>(t); O.mu = qbcast<3>(t);
+    t = hot.env_params; X.trunk_mass_add = qbcast<0>(t); X.trunk_mu = qbcast<1>(t); X.trunk_rest = qbcast<2>(t); X.obj_rest = qbcast<3>(t);
+    t = hot.trunk_fh; X.trunk_fh[0] = qbcast<0>(t); X.trunk_fh[1] = qbcast<1>(t); X.trunk_fh[2] = qbcast<2>(t);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      G.q[k] = *F(LT_F_JOINT_POS, k); G.qd[k] = *F(LT_F_JOINT_VEL, k);
-      G.raw[k] = *F(LT_F_ACT_RAW, k);
+      G.q[k] = hot.q[k]; G.qd[k] = hot.qd[k];
+      G.raw[k] = hot.raw[k];
       G.qdd[k] = 0.f; G.tau[k] = 0.f; G.prev[k] = 0.f; G.prev2[k] = 0.f;
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-      for (int ty = 0; ty < 4; ++ty) G.fh[s][ty] = *F(LT_F_FORCE_HIST, s * 4 + ty);
-    G.cur_air = *F(LT_F_FOOT_CUR_AIR, 0); G.cur_con = *F(LT_F_FOOT_CUR_CONTACT, 0);
-    G.last_air = *F(LT_F_FOOT_LAST_AIR, 0); G.last_con = *F(LT_F_FOOT_LAST_CONTACT, 0);
-    G.mu = *F(LT_F_FOOT_FRICTION, 0);
+      for (int ty = 0; ty < 4; ++ty) G.fh[s][ty] = hot.fh[s * 4 + ty];
+    G.cur_air = hot.cur_air; G.cur_con = hot.cur_con;
+    G.last_air = hot.last_air; G.last_con = hot.last_con;
+    G.mu = hot.mu;
   }
 
   LT_STAMP(1);
@@ -1211,6 +1255,7 @@ KArgs make_args(const lt_env* env, const float* actions) {
   k.d = (const lt_dev_args*)((const char*)env->arena + env->layout.off_dev_args);
   k.arena = (char*)env->arena;
   k.actions = actions;
+  k.npad = env->layout.npad;
   float* const rp = (float*)((char*)env->arena + env->layout.off_obs_policy);
   float* const rc = (float*)((char*)env->arena + env->layout.off_obs_critic);
   k.obs_prev[0] = rp; k.obs_prev[1] = rc;
@@ -1244,6 +1289,12 @@ int launch_step(const lt_env* env, const float* actions, hipStream_t s, const fl
 }
 
 }  // namespace
+
+int lt_check_layout(const lt_layout* L) {
+  for (int f = 0; f < LT_NUM_QUAD_FIELDS; ++f)
+    if (L->quad_off[f] != (int64_t)make_cumq().v[f] * L->npad * 16 || field_quads_c(f) != lt_field_quads(f)) return 0;
+  return 1;
+}
 
 int lt_launch_reset_all(const lt_env* env, void* stream) {
   hipStream_t s = (hipStream_t)stream;

@@ -45,6 +45,11 @@ int lt_env_create(const lt_cfg* cfg, lt_env** out) {
   if (!e) return LT_ENOMEM;
   e->cfg = *cfg;
   lt_layout_init(&e->layout, cfg->num_envs, lt_cfg_obs_dim(cfg));
+  if (!lt_check_layout(&e->layout)) {
+    delete e;
+    lt_set_error("lt_env_create: lt_layout_init and the kernels' compile-time field offsets disagree (library built from mixed sources)");
+    return LT_EINVAL;
+  }
   std::memset(&e->dev_args, 0, sizeof(e->dev_args));
   e->dev_args.cfg = e->cfg;
   e->dev_args.layout = e->layout;

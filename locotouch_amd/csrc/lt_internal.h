@@ -18,6 +18,7 @@ struct lt_env {
 
 // implemented in lt_env.hip -------------------------------------------------------------------------
 // Every launcher enqueues on `stream` and returns a hipError_t value as int (0 = hipSuccess).
+int lt_check_layout(const lt_layout* L);  // 1 if the kernels' compile-time quad-field offsets match this layout
 int lt_launch_reset_all(const lt_env* env, void* stream);
 int lt_launch_step(const lt_env* env, const float* actions, void* stream);
 int lt_launch_step_rows(const lt_env* env, const float* actions, const float* const prev[2], float* const next[2], const float* values,

@@ -40,6 +40,7 @@ class OnPolicyRunner:
         self.log_dir = log_dir if self.dist.is_main else None
         self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0.0, 0
         self.history: list[dict] = []
+        self.git_status_repos: list[str] = []
 
     def learn(self, num_learning_iterations: int, init_at_random_ep_len: bool = False) -> None:
         env, alg = self.env, self.alg
@@ -151,6 +152,21 @@ class OnPolicyRunner:
         if self.dist.world_size > 1:
             self.alg.broadcast_parameters()
         return loaded.get("infos")
+
+    def train_mode(self) -> None:  # reference on_policy_runner.py:466-475
+        self.alg.train_mode()
+
+    def eval_mode(self) -> None:  # reference on_policy_runner.py:477-486
+        self.alg.test_mode()
+
+    def add_git_repo_to_log(self, repo_file_path: str) -> None:
+        """Reference on_policy_runner.py:488-489: remembers code locations whose git state goes into the log directory.  There is
+        no GitPython in this image, so the paths are recorded (`<log_dir>/git/repos.txt`) and no diff is taken."""
+        self.git_status_repos.append(repo_file_path)
+        if self.log_dir is not None:
+            os.makedirs(os.path.join(self.log_dir, "git"), exist_ok=True)
+            with open(os.path.join(self.log_dir, "git", "repos.txt"), "a") as f:
+                f.write(str(repo_file_path) + "\n")
 
     def get_inference_policy(self, device=None):
         self.alg.test_mode()

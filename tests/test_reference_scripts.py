@@ -1,0 +1,78 @@
+"""The reference's launch script runs UNMODIFIED against this package's import surface.
+
+`locotouch/scripts/train.py` is executed from the read-only reference checkout with locotouch_amd.compat.runtime installed:
+its own argparse / config classes / gym registrations / call sequence run as they are; `gym.make` is pointed at the CPU oracle
+(test infrastructure) because this container has no GPU, and `from loco_rl.runners import OnPolicyRunner` resolves to this
+package's trainer.  Skipped where the reference checkout does not exist (the GPU box).
+"""
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+
+REF = "/root/reference"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+DRIVER = r"""
+import os, runpy, sys
+sys.dont_write_bytecode = True
+repo, script = sys.argv[1], sys.argv[2]
+sys.path.insert(0, repo)
+sys.path.insert(0, os.path.dirname(script))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(script))))
+from locotouch_amd.compat import runtime
+from tests.oracle_vec_env import OracleVecEnv
+runtime.install(env_factory=lambda task_id, cfg: OracleVecEnv(task_id, int(cfg.scene.num_envs), seed=int(cfg.seed)))
+sys.argv = [script] + sys.argv[3:]
+runpy.run_path(script, run_name="__main__")
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+@pytest.mark.parametrize("task", ["Isaac-RandCylinderTransportTeacher-LocoTouch-v1", "Isaac-Locomotion-LocoTouch-v1"])
+def test_reference_train_script_runs_unmodified(tmp_path, task):
+    script = os.path.join(REF, "locotouch", "scripts", "train.py")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-c", DRIVER, REPO, script, "--task", task, "--num_envs", "16", "--max_iterations", "2", "--headless",
+           "--device", "cpu", "--logger", "tensorboard", "--seed", "7", "agent.device=cpu"]  # the last one: Hydra-style override
+    out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    runs = glob.glob(os.path.join(str(tmp_path), "logs", "rsl_rl", "*", "*"))
+    assert len(runs) == 1, runs
+    run = runs[0]
+    import pickle
+
+    import yaml
+
+    # the dumps must be READABLE with safe loaders, and carry the values the script set (train.py:76-85)
+    env_y = yaml.safe_load(open(os.path.join(run, "params", "env.yaml")))
+    agent_y = yaml.safe_load(open(os.path.join(run, "params", "agent.yaml")))
+    assert env_y["scene"]["num_envs"] == 16 and env_y["seed"] == 7 and env_y["sim"]["device"] == "cpu"
+    assert agent_y["seed"] == 7 and agent_y["max_iterations"] == 2 and agent_y["policy"]["actor_hidden_dims"] == [512, 256, 128]
+    assert agent_y["algorithm"]["num_learning_epochs"] == 5 and agent_y["algorithm"]["num_mini_batches"] == 4
+    with open(os.path.join(run, "params", "agent.pkl"), "rb") as f:  # written by this process' own code: a plain dict
+        assert pickle.load(f)["num_steps_per_env"] == 24
+    models = sorted(os.path.basename(p) for p in glob.glob(os.path.join(run, "model_*.pt")))
+    assert "model_2.pt" in models, models  # final checkpoint of a 2-iteration run (on_policy_runner.py:243-245 naming)
+    import torch
+
+    ck = torch.load(os.path.join(run, "model_2.pt"), weights_only=True)
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "iter", "infos"}
+    obs_dim = 348 if "Transport" in task else 270
+    assert ck["model_state_dict"]["actor.0.weight"].shape == (512, obs_dim)
+
+
+def test_checkpoint_path_regex_semantics(tmp_path):
+    """`get_checkpoint_path(root, run_regex, ckpt_regex)`: latest matching run, numerically latest matching checkpoint."""
+    from locotouch_amd.compat.runtime import get_checkpoint_path
+
+    for run in ("2025-01-01_10-00-00", "2025-02-09_21-11-23", "2025-02-09_21-11-23_extra"):
+        os.makedirs(tmp_path / run)
+        for it in (0, 50, 1000, 950):
+            (tmp_path / run / f"model_{it}.pt").write_bytes(b"")
+    assert get_checkpoint_path(str(tmp_path), ".*", "model_.*.pt").endswith("2025-02-09_21-11-23_extra/model_1000.pt")
+    assert get_checkpoint_path(str(tmp_path), "2025-01.*", "model_5.*").endswith("2025-01-01_10-00-00/model_50.pt")
+    with pytest.raises(ValueError):
+        get_checkpoint_path(str(tmp_path), "1999.*", ".*")
