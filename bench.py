@@ -28,6 +28,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 ALGO_BYTES_PER_ENV_STEP = {"teacher": 6720, "locomotion": 5344}
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling is 6290 GB/s
 TASKS = {"teacher": "Isaac-RandCylinderTransportTeacher-LocoTouch-v1", "locomotion": "Isaac-Locomotion-LocoTouch-v1"}
 POLICY_CFG = dict(init_noise_std=1.0, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], activation="elu")
@@ -74,6 +75,35 @@ def cpu_baseline(task: str, num_envs: int, budget_s: float = 12.0) -> dict:
             "sample": f"{steps} steps x {num_envs} envs of the same task, 0.5*N(0,1) actions, OpenMP over envs, {el:.1f} s"}
 
 
+def _spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` typed plainly (no torchrun): this parent starts N rank processes of the same script -
+    one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment - BEFORE touching torch or the GPU itself
+    (a process that has initialised HIP must never exec or fork into another GPU program on this pool), forwards
+    rank 0's single JSON line, and exits with the worst child code."""
+    import socket
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,8 +114,11 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager-torch", action="store_true", help="reference-shaped rollout (torch elementwise ops) instead of the fused kernels")
-    ap.add_argument("--with-update", action="store_true", help="also report rollout + PPO update (+ all-reduce) throughput")
+    ap.add_argument("--update-iters", type=int, default=3, help="PPO iterations timed for train_total_fps (0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_spawn_ranks(args))
 
     import torch
 
@@ -94,7 +127,7 @@ def main() -> None:
 
     dist = Dist.from_env()
     if dist.world_size != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={dist.world_size}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={dist.world_size}")
     dev = torch.device(f"cuda:{os.environ.get('LT_FORCE_DEVICE', dist.local_rank)}")  # LT_FORCE_DEVICE: multi-rank rehearsal on one GPU
     torch.cuda.set_device(dev)
     n = args.envs
@@ -110,7 +143,7 @@ def main() -> None:
 
     def rollout_steps(k: int) -> None:
         """k consecutive rollout steps starting at storage slot 0 (k <= ROLLOUT)."""
-        if fused is not None:  # policy GEMMs -> lt_rollout_act -> lt_env_step -> lt_rollout_record
+        if fused is not None:  # [actor+critic MLPs + sampling] -> [env step + storage record (+ curriculum tail)]
             fused.rollout(k)
             return
         alg.storage.clear()  # reference-shaped eager path (every elementwise op its own launch)
@@ -120,35 +153,46 @@ def main() -> None:
                 _, rew, dones, infos = env.step(actions)
                 alg.process_env_step(rew, dones, infos)
 
-    graph = None
+    # One hipGraph per distinct chunk length the run needs (a full 24-step rollout and, when --steps / --warmup are not
+    # multiples of 24, their remainders), all captured before the timed region.
+    graphs: dict[int, "torch.cuda.CUDAGraph"] = {}
+
+    def capture(k: int) -> None:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            rollout_steps(k)  # warm every op / allocation before capture
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            rollout_steps(k)
+        torch.cuda.synchronize(dev)
+        graphs[k] = g
+
     if not args.no_graph:
         try:
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                rollout_steps(ROLLOUT)  # warm every op / allocation before capture
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                rollout_steps(ROLLOUT)
-            torch.cuda.synchronize(dev)
+            for k in sorted({ROLLOUT, args.steps % ROLLOUT, args.warmup % ROLLOUT} - {0}, reverse=True):
+                capture(k)
         except Exception as exc:  # capture is an optimisation, not a requirement
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches", file=sys.stderr)
-            graph = None
+            graphs.clear()
             torch.cuda.synchronize(dev)
+
+    launched = {"graph": 0, "eager": 0}
 
     def run(k: int) -> None:
         full, rem = divmod(k, ROLLOUT)
-        for _ in range(full):
-            if graph is not None:
-                graph.replay()
+        for chunk in [ROLLOUT] * full + ([rem] if rem else []):
+            if chunk in graphs:
+                graphs[chunk].replay()
+                launched["graph"] += chunk
             else:
-                rollout_steps(ROLLOUT)
-        if rem:
-            rollout_steps(rem)
+                rollout_steps(chunk)
+                launched["eager"] += chunk
 
     run(args.warmup)
+    launched = {"graph": 0, "eager": 0}
     dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -179,21 +223,47 @@ def main() -> None:
     roofline = {"bound": "hbm", "kernel": "lt_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes,
                 "env_only_steps_per_s": n / (k_ms * 1e-3)}
+    # the other launch of a rollout step: actor + critic MLPs + sampling in one kernel, against the dense f32 MFMA peak
+    if fused is not None and fused.actor_mlp is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            fused.policy_value_launch(0)
+        e0.record()
+        for _ in range(50):
+            fused.policy_value_launch(0)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        mlp_ms = e0.elapsed_time(e1) / 50
+        dims = [env.num_obs, 512, 256, 128]
+        macs = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+        flop = 2.0 * n * (2 * macs + dims[-1] * (12 + 1))
+        roofline["mlp"] = {"bound": "mfma", "kernel": "lt_mlp_kernel (actor + critic + sampling)", "flop_per_launch": flop,
+                           "kernel_ms": mlp_ms, "achieved": flop / (mlp_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": flop / (mlp_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
 
     extra = {}
-    if args.with_update:  # rollout + GAE + PPO update with the gradient all-reduce (Perf/total_fps of the reference)
-        iters = 3
-        dist.barrier(); torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            rollout_steps(ROLLOUT)
+    if args.update_iters > 0:  # rollout + GAE + PPO update with the gradient all-reduce (Perf/total_fps of the reference)
+        iters = args.update_iters
+
+        def iteration() -> None:
+            if ROLLOUT in graphs:
+                graphs[ROLLOUT].replay()
+            else:
+                rollout_steps(ROLLOUT)
             with torch.inference_mode():
                 alg.compute_returns(critic_obs)
             alg.update()
+
+        iteration()  # warm the update path (allocator, hipBLASLt heuristics)
+        dist.barrier(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            iteration()
         torch.cuda.synchronize(dev); dist.barrier()
         el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         dist.all_reduce_max_(el)
         extra["train_total_fps"] = n * args.gpus * ROLLOUT * iters / float(el)
+        extra["train_iteration_ms"] = 1e3 * float(el) / iters
 
     cpu = None
     if dist.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
@@ -206,7 +276,9 @@ def main() -> None:
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{TASKS[args.task]} rollout (policy act + env step + storage), {n} envs/GPU, "
                                       f"random-init ActorCritic [512,256,128], seed 42+rank",
-                          "envs_per_gpu": n, "rollout_len": ROLLOUT, "hipgraph": graph is not None, "fused_rollout": fused is not None},
+                          "envs_per_gpu": n, "rollout_len": ROLLOUT, "hipgraph_replayed": launched["graph"] > 0 and launched["eager"] == 0,
+                          "steps_replayed_from_graphs": launched["graph"], "steps_launched_eagerly": launched["eager"],
+                          "fused_rollout": fused is not None, "launches_per_step": fused.launches_per_step if fused is not None else None},
                "roofline": roofline, "cpu_baseline": cpu}
         out.update(extra)
         print(json.dumps(out))

@@ -1,10 +1,16 @@
-"""Fused rollout step on the GPU: policy GEMMs (PyTorch-ROCm / hipBLASLt) -> lt_rollout_act -> lt_env_step -> lt_rollout_record.
+"""Fused rollout step on the GPU, semantically one iteration of the reference's rollout loop
+(loco_rl/loco_rl/runners/on_policy_runner.py:154-199):
+`actions = alg.act(obs, critic_obs); obs, rew, dones, infos = env.step(actions); alg.process_env_step(rew, dones, infos)`.
 
-Semantically one iteration of the reference's rollout loop (loco_rl/loco_rl/runners/on_policy_runner.py:154-199):
-`actions = alg.act(obs, critic_obs); obs, rew, dones, infos = env.step(actions); alg.process_env_step(rew, dones, infos)`,
-with the ~30 elementwise launches between the GEMMs and the env step replaced by the two fused kernels of
-locotouch_amd/csrc/lt_rollout.hip, the critic MLP running on a forked stream beside the actor MLP, and no host sync, so a
-whole 24-step rollout captures into one hipGraph.
+Packed path (network shapes lt_mlp.hip covers - every LocoTouch agent config): launches on ONE stream,
+    [lt_rollout_policy_value: actor + critic MLPs, sampling, log-prob, storage writes of actions/mu/sigma/values/log-prob]
+ -> [lt_env_step_rollout: env step, observation rows written into storage slot t+1, bootstrapped reward + dones into slot t]
+ -> [lt_env_post_step: curriculum / population gate / step counter]
+with no host sync, so a whole 24-step rollout captures into one hipGraph.  The chain is kept linear on purpose: forked
+streams turn graph edges into cross-queue dependencies that cost more (~10 us each on this stack) than the overlap returns.
+
+Torch path (shapes outside lt_mlp's limits): torch GEMMs -> lt_rollout_act -> lt_env_step_rows -> lt_rollout_record, with the
+critic and the curriculum pass on side streams.
 """
 from __future__ import annotations
 
@@ -16,16 +22,10 @@ from .. import _abi
 
 
 class FusedRollout:
-    """Stream plan of one step t (main = the caller's current stream, all joins by events, so the rollout captures):
-
-        main : actor(obs[t]) -> lt_rollout_act -> [join post(t-1)] lt_env_step_rows(obs[t] -> obs[t+1]) -> [join critic] lt_rollout_record
-        side : critic(obs_c[t])                                  (beside the actor GEMMs and the env step kernel)
-        post :                                                   lt_env_post_step(t)   (beside record and the next actor GEMMs)
+    """Drives a LocoTouchVecEnv and a PPO instance through rollout steps without leaving the device (module docstring).
 
     The env writes observation rows straight into the storage slots (slot t+1 from slot t; the last step writes the arena
-    rows), so nothing copies observations.  The lone-wave-per-CU step kernel leaves 3 of 4 SIMDs idle at 4096 envs - the
-    critic GEMMs run there.
-    """
+    rows), so nothing copies observations."""
 
     def __init__(self, env, alg, use_packed_mlp: bool = True):
         from ..env import LocoTouchVecEnv
@@ -71,6 +71,22 @@ class FusedRollout:
             return env.obs_policy, env.obs_critic, 0, 0
         nxt = (0, 0) if last else (st.observations[t + 1].data_ptr(), st.privileged_observations[t + 1].data_ptr())
         return st.observations[t], st.privileged_observations[t], nxt[0], nxt[1]
+
+    @property
+    def launches_per_step(self) -> int:
+        """Kernel launches of one rollout step (the reference-shaped eager loop needs ~30)."""
+        return 3 if self.actor_mlp is not None else 12
+
+    def policy_value_launch(self, t: int) -> None:
+        """The MLP launch of step t alone (bench.py times it for the MFMA roofline entry)."""
+        env, alg, st, p = self.env, self.alg, self.alg.storage, self._p
+        obs, cobs, _, _ = self._rows(t, False)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _abi.check(self.lib.lt_rollout_policy_value(
+            ctypes.byref(self.actor_mlp.desc), p(self.actor_mlp.packed), p(obs), ctypes.byref(self.critic_mlp.desc),
+            p(self.critic_mlp.packed), p(cobs), p(st.values[t]), env.num_envs, int(env.cfg.seed), p(self._act_counter), t,
+            p(alg.actor_critic.std.data), p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), p(st.actions_log_prob[t]), p(self.actions), stream),
+            "lt_rollout_policy_value")
 
     def _step_packed(self, t: int, last: bool) -> None:
         """Three launches on ONE stream (a linear graph: cross-queue edges of a forked graph cost ~10 us each on this stack):

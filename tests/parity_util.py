@@ -48,7 +48,7 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
     obs_dim = (45 if cfg.task == C["LT_TASK_LOCOMOTION"] else 58) * int(cfg.obs_history)
     L = Layout(n, obs_dim)
     assert dev.shape == ref.shape == (L.total_bytes,), (dev.shape, ref.shape, L.total_bytes)
-    report, failures, flip_envs, event_envs = [], [], set(), set()
+    report, failures, flip_envs, event_envs, soft_envs = [], [], set(), set(), {}
     for name in QUAD_FIELDS:
         if name in skip:
             continue
@@ -75,6 +75,7 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
             else:
                 failures.append((name, err, np.nonzero(bad)[0][:5].tolist()))
                 event_envs |= set(np.nonzero(bad)[0].tolist())
+    hard = []  # failures that no allowance covers
     for name in L.plain:
         if name in skip or name.startswith("_"):
             continue
@@ -85,44 +86,70 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
             badm = ~(np.abs(a - b) <= atol + rtol * np.abs(b)) | ~np.isfinite(a)
             bad = badm.reshape(n, -1).any(axis=1)
             err = float(np.abs(a - b).max())
-            soft = True
+            if bad.any():
+                soft_envs[name] = (err, set(np.nonzero(bad)[0].tolist()))
         elif name == "LT_F_CMD_PARAMS":
             bad = np.array([not np.allclose(a, b, atol=1e-6)])
             err = float(np.abs(a - b).max())
-            soft = False
+            if bad.any():
+                hard.append((name, err, []))
         elif name == "LT_F_COUNTERS":
             bad = np.array([a[0] != b[0]])
             err = float(abs(int(a[0]) - int(b[0])))
-            soft = False
+            if bad.any():
+                hard.append((name, err, []))
         else:  # integer outputs: bit-exact (reset / episode indexing)
             a, b = a[:n], b[:n]
             bad = a != b
             err = float(bad.mean())
-            soft = name in ("LT_F_TERM_BITS", "LT_F_DONES", "LT_F_TERMINATED")
+            if np.any(bad):
+                if name in ("LT_F_TERM_BITS", "LT_F_DONES", "LT_F_TERMINATED"):
+                    # a termination term decided by a thresholded contact force (|F| history vs 1 N) may flip with it
+                    flip_envs |= set(np.nonzero(bad)[0].tolist())
+                else:
+                    hard.append((name, err, np.nonzero(bad)[0][:5].tolist()))
         report.append((name, err, int(np.sum(bad))))
-        if np.any(bad):
-            if soft and name not in ("LT_F_OBS_POLICY", "LT_F_OBS_CRITIC", "LT_F_REWARD"):
-                flip_envs |= set(np.nonzero(bad)[0].tolist())
-            elif soft:
-                # obs / reward may only differ in envs that already flipped a thresholded contact
-                rest = set(np.nonzero(bad)[0].tolist()) - flip_envs
-                if rest:
-                    flip_envs |= rest
-            else:
-                failures.append((name, err, np.nonzero(bad)[0][:5].tolist()))
-    frac = len(flip_envs) / max(1, n)
-    only_env_fields = all(nm.startswith("LT_F_") and nm not in ("LT_F_CMD_PARAMS", "LT_F_COUNTERS") for nm, _, _ in failures)
-    events_ok = only_env_fields and len(event_envs) / max(1, n) <= max_event_frac
-    if events_ok:
-        flip_envs -= event_envs
-        frac = len(flip_envs) / max(1, n)
-    if (failures and not events_ok) or frac > max_flip_frac:
-        lines = [f"parity {what}: {len(failures)} hard field failures, {len(flip_envs)}/{n} envs differ in thresholded/soft fields "
-                 f"(allowed fraction {max_flip_frac})"]
-        lines += [f"  HARD {nm}: max|err|={e:.3e} envs={ids}" for nm, e, ids in failures]
+    # Observation rows / reward may differ beyond the fp32 band ONLY in envs that, in this very step, flipped a thresholded
+    # contact quantity (FLIP_TOLERANT field, termination bit, dones) or took a discontinuous event (hard-field divergence,
+    # which includes a thresholded reward term in LT_F_REWARD_TERMS).  Anything else is a plain failure.
+    explained = flip_envs | event_envs
+    for name, (err, envs) in soft_envs.items():
+        rest = sorted(envs - explained)
+        if rest:
+            hard.append((name + " (no contact flip / event in these envs)", err, rest[:5]))
+    n_flip, n_event = len(flip_envs - event_envs), len(event_envs)
+    over = []
+    if n_event / max(1, n) > max_event_frac:
+        over.append(f"{n_event}/{n} envs diverge in continuous fields (allowed fraction {max_event_frac:.4g})")
+    if n_flip / max(1, n) > max_flip_frac:
+        over.append(f"{n_flip}/{n} envs differ in thresholded fields (allowed fraction {max_flip_frac:.4g})")
+    if hard or over:
+        lines = [f"parity {what}: {len(hard)} hard failures; " + "; ".join(over)]
+        lines += [f"  HARD {nm}: max|err|={e:.3e} envs={ids}" for nm, e, ids in hard]
+        lines += [f"  EVENT {nm}: max|err|={e:.3e} envs={ids}" for nm, e, ids in failures]
         lines += [f"  {nm:28s} max|err|={e:.3e} bad_envs={nb}" for nm, e, nb in report if nb]
         raise AssertionError("\n".join(lines))
-    return dict(report=report, flip_envs=sorted(flip_envs), event_envs=sorted(event_envs) if failures else [])
+    return dict(report=report, flip_envs=sorted(flip_envs - event_envs), event_envs=sorted(event_envs),
+                forgiven_obs_envs=sorted(set().union(*[e for _, e in soft_envs.values()])) if soft_envs else [])
+
+
+class Tally:
+    """Running count of what the allowances forgave over a multi-step run (printed by the tests, so a regression shows)."""
+
+    def __init__(self, n: int):
+        self.n, self.steps, self.flips, self.events, self.obs = n, 0, 0, 0, 0
+
+    def add(self, res: dict) -> None:
+        self.steps += 1
+        self.flips += len(res["flip_envs"])
+        self.events += len(res["event_envs"])
+        self.obs += len(res["forgiven_obs_envs"])
+
+    def line(self, what: str) -> str:
+        tot = max(1, self.n * self.steps)
+        return (f"[parity] {what}: {self.steps} steps x {self.n} envs; forgiven thresholded-contact flips {self.flips} "
+                f"({self.flips / tot:.2e}), discontinuous events {self.events} ({self.events / tot:.2e}), "
+                f"obs/reward rows outside the band in those envs {self.obs}")
 
 
 def compare_arenas(env, ora, what: str = "", **kw):

@@ -8,7 +8,7 @@ import pytest
 from locotouch_amd import _abi
 from locotouch_amd.layout import Layout
 from tests import oracle_lib as O
-from tests.parity_util import compare_arenas, compare_host_arenas, device_arena_to_host
+from tests.parity_util import Tally, compare_arenas, compare_host_arenas, device_arena_to_host
 
 pytestmark = pytest.mark.gpu
 C = _abi.CONSTS
@@ -47,36 +47,44 @@ def test_reset_all_matches_oracle(task, n):
         off += 6 * d
 
 
-@pytest.mark.parametrize("task,n,steps,phys", [("teacher", 64, 160, 1), ("locomotion", 64, 120, 1), ("teacher", 32, 40, 2)])
-def test_step_parity_resynced(task, n, steps, phys):
+@pytest.mark.parametrize("task,n,steps,phys,pre", [
+    ("teacher", 64, 160, 1, 0), ("locomotion", 64, 120, 1, 0), ("teacher", 32, 40, 2, 0),
+    # > 8192 envs: launch_step picks the register-path (PREFETCH=false) history variant, which shifts the rows in place
+    ("teacher", 8208, 16, 1, 45), ("locomotion", 8208, 12, 1, 45)])
+def test_step_parity_resynced(task, n, steps, phys, pre):
     """Every step starts from byte-identical state (oracle arena copied to the device), then one step on each side.
-    Covers contacts, object resting/rolling, resets with RNG, command resampling, pushes, history shifting."""
+    Covers contacts, object resting/rolling, resets with RNG, command resampling, pushes, history shifting.
+    `pre`: oracle-only warm-up steps (OpenMP) so that a short compared window still holds resets and shifted histories."""
     import torch
 
     env = make_env(task, n, phys_substeps=phys)
     ora = O.OracleEnv(env.cfg)
     ora.reset_all()
     g = torch.Generator().manual_seed(3)
-    n_reset = 0
-    flips = 0
-    events = 0
+    for _ in range(pre):
+        ora.step((0.6 * torch.randn(n, 12, generator=g)).numpy(), nthreads=8)
+    n_reset, n_shift = 0, 0
+    tally = Tally(n)
     L = Layout(n, env.num_obs)
     for t in range(steps):
-        scale = 0.0 if t < 10 else (0.3 if t < steps // 2 else 1.0)
+        scale = 1.0 if pre else (0.0 if t < 10 else (0.3 if t < steps // 2 else 1.0))
         act = scale * torch.randn(n, 12, generator=g)
         if t % 17 == 0:
             act[0, 0] = 400.0  # exercises the +-100 raw clip
         env._arena_aligned.copy_(torch.from_numpy(ora.arena))
         env.step(act.cuda())
-        ora.step(act.numpy())
+        ora.step(act.numpy(), nthreads=8 if n > 1024 else 1)
         torch.cuda.synchronize()
-        res = compare_arenas(env, ora, what=f"{task} step {t}", max_flip_frac=0.05, max_event_frac=2.0 / n)
-        flips += len(res["flip_envs"])
-        events += len(res["event_envs"])
-        n_reset += int(L.arr(ora.arena, "LT_F_DONES")[:n].sum())
+        res = compare_arenas(env, ora, what=f"{task} n={n} step {t}", max_flip_frac=0.05, max_event_frac=max(2.0 / n, 0.003))
+        tally.add(res)
+        d = L.arr(ora.arena, "LT_F_DONES")[:n]
+        n_reset += int(d.sum())
+        n_shift += int((d == 0).sum())
+    print(tally.line(f"{task} n={n} phys={phys}"))
     assert n_reset > 0, "the sequence must include resets"
-    assert flips <= 0.01 * n * steps, f"too many thresholded-contact flips: {flips}"
-    assert events <= 0.003 * n * steps, f"too many discontinuous-event divergences: {events}"
+    assert n_shift > n_reset, "most rows must really shift (not fill)"
+    assert tally.flips <= 0.01 * n * steps, f"too many thresholded-contact flips: {tally.flips}"
+    assert tally.events <= 0.003 * n * steps, f"too many discontinuous-event divergences: {tally.events}"
 
 
 def test_free_running_statistics_teacher():
@@ -195,11 +203,11 @@ def test_reward_terms_against_reference_golden():
 # ------------------------------------------------------------------------------------------------------------------
 # full size (BASELINE.json: 4096 envs/GPU): size-independent properties
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("task", ["teacher", "locomotion"])
-def test_full_size_properties(task):
+@pytest.mark.parametrize("task,n", [("teacher", 4096), ("locomotion", 4096), ("teacher", 32768), ("locomotion", 32768)])
+def test_full_size_properties(task, n):
+    """n = 4096: BASELINE.json's headline size (LDS-DMA history path); n = 32768: config 5's size (register history path)."""
     import torch
 
-    n = 4096
     env = make_env(task, n, seed=42)
     env2 = make_env(task, n, seed=42)
     g = torch.Generator().manual_seed(1)
@@ -240,17 +248,19 @@ def test_time_out_fires_exactly_at_max_episode_length():
     n = 64
     env = make_env("teacher", n)
     env.episode_length_buf = torch.full((n,), 997, dtype=torch.long, device="cuda:0")
-    fired = []
+    fired, term = [], []
     for t in range(4):
         _, _, dones, extras = env.step(torch.zeros(n, 12, device="cuda:0"))
         torch.cuda.synchronize()
         fired.append(extras["time_outs"].clone())
+        term.append(env.terminated_buf.bool().clone())
         if t == 2:
             assert (env.episode_length_buf[fired[2]] == 0).all()
-    # ep_len runs 998, 999, 1000 -> time_out exactly on the third step (for envs that did not terminate earlier)
-    assert not fired[0].any() and not fired[1].any() and fired[2].any() and not fired[3].any()
-    alive = env.terminated_buf == 0
-    assert fired[2].sum() >= 1 and alive is not None
+    # ep_len runs 998, 999, 1000 -> time_out on the third step in exactly the envs that were not reset (terminated) before it
+    assert not fired[0].any() and not fired[1].any() and not fired[3].any()
+    expected = ~(term[0] | term[1])
+    assert expected.any() and torch.equal(fired[2], expected)
+    assert (env.episode_length_buf <= env.max_episode_length).all()
 
 
 def test_velocity_curriculum_kernel_matches_reference_golden():
@@ -340,6 +350,36 @@ def test_fused_rollout_kernels_match_torch():
     alg.compute_returns(env.obs_critic)
     losses = alg.update()
     assert all(np.isfinite(x) for x in losses[:3])
+
+
+def test_rollout_rows_large_grid_register_history_path():
+    """> 8192 envs: the register-path history variant writing rows into rollout-storage slots (distinct prev/next pointers)
+    must equal, bit for bit, the same variant shifting the arena rows in place (which test_step_parity_resynced pins to
+    the oracle at this size)."""
+    import torch
+    from locotouch_amd.rl import PPO, ActorCritic, FusedRollout
+    from tests.rl_synth import POLICY_CFG, PPO_CFG
+
+    n = 8208
+    env, twin = make_env("teacher", n), make_env("teacher", n)
+    torch.manual_seed(3)
+    alg = PPO(ActorCritic(348, 348, 12, **POLICY_CFG), device="cuda:0", **PPO_CFG)
+    alg.init_storage(n, 6, [348], [348], [12])
+    fr = FusedRollout(env, alg)
+    assert fr.rows_in_storage
+    fr.rollout(6)
+    torch.cuda.synchronize()
+    st = alg.storage
+    shifted = 0
+    for t in range(6):
+        o, r, d, _ = twin.step(st.actions[t].clone())
+        nxt_p = st.observations[t + 1] if t < 5 else env.obs_policy
+        nxt_c = st.privileged_observations[t + 1] if t < 5 else env.obs_critic
+        assert torch.equal(o, nxt_p) and torch.equal(twin.obs_critic, nxt_c), f"step {t}"
+        assert torch.equal(d.to(torch.uint8), st.dones[t].squeeze(1))
+        shifted += int((d == 0).sum())
+    assert shifted > 5 * n
+    assert torch.equal(twin._arena_aligned, env._arena_aligned)
 
 
 def test_training_loop_runs_and_checkpoints(tmp_path):
