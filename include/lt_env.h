@@ -14,7 +14,7 @@
  *   env.episode_length_buf = ... (on_policy_runner:121)   lt_env_get_view(LT_F_EP_LEN) (int64, writable)
  *   env.get_observations() (on_policy_runner.py:32,127)   lt_env_get_view(LT_F_OBS_POLICY / _CRITIC)
  *   env.scene[...].data.* / sensors[...].data.* (B3)      lt_env_get_view(field)
- *   command_term.set_ranges (mdp/commands.py:471)         device-side in lt_env_step (curriculum kernel),
+ *   command_term.set_ranges (mdp/commands.py:471)         device-side in lt_env_step (tail of the step kernel),
  *                                                         host override: lt_env_set_command_ranges
  *   term-level evaluation for parity tests                lt_env_eval_terms
  *
@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 2
+#define LT_ABI_VERSION 3
 
 /* error codes */
 #define LT_OK 0
@@ -213,7 +213,8 @@ enum lt_field {
   LT_F_LAST_EPISODE_SUMS,/* 7 quad arrays: snapshot at the last reset (logging) */
   LT_F_LAST_EPISODE_INFO,/* (episodes_finished, last_ep_len, last_term_bits, _) */
   LT_F_CURRICULUM,      /* 3 quad arrays: this step's record (reset, ep_len, sum_lin, sum_ang); trackers
-                         * (reset_lin, len_lin, sum_lin, reset_ang); (len_ang, sum_ang, _, _) */
+                         * (reset_lin, len_lin, sum_lin, reset_ang); (len_ang, sum_ang, _, _).  The trackers lag the
+                         * reference's by one pass: LT_F_CMD_PARAMS[27..30] holds the operations still to be applied */
   LT_F_REWARD_TERMS,    /* 7 quad arrays: unweighted term values of the last step (diagnostics / parity) */
   LT_NUM_QUAD_FIELDS,
   /* plain (non-quad) arrays */
@@ -226,7 +227,7 @@ enum lt_field {
   LT_F_TIME_OUT,        /* uint8 [N] */
   LT_F_TERM_BITS,       /* int32 [N] which termination terms fired this step */
   LT_F_CMD_PARAMS,      /* float [LT_CMD_PARAMS_LEN], device-resident command/curriculum block */
-  LT_F_COUNTERS,        /* int64 [4]: (common_step_counter, ...) */
+  LT_F_COUNTERS,        /* int64 [4]: (common_step_counter, _, arrival ticket of the step kernel's tail reduction, _) */
   LT_F_END
 };
 
@@ -235,7 +236,11 @@ enum lt_field {
  *  [12..14] equal flags (1/0)  [15] zero_steps  [16] rel_standing
  *  [17] lin_forward_bins [18] ang_forward_bins [19] success_lin [20] success_ang
  *  [21..23] expansion per dim  [24] lin gate open (1/0)  [25] ang gate open
- *  [26] any env has a non-zero command (population gate of rewards.py:190) */
+ *  [26] any env has a non-zero command (population gate of rewards.py:190)
+ *  [27..30] tracker operations decided by the last step's curriculum pass and applied to the per-env trackers by the next
+ *           one (the pass runs at the tail of the step kernel, where no wave may touch another wave's envs):
+ *           [27] merge the last record into the lin trackers  [28] ... into the ang trackers
+ *           [29] clear the lin trackers (lin gate passed)      [30] clear the ang trackers */
 #define LT_CMD_PARAMS_LEN 32
 
 typedef struct lt_view {
@@ -270,16 +275,14 @@ int lt_env_step(lt_env* env, const float* actions, void* stream);
 /* Rollout form of lt_env_step for drivers that keep the observation rows in their own rollout storage
  * (loco_rl/loco_rl/storage/rollout_storage.py:79-107 copies obs / critic obs into slot t every step): the step kernel reads the previous
  * rows from (prev_policy, prev_critic) and writes the new ones to (next_policy, next_critic), each float[npad][obs_dim], 16-byte aligned,
- * e.g. storage slots t and t+1.  NULL = the arena's rows.  Only the step kernel is launched: follow it with lt_env_post_step on any
- * stream ordered after it and before the next step (curriculum + step counter), which lets the caller overlap that pass. */
+ * e.g. storage slots t and t+1.  NULL = the arena's rows.  One launch, like lt_env_step (the curriculum pass and the step-counter
+ * increment run at the tail of the step kernel). */
 int lt_env_step_rows(lt_env* env, const float* actions, const float* prev_policy, const float* prev_critic, float* next_policy,
                      float* next_critic, void* stream);
 /* lt_env_step_rows plus the rollout-storage writes of the transition (ppo.py:162-165, rollout_storage.py:79-107):
  * st_rewards[n] = reward + gamma * values * time_out, st_dones[n] = dones != 0.  `values` = V(obs_t), float[n]. */
 int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_policy, const float* prev_critic, float* next_policy,
                         float* next_critic, const float* values, float gamma, float* st_rewards, uint8_t* st_dones, void* stream);
-/* Second half of lt_env_step: curriculum / population gate on this step's records + step-counter increment. */
-int lt_env_post_step(lt_env* env, void* stream);
 /* Profiling variant of lt_env_step: HIP events bracket the step kernel on `stream`; the call WAITS for them (host
  * sync - never use it inside a captured region) and returns the step kernel's duration in milliseconds. */
 int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float* step_kernel_ms);
@@ -287,10 +290,11 @@ int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float*
  * command update (parity-test hook: lets a test write a golden state into the views and read the terms).
  * `terminated_in` (uint8[N], device, may be NULL) feeds the `alive` term. */
 int lt_env_eval_terms(lt_env* env, void* stream);
-/* The curriculum / population-gate pass that lt_env_step runs after its step kernel, on the records currently in
- * LT_F_CURRICULUM (does not advance the step counter).  For drivers that schedule the kernels themselves and for the
- * parity test against the reference's curriculum sequence (mdp/curriculums.py:184-275). */
-int lt_env_curriculum_update(lt_env* env, void* stream);
+/* The curriculum / population-gate pass that lt_env_step runs at the tail of its step kernel, fed with `records`
+ * (device, float[N][4]: reset flag, episode length, episode sum of track_lin_vel_xy, of track_ang_vel_z - what the step
+ * kernel derives per env) instead of a physics step; does not advance the step counter.  Parity-test hook for the
+ * reference's curriculum sequence (mdp/curriculums.py:184-275). */
+int lt_env_curriculum_update(lt_env* env, const float* records, void* stream);
 int lt_env_get_view(lt_env* env, int field, lt_view* view);
 /* Host-side override of the command block (what `set_ranges` does in the reference; resume workflows). */
 int lt_env_set_command_ranges(lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream);

@@ -104,7 +104,7 @@ def load() -> ctypes.CDLL:
     lib.lt_env_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.lt_env_step_profiled.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
     lib.lt_env_eval_terms.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    lib.lt_env_curriculum_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.lt_env_curriculum_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.lt_env_get_view.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(LtView)]
     lib.lt_env_set_command_ranges.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
                                               ctypes.c_float, ctypes.c_void_p]
@@ -112,7 +112,6 @@ def load() -> ctypes.CDLL:
     lib.lt_rollout_act.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_uint64] + [vp] * 15
     lib.lt_rollout_record.argtypes = [ctypes.c_int64, ctypes.c_float] + [vp] * 9
     lib.lt_env_step_rows.argtypes = [ctypes.c_void_p] + [vp] * 6
-    lib.lt_env_post_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     dp = ctypes.POINTER(LtMlpDesc)
     lib.lt_mlp_packed_floats.argtypes = [dp, ctypes.POINTER(ctypes.c_size_t)]
     lib.lt_mlp_pack.argtypes = [dp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]
@@ -132,7 +131,7 @@ def load() -> ctypes.CDLL:
 
 EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_obs_dim", "lt_env_create",
            "lt_env_destroy", "lt_env_state_bytes", "lt_env_bind", "lt_env_reset_all", "lt_env_step", "lt_env_step_profiled", "lt_env_eval_terms",
-           "lt_env_curriculum_update", "lt_env_step_rows", "lt_env_step_rollout", "lt_env_post_step", "lt_env_get_view", "lt_env_set_command_ranges", "lt_rollout_act", "lt_rollout_record", "lt_mlp_packed_floats", "lt_mlp_pack", "lt_mlp_forward", "lt_rollout_policy", "lt_rollout_policy_value",
+           "lt_env_curriculum_update", "lt_env_step_rows", "lt_env_step_rollout", "lt_env_get_view", "lt_env_set_command_ranges", "lt_rollout_act", "lt_rollout_record", "lt_mlp_packed_floats", "lt_mlp_pack", "lt_mlp_forward", "lt_rollout_policy", "lt_rollout_policy_value",
            "lt_env_kernel_name"]
 
 

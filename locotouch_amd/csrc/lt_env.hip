@@ -4,8 +4,8 @@
 //   action term -> 4 x (DC-motor PD -> ABA forward dynamics with implicit penalty contacts -> contact sensors)
 //   -> terminations -> 23 reward terms (incl. the adaptive symmetric-gait class) -> masked reset (events, RNG)
 //   -> command term -> interval pushes -> observation frame + 6-deep history -> outputs.
-// It is followed by the single-block lt_post_kernel (velocity curriculum, population gates, step counter).
-// Neither kernel synchronises with the host; the pair is hipGraph-capturable.
+// The velocity curriculum, the population gates and the step counter run at the kernel's tail (lt_post.h: per-wave partials,
+// the last-arriving wave decides) - one launch per env step, no host synchronisation, hipGraph-capturable.
 //
 // Lane mapping: 4 lanes per env (lane&3 = leg FR/FL/RR/RL, each lane owns the hip-thigh-calf chain of its leg),
 // 16 envs per wave64, one wave per workgroup.  Tree-level coupling (floating base, carried cylinder) and all
@@ -523,8 +523,11 @@ __device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P
 // fetched by LDS-DMA (global_load_lds_dwordx4, no VGPRs) at kernel start and land while the physics runs, so the
 // history pass at the tail has no global-load latency left - a lone wave per SIMD has nothing else to hide it behind.
 // Large grids keep the register path: 57 KB of LDS per wave would cap occupancy at 2 waves per CU.
+#ifndef LT_STEP_MIN_WAVES_LARGE
+#define LT_STEP_MIN_WAVES_LARGE 1
+#endif
 template <int TASK, int MODE, bool PREFETCH>
-__global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
+__global__ __launch_bounds__(64, PREFETCH ? 1 : LT_STEP_MIN_WAVES_LARGE) void lt_step_kernel(const KArgs a) {
 #ifdef LT_STAMPS
   unsigned long long stamps_[8];
   for (int i = 0; i < 8; ++i) stamps_[i] = 0;
@@ -731,6 +734,9 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
   // =================================================================================================
   int bits = 0;
   bool terminated = false, time_out = false, reset = false;
+  bool last_arriver = false;
+  CurIn cur_in;
+  cur_in.valid = env < L.n; cur_in.reset = false; cur_in.ep_len = cur_in.sum_lin = cur_in.sum_ang = 0.f; cur_in.cmd_nonzero = false;
   float sums[LT_REWARD_SLOTS / 4];  // this lane's episode sums: terms leg, leg+4, ...  (quad array q holds terms 4q..4q+3)
 #pragma unroll
   for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) sums[q] = *F(LT_F_EPISODE_SUMS, q);
@@ -908,11 +914,10 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
       ((long long*)(arena + L.off_dones))[env] = reset ? 1 : 0;
     }
     // this step's curriculum record (reset, ep_len, sum_lin, sum_ang): the sums live in lanes 1 and 2 of array 0
-    {
-      const float sum_lin = qbcast<LT_R_TRACK_LIN_VEL_XY & 3>(sums[LT_R_TRACK_LIN_VEL_XY >> 2]);
-      const float sum_ang = qbcast<LT_R_TRACK_ANG_VEL_Z & 3>(sums[LT_R_TRACK_ANG_VEL_Z >> 2]);
-      *F(LT_F_CURRICULUM, 0) = reset ? sel4(leg, 1.f, (float)X.ep_len, sum_lin, sum_ang) : 0.f;
-    }
+    cur_in.reset = reset;
+    cur_in.ep_len = (float)X.ep_len;
+    cur_in.sum_lin = qbcast<LT_R_TRACK_LIN_VEL_XY & 3>(sums[LT_R_TRACK_LIN_VEL_XY >> 2]);
+    cur_in.sum_ang = qbcast<LT_R_TRACK_ANG_VEL_Z & 3>(sums[LT_R_TRACK_ANG_VEL_Z >> 2]);
     if (reset) {
 #pragma unroll
       for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) *F(LT_F_LAST_EPISODE_SUMS, q) = sums[q];
@@ -1004,6 +1009,10 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
         O.w += v3(lerp2(c.push_obj_vel[3], w4.a), lerp2(c.push_obj_vel[4], w4.b), lerp2(c.push_obj_vel[5], w4.c));
       }
     }
+    // curriculum / population gate (lt_post.h): publish this wave's partials here - after the last read of the command
+    // block, with few memory operations outstanding; the wave that arrives last decides at the very end of the kernel.
+    cur_in.cmd_nonzero = X.cmd.x != 0.f || X.cmd.y != 0.f || X.cmd.z != 0.f;
+    last_arriver = curriculum_publish(L, arena, gid, leg, cur_in);
   }
 
   LT_STAMP(4);
@@ -1207,6 +1216,7 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
 #pragma unroll
     for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) *F(LT_F_EPISODE_SUMS, q) = sums[q];
   }
+  if (MODE == MODE_STEP && last_arriver) curriculum_decide(c, L, arena, 1);  // + common_step_counter += 1
 #ifdef LT_STAMPS
   LT_STAMP(7);
   if (lane == 0)
@@ -1215,12 +1225,34 @@ __global__ __launch_bounds__(64) void lt_step_kernel(const KArgs a) {
 }
 
 // =====================================================================================================
-// post kernel (one block): velocity curriculum (reference mdp/curriculums.py:184-275 + commands.py:471-505),
-// population gate of rewards.py:190, common step counter.  Runs after every step kernel, on the same stream.
+// the curriculum pass on caller-supplied records (parity-test hook for the reference's curriculum sequence): the step
+// kernel's tail without a physics step.  Same grid and lane mapping as the step kernel.
 // =====================================================================================================
-__global__ __launch_bounds__(1024) void lt_post_kernel(const KArgs a, int bump_counter, int gates_only) {
-  __shared__ float sh[16 * 8];
-  post_body<4>(a.d, a.arena, bump_counter, gates_only, sh);
+__global__ __launch_bounds__(64) void lt_curriculum_kernel(const KArgs a, const float* __restrict__ records) {
+  const lt_cfg& c = a.d->cfg;
+  const lt_layout& L = a.d->layout;
+  const int leg = threadIdx.x & 3;
+  const long long gid = (long long)blockIdx.x * 64 + threadIdx.x, env = gid >> 2;
+  CurIn in;
+  in.valid = env < L.n;
+  const float* r = records + (in.valid ? env : 0) * 4;
+  in.reset = in.valid && r[0] != 0.f;
+  in.ep_len = r[1]; in.sum_lin = r[2]; in.sum_ang = r[3];
+  const float cm = ((const float*)(a.arena + L.quad_off[LT_F_CMD]))[gid];
+  in.cmd_nonzero = qor((leg < 3 && cm != 0.f) ? 1 : 0) != 0;
+  if (curriculum_publish(L, a.arena, gid, leg, in)) curriculum_decide(c, L, a.arena, 0);
+}
+// population gate of rewards.py:190 from the commands currently in the arena (lt_env_eval_terms; one block)
+__global__ __launch_bounds__(1024) void lt_gate_kernel(const KArgs a) {
+  const lt_layout& L = a.d->layout;
+  const float4* cmd = (const float4*)(a.arena + L.quad_off[LT_F_CMD]);
+  int nz = 0;
+  for (long long e = threadIdx.x; e < L.n; e += blockDim.x) {
+    const float4 v = cmd[e];
+    nz |= (v.x != 0.f || v.y != 0.f || v.z != 0.f) ? 1 : 0;
+  }
+  nz = __syncthreads_or(nz);
+  if (threadIdx.x == 0) ((float*)(a.arena + L.off_cmd_params))[26] = nz ? 1.f : 0.f;
 }
 
 // command/curriculum block initialisation (reference mdp/curriculums.py:187-193, commands.py:427-469)
@@ -1310,24 +1342,13 @@ int lt_launch_reset_all(const lt_env* env, void* stream) {
 }
 
 int lt_launch_step(const lt_env* env, const float* actions, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
-  int e = launch_step<MODE_STEP>(env, actions, s);
-  if (e != 0) return e;
-  const KArgs k = make_args(env, actions);
-  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, s, k, 1, 0);
-  return (int)hipGetLastError();
+  return launch_step<MODE_STEP>(env, actions, (hipStream_t)stream);
 }
 
 int lt_launch_step_rows(const lt_env* env, const float* actions, const float* const prev[2], float* const next[2], const float* values,
                         float gamma, float* st_rewards, unsigned char* st_dones, void* stream) {
   const RecordArgs rec = {values, gamma, st_rewards, st_dones};
   return launch_step<MODE_STEP>(env, actions, (hipStream_t)stream, prev, next, st_rewards ? &rec : nullptr);
-}
-
-int lt_launch_post_step(const lt_env* env, void* stream) {
-  const KArgs k = make_args(env, nullptr);
-  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, k, 1, 0);
-  return (int)hipGetLastError();
 }
 
 int lt_launch_step_profiled(lt_env* env, const float* actions, void* stream, float* ms) {
@@ -1343,9 +1364,6 @@ int lt_launch_step_profiled(lt_env* env, const float* actions, void* stream, flo
   int rc = launch_step<MODE_STEP>(env, actions, s);
   if (rc != 0) return rc;
   if ((e = hipEventRecord((hipEvent_t)env->ev_stop, s)) != hipSuccess) return (int)e;
-  const KArgs k = make_args(env, actions);
-  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, s, k, 1, 0);
-  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   if ((e = hipEventSynchronize((hipEvent_t)env->ev_stop)) != hipSuccess) return (int)e;
   return (int)hipEventElapsedTime(ms, (hipEvent_t)env->ev_start, (hipEvent_t)env->ev_stop);
 }
@@ -1359,15 +1377,15 @@ int lt_launch_eval_terms(const lt_env* env, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // refresh the population gate from the commands currently in the arena, then evaluate the terms
   const KArgs k = make_args(env, nullptr);
-  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, s, k, 0, 1);
+  hipLaunchKernelGGL(lt_gate_kernel, dim3(1), dim3(1024), 0, s, k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return launch_step<MODE_TERMS>(env, nullptr, s);
 }
 
-int lt_launch_curriculum(const lt_env* env, void* stream) {
+int lt_launch_curriculum(const lt_env* env, const float* records, void* stream) {
   const KArgs k = make_args(env, nullptr);
-  hipLaunchKernelGGL(lt_post_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, k, 0, 0);
+  hipLaunchKernelGGL(lt_curriculum_kernel, dim3((unsigned)(env->layout.npad / 16)), dim3(64), 0, (hipStream_t)stream, k, records);
   return (int)hipGetLastError();
 }
 

@@ -154,12 +154,6 @@ int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_pol
   return finish(lt_launch_step_rows(env, actions, prev, next, values, gamma, st_rewards, st_dones, stream), "lt_env_step_rollout");
 }
 
-int lt_env_post_step(lt_env* env, void* stream) {
-  if (!env) return LT_EINVAL;
-  if (!env->arena) { lt_set_error("lt_env_post_step: arena not bound"); return LT_EFAULT; }
-  return finish(lt_launch_post_step(env, stream), "lt_env_post_step");
-}
-
 int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float* step_kernel_ms) {
   if (!env || !actions || !step_kernel_ms) return LT_EINVAL;
   if (!env->arena) { lt_set_error("lt_env_step_profiled: arena not bound"); return LT_EFAULT; }
@@ -172,10 +166,10 @@ int lt_env_eval_terms(lt_env* env, void* stream) {
   return finish(lt_launch_eval_terms(env, stream), "lt_env_eval_terms");
 }
 
-int lt_env_curriculum_update(lt_env* env, void* stream) {
-  if (!env) return LT_EINVAL;
+int lt_env_curriculum_update(lt_env* env, const float* records, void* stream) {
+  if (!env || !records) return LT_EINVAL;
   if (!env->arena) { lt_set_error("lt_env_curriculum_update: arena not bound"); return LT_EFAULT; }
-  return finish(lt_launch_curriculum(env, stream), "lt_env_curriculum_update");
+  return finish(lt_launch_curriculum(env, records, stream), "lt_env_curriculum_update");
 }
 
 int lt_env_set_command_ranges(lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream) {

@@ -23,11 +23,10 @@ int lt_launch_reset_all(const lt_env* env, void* stream);
 int lt_launch_step(const lt_env* env, const float* actions, void* stream);
 int lt_launch_step_rows(const lt_env* env, const float* actions, const float* const prev[2], float* const next[2], const float* values,
                         float gamma, float* st_rewards, unsigned char* st_dones, void* stream);
-int lt_launch_post_step(const lt_env* env, void* stream);
 int lt_launch_step_profiled(lt_env* env, const float* actions, void* stream, float* ms);
 int lt_launch_eval_terms(const lt_env* env, void* stream);
 void lt_release_events(lt_env* env);
-int lt_launch_curriculum(const lt_env* env, void* stream);
+int lt_launch_curriculum(const lt_env* env, const float* records, void* stream);
 int lt_launch_set_command_ranges(const lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream);
 const char* lt_hip_error_string(int err);
 

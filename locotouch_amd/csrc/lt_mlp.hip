@@ -1,24 +1,37 @@
-// lt_mlp.hip - fused fp32 MLP forward (actor / critic inference of the rollout) on the f32-input MFMA.
+// lt_mlp.hip - fused MLP forward (actor / critic inference of the rollout) on the f16 MFMA with error-compensated
+// operand splitting: f32-equivalent results at a multiple of the f32-MFMA rate.
 //
 // Reference: the policy evaluation inside the rollout loop, loco_rl/loco_rl/modules/actor_critic.py:113-131
 // (`act` -> update_distribution -> self.actor(obs); `evaluate` -> self.critic(obs)) - four Linear layers with ELU between,
 // which PyTorch runs as 4 GEMM launches + 3 activation launches per network and step.  Here a whole network - or the actor
-// and the critic side by side - is ONE launch:
+// and the critic side by side - is ONE launch.
 //
-//   * a workgroup (NW = 4 waves, one per SIMD) owns 16 * RT batch rows; their activations live in LDS ([16][S] floats, S = widest layer + 4 so that
-//     the 16 rows of a ds_read_b128 / ds_write_b128 phase fall on distinct banks) and never visit HBM between layers;
-//   * out^T = W . act^T on v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain, no reduced precision): the weight
-//     tile is the A operand (16 output features x 4 k), the activations are the B operand (4 k x 16 rows), so a lane ends
-//     up with 4 CONSECUTIVE output features of ONE row -> the next layer's input is written back with one ds_write_b128;
-//   * each wave owns T = N/(16 NW) output tiles (independent accumulators -> the 40-cycle dependent MFMA latency never shows);
-//   * k inside a 16-group is permuted (lane quarter q takes k = 16g + 4q + i for MFMA i) - a summation-index relabelling
-//     applied to both operands - which is what makes both operand fetches 16-byte vectors;
+// Arithmetic.  The reference rolls out in fp32, and gfx950 has no TF32-like mode: the f32-input MFMA runs at the f32 vector
+// rate (157 TF), 1/16 of the f16/bf16 MFMA.  Every f32 operand x is therefore split into two f16 numbers,
+//     x = hi + lo * 2^-11,   hi = f16(x),  lo = f16((x - hi) * 2^11)      (22 significand bits; x - hi is exact in f32)
+// and a product sum  sum_k w_k x_k  is evaluated as three f16 MFMAs with f32 accumulation:
+//     main += w_hi x_hi          corr += w_hi x_lo + w_lo x_hi          result = main + corr * 2^-11
+// (the dropped w_lo x_lo term is 2^-22 relative).  f16 x f16 products are exact in the f32 accumulator, so the only errors
+// are the 2^-22 operand truncation and the f32 accumulation itself - measured against an fp64 reference the result is as
+// close as PyTorch's own fp32 GEMM chain (tests/test_hip_parity.py::test_fused_mlp_matches_torch keeps the round-1
+// tolerance).  3 MFMAs at 16x the f32-MFMA rate: 5.3x less matrix-pipe time than the exact-f32 form.
+//
+// Structure:
+//   * a workgroup (NW = 4 waves, one per SIMD) owns 16 * RT batch rows; their activations live in LDS as two f16 planes
+//     (hi, lo) and never visit HBM between layers;
+//   * out^T = W . act^T on v_mfma_f32_16x16x32_f16: the weight tile is the A operand (16 output features x 32 k), the
+//     activations are the B operand (32 k x 16 rows), so a lane ends up with 4 CONSECUTIVE output features of ONE row ->
+//     the next layer's input is written back with one ds_write_b64 per plane;
+//   * LDS image of a row: k = 32 g + 8 q + j lives at half index q * PLANE + 8 g + j (PLANE = 128-half multiple), row
+//     stride 4 * PLANE + 8 halfs.  A B-fragment read is then one ds_read_b128 per plane whose bank depends on the row
+//     only (the 16 lanes of every ds_read_b128 service group hold 16 distinct rows): conflict-free;
+//   * each wave owns T = N/(16 NW) output tiles x RT row tiles (independent accumulators);
 //   * the parameters are pre-packed once per policy update (lt_mlp_pack) into ONE LINEAR STREAM PER WAVE of 1-KiB chunks
-//     (64 lanes x float4) in exactly the order the wave consumes them, across layers: [bias chunks of layer 0][weight
-//     chunks g-major, tile-minor][pad to 16]...[layer 1]...  The kernel keeps a 16-chunk register ring per wave and refills
-//     a slot right after its MFMAs, so 16 KiB per wave are always in flight and the first weights of layer l+1 are already
-//     on their way while layer l finishes - no pipeline restart at layer boundaries.  Every wave-instruction of the stream
-//     is one fully coalesced global_load_dwordx4; all workgroups stream the same ~1.4 MB, which stays L2-resident.
+//     (64 lanes x 16 B) in exactly the order the wave consumes them, across layers: per layer one bias item, then per
+//     32-wide k-group one item of T x (hi chunk, lo chunk).  The kernel keeps a 32-chunk register ring per wave and
+//     refills a slot right after its MFMAs, so 32 KiB per wave are always in flight and the first weights of layer l+1
+//     are already on their way while layer l finishes.  Every wave-instruction of the stream is one fully coalesced
+//     global_load_dwordx4; all workgroups stream the same ~1.4 MB per network, which stays L2-resident.
 //
 // The policy network's last layer carries the sampling epilogue of lt_rollout_act (a = mu + sigma N(0,1), log-prob,
 // storage-slot writes), so the actor side of a rollout step needs no further launch.
@@ -34,38 +47,45 @@ using namespace lt;
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RING = 16;               // chunks in flight per wave
+constexpr int RING = 32;               // chunks in flight per wave
 #ifndef LT_MLP_WAVES
 #define LT_MLP_WAVES 4
 #endif
-constexpr int NW = LT_MLP_WAVES;       // waves per workgroup (4 or 8).  Measured: 8 (two per SIMD) buys nothing - the waves of a workgroup
-                                       // run in lockstep, so their epilogues and barriers coincide instead of hiding behind MFMAs
+constexpr int NW = LT_MLP_WAVES;       // waves per workgroup (one per SIMD)
 constexpr unsigned RS_POLICY = 0x400;  // same Philox stream id as lt_rollout_act
 constexpr int MODE_FORWARD = 0, MODE_POLICY = 1;
+constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
+constexpr float F16_CLAMP = 60000.f;   // |x| beyond the f16 range saturates instead of turning into inf - inf
 
 __host__ __device__ inline int pad16(int x) { return (x + 15) & ~15; }
+__host__ __device__ inline int pad32(int x) { return (x + 31) & ~31; }
 // Tiles per wave of a layer with `ntiles` 16-feature output tiles: the smallest of {1, 2, 4, 8} that covers ntiles with NW waves.
 __host__ __device__ inline int tiles_per_wave(int ntiles) {
   const int per = (ntiles + NW - 1) / NW;
   return per > 4 ? 8 : (per > 2 ? 4 : (per > 1 ? 2 : 1));
 }
-// chunks of one layer in the stream of an ACTIVE wave: T bias chunks + G*T weight chunks, padded to whole rings
+// chunks of one layer in the stream of an ACTIVE wave: G + 1 items (bias, then one per 32-wide k-group) of 2T chunks each,
+// padded to whole ring rounds
 __host__ __device__ inline int layer_chunks(int K, int N) {
-  const int T = tiles_per_wave(pad16(N) / 16), G = pad16(K) / 16;
-  return (T * (G + 1) + RING - 1) / RING * RING;
+  const int T = tiles_per_wave(pad16(N) / 16), G = pad32(K) / 32, R = RING / (2 * T);
+  return (G + 1 + R - 1) / R * RING;
 }
 __host__ __device__ inline int active_waves(int N) {
   const int nt = pad16(N) / 16, T = tiles_per_wave(nt);
   return (nt + T - 1) / T;
 }
+// LDS image: halfs per q-plane of a row (128-half multiples keep the four lane quarters on the same banks)
+__host__ __device__ inline int plane_halfs(int widest) { return (pad32(widest) / 4 + 127) / 128 * 128; }
 
 struct MlpArgs {
   int L;
   int dims[LT_MLP_MAX_LAYERS + 1];
   int activation;
   int mode;
-  int stride;                 // LDS row stride in floats
+  int plane;                  // halfs per q-plane; LDS row stride = 4 * plane + 8 halfs
   long long wave_base[NW];    // chunk offset of each wave's stream inside `packed`
   const float* packed;
   const float* x;
@@ -80,7 +100,9 @@ struct MlpArgs {
 };
 struct DualArgs {
   MlpArgs net[2];
-  int split;  // blocks [0, split) run net[0], the rest net[1]
+  int split;     // blocks [0, split) run net[0], the rest net[1] ...
+  int xcd_split; // ... unless set: blocks with (blockIdx % 8) < 4 run net[0], the others net[1] (see launch())
+  int blocks_per_net;
 };
 
 template <int KIND>
@@ -90,19 +112,17 @@ __device__ __forceinline__ float activate(float x) {
   if (KIND == LT_ACT_TANH) return tanhf(x);
   return x;
 }
-// activation + write-back of a wave's T output tiles as the next layer's input (KIND is a compile-time constant per call
-// site: a runtime `kind` inside the loop gets if-converted into computing EVERY activation for every element)
-template <int KIND, int T>
-__device__ __forceinline__ void write_activated(const f32x4 (&acc)[T], float* dst, int tile0, int npad) {
+// x = hi + lo / 2048 with hi, lo in f16 (module header)
+__device__ __forceinline__ void split4(const float (&v)[4], f16x4& hi, f16x4& lo) {
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    float4 o;
-    o.x = activate<KIND>(acc[t][0]); o.y = activate<KIND>(acc[t][1]); o.z = activate<KIND>(acc[t][2]); o.w = activate<KIND>(acc[t][3]);
-    if (16 * (tile0 + t) < npad) *(float4*)(dst + 16 * t) = o;  // zero-pad tiles stay out of LDS
+  for (int i = 0; i < 4; ++i) {
+    const float x = fminf(fmaxf(v[i], -F16_CLAMP), F16_CLAMP);
+    const _Float16 h = (_Float16)x;
+    hi[i] = h;
+    lo[i] = (_Float16)((x - (float)h) * LO_SCALE);
   }
 }
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the 16 weight
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the weight
 // chunks every wave keeps in flight - twice per layer - and undo the streaming across layer boundaries.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -114,66 +134,101 @@ __device__ unsigned long long g_mlp_stamps[1024 * 8 * NW];
 #define MLP_STAMP(i) do { } while (0)
 #endif
 
-// One layer for this wave.  `ring` slot s holds chunk c0 + s of the wave's stream; the layer consumes its chunks in order
-// (item 0 = the T bias chunks, item i = k-group i-1) and leaves the ring positioned on the next layer's first chunk.
+// half index (inside a row's LDS image) of input feature k
+__device__ __forceinline__ int k_pos(int k, int plane) { return ((k >> 3) & 3) * plane + ((k >> 5) << 3) + (k & 7); }
+
+// activation + (hi, lo) split + write-back of a wave's output tiles as the next layer's input.  KIND is a compile-time constant
+// per call site: a runtime `kind` inside the loop gets if-converted into computing EVERY activation for every element.
+// Tiles up to the next layer's k padding (32) are written even when they lie beyond N (their weights and bias are zero, so
+// they hold activation(0) = 0; an inactive wave writes plain zeros): the next layer multiplies those columns by zero
+// weights, and 0 x (stale LDS bits) could be 0 x NaN.
+template <int KIND, int T, int RT>
+__device__ __forceinline__ void write_back(const f32x4 (&am)[RT][T], const f32x4 (&ac)[RT][T], bool active, _Float16* s_hi, _Float16* s_lo,
+                                           int r, int q, int S, int plane, int tile0, int nwrite) {
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int n0 = 16 * (tile0 + t) + 4 * q;  // this lane's 4 consecutive output features = next layer's k
+      if (16 * (tile0 + t) >= nwrite) continue;
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = activate<KIND>(am[rt][t][i] + ac[rt][t][i] * LO_INV);
+      }
+      f16x4 h, lo4;
+      split4(o, h, lo4);
+      const int pos = (r + 16 * rt) * S + k_pos(n0, plane);
+      *(f16x4*)(s_hi + pos) = h;
+      *(f16x4*)(s_lo + pos) = lo4;
+    }
+  }
+}
+
+// One layer for this wave.  `ring` slot s holds chunk c0 + s of the wave's stream; the layer consumes its items in order
+// (item 0 = bias, item i = k-group i-1; 2T chunks each) and leaves the ring positioned on the next layer's first chunk.
 // RT row tiles (16 rows each) share every weight chunk: RT x the MFMA work per byte streamed from L2.
 template <int T, int RT>
-__device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, float* s_act, int wave, int lane, long long row_block,
-                                          float4 (&ring)[RING], const float4* __restrict__ stream, long long& c0) {
-  constexpr int R = RING / T;  // items per ring round
+__device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, _Float16* s_hi, _Float16* s_lo, int wave, int lane,
+                                          long long row_block, float4 (&ring)[RING], const float4* __restrict__ stream, long long& c0) {
+  constexpr int C = 2 * T;      // chunks per item
+  constexpr int R = RING / C;   // items per ring round (even for every T)
+  static_assert(R >= 2 && (R & 1) == 0, "the activation double buffer alternates by item parity");
   const int r = lane & 15, q = lane >> 4;
-  const int S = a.stride;
-  const int G = pad16(a.dims[l]) / 16;
+  const int S = 4 * a.plane + 8;
+  const int G = pad32(a.dims[l]) / 32;
   const int N = a.dims[l + 1];
   const int tile0 = wave * T;
   const bool active = wave < active_waves(N);
-  const float* const xrow = s_act + r * S + 4 * q;  // row tile rt: + 16 * rt * S
-  f32x4 acc[RT][T];
+  const int xoff = r * S + q * a.plane;  // row tile rt: + 16 * rt * S; k-group g: + 8 g
+  f32x4 am[RT][T], ac[RT][T];
   if (active) {
-    float4 xa[RT], xb[RT];
+    f16x8 xh[2][RT], xl[2][RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) { xa[rt] = *(const float4*)(xrow + 16 * rt * S); xb[rt] = xa[rt]; }
+    for (int rt = 0; rt < RT; ++rt) {
+      xh[0][rt] = *(const f16x8*)(s_hi + xoff + 16 * rt * S); xl[0][rt] = *(const f16x8*)(s_lo + xoff + 16 * rt * S);
+      xh[1][rt] = xh[0][rt]; xl[1][rt] = xl[0][rt];
+    }
     for (int i0 = 0; i0 <= G; i0 += R) {
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         const int i = i0 + j;  // item: 0 = bias, 1..G = k-group i-1
-        // the activations of the NEXT item are fetched before this item's MFMAs (two alternating register sets)
+        // the activations of the NEXT item (k-group i) are fetched before this item's MFMAs (two alternating register sets):
+        // item i consumes set (i & 1) ^ 1, i.e. the set written while item i-1 ran
         const int gx = i < G ? i : G - 1;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          if ((j & 1) == 0) xb[rt] = *(const float4*)(xrow + 16 * rt * S + 16 * gx);
-          else xa[rt] = *(const float4*)(xrow + 16 * rt * S + 16 * gx);
+          xh[j & 1][rt] = *(const f16x8*)(s_hi + xoff + 16 * rt * S + 8 * gx);
+          xl[j & 1][rt] = *(const f16x8*)(s_lo + xoff + 16 * rt * S + 8 * gx);
         }
         if (i == 0) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int t = 0; t < T; ++t) acc[rt][t] = f32x4{ring[j * T + t].x, ring[j * T + t].y, ring[j * T + t].z, ring[j * T + t].w};
+            for (int t = 0; t < T; ++t) {
+              am[rt][t] = f32x4{ring[j * C + t].x, ring[j * C + t].y, ring[j * C + t].z, ring[j * C + t].w};
+              ac[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         } else if (i <= G) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
-            const float4 x = (j & 1) == 0 ? xa[rt] : xb[rt];
+            const f16x8 bh = xh[(j & 1) ^ 1][rt], bl = xl[(j & 1) ^ 1][rt];
 #pragma unroll
-            for (int t = 0; t < T; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].x, x.x, acc[rt][t], 0, 0, 0);
+            for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[j * C + 2 * t]), bh, am[rt][t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < T; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].y, x.y, acc[rt][t], 0, 0, 0);
+            for (int t = 0; t < T; ++t) ac[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[j * C + 2 * t]), bl, ac[rt][t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < T; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].z, x.z, acc[rt][t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < T; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[j * T + t].w, x.w, acc[rt][t], 0, 0, 0);
+            for (int t = 0; t < T; ++t) ac[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[j * C + 2 * t + 1]), bh, ac[rt][t], 0, 0, 0);
           }
         }
-        // refill the slots just consumed (pad chunks of a partial last round included: the ring invariant must hold)
+        // refill the slots just consumed (pad items of a partial last round included: the ring invariant must hold)
 #pragma unroll
-        for (int t = 0; t < T; ++t) ring[j * T + t] = stream[(c0 + RING + j * T + t) * 64];
+        for (int s = 0; s < C; ++s) ring[j * C + s] = stream[(c0 + RING + j * C + s) * 64];
         // keep the refill HERE: left alone, the scheduler sinks it behind the next item's MFMAs to save registers, which
-        // collapses the ring to one group in flight
+        // collapses the ring to one item in flight
         __builtin_amdgcn_sched_barrier(0);
       }
       c0 += RING;
-#ifdef LT_MLP_STAMPS
-      if (l == 0 && i0 == 0) MLP_STAMP(7);
-#endif
     }
   }
 #ifdef LT_MLP_STAMPS
@@ -181,22 +236,22 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
 #endif
   lds_barrier();  // every wave is done reading this layer's input
   if (!last) {
-    if (active) {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        float* const dst = s_act + (r + 16 * rt) * S + 16 * tile0 + 4 * q;
-        if (a.activation == LT_ACT_ELU) write_activated<LT_ACT_ELU, T>(acc[rt], dst, tile0, pad16(N));
-        else if (a.activation == LT_ACT_RELU) write_activated<LT_ACT_RELU, T>(acc[rt], dst, tile0, pad16(N));
-        else if (a.activation == LT_ACT_TANH) write_activated<LT_ACT_TANH, T>(acc[rt], dst, tile0, pad16(N));
-        else write_activated<LT_ACT_NONE, T>(acc[rt], dst, tile0, pad16(N));
-      }
-    }
+    const int nwrite = pad32(N);
+    if (a.activation == LT_ACT_ELU) write_back<LT_ACT_ELU, T, RT>(am, ac, active, s_hi, s_lo, r, q, S, a.plane, tile0, nwrite);
+    else if (a.activation == LT_ACT_RELU) write_back<LT_ACT_RELU, T, RT>(am, ac, active, s_hi, s_lo, r, q, S, a.plane, tile0, nwrite);
+    else if (a.activation == LT_ACT_TANH) write_back<LT_ACT_TANH, T, RT>(am, ac, active, s_hi, s_lo, r, q, S, a.plane, tile0, nwrite);
+    else write_back<LT_ACT_NONE, T, RT>(am, ac, active, s_hi, s_lo, r, q, S, a.plane, tile0, nwrite);
     lds_barrier();
     return;
   }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const long long e = row_block * (16 * RT) + 16 * rt + r;
+    float out[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[t][i] = active ? am[rt][t][i] + ac[rt][t][i] * LO_INV : 0.f;
     if (a.mode == MODE_FORWARD) {
       if (active && e < a.m) {
 #pragma unroll
@@ -204,7 +259,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int n = 16 * (tile0 + t) + 4 * q + i;
-            if (n < N) a.y[e * N + n] = acc[rt][t][i];
+            if (n < N) a.y[e * N + n] = out[t][i];
           }
         }
       }
@@ -225,14 +280,14 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
           float xv[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            xv[i] = acc[rt][0][i] + sgv[i] * z[i];
+            xv[i] = out[0][i] + sgv[i] * z[i];
             lp += -(z[i] * z[i]) * 0.5f - __logf(sgv[i]) - 0.91893853320467274178f;  // Normal.log_prob
           }
           const long long o = e * 12 + 4 * q;
           const float4 xo = make_float4(xv[0], xv[1], xv[2], xv[3]);
           *(float4*)(a.st_actions + o) = xo;
           *(float4*)(a.actions_out + o) = xo;
-          *(float4*)(a.st_mu + o) = make_float4(acc[rt][0][0], acc[rt][0][1], acc[rt][0][2], acc[rt][0][3]);
+          *(float4*)(a.st_mu + o) = make_float4(out[0][0], out[0][1], out[0][2], out[0][3]);
           *(float4*)(a.st_sigma + o) = sg;
         }
         lp += __shfl_xor(lp, 16, 64);
@@ -245,36 +300,59 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
 
 template <int RT>
 __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
-  extern __shared__ __attribute__((aligned(16))) float s_act[];
+  extern __shared__ __attribute__((aligned(16))) _Float16 s_img[];
   constexpr int ROWS = 16 * RT;
-  const bool second = (int)blockIdx.x >= d.split;
+  bool second;
+  long long row_block;
+  if (d.xcd_split) {  // workgroups are dealt round-robin over the 8 XCDs: net 0 on four of them, net 1 on the other four
+    const int x = blockIdx.x & 7;
+    second = x >= 4;
+    row_block = (long long)(blockIdx.x >> 3) * 4 + (x & 3);
+    if (row_block >= d.blocks_per_net) return;
+  } else {
+    second = (int)blockIdx.x >= d.split;
+    row_block = second ? (long long)blockIdx.x - d.split : (long long)blockIdx.x;
+  }
   const MlpArgs& a = second ? d.net[1] : d.net[0];
-  const long long row_block = second ? (long long)blockIdx.x - d.split : (long long)blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   MLP_STAMP(0);
-  // weight stream: 16 chunks in flight before anything else
+  // weight stream: a full ring in flight before anything else
   const float4* __restrict__ stream = (const float4*)a.packed + a.wave_base[wave] * 64 + lane;
   float4 ring[RING];
 #pragma unroll
   for (int s = 0; s < RING; ++s) ring[s] = stream[s * 64];
   long long c0 = 0;
   const long long row0 = row_block * ROWS;
-  const int S = a.stride;
+  const int S = 4 * a.plane + 8;
+  _Float16* const s_hi = s_img;
+  _Float16* const s_lo = s_img + ROWS * S;
   {
-    const int K0 = a.dims[0], K0p = pad16(K0);
+    // input rows -> (hi, lo) planes in the k-permuted image; pad columns and rows beyond m are zero
+    const int K0 = a.dims[0], K0p = pad32(K0);
     if ((K0 & 3) == 0) {
       const int kv = K0p >> 2, k4 = K0 >> 2;
       for (int idx = tid; idx < ROWS * kv; idx += 64 * NW) {
         const int rr = idx / kv, cc = idx - rr * kv;
         const long long e = row0 + rr;
-        const float4 v = (cc < k4 && e < a.m) ? *(const float4*)(a.x + e * K0 + 4 * cc) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *(float4*)(s_act + rr * S + 4 * cc) = v;
+        // read-once rows: nontemporal, so they do not push the weight stream out of the XCD's L2
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (cc < k4 && e < a.m) v = __builtin_nontemporal_load((const f32x4*)(a.x + e * K0 + 4 * cc));
+        const float vv[4] = {v[0], v[1], v[2], v[3]};
+        f16x4 h, lo4;
+        split4(vv, h, lo4);
+        const int pos = rr * S + k_pos(4 * cc, a.plane);
+        *(f16x4*)(s_hi + pos) = h;
+        *(f16x4*)(s_lo + pos) = lo4;
       }
     } else {
       for (int idx = tid; idx < ROWS * K0p; idx += 64 * NW) {
         const int rr = idx / K0p, cc = idx - rr * K0p;
         const long long e = row0 + rr;
-        s_act[rr * S + cc] = (cc < K0 && e < a.m) ? a.x[e * K0 + cc] : 0.f;
+        const float x = fminf(fmaxf((cc < K0 && e < a.m) ? a.x[e * K0 + cc] : 0.f, -F16_CLAMP), F16_CLAMP);
+        const _Float16 h = (_Float16)x;
+        const int pos = rr * S + k_pos(cc, a.plane);
+        s_hi[pos] = h;
+        s_lo[pos] = (_Float16)((x - (float)h) * LO_SCALE);
       }
     }
   }
@@ -283,10 +361,10 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
   for (int l = 0; l < a.L; ++l) {
     const int T = tiles_per_wave(pad16(a.dims[l + 1]) / 16);
     const bool last = l == a.L - 1;
-    if (T == 8) mlp_layer<8, RT>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
-    else if (T == 4) mlp_layer<4, RT>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
-    else if (T == 2) mlp_layer<2, RT>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
-    else mlp_layer<1, RT>(a, l, last, s_act, wave, lane, row_block, ring, stream, c0);
+    if (T == 8) mlp_layer<8, RT>(a, l, last, s_hi, s_lo, wave, lane, row_block, ring, stream, c0);
+    else if (T == 4) mlp_layer<4, RT>(a, l, last, s_hi, s_lo, wave, lane, row_block, ring, stream, c0);
+    else if (T == 2) mlp_layer<2, RT>(a, l, last, s_hi, s_lo, wave, lane, row_block, ring, stream, c0);
+    else mlp_layer<1, RT>(a, l, last, s_hi, s_lo, wave, lane, row_block, ring, stream, c0);
     MLP_STAMP(2 + l);
   }
 }
@@ -299,27 +377,39 @@ struct PackArgs {
   float* packed;
 };
 __global__ void lt_mlp_pack_kernel(const PackArgs p) {
-  const int T = tiles_per_wave(pad16(p.N) / 16), G = pad16(p.K) / 16;
+  const int T = tiles_per_wave(pad16(p.N) / 16), G = pad32(p.K) / 32, C = 2 * T;
   const int chunks = layer_chunks(p.K, p.N), nact = active_waves(p.N);
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (wave, chunk, lane)
   if (idx >= (long long)nact * chunks * 64) return;
   const int lane = (int)(idx & 63);
   const int c = (int)((idx >> 6) % chunks), wv = (int)((idx >> 6) / chunks);
   const int r = lane & 15, q = lane >> 4;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  if (c < T) {  // bias chunk of tile wv*T + c: lane (r, q) starts its accumulator with features 4q..4q+3
+  const int item = c / C, slot = c - item * C;
+  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (item == 0) {
+    if (slot < T) {  // bias chunk of tile wv*T + slot: lane (r, q) starts its accumulator with features 4q..4q+3
+      float v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = 16 * (wv * T + c) + 4 * q + i;
-      v[i] = n < p.N ? p.b[n] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const int n = 16 * (wv * T + slot) + 4 * q + i;
+        v[i] = n < p.N ? p.b[n] : 0.f;
+      }
+      out = make_float4(v[0], v[1], v[2], v[3]);
     }
-  } else if (c < T * (G + 1)) {
-    const int cc = c - T, g = cc / T, t = cc - g * T;
-    const int n = 16 * (wv * T + t) + r, k0 = 16 * g + 4 * q;
+  } else if (item <= G) {
+    const int g = item - 1, t = slot >> 1, comp = slot & 1;
+    const int n = 16 * (wv * T + t) + r, k0 = 32 * g + 8 * q;
+    f16x8 h;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (n < p.N && k0 + i < p.K) ? p.w[(long long)n * p.K + k0 + i] : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      float x = (n < p.N && k0 + j < p.K) ? p.w[(long long)n * p.K + k0 + j] : 0.f;
+      x = fminf(fmaxf(x, -F16_CLAMP), F16_CLAMP);
+      const _Float16 hi = (_Float16)x;
+      h[j] = comp == 0 ? hi : (_Float16)((x - (float)hi) * LO_SCALE);
+    }
+    out = __builtin_bit_cast(float4, h);
   }
-  *(float4*)(p.packed + ((p.chunk_off[wv] + c) * 64 + lane) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  *(float4*)(p.packed + ((p.chunk_off[wv] + c) * 64 + lane) * 4) = out;
 }
 
 bool desc_ok(const lt_mlp_desc* d) {
@@ -360,40 +450,48 @@ void fill_args(const lt_mlp_desc* d, MlpArgs& a) {
   int widest = 0;
   for (int l = 0; l <= d->num_layers; ++l) {
     a.dims[l] = d->dims[l];
-    widest = pad16(d->dims[l]) > widest ? pad16(d->dims[l]) : widest;
+    widest = d->dims[l] > widest ? d->dims[l] : widest;
   }
   const Geometry g = geometry(d);
   for (int w = 0; w < NW; ++w) a.wave_base[w] = g.wave_base[w];
-  a.stride = widest + 4;
+  a.plane = plane_halfs(widest);
 }
 
-// Row tiles per workgroup: the most (of 1, 2, 4) that still leaves every CU a workgroup - each doubling halves the bytes
-// streamed from L2 per FLOP, and at one 16-row tile per CU the kernel is bound by L2 -> CU bandwidth, not by the MFMA rate.
+// Row tiles per workgroup: the most (of 1, 2) that still leaves every CU a workgroup - doubling halves the bytes streamed
+// from L2 per FLOP, and the kernel is bound by L2 -> CU bandwidth (every workgroup streams the whole network), not by the
+// MFMA rate.  (4 row tiles = 256 accumulator + 128 ring registers per lane: past the point where the allocator spills.)
 int pick_row_tiles(long long rows_total_blocks16) {
-  int rt = 1;
-  while (rt < 4 && rows_total_blocks16 / (2 * rt) >= 256) rt *= 2;
-  return rt;
+  return rows_total_blocks16 / 2 >= 256 ? 2 : 1;
 }
 
 int launch(DualArgs& d, int nets, hipStream_t s) {
-  int stride = d.net[0].stride;
-  if (nets == 2 && d.net[1].stride > stride) stride = d.net[1].stride;
+  int plane = d.net[0].plane;
+  if (nets == 2 && d.net[1].plane > plane) plane = d.net[1].plane;
+  d.net[0].plane = plane;  // both networks of a launch share one LDS geometry
+  if (nets == 2) d.net[1].plane = plane;
+  const size_t row_bytes = (size_t)(4 * plane + 8) * 2 /* halfs */ * 2 /* hi, lo */;
   const long long t0 = (d.net[0].m + 15) / 16, t1 = nets == 2 ? (d.net[1].m + 15) / 16 : 0;
   int rt = pick_row_tiles(t0 + t1);
-  if (const char* o = getenv("LT_MLP_ROW_TILES")) rt = atoi(o) == 4 ? 4 : (atoi(o) == 2 ? 2 : 1);  // diagnostic override
-  while (rt > 1 && (size_t)16 * rt * stride * sizeof(float) > 160 * 1024) rt /= 2;  // one workgroup's activations must fit the LDS
-  const size_t lds = (size_t)16 * rt * stride * sizeof(float);
+  if (const char* o = getenv("LT_MLP_ROW_TILES")) rt = atoi(o) == 2 ? 2 : 1;  // diagnostic override
+  while (rt > 1 && (size_t)16 * rt * row_bytes > 160 * 1024) rt /= 2;  // one workgroup's activations must fit the LDS
+  const size_t lds = (size_t)16 * rt * row_bytes;
   const long long b0 = (t0 + rt - 1) / rt, b1 = (t1 + rt - 1) / rt;
   d.split = (int)b0;
-  const dim3 grid((unsigned)(b0 + b1)), block(64 * NW);
+  // Two networks of equal row count: split them by XCD instead of by block range.  Each XCD's 4 MiB L2 then holds ONE
+  // network's weight stream (~1.5 MB) instead of both - with both resident plus the observation rows streaming through,
+  // the L2 thrashes and the launch runs at half the stream rate.  (Round-robin dealing of blocks over XCDs is observed
+  // behaviour used for speed only; any placement computes the same result.)
+  d.xcd_split = (nets == 2 && b0 == b1) ? 1 : 0;
+  d.blocks_per_net = (int)b0;
+  const long long nblocks = d.xcd_split ? (b0 + 3) / 4 * 8 : b0 + b1;
+  const dim3 grid((unsigned)nblocks), block(64 * NW);
   static bool attr_set = false;
   if (!attr_set) {  // more than the default 64 KB of dynamic LDS
     attr_set = true;
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  if (rt == 4) hipLaunchKernelGGL(lt_mlp_kernel<4>, grid, block, lds, s, d);
-  else if (rt == 2) hipLaunchKernelGGL(lt_mlp_kernel<2>, grid, block, lds, s, d);
+  if (rt == 2) hipLaunchKernelGGL(lt_mlp_kernel<2>, grid, block, lds, s, d);
   else hipLaunchKernelGGL(lt_mlp_kernel<1>, grid, block, lds, s, d);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }

@@ -1,103 +1,137 @@
-// Curriculum / population-gate pass of one env step (one workgroup): body of lt_post_kernel (lt_env.hip).
+// Curriculum / population-gate pass of one env step, run at the TAIL of the step kernel (lt_env.hip) - no launch of its own.
+//
+// Reference: ModifyVelCommandsRangeBasedonReward (locotouch/mdp/curriculums.py:184-275) + MultiSampling.set_ranges
+// (locotouch/mdp/commands.py:471-505), the population gate of rewards.py:190 and `common_step_counter += 1`.
+//
+// The pass needs sums over ALL envs and then a global decision.  Protocol (MI355X_MICROARCH.md, "Valid forms" row 1):
+//   1. every wave (16 envs) first applies the tracker operations the PREVIOUS pass decided (LT_F_CMD_PARAMS[27..30]) to its
+//      own envs' trackers, then forms its partial sums with this step's records merged in hypothetically (registers only),
+//   2. publishes them - 8 floats, one write-through (sc1) dword store per lane - drains its stores and takes a ticket
+//      (agent-scope atomic add on one counter),
+//   3. the wave whose ticket is the last one reduces the slots in a fixed order (sc1 loads: deterministic, run-to-run
+//      identical), replays the reference's decision sequence (lin gate -> maybe widen -> ang gate -> maybe widen), writes
+//      the command block + the tracker operations for the next pass, bumps the step counter and re-arms the ticket.
+// No wave ever touches another wave's envs, so the per-env trackers need no cross-XCD visibility at all; they simply lag
+// the reference's by one pass (the oracle keeps the same representation; the decisions are the reference's own).
+// Every read of the command block by any wave of the launch precedes that wave's ticket, hence the last arriver's writes.
 #pragma once
 
 namespace lt {
 
-// block-wide sum of K values at once (one LDS round, two barriers); result replicated in every thread
-template <int K>
-__device__ __forceinline__ void block_sum(float (&v)[K], float* sh) {
-  const int tid = threadIdx.x, nw = blockDim.x >> 6;
-#pragma unroll
-  for (int k = 0; k < K; ++k)
-    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
-  __syncthreads();  // protect sh against the previous use
-  if ((tid & 63) == 0)
-#pragma unroll
-    for (int k = 0; k < K; ++k) sh[(tid >> 6) * K + k] = v[k];
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    float t = 0.f;
-    for (int w = 0; w < nw; ++w) t += sh[w * K + k];
-    v[k] = t;
-  }
-}
 __device__ __forceinline__ void set_range(float* P, int d, float lo, float hi) {
   P[6 + 2 * d] = P[2 * d]; P[6 + 2 * d + 1] = P[2 * d + 1];
   P[2 * d] = lo; P[2 * d + 1] = hi;
   P[12 + d] = (P[6 + 2 * d] == P[2 * d] && P[6 + 2 * d + 1] == P[2 * d + 1]) ? 1.f : 0.f;
 }
-// Every thread keeps the per-env trackers of its envs in registers for the whole kernel (<= 8 envs per thread at
-// N = 8192; larger N strides further) and replays the reference's call order: lin gate -> maybe widen -> ang gate.
-// One workgroup (any multiple of 64 threads up to 1024); `sh`: 128 floats of LDS.
-// Every thread keeps its envs' records and trackers in registers from ONE batch of loads to the final write-back, so the
-// pass costs two memory round trips (command block, env rows) however many reduction phases the curriculum has.  Rounds of E envs per thread
-// cover any N; the cross-phase decisions are global, so with more than one round the phases re-read instead (kept simple:
-// rounds > 1 only happens for N > E * threads; E = 4 in the 1024-thread kernel).
-template <int E>
-__device__ __forceinline__ void post_body(const lt_dev_args* __restrict__ d, char* const arena, int bump_counter, int gates_only, float* sh) {
-  const lt_cfg& c = d->cfg;
-  const lt_layout& L = d->layout;
-  float* P = (float*)(arena + L.off_cmd_params);
-  const long long n = L.n, q4 = L.npad * 4;
-  const float4* rec = (const float4*)(arena + L.quad_off[LT_F_CURRICULUM]);
-  float4* trk1 = (float4*)((float*)(arena + L.quad_off[LT_F_CURRICULUM]) + q4);
-  float4* trk2 = (float4*)((float*)(arena + L.quad_off[LT_F_CURRICULUM]) + 2 * q4);
-  const float4* cmd = (const float4*)(arena + L.quad_off[LT_F_CMD]);
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const bool one_round = n <= (long long)E * nt;
-  // env rows of this thread (round 0), all loads in flight together with the command block
-  float4 cc[E], rc[E], t1[E];
-  float2 t2[E];  // only .x/.y of the second tracker row are ever touched
+// wave-wide butterflies (fixed order: deterministic); every lane ends with the total
+__device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-  for (int k = 0; k < E; ++k) {
-    const long long e = tid + (long long)k * nt;
-    const long long ec = e < n ? e : n - 1;  // clamped, unconditional: a predicated load would get a wait of its own
-    cc[k] = cmd[ec]; rc[k] = rec[ec]; t1[k] = trk1[ec]; t2[k] = *(const float2*)(trk2 + ec);
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_or(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
+  return v;
+}
+
+// This step's record of the lane's env (replicated inside the quad) + what the population gate needs.
+struct CurIn {
+  bool valid;        // env < n (padded tail envs take no part)
+  bool reset;        // the env reset this step
+  float ep_len;      // episode length / episode sums of the two tracking rewards at the reset
+  float sum_lin, sum_ang;
+  bool cmd_nonzero;  // the env's command after this step's command update
+};
+
+// Steps 1-3.  One block of the launch = one wave64 with lane = env * 4 + leg (the step kernel's mapping); every wave of the
+// grid calls this exactly once, after its last read of the command block.  Returns true in the wave that arrived last:
+// that wave (only) then calls curriculum_decide - at the very end of the kernel, where nothing else is live in registers.
+__device__ __forceinline__ bool curriculum_publish(const lt_layout& L, char* const arena, long long gid, int leg, const CurIn& in) {
+  float* const P = (float*)(arena + L.off_cmd_params);
+  const long long q4 = L.npad * 4;
+  float* const rec_p = (float*)(arena + L.quad_off[LT_F_CURRICULUM]) + gid;
+  float* const t1_p = rec_p + q4;
+  float* const t2_p = rec_p + 2 * q4;
+  const float recp = *rec_p;
+  float t1 = *t1_p, t2 = *t2_p;
+  // ---- 1. tracker operations decided by the previous pass, on the record that pass saw ----
+  {
+    const bool had = qbcast<0>(recp) != 0.f;
+    const float rp_len = qbcast<1>(recp), rp_lin = qbcast<2>(recp), rp_ang = qbcast<3>(recp);
+    const bool mlin = P[27] != 0.f && had, mang = P[28] != 0.f && had, clin = P[29] != 0.f, cang = P[30] != 0.f;
+    if (leg < 3) {  // (reset_lin, len_lin, sum_lin)
+      if (mlin) t1 = sel4(leg, 1.f, rp_len, rp_lin, 0.f);
+      if (clin) t1 = 0.f;
+    } else {        // reset_ang
+      if (mang) t1 = 1.f;
+      if (cang) t1 = 0.f;
+    }
+    if (leg < 2) {  // (len_ang, sum_ang)
+      if (mang) t2 = leg == 0 ? rp_len : rp_ang;
+      if (cang) t2 = 0.f;
+    }
+    *t1_p = t1; *t2_p = t2;
+    *rec_p = in.reset ? sel4(leg, 1.f, in.ep_len, in.sum_lin, in.sum_ang) : 0.f;
   }
-  // command block snapshot (uniform; thread 0 is the only writer, at the very end)
-  float Pl[27];
+  // ---- 2. partial sums with this step's record merged in (curriculums.py:221-224, 241-244) ----
+  const float f_lin = in.reset ? 1.f : qbcast<0>(t1), l_lin = in.reset ? in.ep_len : qbcast<1>(t1), s_lin = in.reset ? in.sum_lin : qbcast<2>(t1);
+  const float f_ang = in.reset ? 1.f : qbcast<3>(t1), l_ang = in.reset ? in.ep_len : qbcast<0>(t2), s_ang = in.reset ? in.sum_ang : qbcast<1>(t2);
+  const bool mine = in.valid && leg == 0;
+  int flags = mine ? ((in.cmd_nonzero ? 1 : 0) | (in.reset ? 2 : 0) | (f_lin == 0.f ? 4 : 0) | (f_ang == 0.f ? 8 : 0)) : 0;
+  flags = wave_or(flags);
+  const float w_llin = wave_sum(mine ? l_lin : 0.f), w_slin = wave_sum(mine ? s_lin : 0.f);
+  const float w_lang = wave_sum(mine ? l_ang : 0.f), w_sang = wave_sum(mine ? s_ang : 0.f);
+  // ---- 3. publish (write-through stores), drain, take a ticket ----
+  const int lane = threadIdx.x & 63;
+  const unsigned nwaves = (unsigned)(L.npad / 16);
+  float* const slots = (float*)(arena + L.off_partials);
+  unsigned* const ticket_p = (unsigned*)(arena + L.off_counters) + 4;  // counters[2], low word
+  {
+    const float bit[4] = {(float)(flags & 1), (float)((flags >> 1) & 1), (float)((flags >> 2) & 1), (float)((flags >> 3) & 1)};
+    const float v = lane == 0 ? bit[0] : lane == 1 ? bit[1] : lane == 2 ? bit[2] : lane == 3 ? w_llin : lane == 4 ? w_slin
+                    : lane == 5 ? bit[3] : lane == 6 ? w_lang : w_sang;
+    if (lane < LT_PARTIAL_FLOATS) __hip_atomic_store(slots + (long long)blockIdx.x * LT_PARTIAL_FLOATS + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(ticket_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+  return ticket == nwaves - 1;
+}
+
+// Step 4, last arriver only: fixed-order reduction of the slots, then the reference's decision sequence.
+__device__ __forceinline__ void curriculum_decide(const lt_cfg& c, const lt_layout& L, char* const arena, int bump_counter) {
+  float* const P = (float*)(arena + L.off_cmd_params);
+  const int lane = threadIdx.x & 63;
+  const unsigned nwaves = (unsigned)(L.npad / 16);
+  float* const slots = (float*)(arena + L.off_partials);
+  unsigned* const ticket_p = (unsigned*)(arena + L.off_counters) + 4;  // counters[2], low word
+  float r[LT_PARTIAL_FLOATS];
 #pragma unroll
-  for (int i = 0; i < 27; ++i) Pl[i] = P[i];
+  for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] = 0.f;
+  for (unsigned w = (unsigned)lane; w < nwaves; w += 64) {
+#pragma unroll
+    for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] += __hip_atomic_load(slots + (long long)w * LT_PARTIAL_FLOATS + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] = wave_sum(r[i]);
+  float Pl[31];
+#pragma unroll
+  for (int i = 0; i < 31; ++i) Pl[i] = P[i];
   const float* mx = c.cmd_range_max;
-  const bool cur = c.cur_enabled != 0 && !gates_only;
-  const bool lin_open = cur && (Pl[1] != mx[0] || Pl[12] == 0.f || Pl[3] != mx[1] || Pl[13] == 0.f) && (Pl[17] - Pl[18] <= (float)c.cur_max_distance_bins);
-  // pass 1: population gate, any-reset flag, lin statistics with this step's records merged in
-  float r1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // nz, any, not-all-reset(lin), sum len, sum reward
-#pragma unroll
-  for (int k = 0; k < E; ++k) {
-    if (tid + (long long)k * nt >= n) continue;
-    if (cc[k].x != 0.f || cc[k].y != 0.f || cc[k].z != 0.f) r1[0] = 1.f;
-    if (rc[k].x != 0.f) r1[1] = 1.f;
-    if (lin_open) {
-      float4 t = t1[k];
-      if (rc[k].x != 0.f) { t.x = 1.f; t.y = rc[k].y; t.z = rc[k].z; }
-      if (t.x == 0.f) r1[2] = 1.f;
-      r1[3] += t.y; r1[4] += t.z;
-    }
-  }
-  if (!one_round)
-    for (long long e = tid + (long long)E * nt; e < n; e += nt) {
-      const float4 c4 = cmd[e], r4 = rec[e];
-      if (c4.x != 0.f || c4.y != 0.f || c4.z != 0.f) r1[0] = 1.f;
-      if (r4.x != 0.f) r1[1] = 1.f;
-      if (lin_open) {
-        float4 t = trk1[e];
-        if (r4.x != 0.f) { t.x = 1.f; t.y = r4.y; t.z = r4.z; }
-        if (t.x == 0.f) r1[2] = 1.f;
-        r1[3] += t.y; r1[4] += t.z;
-      }
-    }
-  block_sum<5>(r1, sh);
-  const bool any = r1[1] > 0.f;
-  const float inv_n = 1.f / (float)n;
+  const bool cur = c.cur_enabled != 0;
+  const bool any = r[1] > 0.f;
   const bool run = cur && any;  // _reset_idx (and the curriculum with it) only runs when some env reset this step
+  const float inv_n = 1.f / (float)L.n;
+  const bool lin_open = run && (Pl[1] != mx[0] || Pl[12] == 0.f || Pl[3] != mx[1] || Pl[13] == 0.f) &&
+                        (Pl[17] - Pl[18] <= (float)c.cur_max_distance_bins);                               // curriculums.py:218-220
   bool lin_pass = false;
-  if (run && lin_open) {
-    lin_pass = r1[2] == 0.f && r1[3] * inv_n > c.cur_len_threshold && r1[4] * inv_n > c.cur_reward_threshold[0];
+  if (lin_open) {
+    lin_pass = r[2] == 0.f && r[3] * inv_n > c.cur_len_threshold && r[4] * inv_n > c.cur_reward_threshold[0];  // :224
     if (lin_pass) {
       Pl[19] += 1.f;
-      if ((int)Pl[19] == c.cur_repeat_times[0]) {
+      if ((int)Pl[19] == c.cur_repeat_times[0]) {                                                          // :226-235
         const float lx = clampf(Pl[0] - Pl[21], -mx[0], 0.f), ly = clampf(Pl[2] - Pl[22], -mx[1], 0.f);
         set_range(Pl, 0, lx, -lx);
         set_range(Pl, 1, ly, -ly);
@@ -106,74 +140,30 @@ __device__ __forceinline__ void post_body(const lt_dev_args* __restrict__ d, cha
       }
     }
   }
+  // the ang gate is evaluated after the lin update, as in the reference's call order (:239-240)
   const bool ang_open = run && (Pl[5] != mx[2] || Pl[14] == 0.f) && (Pl[18] - Pl[17] <= (float)c.cur_max_distance_bins);
-  // pass 2: ang statistics (gate evaluated after the lin update, as in the reference's call order) + tracker update
-  float r2[3] = {0.f, 0.f, 0.f};
-  if (run) {
-#pragma unroll
-    for (int k = 0; k < E; ++k) {
-      if (tid + (long long)k * nt >= n) continue;
-      if (lin_open) {
-        if (rc[k].x != 0.f) { t1[k].x = 1.f; t1[k].y = rc[k].y; t1[k].z = rc[k].z; }
-        if (lin_pass) { t1[k].x = 0.f; t1[k].y = 0.f; t1[k].z = 0.f; }
-      }
-      if (ang_open) {
-        if (rc[k].x != 0.f) { t1[k].w = 1.f; t2[k].x = rc[k].y; t2[k].y = rc[k].w; }
-        if (t1[k].w == 0.f) r2[0] = 1.f;
-        r2[1] += t2[k].x; r2[2] += t2[k].y;
+  bool ang_pass = false;
+  if (ang_open) {
+    ang_pass = r[5] == 0.f && r[6] * inv_n > c.cur_len_threshold && r[7] * inv_n > c.cur_reward_threshold[1];
+    if (ang_pass) {
+      Pl[20] += 1.f;
+      if ((int)Pl[20] == c.cur_repeat_times[1]) {
+        const float lz = clampf(Pl[4] - Pl[23], -mx[2], 0.f);
+        set_range(Pl, 2, lz, -lz);
+        if (Pl[12] != 0.f && Pl[13] != 0.f && Pl[14] != 0.f) { Pl[15] = (float)c.cmd_zero_steps_final; Pl[16] = c.cmd_rel_standing_final; }
+        Pl[20] = 0.f; Pl[18] += 1.f;
       }
     }
-    if (!one_round)
-      for (long long e = tid + (long long)E * nt; e < n; e += nt) {
-        const float4 r4 = rec[e];
-        float4 a1 = trk1[e], a2 = trk2[e];
-        if (lin_open) {
-          if (r4.x != 0.f) { a1.x = 1.f; a1.y = r4.y; a1.z = r4.z; }
-          if (lin_pass) { a1.x = 0.f; a1.y = 0.f; a1.z = 0.f; }
-        }
-        if (ang_open) {
-          if (r4.x != 0.f) { a1.w = 1.f; a2.x = r4.y; a2.y = r4.w; }
-          if (a1.w == 0.f) r2[0] = 1.f;
-          r2[1] += a2.x; r2[2] += a2.y;
-        }
-        trk1[e] = a1; trk2[e] = a2;
-      }
-    bool ang_pass = false;
-    if (ang_open) {
-      block_sum<3>(r2, sh);
-      ang_pass = r2[0] == 0.f && r2[1] * inv_n > c.cur_len_threshold && r2[2] * inv_n > c.cur_reward_threshold[1];
-      if (ang_pass) {
-        Pl[20] += 1.f;
-        if ((int)Pl[20] == c.cur_repeat_times[1]) {
-          const float lz = clampf(Pl[4] - Pl[23], -mx[2], 0.f);
-          set_range(Pl, 2, lz, -lz);
-          if (Pl[12] != 0.f && Pl[13] != 0.f && Pl[14] != 0.f) { Pl[15] = (float)c.cmd_zero_steps_final; Pl[16] = c.cmd_rel_standing_final; }
-          Pl[20] = 0.f; Pl[18] += 1.f;
-        }
-      }
-    }
-    // write-back (each thread only ever touches its own rows)
-#pragma unroll
-    for (int k = 0; k < E; ++k) {
-      const long long e = tid + (long long)k * nt;
-      if (e >= n) continue;
-      if (ang_pass) { t1[k].w = 0.f; t2[k].x = 0.f; t2[k].y = 0.f; }
-      trk1[e] = t1[k]; *(float2*)(trk2 + e) = t2[k];
-    }
-    if (!one_round && ang_pass)
-      for (long long e = tid + (long long)E * nt; e < n; e += nt) {
-        float4 a1 = trk1[e];
-        a1.w = 0.f;
-        trk1[e] = a1;
-        trk2[e] = make_float4(0.f, 0.f, trk2[e].z, trk2[e].w);
-      }
-    Pl[24] = lin_open ? 1.f : 0.f; Pl[25] = ang_open ? 1.f : 0.f;
   }
-  Pl[26] = r1[0] > 0.f ? 1.f : 0.f;
-  if (tid == 0) {
+  if (run) { Pl[24] = lin_open ? 1.f : 0.f; Pl[25] = ang_open ? 1.f : 0.f; }
+  Pl[26] = r[0] > 0.f ? 1.f : 0.f;
+  Pl[27] = lin_open ? 1.f : 0.f; Pl[28] = ang_open ? 1.f : 0.f;  // tracker operations for the next pass
+  Pl[29] = lin_pass ? 1.f : 0.f; Pl[30] = ang_pass ? 1.f : 0.f;
+  if (lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 27; ++i) P[i] = Pl[i];
+    for (int i = 0; i < 31; ++i) P[i] = Pl[i];
     if (bump_counter) ((long long*)(arena + L.off_counters))[0] += 1;
+    __hip_atomic_store(ticket_p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
   }
 }
 

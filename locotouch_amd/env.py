@@ -146,7 +146,7 @@ class LocoTouchVecEnv:
         _abi.check(self._lib.lt_env_step(self._handle, ctypes.c_void_p(actions_ptr), self._stream()), "lt_env_step")
 
     def step_rows_raw(self, actions_ptr: int, prev_policy: int, prev_critic: int, next_policy: int, next_critic: int) -> None:
-        """lt_env_step_rows: step kernel only, observation rows read from / written to caller storage (0 = arena rows)."""
+        """lt_env_step_rows: observation rows read from / written to caller storage (0 = arena rows)."""
         vp = ctypes.c_void_p
         _abi.check(self._lib.lt_env_step_rows(self._handle, vp(actions_ptr), vp(prev_policy or None), vp(prev_critic or None),
                                               vp(next_policy or None), vp(next_critic or None), self._stream()), "lt_env_step_rows")
@@ -163,10 +163,6 @@ class LocoTouchVecEnv:
     def handle(self) -> ctypes.c_void_p:
         return self._handle
 
-    def post_step_raw(self) -> None:
-        """lt_env_post_step on the current stream (curriculum + step counter); pairs with step_rows_raw."""
-        _abi.check(self._lib.lt_env_post_step(self._handle, self._stream()), "lt_env_post_step")
-
     def step_profiled(self, actions: torch.Tensor) -> float:
         """lt_env_step with HIP events around the step kernel; returns its duration in ms (host-syncing)."""
         ms = ctypes.c_float()
@@ -177,8 +173,11 @@ class LocoTouchVecEnv:
     def eval_terms(self) -> None:
         _abi.check(self._lib.lt_env_eval_terms(self._handle, self._stream()), "lt_env_eval_terms")
 
-    def curriculum_update(self) -> None:
-        _abi.check(self._lib.lt_env_curriculum_update(self._handle, self._stream()), "lt_env_curriculum_update")
+    def curriculum_update(self, records: torch.Tensor) -> None:
+        """The curriculum pass of the step kernel's tail on caller-supplied records [N][4] (parity-test hook)."""
+        assert records.dtype == torch.float32 and records.is_contiguous() and records.shape == (self.num_envs, 4) and records.is_cuda
+        _abi.check(self._lib.lt_env_curriculum_update(self._handle, ctypes.c_void_p(records.data_ptr()), self._stream()),
+                   "lt_env_curriculum_update")
 
     def set_command_ranges(self, ranges, zero_steps: int, rel_standing: float) -> None:
         arr = (ctypes.c_float * 6)(*[float(x) for x in ranges])

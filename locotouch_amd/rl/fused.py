@@ -4,13 +4,13 @@
 
 Packed path (network shapes lt_mlp.hip covers - every LocoTouch agent config): launches on ONE stream,
     [lt_rollout_policy_value: actor + critic MLPs, sampling, log-prob, storage writes of actions/mu/sigma/values/log-prob]
- -> [lt_env_step_rollout: env step, observation rows written into storage slot t+1, bootstrapped reward + dones into slot t]
- -> [lt_env_post_step: curriculum / population gate / step counter]
+ -> [lt_env_step_rollout: env step, observation rows written into storage slot t+1, bootstrapped reward + dones into slot t,
+     curriculum / population gate / step counter at the kernel's tail]
 with no host sync, so a whole 24-step rollout captures into one hipGraph.  The chain is kept linear on purpose: forked
 streams turn graph edges into cross-queue dependencies that cost more (~10 us each on this stack) than the overlap returns.
 
 Torch path (shapes outside lt_mlp's limits): torch GEMMs -> lt_rollout_act -> lt_env_step_rows -> lt_rollout_record, with the
-critic and the curriculum pass on side streams.
+critic on a side stream.
 """
 from __future__ import annotations
 
@@ -39,7 +39,6 @@ class FusedRollout:
         self.device = env.device
         self.actions = torch.zeros(env.num_envs, 12, device=self.device)
         self.side = torch.cuda.Stream(device=self.device)
-        self.post = torch.cuda.Stream(device=self.device)
         # policy-noise RNG key: a copy of the env's common step counter (refreshed at every rollout start, advanced by
         # lt_rollout_record) so that lt_rollout_act never has to wait for the overlapped post kernel
         self._act_counter = env.counters[:1].clone()
@@ -75,7 +74,7 @@ class FusedRollout:
     @property
     def launches_per_step(self) -> int:
         """Kernel launches of one rollout step (the reference-shaped eager loop needs ~30)."""
-        return 3 if self.actor_mlp is not None else 12
+        return 2 if self.actor_mlp is not None else 11
 
     def policy_value_launch(self, t: int) -> None:
         """The MLP launch of step t alone (bench.py times it for the MFMA roofline entry)."""
@@ -89,8 +88,8 @@ class FusedRollout:
             "lt_rollout_policy_value")
 
     def _step_packed(self, t: int, last: bool) -> None:
-        """Three launches on ONE stream (a linear graph: cross-queue edges of a forked graph cost ~10 us each on this stack):
-        [actor + critic MLPs + sampling] -> [env step + storage record] -> [curriculum pass]."""
+        """Two launches on ONE stream (a linear graph: cross-queue edges of a forked graph cost ~10 us each on this stack):
+        [actor + critic MLPs + sampling] -> [env step + storage record + curriculum tail]."""
         env, alg, st, p = self.env, self.alg, self.alg.storage, self._p
         ac = alg.actor_critic
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -107,7 +106,6 @@ class FusedRollout:
         prev = (obs.data_ptr(), cobs.data_ptr()) if self.rows_in_storage else (0, 0)
         env.step_rollout_raw(self.actions.data_ptr(), prev[0], prev[1], nxt_p, nxt_c, st.values[t].data_ptr(), float(alg.gamma),
                              st.rewards[t].data_ptr(), st.dones[t].data_ptr())
-        env.post_step_raw()
 
     def _step_torch(self, t: int, last: bool) -> None:
         """torch modules for the networks (shapes outside lt_mlp's limits): GEMMs -> lt_rollout_act -> env step -> record,
@@ -127,12 +125,8 @@ class FusedRollout:
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             value = ac.critic(cobs)
-        main.wait_stream(self.post)  # previous step's curriculum pass / counter increment
         prev = (obs.data_ptr(), cobs.data_ptr()) if self.rows_in_storage else (0, 0)
         env.step_rows_raw(self.actions.data_ptr(), prev[0], prev[1], nxt_p, nxt_c)
-        self.post.wait_stream(main)
-        with torch.cuda.stream(self.post):
-            env.post_step_raw()
         main.wait_stream(self.side)
         value.record_stream(main)
         _abi.check(self.lib.lt_rollout_record(n, float(alg.gamma), p(env.reward_buf), p(env.dones_buf), p(env.time_out_buf), p(value),
@@ -154,4 +148,3 @@ class FusedRollout:
                 st.privileged_observations[0].copy_(env.obs_critic)
             for t in range(num_steps):
                 self.step(t, last=t == num_steps - 1)
-            main.wait_stream(self.post)  # joins the forked streams (required at the end of a capture)

@@ -1088,12 +1088,11 @@ void lt_oracle_object_state_obs(const lt_cfg* cfg, const lt_term_in* in, const f
 /* ------------------------------------------------------------------------------------------------ */
 /* K7: command term (reference locotouch/mdp/commands.py:517-576 + UniformVelocityCommand [DEP])     */
 /* ------------------------------------------------------------------------------------------------ */
-static void command_resample(const lt_cfg* cfg, const float* P, uint64_t seed, uint32_t env, uint64_t step, uint32_t stream,
-                             real cmd[3], real cmd_buf[3], real* standing, real* time_left) {
-  float u0[4], u1[4];
-  lt_rng4(seed, env, step, stream, u0);
-  lt_rng4(seed, env, step, stream + 1, u1);
-  const float ub[3] = {u0[0], u0[2], u1[0]}, uv[3] = {u0[1], u0[3], u1[1]};
+/* explicit-uniform form (pinned by tests/golden/mdp_replay.npz, which replays recorded uniforms through the reference's own
+ * _resample_command): ub = bin draws (torch.multinomial by inverse CDF over (p, 1-2p, p)), uv = value draws, ustand = the
+ * standing draw, utime = the resampling-period draw [DEP CommandTerm]. */
+void lt_oracle_command_resample_u(const lt_cfg* cfg, const float* P, const float ub[3], const float uv[3], float ustand, float utime,
+                                  float cmd[3], float cmd_buf[3], float* standing, float* time_left) {
   for (int d = 0; d < 3; ++d) {
     real lo = P[2 * d], hi = P[2 * d + 1];
     if (cfg->cmd_multi_sampling && P[12 + d] == 0) {                                            /* commands.py:530-553 */
@@ -1105,9 +1104,17 @@ static void command_resample(const lt_cfg* cfg, const float* P, uint64_t seed, u
     }
     cmd[d] = lo + (real)uv[d] * (hi - lo);
   }
-  *standing = (u1[2] <= P[16]) ? 1 : 0;                                                         /* :555 */
-  *time_left = cfg->cmd_resample_time[0] + (real)u1[3] * (cfg->cmd_resample_time[1] - cfg->cmd_resample_time[0]);
+  *standing = (ustand <= P[16]) ? 1 : 0;                                                        /* :555 */
+  *time_left = cfg->cmd_resample_time[0] + (real)utime * (cfg->cmd_resample_time[1] - cfg->cmd_resample_time[0]);
   for (int d = 0; d < 3; ++d) cmd_buf[d] = cmd[d];                                              /* :558 */
+}
+static void command_resample(const lt_cfg* cfg, const float* P, uint64_t seed, uint32_t env, uint64_t step, uint32_t stream,
+                             real cmd[3], real cmd_buf[3], real* standing, real* time_left) {
+  float u0[4], u1[4];
+  lt_rng4(seed, env, step, stream, u0);
+  lt_rng4(seed, env, step, stream + 1, u1);
+  const float ub[3] = {u0[0], u0[2], u1[0]}, uv[3] = {u0[1], u0[3], u1[1]};
+  lt_oracle_command_resample_u(cfg, P, ub, uv, u1[2], u1[3], cmd, cmd_buf, standing, time_left);
 }
 /* commands.py:561-576 + base class standing zero */
 void lt_oracle_command_update(int64_t ep_len, int zero_steps, const float buf[3], int standing, float cmd[3]) {
@@ -1145,8 +1152,13 @@ static void set_ranges_done(const lt_cfg* cfg, float* P) {                      
 static float clipf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 /* One curriculum call for a reset batch.  rec = per-env (reset_flag, ep_len, sum_lin, sum_ang) of this step;
- * trk = per-env trackers (reset_lin, len_lin, sum_lin, reset_ang, len_ang, sum_ang, _, _). */
-void lt_oracle_curriculum(const lt_cfg* cfg, float* P, int64_t n, const float* rec, float* trk) {
+ * trk = per-env trackers (reset_lin, len_lin, sum_lin, reset_ang, len_ang, sum_ang, _, _).
+ * ops (may be NULL) receives what the call did to the trackers: [0] merged the records into the lin trackers,
+ * [1] ... into the ang trackers, [2] cleared the lin trackers, [3] cleared the ang trackers. */
+static void curriculum_core(const lt_cfg* cfg, float* P, int64_t n, const float* rec, float* trk, int ops[4]) {
+  int dummy[4];
+  if (!ops) ops = dummy;
+  ops[0] = ops[1] = ops[2] = ops[3] = 0;
   if (!cfg->cur_enabled) return;
   int any = 0;
   for (int64_t e = 0; e < n; ++e) any |= rec[e * 4] != 0;
@@ -1155,6 +1167,7 @@ void lt_oracle_curriculum(const lt_cfg* cfg, float* P, int64_t n, const float* r
   int lin_open = (P[1] != mx[0] || P[12] == 0 || P[3] != mx[1] || P[13] == 0) && (P[17] - P[18] <= (float)cfg->cur_max_distance_bins); /* :218-220 */
   if (lin_open) {
     int all = 1; double sl = 0, sr = 0;
+    ops[0] = 1;
     for (int64_t e = 0; e < n; ++e) {
       if (rec[e * 4] != 0) { trk[e * 8 + 0] = 1; trk[e * 8 + 1] = rec[e * 4 + 1]; trk[e * 8 + 2] = rec[e * 4 + 2]; } /* :221-223 */
       all &= trk[e * 8 + 0] != 0; sl += trk[e * 8 + 1]; sr += trk[e * 8 + 2];
@@ -1168,12 +1181,14 @@ void lt_oracle_curriculum(const lt_cfg* cfg, float* P, int64_t n, const float* r
         set_ranges_done(cfg, P);
         P[19] = 0; P[17] += 1;
       }
+      ops[2] = 1;
       for (int64_t e = 0; e < n; ++e) { trk[e * 8 + 0] = 0; trk[e * 8 + 1] = 0; trk[e * 8 + 2] = 0; } /* :236-238 */
     }
   }
   int ang_open = (P[5] != mx[2] || P[14] == 0) && (P[18] - P[17] <= (float)cfg->cur_max_distance_bins); /* :239-240 */
   if (ang_open) {
     int all = 1; double sl = 0, sr = 0;
+    ops[1] = 1;
     for (int64_t e = 0; e < n; ++e) {
       if (rec[e * 4] != 0) { trk[e * 8 + 3] = 1; trk[e * 8 + 4] = rec[e * 4 + 1]; trk[e * 8 + 5] = rec[e * 4 + 3]; }
       all &= trk[e * 8 + 3] != 0; sl += trk[e * 8 + 4]; sr += trk[e * 8 + 5];
@@ -1186,10 +1201,67 @@ void lt_oracle_curriculum(const lt_cfg* cfg, float* P, int64_t n, const float* r
         set_ranges_done(cfg, P);
         P[20] = 0; P[18] += 1;
       }
+      ops[3] = 1;
       for (int64_t e = 0; e < n; ++e) { trk[e * 8 + 3] = 0; trk[e * 8 + 4] = 0; trk[e * 8 + 5] = 0; }
     }
   }
   P[24] = (float)lin_open; P[25] = (float)ang_open;
+}
+void lt_oracle_curriculum(const lt_cfg* cfg, float* P, int64_t n, const float* rec, float* trk) { curriculum_core(cfg, P, n, rec, trk, NULL); }
+
+/* Arena form of the curriculum state (shared with the HIP library, whose pass runs at the tail of the step kernel where
+ * no wave may touch another wave's envs): the trackers in the arena lag the reference's by one pass, and
+ * LT_F_CMD_PARAMS[27..30] holds the operations that pass decided - (merge lin, merge ang, clear lin, clear ang) - to be
+ * applied, on the record that pass saw, by the next one.  The decisions themselves are curriculum_core's, i.e. the
+ * reference's (pinned by tests/golden/mdp_curriculum.npz). */
+static void curriculum_apply_pending(void* arena, const lt_layout* L) {
+  const float* P = (const float*)((char*)arena + L->off_cmd_params);
+  const float* rec = lt_quad(arena, L, LT_F_CURRICULUM, 0);
+  float* t1 = lt_quad(arena, L, LT_F_CURRICULUM, 1);
+  float* t2 = lt_quad(arena, L, LT_F_CURRICULUM, 2);
+  for (int64_t e = 0; e < L->npad; ++e) {  /* padded tail envs never reset: their records stay zero */
+    const float* r = rec + e * 4;
+    const int had = r[0] != 0;
+    if (P[27] != 0 && had) { t1[e * 4 + 0] = 1; t1[e * 4 + 1] = r[1]; t1[e * 4 + 2] = r[2]; }
+    if (P[29] != 0) { t1[e * 4 + 0] = 0; t1[e * 4 + 1] = 0; t1[e * 4 + 2] = 0; }
+    if (P[28] != 0 && had) { t1[e * 4 + 3] = 1; t2[e * 4 + 0] = r[1]; t2[e * 4 + 1] = r[3]; }
+    if (P[30] != 0) { t1[e * 4 + 3] = 0; t2[e * 4 + 0] = 0; t2[e * 4 + 1] = 0; }
+  }
+}
+/* the pass proper on the (now up-to-date) trackers and this step's records: decisions into P, tracker operations deferred */
+static void curriculum_decide(const lt_cfg* cfg, void* arena, const lt_layout* L) {
+  float* P = (float*)((char*)arena + L->off_cmd_params);
+  int64_t n = L->n;
+  float* rec = (float*)malloc(sizeof(float) * 4 * (size_t)n);
+  float* trk = (float*)malloc(sizeof(float) * 8 * (size_t)n);
+  for (int64_t e = 0; e < n; ++e)
+    for (int c = 0; c < 4; ++c) {
+      rec[e * 4 + c] = lt_quad(arena, L, LT_F_CURRICULUM, 0)[e * 4 + c];
+      /* tracker memory order in the arena: (reset_lin,len_lin,sum_lin,reset_ang),(len_ang,sum_ang,_,_) */
+      trk[e * 8 + c] = lt_quad(arena, L, LT_F_CURRICULUM, 1)[e * 4 + c];
+      trk[e * 8 + 4 + c] = lt_quad(arena, L, LT_F_CURRICULUM, 2)[e * 4 + c];
+    }
+  int ops[4];
+  curriculum_core(cfg, P, n, rec, trk, ops);  /* works on the copy: the arena's trackers are updated by the next pass */
+  P[27] = (float)ops[0]; P[28] = (float)ops[1]; P[29] = (float)ops[2]; P[30] = (float)ops[3];
+  free(rec); free(trk);
+}
+/* HIP-hook twin (lt_env_curriculum_update): one pass on caller-supplied records, no step-counter increment */
+int lt_oracle_curriculum_update(const lt_cfg* cfg, void* arena, const float* records) {
+  lt_layout L;
+  lt_layout_init(&L, cfg->num_envs, (cfg->task == LT_TASK_LOCOMOTION ? 45 : 58) * cfg->obs_history);
+  curriculum_apply_pending(arena, &L);
+  float* rec = lt_quad(arena, &L, LT_F_CURRICULUM, 0);
+  for (int64_t e = 0; e < L.n; ++e)
+    for (int c = 0; c < 4; ++c) rec[e * 4 + c] = records[e * 4] != 0 ? (c == 0 ? 1.0f : records[e * 4 + c]) : 0.0f;
+  curriculum_decide(cfg, arena, &L);
+  int nz = 0;
+  for (int64_t e = 0; e < L.n; ++e) {
+    const float* cm = lt_quad(arena, &L, LT_F_CMD, 0) + e * 4;
+    nz |= cm[0] != 0 || cm[1] != 0 || cm[2] != 0;
+  }
+  ((float*)((char*)arena + L.off_cmd_params))[26] = nz ? 1.0f : 0.0f;
+  return 0;
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -1216,6 +1288,29 @@ static void startup_env(const lt_cfg* cfg, env_t* E, uint32_t env) {
     E->foot_mu[l] = md < ms ? md : ms; /* make_consistent: dynamic = min(static, dynamic); the contact law uses it */
   }
   E->obj_mass = 1.0f; E->obj_mu = 1.0f; E->trunk_mu = 1.0f; E->trunk_rest = 0; E->obj_rest = 0;
+}
+
+/* E3 randomize_friction_restitution.__call__ (events.py:160-196): (static, dynamic, restitution) = lo + u * (hi - lo), then
+ * make_consistent => dynamic = min(static, dynamic).  Explicit-uniform form, pinned by tests/golden/mdp_replay.npz. */
+void lt_oracle_material_u(const float range_static[2], const float range_dynamic[2], const float range_restitution[2],
+                          const float u[3], float out[3]) {
+  out[0] = lt_lerp(range_static, u[0]);
+  out[1] = lt_lerp(range_dynamic, u[1]);
+  out[2] = lt_lerp(range_restitution, u[2]);
+  if (out[0] < out[1]) out[1] = out[0];
+}
+/* E6 ResetObjectStateUniform.__call__ (events.py:85-109): offset added in WORLD axes (:98), + height/2 (:99), orientation
+ * = robot quat (x) euler(roll, pitch, yaw) (:100-101), velocity = robot root velocity (+ zero-range samples) (:104-105).
+ * Explicit-uniform form, pinned by tests/golden/mdp_replay.npz. */
+void lt_oracle_reset_object_u(const lt_cfg* cfg, const float root_pos[3], const float root_quat[4], const float root_lin[3],
+                              const float root_ang[3], float obj_length, const float u_pose[6], float pos[3], float quat[4],
+                              float lin[3], float ang[3]) {
+  for (int c = 0; c < 3; ++c) pos[c] = root_pos[c] + lt_lerp(cfg->obj_reset_pos[c], u_pose[c]);
+  pos[2] += obj_length / 2;
+  real dq[4];
+  quat_from_euler(dq, lt_lerp(cfg->obj_reset_rpy[0], u_pose[3]), lt_lerp(cfg->obj_reset_rpy[1], u_pose[4]), lt_lerp(cfg->obj_reset_rpy[2], u_pose[5]));
+  quat_mul(quat, root_quat, dq);
+  for (int c = 0; c < 3; ++c) { lin[c] = root_lin[c]; ang[c] = root_ang[c]; }
 }
 
 static void reset_env(const lt_cfg* cfg, const float* P, env_t* E, uint32_t env, uint64_t step, int has_object) {
@@ -1251,19 +1346,24 @@ static void reset_env(const lt_cfg* cfg, const float* P, env_t* E, uint32_t env,
   if (has_object) {
     /* E3 randomize_friction_restitution (events.py:160-196, make_consistent) and E2 object material */
     lt_rng4(cfg->seed, env, step, RS_RESET_MAT, u);
-    E->trunk_mu = lt_lerp(cfg->trunk_friction, u[0]); if (E->trunk_mu > 1) E->trunk_mu = 1;
-    E->trunk_rest = lt_lerp(cfg->trunk_restitution, u[1]);
-    E->obj_mu = lt_lerp(cfg->obj_friction, u[2]); if (E->obj_mu > 1) E->obj_mu = 1;
-    E->obj_rest = lt_lerp(cfg->obj_restitution, u[3]);
+    {
+      /* the dynamic-friction range of both cfgs is (1, 1): its draw does not matter (object_transport_teacher_env_cfg.py:121-143) */
+      const float one[2] = {1.0f, 1.0f};
+      const float ut[3] = {u[0], 0.0f, u[1]}, uo[3] = {u[2], 0.0f, u[3]};
+      float m[3];
+      lt_oracle_material_u(cfg->trunk_friction, one, cfg->trunk_restitution, ut, m);
+      E->trunk_mu = m[1]; E->trunk_rest = m[2];       /* the contact law takes the consistent (dynamic) coefficient */
+      lt_oracle_material_u(cfg->obj_friction, one, cfg->obj_restitution, uo, m);
+      E->obj_mu = m[1]; E->obj_rest = m[2];
+    }
     /* E6 ResetObjectStateUniform.__call__ (events.py:85-109): world-axis offset, + length/2, robot velocity */
     lt_rng4(cfg->seed, env, step, RS_RESET_OBJ, u);
     lt_rng4(cfg->seed, env, step, RS_RESET_OBJ + 1, w);
-    for (int c = 0; c < 3; ++c) E->obj_pos[c] = E->root_pos[c] + lt_lerp(cfg->obj_reset_pos[c], u[c]);
-    E->obj_pos[2] += E->obj_length / 2;
-    real dq[4];
-    quat_from_euler(dq, lt_lerp(cfg->obj_reset_rpy[0], w[0]), lt_lerp(cfg->obj_reset_rpy[1], w[1]), lt_lerp(cfg->obj_reset_rpy[2], w[2]));
-    quat_mul(E->obj_quat, E->root_quat, dq);
-    v3_copy(E->obj_lin, E->root_lin); v3_copy(E->obj_ang, E->root_ang);
+    {
+      const float up[6] = {u[0], u[1], u[2], w[0], w[1], w[2]};
+      lt_oracle_reset_object_u(cfg, E->root_pos, E->root_quat, E->root_lin, E->root_ang, E->obj_length, up, E->obj_pos, E->obj_quat,
+                               E->obj_lin, E->obj_ang);
+    }
     /* E1 object mass: default 1.0 + U (operation add on the default) */
     E->obj_mass = 1.0f + lt_lerp(cfg->obj_mass_add, w[3]);
     for (int c = 0; c < 4; ++c) E->obj_timers[c] = 0;
@@ -1509,24 +1609,7 @@ static int any_nonzero(void* arena, const lt_layout* L) {
 
 static void post_step(const lt_cfg* cfg, void* arena, const lt_layout* L) {
   float* P = (float*)((char*)arena + L->off_cmd_params);
-  int64_t n = L->n;
-  float* rec = (float*)malloc(sizeof(float) * 4 * (size_t)n);
-  float* trk = (float*)malloc(sizeof(float) * 8 * (size_t)n);
-  for (int64_t e = 0; e < n; ++e) {
-    for (int c = 0; c < 4; ++c) {
-      rec[e * 4 + c] = lt_quad(arena, L, LT_F_CURRICULUM, 0)[e * 4 + c];
-      trk[e * 8 + c] = lt_quad(arena, L, LT_F_CURRICULUM, 1)[e * 4 + c];
-      trk[e * 8 + 4 + c] = lt_quad(arena, L, LT_F_CURRICULUM, 2)[e * 4 + c];
-    }
-    /* tracker memory order in the arena: (reset_lin,len_lin,sum_lin,reset_ang),(len_ang,sum_ang,_,_) */
-  }
-  lt_oracle_curriculum(cfg, P, n, rec, trk);
-  for (int64_t e = 0; e < n; ++e)
-    for (int c = 0; c < 4; ++c) {
-      lt_quad(arena, L, LT_F_CURRICULUM, 1)[e * 4 + c] = trk[e * 8 + c];
-      lt_quad(arena, L, LT_F_CURRICULUM, 2)[e * 4 + c] = trk[e * 8 + 4 + c];
-    }
-  free(rec); free(trk);
+  curriculum_decide(cfg, arena, L);
   P[26] = any_nonzero(arena, L) ? 1.0f : 0.0f; /* population gate of rewards.py:190 for the next step */
   counters(arena, L)[0] += 1;
 }
@@ -1570,6 +1653,7 @@ int lt_oracle_step(const lt_cfg* cfg, void* arena, const float* actions, int nth
   int nz = ((const float*)((char*)arena + L.off_cmd_params))[26] != 0;
   int64_t n = L.n;
   (void)nthreads;
+  curriculum_apply_pending(arena, &L);  /* before the env loop overwrites the records the pending operations refer to */
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
 #endif

@@ -61,8 +61,19 @@ void lt_oracle_rewards(const lt_cfg* cfg, const lt_term_in* in, lt_gait_io* G, f
 int lt_oracle_terminations(const lt_cfg* cfg, const lt_term_in* in, int64_t ep_len, int64_t max_len);
 void lt_oracle_object_state_obs(const lt_cfg* cfg, const lt_term_in* in, const float* noise16, float out[13]);
 void lt_oracle_command_update(int64_t ep_len, int zero_steps, const float buf[3], int standing, float cmd[3]);
+/* explicit-uniform forms of the RNG-consuming terms (tests/golden/mdp_replay.npz replays recorded uniforms through the
+ * reference's own code; the oracle's step path calls these very functions with Philox uniforms) */
+void lt_oracle_command_resample_u(const lt_cfg* cfg, const float* P, const float ub[3], const float uv[3], float ustand, float utime,
+                                  float cmd[3], float cmd_buf[3], float* standing, float* time_left);
+void lt_oracle_material_u(const float range_static[2], const float range_dynamic[2], const float range_restitution[2],
+                          const float u[3], float out[3]);
+void lt_oracle_reset_object_u(const lt_cfg* cfg, const float root_pos[3], const float root_quat[4], const float root_lin[3],
+                              const float root_ang[3], float obj_length, const float u_pose[6], float pos[3], float quat[4],
+                              float lin[3], float ang[3]);
 void lt_oracle_cmd_params_init(const lt_cfg* cfg, float* P);
 void lt_oracle_curriculum(const lt_cfg* cfg, float* P, int64_t n, const float* rec, float* trk);
+/* arena twin of lt_env_curriculum_update: one curriculum pass on caller-supplied records [n][4] (trackers lag by one pass) */
+int lt_oracle_curriculum_update(const lt_cfg* cfg, void* arena, const float* records);
 void lt_oracle_obs_push(const int* term_dims, int nterms, int hist, const float* frame, int fill, float* row);
 
 #ifdef __cplusplus

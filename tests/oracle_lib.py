@@ -63,6 +63,7 @@ def load() -> ctypes.CDLL:
     lib.lt_oracle_command_update.argtypes = [ctypes.c_int64, ctypes.c_int, P(f32), ctypes.c_int, P(f32)]
     lib.lt_oracle_cmd_params_init.argtypes = [P(_abi.LtCfg), P(f32)]
     lib.lt_oracle_curriculum.argtypes = [P(_abi.LtCfg), P(f32), ctypes.c_int64, P(f32), P(f32)]
+    lib.lt_oracle_curriculum_update.argtypes = [P(_abi.LtCfg), ctypes.c_void_p, P(f32)]
     lib.lt_oracle_obs_push.argtypes = [P(i32), ctypes.c_int, ctypes.c_int, P(f32), ctypes.c_int, P(f32)]
     _lib = lib
     return lib
@@ -92,6 +93,10 @@ class OracleEnv:
     def step(self, actions: np.ndarray, nthreads: int = 1):
         a = np.ascontiguousarray(actions, dtype=np.float32)
         self.lib.lt_oracle_step(ctypes.byref(self.cfg), self.ptr, a.ctypes.data_as(ctypes.c_void_p), nthreads)
+
+    def curriculum_update(self, records: np.ndarray):
+        r = np.ascontiguousarray(records, dtype=np.float32)
+        self.lib.lt_oracle_curriculum_update(ctypes.byref(self.cfg), self.ptr, fptr(r))
 
     def eval_terms(self):
         self.lib.lt_oracle_eval_terms(ctypes.byref(self.cfg), self.ptr)

@@ -264,15 +264,18 @@ def test_time_out_fires_exactly_at_max_episode_length():
 
 
 def test_velocity_curriculum_kernel_matches_reference_golden():
-    """lt_post_kernel against the reference's own curriculum sequence (tests/golden/mdp_curriculum.npz): the per-step
-    record quad is written exactly as the step kernel would, then lt_env_curriculum_update applies the gate."""
+    """The curriculum pass of the step kernel's tail (per-wave partials, last arriver decides) against the reference's own
+    curriculum sequence (tests/golden/mdp_curriculum.npz): lt_env_curriculum_update feeds the golden reset batches as the
+    per-env records the step kernel would derive.  The oracle twin runs beside it: byte-equal command block and trackers."""
     import torch
 
     g = np.load(os.path.join(GOLD, "mdp_curriculum.npz"))
     calls, n = g["reset_mask"].shape
     env = make_env("teacher", n)
-    rec = env.field("LT_F_CURRICULUM")  # [n, 3, 4]
+    ora = O.OracleEnv(env.cfg)
+    ora.reset_all()
     P = env.cmd_params
+    L = Layout(n, env.num_obs)
     for c in range(calls):
         m = torch.from_numpy(g["reset_mask"][c])
         r = torch.zeros(n, 4)
@@ -280,8 +283,8 @@ def test_velocity_curriculum_kernel_matches_reference_golden():
         r[m, 1] = torch.from_numpy(g["ep_len"][c]).float()[m]
         r[m, 2] = torch.from_numpy(g["sum_lin"][c])[m]
         r[m, 3] = torch.from_numpy(g["sum_ang"][c])[m]
-        rec[:, 0, :] = r.cuda()
-        env.curriculum_update()
+        env.curriculum_update(r.cuda())
+        ora.curriculum_update(r.numpy())
         p = P.cpu().numpy()
         ref = g["ranges"][c]
         np.testing.assert_allclose(p[0:6].reshape(3, 2), ref[0:3], rtol=0, atol=2e-6, err_msg=f"call {c}")
@@ -289,7 +292,11 @@ def test_velocity_curriculum_kernel_matches_reference_golden():
         assert [bool(x) for x in p[12:15]] == [bool(x) for x in g["equal"][c]], f"call {c}"
         assert int(p[15]) == int(g["zero_steps"][c]) and abs(p[16] - float(g["rel_standing"][c])) < 1e-7
         assert int(p[17]) == int(g["lin_bins"][c]) and int(p[18]) == int(g["ang_bins"][c]), f"call {c}"
+        a = device_arena_to_host(env)
+        np.testing.assert_array_equal(L.arr(a, "LT_F_CMD_PARAMS"), L.arr(ora.arena, "LT_F_CMD_PARAMS"), err_msg=f"call {c}")
+        np.testing.assert_array_equal(L.vec(a, "LT_F_CURRICULUM"), L.vec(ora.arena, "LT_F_CURRICULUM"), err_msg=f"call {c}")
     assert int(p[17]) > 5 and int(p[18]) > 5
+    assert int(env.counters[0]) == 1 and int(env.counters[2]) == 0  # no step-counter increment; arrival ticket re-armed
 
 
 def test_fused_rollout_kernels_match_torch():
