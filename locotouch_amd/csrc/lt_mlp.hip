@@ -17,21 +17,23 @@
 // tolerance).  3 MFMAs at 16x the f32-MFMA rate: 5.3x less matrix-pipe time than the exact-f32 form.
 //
 // Structure:
-//   * a workgroup (NW = 4 waves, one per SIMD) owns 16 * RT batch rows; their activations live in LDS as two f16 planes
-//     (hi, lo) and never visit HBM between layers;
+//   * a workgroup (NW = 4 waves, one per SIMD) owns 16 * RT batch rows; their activations live in LDS as f32 rows
+//     ([rows][S], S = widest layer + 4 floats) and never visit HBM between layers.  The (hi, lo) split of the activations
+//     happens in the HOT loop, on the VALU slots the MFMAs leave idle - not in the per-layer epilogues: straight-line code
+//     that runs once per layer is instruction-cache-cold, and measured 3 x slower per instruction than the loop body;
 //   * out^T = W . act^T on v_mfma_f32_16x16x32_f16: the weight tile is the A operand (16 output features x 32 k), the
 //     activations are the B operand (32 k x 16 rows), so a lane ends up with 4 CONSECUTIVE output features of ONE row ->
-//     the next layer's input is written back with one ds_write_b64 per plane;
-//   * LDS image of a row: k = 32 g + 8 q + j lives at half index q * PLANE + 8 g + j (PLANE = 128-half multiple), row
-//     stride 4 * PLANE + 8 halfs.  A B-fragment read is then one ds_read_b128 per plane whose bank depends on the row
-//     only (the 16 lanes of every ds_read_b128 service group hold 16 distinct rows): conflict-free;
+//     the next layer's input is written back with one ds_write_b128;
 //   * each wave owns T = N/(16 NW) output tiles x RT row tiles (independent accumulators);
-//   * the parameters are pre-packed once per policy update (lt_mlp_pack) into ONE LINEAR STREAM PER WAVE of 1-KiB chunks
-//     (64 lanes x 16 B) in exactly the order the wave consumes them, across layers: per layer one bias item, then per
-//     32-wide k-group one item of T x (hi chunk, lo chunk).  The kernel keeps a 32-chunk register ring per wave and
-//     refills a slot right after its MFMAs, so 32 KiB per wave are always in flight and the first weights of layer l+1
-//     are already on their way while layer l finishes.  Every wave-instruction of the stream is one fully coalesced
-//     global_load_dwordx4; all workgroups stream the same ~1.4 MB per network, which stays L2-resident.
+//   * the weights are pre-packed once per policy update (lt_mlp_pack) - already split into (hi, lo) f16 - into ONE LINEAR
+//     STREAM PER WAVE of 1-KiB chunks (64 lanes x 16 B) in exactly the order the wave consumes them, across layers: per
+//     32-wide k-group one item of T x (hi chunk, lo chunk).  The kernel keeps a 32-chunk register ring per wave and refills
+//     a slot right after its MFMAs, so 32 KiB per wave are always in flight and the first weights of layer l+1 are already
+//     on their way while layer l finishes.  Every wave-instruction of the stream is one fully coalesced
+//     global_load_dwordx4; all workgroups stream the same ~1.5 MB per network from L2.  That stream is what bounds the
+//     kernel: a CU draws ~30 B/clk from L2 however many CUs stream (MI355X_MICROARCH.md, indexed rows from L2), i.e.
+//     ~20 us per network - the MFMAs of 32 rows take 7 us;
+//   * biases live in LDS (staged once) and are added in the epilogue.
 //
 // The policy network's last layer carries the sampling epilogue of lt_rollout_act (a = mu + sigma N(0,1), log-prob,
 // storage-slot writes), so the actor side of a rollout step needs no further launch.
@@ -48,9 +50,8 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RING = 32;               // chunks in flight per wave
+constexpr int RING = 32;               // chunk granularity of the packed streams (layers are padded to multiples of it)
 #ifndef LT_MLP_WAVES
 #define LT_MLP_WAVES 4
 #endif
@@ -67,25 +68,24 @@ __host__ __device__ inline int tiles_per_wave(int ntiles) {
   const int per = (ntiles + NW - 1) / NW;
   return per > 4 ? 8 : (per > 2 ? 4 : (per > 1 ? 2 : 1));
 }
-// chunks of one layer in the stream of an ACTIVE wave: G + 1 items (bias, then one per 32-wide k-group) of 2T chunks each,
-// padded to whole ring rounds
+// chunks of one layer in the stream of an ACTIVE wave: one item of 2T chunks per 32-wide k-group, padded to whole ring rounds
 __host__ __device__ inline int layer_chunks(int K, int N) {
   const int T = tiles_per_wave(pad16(N) / 16), G = pad32(K) / 32, R = RING / (2 * T);
-  return (G + 1 + R - 1) / R * RING;
+  return (G + R - 1) / R * RING;
 }
 __host__ __device__ inline int active_waves(int N) {
   const int nt = pad16(N) / 16, T = tiles_per_wave(nt);
   return (nt + T - 1) / T;
 }
-// LDS image: halfs per q-plane of a row (128-half multiples keep the four lane quarters on the same banks)
-__host__ __device__ inline int plane_halfs(int widest) { return (pad32(widest) / 4 + 127) / 128 * 128; }
 
 struct MlpArgs {
   int L;
   int dims[LT_MLP_MAX_LAYERS + 1];
   int activation;
   int mode;
-  int plane;                  // halfs per q-plane; LDS row stride = 4 * plane + 8 halfs
+  int stride;                 // LDS row stride in floats (== 4 mod 64: the 16 rows of a ds_read_b128 phase fall on distinct banks)
+  int bias_total;             // floats of the bias block (sum of pad16(N_l))
+  long long bias_chunk;       // chunk offset of the bias block inside `packed`
   long long wave_base[NW];    // chunk offset of each wave's stream inside `packed`
   const float* packed;
   const float* x;
@@ -112,16 +112,17 @@ __device__ __forceinline__ float activate(float x) {
   if (KIND == LT_ACT_TANH) return tanhf(x);
   return x;
 }
-// x = hi + lo / 2048 with hi, lo in f16 (module header)
-__device__ __forceinline__ void split4(const float (&v)[4], f16x4& hi, f16x4& lo) {
+// 8 consecutive f32 activations -> the (hi, lo) f16 B-fragments:  x = hi + lo / 2048  (module header)
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float x = fminf(fmaxf(v[i], -F16_CLAMP), F16_CLAMP);
+  for (int i = 0; i < 8; ++i) {
+    const float x = fminf(fmaxf(i < 4 ? a[i] : b[i - 4], -F16_CLAMP), F16_CLAMP);
     const _Float16 h = (_Float16)x;
     hi[i] = h;
     lo[i] = (_Float16)((x - (float)h) * LO_SCALE);
   }
 }
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the weight
 // chunks every wave keeps in flight - twice per layer - and undo the streaming across layer boundaries.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -134,101 +135,110 @@ __device__ unsigned long long g_mlp_stamps[1024 * 8 * NW];
 #define MLP_STAMP(i) do { } while (0)
 #endif
 
-// half index (inside a row's LDS image) of input feature k
-__device__ __forceinline__ int k_pos(int k, int plane) { return ((k >> 3) & 3) * plane + ((k >> 5) << 3) + (k & 7); }
-
-// activation + (hi, lo) split + write-back of a wave's output tiles as the next layer's input.  KIND is a compile-time constant
-// per call site: a runtime `kind` inside the loop gets if-converted into computing EVERY activation for every element.
-// Tiles up to the next layer's k padding (32) are written even when they lie beyond N (their weights and bias are zero, so
-// they hold activation(0) = 0; an inactive wave writes plain zeros): the next layer multiplies those columns by zero
-// weights, and 0 x (stale LDS bits) could be 0 x NaN.
+// Epilogue of a hidden layer: bias + compensation + activation, written back as the next layer's f32 input.  KIND is a
+// compile-time constant per call site (a runtime `kind` inside the loop gets if-converted into computing EVERY activation).
+// Tiles up to the next layer's k padding (32) are written even when they lie beyond N (zero weights and bias give
+// activation(0) = 0; an inactive wave writes plain zeros): the next layer multiplies those columns by zero weights, and
+// 0 x (stale LDS bits) could be 0 x NaN.
 template <int KIND, int T, int RT>
-__device__ __forceinline__ void write_back(const f32x4 (&am)[RT][T], const f32x4 (&ac)[RT][T], bool active, _Float16* s_hi, _Float16* s_lo,
-                                           int r, int q, int S, int plane, int tile0, int nwrite) {
+__device__ __forceinline__ void write_back(const f32x4 (&am)[RT][T], const f32x4 (&ac)[RT][T], bool active, float* s_act, const float* s_bias,
+                                           int r, int q, int S, int tile0, int nwrite) {
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
+  for (int t = 0; t < T; ++t) {
+    const int n0 = 16 * (tile0 + t) + 4 * q;  // this lane's 4 consecutive output features = next layer's k
+    if (16 * (tile0 + t) >= nwrite) continue;
+    const f32x4 bias = active ? *(const f32x4*)(s_bias + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int n0 = 16 * (tile0 + t) + 4 * q;  // this lane's 4 consecutive output features = next layer's k
-      if (16 * (tile0 + t) >= nwrite) continue;
-      float o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < RT; ++rt) {
+      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
       if (active) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = activate<KIND>(am[rt][t][i] + ac[rt][t][i] * LO_INV);
+        for (int i = 0; i < 4; ++i) o[i] = activate<KIND>(am[rt][t][i] + ac[rt][t][i] * LO_INV + bias[i]);
       }
-      f16x4 h, lo4;
-      split4(o, h, lo4);
-      const int pos = (r + 16 * rt) * S + k_pos(n0, plane);
-      *(f16x4*)(s_hi + pos) = h;
-      *(f16x4*)(s_lo + pos) = lo4;
+      *(f32x4*)(s_act + (r + 16 * rt) * S + n0) = o;
     }
+    // one tile at a time: left alone, the scheduler reads ALL accumulators out of the AGPRs up front (128 more live
+    // registers beside the weight ring) and spills - and a scratch reload queues behind the 32 KiB of weight loads in flight
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 // One layer for this wave.  `ring` slot s holds chunk c0 + s of the wave's stream; the layer consumes its items in order
-// (item 0 = bias, item i = k-group i-1; 2T chunks each) and leaves the ring positioned on the next layer's first chunk.
+// (item i = k-group i: T x (hi chunk, lo chunk)) and leaves the ring positioned on the next layer's first chunk.
 // RT row tiles (16 rows each) share every weight chunk: RT x the MFMA work per byte streamed from L2.
-template <int T, int RT>
-__device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, _Float16* s_hi, _Float16* s_lo, int wave, int lane,
-                                          long long row_block, float4 (&ring)[RING], const float4* __restrict__ stream, long long& c0) {
+// RG = ring slots (chunks in flight per wave): 32, or 16 where the accumulators need the registers (RG divides RING, so a
+// ring round never straddles a layer).
+template <int T, int RT, int RG>
+__device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, float* s_act, const float* s_bias, int wave, int lane,
+                                          long long row_block, float4 (&ring)[RG], const float4* __restrict__ stream, long long& c0) {
   constexpr int C = 2 * T;      // chunks per item
-  constexpr int R = RING / C;   // items per ring round (even for every T)
-  static_assert(R >= 2 && (R & 1) == 0, "the activation double buffer alternates by item parity");
+  constexpr int R = RG / C;     // items per ring round
+  constexpr int U = (R & 1) ? 2 : 1;  // rounds per loop trip: the activation double buffer alternates by (compile-time) item parity
+  static_assert(R >= 1 && RING % RG == 0, "ring geometry");
   const int r = lane & 15, q = lane >> 4;
-  const int S = 4 * a.plane + 8;
+  const int S = a.stride;
   const int G = pad32(a.dims[l]) / 32;
   const int N = a.dims[l + 1];
   const int tile0 = wave * T;
   const bool active = wave < active_waves(N);
-  const int xoff = r * S + q * a.plane;  // row tile rt: + 16 * rt * S; k-group g: + 8 g
+  const float* const xrow = s_act + r * S + 8 * q;  // row tile rt: + 16 * rt * S; k-group g: + 32 g
   f32x4 am[RT][T], ac[RT][T];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int t = 0; t < T; ++t) { am[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   if (active) {
+    // software pipeline over items: raw f32 of item i+2 in flight from LDS, item i+1 being split on the VALU, item i in the MFMAs
+    f32x4 raw[RT][2];
     f16x8 xh[2][RT], xl[2][RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      xh[0][rt] = *(const f16x8*)(s_hi + xoff + 16 * rt * S); xl[0][rt] = *(const f16x8*)(s_lo + xoff + 16 * rt * S);
-      xh[1][rt] = xh[0][rt]; xl[1][rt] = xl[0][rt];
+      raw[rt][0] = *(const f32x4*)(xrow + 16 * rt * S);
+      raw[rt][1] = *(const f32x4*)(xrow + 16 * rt * S + 4);
+      split8(raw[rt][0], raw[rt][1], xh[0][rt], xl[0][rt]);
+      const int g1 = G > 1 ? 1 : 0;
+      raw[rt][0] = *(const f32x4*)(xrow + 16 * rt * S + 32 * g1);
+      raw[rt][1] = *(const f32x4*)(xrow + 16 * rt * S + 32 * g1 + 4);
     }
-    for (int i0 = 0; i0 <= G; i0 += R) {
+    // items incl. the zero-weight pad items of the last RING round: they are walked (refill only) to leave the ring on the
+    // next layer's first chunk - except behind the last layer, where nothing follows
+    const int Gp = last ? G : (G + RING / C - 1) / (RING / C) * (RING / C);
+    for (int i0 = 0; i0 < Gp; i0 += R * U) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const int i = i0 + j;  // item: 0 = bias, 1..G = k-group i-1
-        // the activations of the NEXT item (k-group i) are fetched before this item's MFMAs (two alternating register sets):
-        // item i consumes set (i & 1) ^ 1, i.e. the set written while item i-1 ran
-        const int gx = i < G ? i : G - 1;
+      for (int j = 0; j < R * U; ++j) {
+        const int i = i0 + j;  // item = k-group
+        const int sl = (j % R) * C;  // first ring slot of the item
+        if (i < G) {
+          // split item i+1 (its raw values were fetched during item i-1), then fetch the raw values of item i+2
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          xh[j & 1][rt] = *(const f16x8*)(s_hi + xoff + 16 * rt * S + 8 * gx);
-          xl[j & 1][rt] = *(const f16x8*)(s_lo + xoff + 16 * rt * S + 8 * gx);
-        }
-        if (i == 0) {
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-              am[rt][t] = f32x4{ring[j * C + t].x, ring[j * C + t].y, ring[j * C + t].z, ring[j * C + t].w};
-              ac[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        } else if (i <= G) {
+          for (int rt = 0; rt < RT; ++rt) split8(raw[rt][0], raw[rt][1], xh[(j & 1) ^ 1][rt], xl[(j & 1) ^ 1][rt]);
+          const int gx = i + 2 < G ? i + 2 : G - 1;
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
-            const f16x8 bh = xh[(j & 1) ^ 1][rt], bl = xl[(j & 1) ^ 1][rt];
+            raw[rt][0] = *(const f32x4*)(xrow + 16 * rt * S + 32 * gx);
+            raw[rt][1] = *(const f32x4*)(xrow + 16 * rt * S + 32 * gx + 4);
+          }
 #pragma unroll
-            for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[j * C + 2 * t]), bh, am[rt][t], 0, 0, 0);
+          for (int rt = 0; rt < RT; ++rt) {
+            const f16x8 bh = xh[j & 1][rt], bl = xl[j & 1][rt];
 #pragma unroll
-            for (int t = 0; t < T; ++t) ac[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[j * C + 2 * t]), bl, ac[rt][t], 0, 0, 0);
+            for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bh, am[rt][t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < T; ++t) ac[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[j * C + 2 * t + 1]), bh, ac[rt][t], 0, 0, 0);
+            for (int t = 0; t < T; ++t) ac[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bl, ac[rt][t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < T; ++t) ac[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t + 1]), bh, ac[rt][t], 0, 0, 0);
           }
         }
-        // refill the slots just consumed (pad items of a partial last round included: the ring invariant must hold)
+        // refill the slots just consumed (pad items included: the ring invariant must hold for the next layer)
+        if (!last || i < G) {
 #pragma unroll
-        for (int s = 0; s < C; ++s) ring[j * C + s] = stream[(c0 + RING + j * C + s) * 64];
+          for (int s = 0; s < C; ++s) ring[sl + s] = stream[(c0 + RG + (j / R) * RG + sl + s) * 64];
+        }
         // keep the refill HERE: left alone, the scheduler sinks it behind the next item's MFMAs to save registers, which
         // collapses the ring to one item in flight
         __builtin_amdgcn_sched_barrier(0);
       }
-      c0 += RING;
+      c0 += RG * U;
     }
   }
 #ifdef LT_MLP_STAMPS
@@ -237,10 +247,10 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, _F
   lds_barrier();  // every wave is done reading this layer's input
   if (!last) {
     const int nwrite = pad32(N);
-    if (a.activation == LT_ACT_ELU) write_back<LT_ACT_ELU, T, RT>(am, ac, active, s_hi, s_lo, r, q, S, a.plane, tile0, nwrite);
-    else if (a.activation == LT_ACT_RELU) write_back<LT_ACT_RELU, T, RT>(am, ac, active, s_hi, s_lo, r, q, S, a.plane, tile0, nwrite);
-    else if (a.activation == LT_ACT_TANH) write_back<LT_ACT_TANH, T, RT>(am, ac, active, s_hi, s_lo, r, q, S, a.plane, tile0, nwrite);
-    else write_back<LT_ACT_NONE, T, RT>(am, ac, active, s_hi, s_lo, r, q, S, a.plane, tile0, nwrite);
+    if (a.activation == LT_ACT_ELU) write_back<LT_ACT_ELU, T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
+    else if (a.activation == LT_ACT_RELU) write_back<LT_ACT_RELU, T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
+    else if (a.activation == LT_ACT_TANH) write_back<LT_ACT_TANH, T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
+    else write_back<LT_ACT_NONE, T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
     lds_barrier();
     return;
   }
@@ -249,9 +259,11 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, _F
     const long long e = row_block * (16 * RT) + 16 * rt + r;
     float out[T][4];
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < T; ++t) {
+      const f32x4 bias = active ? *(const f32x4*)(s_bias + 16 * (tile0 + t) + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) out[t][i] = active ? am[rt][t][i] + ac[rt][t][i] * LO_INV : 0.f;
+      for (int i = 0; i < 4; ++i) out[t][i] = active ? am[rt][t][i] + ac[rt][t][i] * LO_INV + bias[i] : 0.f;
+    }
     if (a.mode == MODE_FORWARD) {
       if (active && e < a.m) {
 #pragma unroll
@@ -300,7 +312,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, _F
 
 template <int RT>
 __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
-  extern __shared__ __attribute__((aligned(16))) _Float16 s_img[];
+  extern __shared__ __attribute__((aligned(16))) float s_img[];
   constexpr int ROWS = 16 * RT;
   bool second;
   long long row_block;
@@ -314,90 +326,101 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
     row_block = second ? (long long)blockIdx.x - d.split : (long long)blockIdx.x;
   }
   const MlpArgs& a = second ? d.net[1] : d.net[0];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: per-wave decisions become s_cbranch, not exec masks
   MLP_STAMP(0);
-  // weight stream: a full ring in flight before anything else
-  const float4* __restrict__ stream = (const float4*)a.packed + a.wave_base[wave] * 64 + lane;
-  float4 ring[RING];
-#pragma unroll
-  for (int s = 0; s < RING; ++s) ring[s] = stream[s * 64];
-  long long c0 = 0;
   const long long row0 = row_block * ROWS;
-  const int S = 4 * a.plane + 8;
-  _Float16* const s_hi = s_img;
-  _Float16* const s_lo = s_img + ROWS * S;
+  const int S = a.stride;
+  float* const s_act = s_img;
+  float* const s_bias = s_img + ROWS * S;
+  // Input rows first: their loads enter the memory queue AHEAD of the weight ring (vmcnt retires in order - behind 128 KiB
+  // of weight chunks the 45 KB of rows would arrive ~2 us later).  Read-once rows: nontemporal, so they do not push the
+  // weight stream out of the XCD's L2.  Pad columns and rows beyond m are zero.
+  const int K0 = a.dims[0], K0p = pad32(K0);
+  const bool vec_in = (K0 & 3) == 0;
+  constexpr int B = 12;  // float4 in flight per thread: one batch covers a 348-wide input (11 per thread at two row tiles)
+  const int kv = K0p >> 2, k4 = K0 >> 2, total = ROWS * kv;
+  f32x4 vin[B];
+  if (vec_in) {
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      const int idx = tid + u * 64 * NW;
+      const int rr = idx / kv, cc = idx - rr * kv;
+      const long long e = row0 + rr;
+      vin[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < total && cc < k4 && e < a.m) vin[u] = __builtin_nontemporal_load((const f32x4*)(a.x + e * K0 + 4 * cc));
+    }
+  }
+  // weight stream: a full ring in flight.  Two row tiles need 128 accumulator registers per lane: a 16-slot ring then
+  // keeps the allocation clear of spills (a scratch reload in a layer epilogue would sit behind the whole ring in the queue).
+  constexpr int RG = RT >= 2 ? 16 : 32;
+  const float4* __restrict__ stream = (const float4*)a.packed + a.wave_base[wave] * 64 + lane;
+  float4 ring[RG];
+#pragma unroll
+  for (int s = 0; s < RG; ++s) ring[s] = stream[s * 64];
+  long long c0 = 0;
   {
-    // input rows -> (hi, lo) planes in the k-permuted image; pad columns and rows beyond m are zero
-    const int K0 = a.dims[0], K0p = pad32(K0);
-    if ((K0 & 3) == 0) {
-      const int kv = K0p >> 2, k4 = K0 >> 2;
-      for (int idx = tid; idx < ROWS * kv; idx += 64 * NW) {
+    // biases -> LDS
+    const float* bsrc = a.packed + a.bias_chunk * 256;
+    for (int i = tid; i < a.bias_total; i += 64 * NW) s_bias[i] = bsrc[i];
+    if (vec_in) {
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        const int idx = tid + u * 64 * NW;
         const int rr = idx / kv, cc = idx - rr * kv;
+        if (idx < total) *(f32x4*)(s_act + rr * S + 4 * cc) = vin[u];
+      }
+      for (int base = tid + B * 64 * NW; base < total; base += 64 * NW) {  // inputs wider than one batch
+        const int rr = base / kv, cc = base - rr * kv;
         const long long e = row0 + rr;
-        // read-once rows: nontemporal, so they do not push the weight stream out of the XCD's L2
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (cc < k4 && e < a.m) v = __builtin_nontemporal_load((const f32x4*)(a.x + e * K0 + 4 * cc));
-        const float vv[4] = {v[0], v[1], v[2], v[3]};
-        f16x4 h, lo4;
-        split4(vv, h, lo4);
-        const int pos = rr * S + k_pos(4 * cc, a.plane);
-        *(f16x4*)(s_hi + pos) = h;
-        *(f16x4*)(s_lo + pos) = lo4;
+        *(f32x4*)(s_act + rr * S + 4 * cc) = v;
       }
     } else {
       for (int idx = tid; idx < ROWS * K0p; idx += 64 * NW) {
         const int rr = idx / K0p, cc = idx - rr * K0p;
         const long long e = row0 + rr;
-        const float x = fminf(fmaxf((cc < K0 && e < a.m) ? a.x[e * K0 + cc] : 0.f, -F16_CLAMP), F16_CLAMP);
-        const _Float16 h = (_Float16)x;
-        const int pos = rr * S + k_pos(cc, a.plane);
-        s_hi[pos] = h;
-        s_lo[pos] = (_Float16)((x - (float)h) * LO_SCALE);
+        s_act[rr * S + cc] = (cc < K0 && e < a.m) ? a.x[e * K0 + cc] : 0.f;
       }
     }
   }
   __syncthreads();
   MLP_STAMP(1);
+  int boff = 0;
   for (int l = 0; l < a.L; ++l) {
     const int T = tiles_per_wave(pad16(a.dims[l + 1]) / 16);
     const bool last = l == a.L - 1;
-    if (T == 8) mlp_layer<8, RT>(a, l, last, s_hi, s_lo, wave, lane, row_block, ring, stream, c0);
-    else if (T == 4) mlp_layer<4, RT>(a, l, last, s_hi, s_lo, wave, lane, row_block, ring, stream, c0);
-    else if (T == 2) mlp_layer<2, RT>(a, l, last, s_hi, s_lo, wave, lane, row_block, ring, stream, c0);
-    else mlp_layer<1, RT>(a, l, last, s_hi, s_lo, wave, lane, row_block, ring, stream, c0);
+    if (T == 8) mlp_layer<8, RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);
+    else if (T == 4) mlp_layer<4, RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);
+    else if (T == 2) mlp_layer<2, RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);
+    else mlp_layer<1, RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);
+    boff += pad16(a.dims[l + 1]);
     MLP_STAMP(2 + l);
   }
 }
 
-// One layer of one network: weights [N][K] (torch.nn.Linear layout) + bias [N] -> the per-wave chunk streams.
+// One layer of one network: weights [N][K] (torch.nn.Linear layout) -> the per-wave chunk streams, bias [N] -> the bias block.
 struct PackArgs {
   const float* w; const float* b;
   int K, N;
   long long chunk_off[NW];  // first chunk of this layer in each wave's stream (absolute, in chunks)
+  long long bias_float_off; // first float of this layer's (pad16(N)) bias slice
   float* packed;
 };
 __global__ void lt_mlp_pack_kernel(const PackArgs p) {
   const int T = tiles_per_wave(pad16(p.N) / 16), G = pad32(p.K) / 32, C = 2 * T;
   const int chunks = layer_chunks(p.K, p.N), nact = active_waves(p.N);
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (wave, chunk, lane)
+  if (idx < pad16(p.N)) p.packed[p.bias_float_off + idx] = idx < p.N ? p.b[idx] : 0.f;
   if (idx >= (long long)nact * chunks * 64) return;
   const int lane = (int)(idx & 63);
   const int c = (int)((idx >> 6) % chunks), wv = (int)((idx >> 6) / chunks);
   const int r = lane & 15, q = lane >> 4;
-  const int item = c / C, slot = c - item * C;
+  const int g = c / C, slot = c - g * C;
   float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (item == 0) {
-    if (slot < T) {  // bias chunk of tile wv*T + slot: lane (r, q) starts its accumulator with features 4q..4q+3
-      float v[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int n = 16 * (wv * T + slot) + 4 * q + i;
-        v[i] = n < p.N ? p.b[n] : 0.f;
-      }
-      out = make_float4(v[0], v[1], v[2], v[3]);
-    }
-  } else if (item <= G) {
-    const int g = item - 1, t = slot >> 1, comp = slot & 1;
+  if (g < G) {
+    const int t = slot >> 1, comp = slot & 1;
     const int n = 16 * (wv * T + t) + r, k0 = 32 * g + 8 * q;
     f16x8 h;
 #pragma unroll
@@ -426,6 +449,8 @@ bool desc_ok(const lt_mlp_desc* d) {
 struct Geometry {
   long long wave_base[NW];
   long long layer_off[LT_MLP_MAX_LAYERS][NW];
+  long long bias_chunk;   // the bias block (sum of pad16(N_l) floats) sits behind the streams
+  int bias_total;
   long long total_chunks;
 };
 Geometry geometry(const lt_mlp_desc* d) {
@@ -440,7 +465,10 @@ Geometry geometry(const lt_mlp_desc* d) {
     }
     base += off + RING;
   }
-  g.total_chunks = base;
+  g.bias_chunk = base;
+  g.bias_total = 0;
+  for (int l = 0; l < d->num_layers; ++l) g.bias_total += pad16(d->dims[l + 1]);
+  g.total_chunks = base + (g.bias_total + 255) / 256;
   return g;
 }
 
@@ -454,7 +482,9 @@ void fill_args(const lt_mlp_desc* d, MlpArgs& a) {
   }
   const Geometry g = geometry(d);
   for (int w = 0; w < NW; ++w) a.wave_base[w] = g.wave_base[w];
-  a.plane = plane_halfs(widest);
+  a.stride = pad32(widest) + 4;
+  a.bias_total = g.bias_total;
+  a.bias_chunk = g.bias_chunk;
 }
 
 // Row tiles per workgroup: the most (of 1, 2) that still leaves every CU a workgroup - doubling halves the bytes streamed
@@ -465,16 +495,18 @@ int pick_row_tiles(long long rows_total_blocks16) {
 }
 
 int launch(DualArgs& d, int nets, hipStream_t s) {
-  int plane = d.net[0].plane;
-  if (nets == 2 && d.net[1].plane > plane) plane = d.net[1].plane;
-  d.net[0].plane = plane;  // both networks of a launch share one LDS geometry
-  if (nets == 2) d.net[1].plane = plane;
-  const size_t row_bytes = (size_t)(4 * plane + 8) * 2 /* halfs */ * 2 /* hi, lo */;
+  int stride = d.net[0].stride, bias = d.net[0].bias_total;
+  if (nets == 2 && d.net[1].stride > stride) stride = d.net[1].stride;
+  if (nets == 2 && d.net[1].bias_total > bias) bias = d.net[1].bias_total;
+  d.net[0].stride = stride;  // both networks of a launch share one LDS geometry
+  if (nets == 2) d.net[1].stride = stride;
+  const size_t row_bytes = (size_t)stride * sizeof(float);
+  const size_t bias_bytes = (size_t)bias * sizeof(float);
   const long long t0 = (d.net[0].m + 15) / 16, t1 = nets == 2 ? (d.net[1].m + 15) / 16 : 0;
   int rt = pick_row_tiles(t0 + t1);
   if (const char* o = getenv("LT_MLP_ROW_TILES")) rt = atoi(o) == 2 ? 2 : 1;  // diagnostic override
-  while (rt > 1 && (size_t)16 * rt * row_bytes > 160 * 1024) rt /= 2;  // one workgroup's activations must fit the LDS
-  const size_t lds = (size_t)16 * rt * row_bytes;
+  while (rt > 1 && (size_t)16 * rt * row_bytes + bias_bytes > 160 * 1024) rt /= 2;  // one workgroup's activations must fit the LDS
+  const size_t lds = (size_t)16 * rt * row_bytes + bias_bytes;
   const long long b0 = (t0 + rt - 1) / rt, b1 = (t1 + rt - 1) / rt;
   d.split = (int)b0;
   // Two networks of equal row count: split them by XCD instead of by block range.  Each XCD's 4 MiB L2 then holds ONE
@@ -533,11 +565,14 @@ int lt_mlp_packed_floats(const lt_mlp_desc* desc, size_t* floats) {
 int lt_mlp_pack(const lt_mlp_desc* desc, const float* const* weights, const float* const* biases, float* packed, void* stream) {
   if (!desc_ok(desc) || !weights || !biases || !packed) { lt_set_error("lt_mlp_pack: invalid argument"); return LT_EINVAL; }
   const Geometry g = geometry(desc);
+  long long bias_off = 0;
   for (int l = 0; l < desc->num_layers; ++l) {
     if (!weights[l] || !biases[l]) { lt_set_error("lt_mlp_pack: null layer pointer"); return LT_EINVAL; }
     PackArgs p;
     p.w = weights[l]; p.b = biases[l]; p.K = desc->dims[l]; p.N = desc->dims[l + 1]; p.packed = packed;
     for (int w = 0; w < NW; ++w) p.chunk_off[w] = g.layer_off[l][w];
+    p.bias_float_off = g.bias_chunk * 256 + bias_off;
+    bias_off += pad16(p.N);
     const long long total = (long long)active_waves(p.N) * layer_chunks(p.K, p.N) * 64;
     hipLaunchKernelGGL(lt_mlp_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     const hipError_t e = hipGetLastError();
