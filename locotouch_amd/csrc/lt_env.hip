@@ -519,15 +519,22 @@ __device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P
 #define LT_STAMP(i) do { } while (0)
 #endif
 
-// PREFETCH (small grids, <= 2 waves per CU): the previous observation rows of the wave (2 x 16 x OBS floats, 44.5 KB) are
-// fetched by LDS-DMA (global_load_lds_dwordx4, no VGPRs) at kernel start and land while the physics runs, so the
-// history pass at the tail has no global-load latency left - a lone wave per SIMD has nothing else to hide it behind.
-// Large grids keep the register path: 57 KB of LDS per wave would cap occupancy at 2 waves per CU.
+// HELPERS (small grids, <= 2 workgroups per CU - at 4096 envs there is ONE 16-env tile per CU, and a lone wave per SIMD has
+// nothing to hide latency behind): the workgroup is 4 waves, one per SIMD, that split one 16-env tile by TASK:
+//   wave 0    the env step proper (everything below); it leaves the newest observation frame, the reset flags and the
+//             curriculum record in LDS and meets the others at ONE barrier;
+//   wave 1/2  the 6-deep history rows of the policy / critic group: the previous rows (16 x OBS floats) come in by LDS-DMA
+//             (global_load_lds_dwordx4, no VGPRs) at kernel start, the shifted 5/6 of every row is stored back while the
+//             physics runs, the newest frame (and whole rows of envs that reset) after the barrier;
+//   wave 3    the curriculum / population-gate publish (lt_post.h) - its write-through stores and the ticket round trip
+//             stall this wave, not the step.
+// Large grids run the single-wave form (HELPERS = false): there every SIMD already has work, the history pass uses a
+// register path (57 KB of LDS per tile would cap occupancy) and the tail runs inline.
 #ifndef LT_STEP_MIN_WAVES_LARGE
 #define LT_STEP_MIN_WAVES_LARGE 1
 #endif
-template <int TASK, int MODE, bool PREFETCH>
-__global__ __launch_bounds__(64, PREFETCH ? 1 : LT_STEP_MIN_WAVES_LARGE) void lt_step_kernel(const KArgs a) {
+template <int TASK, int MODE, bool HELPERS>
+__global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES_LARGE) void lt_step_kernel(const KArgs a) {
 #ifdef LT_STAMPS
   unsigned long long stamps_[8];
   for (int i = 0; i < 8; ++i) stamps_[i] = 0;
@@ -536,7 +543,8 @@ __global__ __launch_bounds__(64, PREFETCH ? 1 : LT_STEP_MIN_WAVES_LARGE) void lt
   constexpr bool HAS_OBJ = TASK != LT_TASK_LOCOMOTION;
   constexpr int FRAME = HAS_OBJ ? 58 : 45;
   constexpr int OBS = FRAME * 6;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = HELPERS ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;  // scalar: role branches are s_cbranch
   const int leg = lane & 3;
   const long long gid = (long long)blockIdx.x * 64 + lane;  // == env*4 + leg
   const long long env = gid >> 2;
@@ -554,57 +562,106 @@ __global__ __launch_bounds__(64, PREFETCH ? 1 : LT_STEP_MIN_WAVES_LARGE) void lt
   constexpr int STG = (int)(sizeof(lt_dev_args) / 16);
   static_assert(STG <= 128, "staging assumes at most two 16-byte pieces per lane");
   const uint4* const stg_src = (const uint4*)a.d;
-  const uint4 stg0 = stg_src[lane < STG ? lane : 0], stg1 = stg_src[lane + 64 < STG ? lane + 64 : 0];
+  uint4 stg0 = make_uint4(0, 0, 0, 0), stg1 = stg0;
   struct {
     float root_pos, root_quat, root_lin, root_ang, obj_pos, obj_quat, obj_lin, obj_ang, obj_timers, obj_params, env_params, trunk_fh;
     float q[3], qd[3], raw[3], fh[12], cur_air, cur_con, last_air, last_con, mu;
   } hot;
-  hot.root_pos = *F(LT_F_ROOT_POS, 0); hot.root_quat = *F(LT_F_ROOT_QUAT, 0);
-  hot.root_lin = *F(LT_F_ROOT_LIN_VEL_W, 0); hot.root_ang = *F(LT_F_ROOT_ANG_VEL_W, 0);
-  hot.obj_pos = *F(LT_F_OBJ_POS, 0); hot.obj_quat = *F(LT_F_OBJ_QUAT, 0);
-  hot.obj_lin = *F(LT_F_OBJ_LIN_VEL_W, 0); hot.obj_ang = *F(LT_F_OBJ_ANG_VEL_W, 0);
-  hot.obj_timers = *F(LT_F_OBJ_TIMERS, 0); hot.obj_params = *F(LT_F_OBJ_PARAMS, 0);
-  hot.env_params = *F(LT_F_ENV_PARAMS, 0); hot.trunk_fh = *F(LT_F_TRUNK_FORCE_HIST, 0);
+  if (wave == 0) {
+    stg0 = stg_src[lane < STG ? lane : 0]; stg1 = stg_src[lane + 64 < STG ? lane + 64 : 0];
+    hot.root_pos = *F(LT_F_ROOT_POS, 0); hot.root_quat = *F(LT_F_ROOT_QUAT, 0);
+    hot.root_lin = *F(LT_F_ROOT_LIN_VEL_W, 0); hot.root_ang = *F(LT_F_ROOT_ANG_VEL_W, 0);
+    hot.obj_pos = *F(LT_F_OBJ_POS, 0); hot.obj_quat = *F(LT_F_OBJ_QUAT, 0);
+    hot.obj_lin = *F(LT_F_OBJ_LIN_VEL_W, 0); hot.obj_ang = *F(LT_F_OBJ_ANG_VEL_W, 0);
+    hot.obj_timers = *F(LT_F_OBJ_TIMERS, 0); hot.obj_params = *F(LT_F_OBJ_PARAMS, 0);
+    hot.env_params = *F(LT_F_ENV_PARAMS, 0); hot.trunk_fh = *F(LT_F_TRUNK_FORCE_HIST, 0);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { hot.q[k] = *F(LT_F_JOINT_POS, k); hot.qd[k] = *F(LT_F_JOINT_VEL, k); hot.raw[k] = *F(LT_F_ACT_RAW, k); }
+    for (int k = 0; k < 3; ++k) { hot.q[k] = *F(LT_F_JOINT_POS, k); hot.qd[k] = *F(LT_F_JOINT_VEL, k); hot.raw[k] = *F(LT_F_ACT_RAW, k); }
 #pragma unroll
-  for (int i = 0; i < 12; ++i) hot.fh[i] = *F(LT_F_FORCE_HIST, i);
-  hot.cur_air = *F(LT_F_FOOT_CUR_AIR, 0); hot.cur_con = *F(LT_F_FOOT_CUR_CONTACT, 0);
-  hot.last_air = *F(LT_F_FOOT_LAST_AIR, 0); hot.last_con = *F(LT_F_FOOT_LAST_CONTACT, 0);
-  hot.mu = *F(LT_F_FOOT_FRICTION, 0);
-  {
+    for (int i = 0; i < 12; ++i) hot.fh[i] = *F(LT_F_FORCE_HIST, i);
+    hot.cur_air = *F(LT_F_FOOT_CUR_AIR, 0); hot.cur_con = *F(LT_F_FOOT_CUR_CONTACT, 0);
+    hot.last_air = *F(LT_F_FOOT_LAST_AIR, 0); hot.last_con = *F(LT_F_FOOT_LAST_CONTACT, 0);
+    hot.mu = *F(LT_F_FOOT_FRICTION, 0);
     uint4* dst = (uint4*)&s_d;
     if (lane < STG) dst[lane] = stg0;
     if (lane + 64 < STG) dst[lane + 64] = stg1;
   }
-  __syncthreads();
+  __shared__ float s_frame[2][16][64];
+  __shared__ int s_fill[16];
+  __shared__ short s_tab[HELPERS ? 2 : 1][704];  // observation history tables (src[352] | frame[352]), one copy per history wave
+  __shared__ __attribute__((aligned(16))) float s_old[HELPERS ? 2 * 16 * OBS : 4];
+  __shared__ float s_cur[HELPERS ? 64 * 5 : 1];  // wave 0 -> wave 3: this step's curriculum record per lane
+  if (!HELPERS) {
+    const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
+    for (int i = lane; i < 352; i += 64) { s_tab[0][i] = tab.src[i]; s_tab[0][352 + i] = tab.frame[i]; }
+  }
+  __syncthreads();  // B0: the (cfg, layout) block is in LDS
   const lt_cfg& c = s_d.cfg;
   const lt_layout& L = s_d.layout;
   const float* P = (const float*)(arena + L.off_cmd_params);
   const uint64_t step = MODE == MODE_RESET_ALL ? 0ull : (uint64_t)((const long long*)(arena + L.off_counters))[0];
   const float step_dt = c.sim_dt * (float)c.decimation;
 
-  __shared__ float s_frame[2][16][64];
-  __shared__ int s_fill[16];
-  __shared__ short s_tab[704];  // observation history tables (src[352] | frame[352]) staged once per wave
-  __shared__ __attribute__((aligned(16))) float s_old[PREFETCH ? 2 * 16 * OBS : 4];
-  if (PREFETCH) {
-    // 16*OBS floats per group = one contiguous chunk; each wave-instruction moves 64 lanes x 16 B = 1 KiB, lane-linear in LDS
-    constexpr int CHUNK16 = 16 * OBS / 4;  // float4 count per group (OBS*16 is a multiple of 4 for both tasks)
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
+  if (HELPERS && wave != 0) {
+    if (wave == 3) {
+      // ---- wave 3: curriculum / population gate / step counter (lt_post.h) on the record wave 0 leaves in LDS ----
+      __syncthreads();  // B1
+      CurIn in;
+      in.valid = env < L.n;
+      in.reset = s_cur[lane * 5 + 0] != 0.f; in.ep_len = s_cur[lane * 5 + 1];
+      in.sum_lin = s_cur[lane * 5 + 2]; in.sum_ang = s_cur[lane * 5 + 3]; in.cmd_nonzero = s_cur[lane * 5 + 4] != 0.f;
+      if (curriculum_publish(L, arena, gid, leg, in)) curriculum_decide(c, L, arena, 1);  // + common_step_counter += 1
+      return;
+    }
+    // ---- waves 1, 2: history rows of group g.  Row(t) is built from row(t-1): every term block shifts left by one frame
+    //      and takes the newest frame from wave 0.  Lane l owns columns l, l+64, ... of EVERY row, so the per-column routing
+    //      (table lookups) is done once per lane.  In-place safety (rows updated in the arena): the DMA of the whole chunk
+    //      has landed (vmcnt(0)) before this wave stores anything, and only this wave touches the group's rows. ----
+    const int g = wave - 1;
+    constexpr int NCH = (OBS + 63) / 64;
+    {
+      // the group's 16 old rows = one contiguous chunk of 16*OBS floats; each wave-instruction moves 64 lanes x 16 B = 1 KiB,
+      // lane-linear in LDS.  (Issued after B0: a workgroup barrier drains vmcnt, so an earlier issue would hold wave 0 up.)
+      constexpr int CHUNK16 = 16 * OBS / 4;  // float4 count per group (OBS*16 is a multiple of 4 for both tasks)
       const float* gsrc = a.obs_prev[g] + (long long)blockIdx.x * 16 * OBS;
       for (int i = 0; i < (CHUNK16 + 63) / 64; ++i) {
-        const int v = i * 64 + threadIdx.x;
+        const int v = i * 64 + lane;
         if (v < CHUNK16)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + v * 4),
                                            (__attribute__((address_space(3))) void*)(s_old + g * 16 * OBS + i * 256), 16, 0, 0);
       }
+      const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
+      for (int i = lane; i < 352; i += 64) { s_tab[g][i] = tab.src[i]; s_tab[g][352 + i] = tab.frame[i]; }
     }
-  }
-  {
-    const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
-    for (int i = lane; i < 352; i += 64) { s_tab[i] = tab.src[i]; s_tab[352 + i] = tab.frame[i]; }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    int src[NCH], frm[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int col = i * 64 + lane;
+      const int cc = col < OBS ? col : OBS - 1;
+      src[i] = s_tab[g][cc];         // >= 0: old column (one slot newer); < 0: newest frame element -src-1
+      frm[i] = s_tab[g][352 + cc];   // newest-frame element of this column's term (rows that were just reset)
+    }
+    float* const rows = a.obs_next[g] + (long long)blockIdx.x * 16 * OBS;
+    const float* const old = s_old + g * 16 * OBS;
+    // before the barrier (beside the physics): the shifted 5/6 of every row, as if no env reset
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int col = i * 64 + lane;
+        if (col < OBS && src[i] >= 0) rows[r * OBS + col] = old[r * OBS + src[i]];
+      }
+    }
+    __syncthreads();  // B1: newest frame + reset flags are in LDS
+    for (int r = 0; r < 16; ++r) {
+      const bool fill = s_fill[r] != 0;  // first push after a reset fills all 6 slots
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int col = i * 64 + lane;
+        if (col < OBS && (fill || src[i] < 0)) rows[r * OBS + col] = s_frame[g][r][(fill ? frm[i] : (-src[i] - 1)) & 63];
+      }
+    }
+    return;
   }
 
   // ---- sign pattern of this lane's leg (mirror form of the model constants) ----
@@ -1009,10 +1066,16 @@ __global__ __launch_bounds__(64, PREFETCH ? 1 : LT_STEP_MIN_WAVES_LARGE) void lt
         O.w += v3(lerp2(c.push_obj_vel[3], w4.a), lerp2(c.push_obj_vel[4], w4.b), lerp2(c.push_obj_vel[5], w4.c));
       }
     }
-    // curriculum / population gate (lt_post.h): publish this wave's partials here - after the last read of the command
-    // block, with few memory operations outstanding; the wave that arrives last decides at the very end of the kernel.
+    // curriculum / population gate (lt_post.h).  Single-wave form: publish this wave's partials here - after the last read
+    // of the command block, with few memory operations outstanding; the wave that arrives last decides at the very end of
+    // the kernel.  With helper waves the record goes to wave 3 through LDS.
     cur_in.cmd_nonzero = X.cmd.x != 0.f || X.cmd.y != 0.f || X.cmd.z != 0.f;
-    last_arriver = curriculum_publish(L, arena, gid, leg, cur_in);
+    if (HELPERS) {
+      s_cur[lane * 5 + 0] = cur_in.reset ? 1.f : 0.f; s_cur[lane * 5 + 1] = cur_in.ep_len;
+      s_cur[lane * 5 + 2] = cur_in.sum_lin; s_cur[lane * 5 + 3] = cur_in.sum_ang; s_cur[lane * 5 + 4] = cur_in.cmd_nonzero ? 1.f : 0.f;
+    } else {
+      last_arriver = curriculum_publish(L, arena, gid, leg, cur_in);
+    }
   }
 
   LT_STAMP(4);
@@ -1070,58 +1133,9 @@ __global__ __launch_bounds__(64, PREFETCH ? 1 : LT_STEP_MIN_WAVES_LARGE) void lt
       for (int i = 0; i < 13; ++i) fc[45 + i] = o[i];
     }
   }
-  __syncthreads();
+  __syncthreads();  // B1 (helper form): frame, reset flags and curriculum record are in LDS for waves 1-3
   LT_STAMP(5);
-  if (PREFETCH) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of the old rows has long landed
-    __syncthreads();
-  }
-  if (PREFETCH)
-  {
-    // History rows (PREFETCH path: the old rows were DMA-ed into LDS at kernel start, behind the physics).
-    // The 16 env rows of this wave are one contiguous chunk of 16*OBS floats per group.  Row(t) is built in
-    // place from row(t-1): every term block shifts left by one frame and takes the newest frame from LDS.
-    // Lane l owns columns l, l+64, ... of EVERY row, so the per-column routing (table lookups) is done once per lane and
-    // reused for all 16 rows x 2 groups; each row is then NCH coalesced dword loads + NCH coalesced dword stores per group.
-    // In-place safety: a column only reads higher columns of its own row, and all loads of a row precede its stores.
-    constexpr int NCH = (OBS + 63) / 64;
-    int src[NCH], frm[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int col = i * 64 + lane;
-      const int cc = col < OBS ? col : OBS - 1;
-      src[i] = s_tab[cc];         // >= 0: old column (one slot newer); < 0: newest frame element -src-1
-      frm[i] = s_tab[352 + cc];   // newest-frame element of this column's term (rows that were just reset)
-    }
-    float* const rows_p = a.obs_next[0] + (long long)blockIdx.x * 16 * OBS;
-    float* const rows_c = a.obs_next[1] + (long long)blockIdx.x * 16 * OBS;
-    constexpr int RB = 4;  // rows per batch: only LDS reads and fire-and-forget stores, no global load in this tail
-    for (int r0 = 0; r0 < 16; r0 += RB) {
-      float vp[RB][NCH], vc[RB][NCH];
-#pragma unroll
-      for (int rr = 0; rr < RB; ++rr) {
-        const int r = r0 + rr;
-        const bool fill = s_fill[r] != 0;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-          const bool from_frame = fill || src[i] < 0;
-          const int fi = fill ? frm[i] : (-src[i] - 1);
-          if (from_frame) { vp[rr][i] = s_frame[0][r][fi & 63]; vc[rr][i] = s_frame[1][r][fi & 63]; }
-          else { vp[rr][i] = s_old[r * OBS + src[i]]; vc[rr][i] = s_old[16 * OBS + r * OBS + src[i]]; }
-        }
-      }
-#pragma unroll
-      for (int rr = 0; rr < RB; ++rr) {
-        const int r = r0 + rr;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-          const int col = i * 64 + lane;
-          if (col < OBS) { rows_p[r * OBS + col] = vp[rr][i]; rows_c[r * OBS + col] = vc[rr][i]; }
-        }
-      }
-    }
-  }
-  else
+  if (!HELPERS)
   {
     // History rows.  The 16 env rows of this wave are one contiguous chunk of 16*OBS floats per group.  Row(t) is built in
     // place from row(t-1): every term block shifts left by one frame and takes the newest frame from LDS.  Work is
@@ -1147,8 +1161,8 @@ __global__ __launch_bounds__(64, PREFETCH ? 1 : LT_STEP_MIN_WAVES_LARGE) void lt
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const int col = cv * VEC + e;
-            const int sidx = s_tab[col];         // >= 0: old column (one slot newer); < 0: newest frame element -sidx-1
-            const int fidx = s_tab[352 + col];   // newest-frame element of this column's term
+            const int sidx = s_tab[0][col];         // >= 0: old column (one slot newer); < 0: newest frame element -sidx-1
+            const int fidx = s_tab[0][352 + col];   // newest-frame element of this column's term
             const bool from_frame = fill || sidx < 0;
             const int fi = fill ? fidx : (-sidx - 1);
             vp[j][e] = from_frame ? s_frame[0][r][fi & 63] : old_p[r * OBS + sidx];
@@ -1216,7 +1230,7 @@ __global__ __launch_bounds__(64, PREFETCH ? 1 : LT_STEP_MIN_WAVES_LARGE) void lt
 #pragma unroll
     for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) *F(LT_F_EPISODE_SUMS, q) = sums[q];
   }
-  if (MODE == MODE_STEP && last_arriver) curriculum_decide(c, L, arena, 1);  // + common_step_counter += 1
+  if (MODE == MODE_STEP && !HELPERS && last_arriver) curriculum_decide(c, L, arena, 1);  // + common_step_counter += 1
 #ifdef LT_STAMPS
   LT_STAMP(7);
   if (lane == 0)
@@ -1307,15 +1321,15 @@ int launch_step(const lt_env* env, const float* actions, hipStream_t s, const fl
     if (prev && prev[g]) k.obs_prev[g] = prev[g];
     if (next && next[g]) k.obs_next[g] = next[g];
   }
-  const dim3 grid((unsigned)(env->layout.npad / 16)), block(64);
-  // LDS-DMA prefetch of the history rows only where the grid is small enough that LDS does not cap occupancy
-  const bool prefetch = MODE == MODE_STEP && grid.x <= 2 * 256;
+  const dim3 grid((unsigned)(env->layout.npad / 16));
+  // the 4-wave (helper) form only where the grid leaves SIMDs idle: up to two 16-env tiles per CU
+  const bool helpers = MODE == MODE_STEP && grid.x <= 2 * 256;
   if (env->cfg.task == LT_TASK_LOCOMOTION) {
-    if (prefetch) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, MODE == MODE_STEP>), grid, block, 0, s, k);
-    else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, false>), grid, block, 0, s, k);
+    if (helpers) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, MODE == MODE_STEP>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, false>), grid, dim3(64), 0, s, k);
   } else {
-    if (prefetch) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE, MODE == MODE_STEP>), grid, block, 0, s, k);
-    else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE, false>), grid, block, 0, s, k);
+    if (helpers) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE, MODE == MODE_STEP>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE, false>), grid, dim3(64), 0, s, k);
   }
   return (int)hipGetLastError();
 }
