@@ -1,0 +1,116 @@
+"""Pin the RNG-consuming terms of the oracle to the reference: tests/golden/mdp_replay.npz holds (per-env uniforms -> outputs)
+recorded while REPLAYING those uniforms through the reference's own functions (tools/gen_golden_replay.py); the oracle's
+explicit-uniform entry points - which its step path calls with Philox uniforms - must reproduce the outputs from the same
+uniforms with lt_cfg_default's parameters.  CPU only.
+
+  C4 commands.py:517-559   E3 events.py:160-196   E6 events.py:85-109   O1 (noise) observations.py:71-83
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from locotouch_amd import _abi
+from tests import oracle_lib as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mdp_replay.npz")
+C = _abi.CONSTS
+f32 = ctypes.c_float
+
+
+def _cfg():
+    return _abi.default_cfg(C["LT_TASK_TRANSPORT_TEACHER"], num_envs=16)
+
+
+def _arr(vals):
+    return (f32 * len(vals))(*[float(v) for v in vals])
+
+
+def test_command_resample_matches_reference_replay():
+    """Bin selection by inverse CDF over (p, 1 - 2p, p), per-bin ranges [new_lo, old_lo], [old_lo, old_hi], [old_hi, new_hi],
+    the equal-range shortcut, the standing draw (<=) and the buffer copy."""
+    g = np.load(GOLD)
+    lib, cfg = O.load(), _cfg()
+    assert abs(cfg.cmd_new_probs - float(g["cmd_new_probs"])) < 1e-7
+    S, n = g["cmd_ub"].shape[:2]
+    seen_bins = set()
+    for s in range(S):
+        P = np.zeros(C["LT_CMD_PARAMS_LEN"], np.float32)
+        P[0:6] = g["cmd_ranges"][s].reshape(-1)
+        P[6:12] = g["cmd_prev_ranges"][s].reshape(-1)
+        P[12:15] = g["cmd_equal"][s].astype(np.float32)
+        P[15] = float(g["cmd_zero_steps"][s])
+        P[16] = float(g["cmd_rel_standing"][s])
+        for e in range(n):
+            cmd, buf = (f32 * 3)(), (f32 * 3)()
+            standing, tleft = f32(), f32()
+            ub, uv = g["cmd_ub"][s, e], g["cmd_uv"][s, e]
+            lib.lt_oracle_command_resample_u(ctypes.byref(cfg), O.fptr(P), _arr(ub), _arr(uv), float(g["cmd_ustand"][s, e]), 0.5,
+                                             cmd, buf, ctypes.byref(standing), ctypes.byref(tleft))
+            np.testing.assert_allclose(np.array(buf[:]), g["cmd_out_buffer"][s, e], rtol=0, atol=2e-7, err_msg=f"scenario {s} env {e}")
+            assert bool(standing.value) == bool(g["cmd_out_standing"][s, e]), (s, e)
+            # _resample_command ends with the zero-command window (commands.py:559): cmd = buffer, or 0 inside the window
+            exp = np.array(buf[:]) * (0.0 if g["cmd_ep_len"][s, e] < g["cmd_zero_steps"][s] else 1.0)
+            np.testing.assert_allclose(exp, g["cmd_out_cmd"][s, e], rtol=0, atol=2e-7)
+            if not g["cmd_equal"][s].all():
+                for d in range(3):
+                    if not g["cmd_equal"][s, d]:
+                        seen_bins.add(int(ub[d] >= cfg.cmd_new_probs) + int(ub[d] >= 1.0 - cfg.cmd_new_probs))
+    assert seen_bins == {0, 1, 2}
+
+
+def test_trunk_material_matches_reference_replay():
+    g = np.load(GOLD)
+    lib, cfg = O.load(), _cfg()
+    # lt_cfg_default carries the reference's resolved ranges (rand_cylinder cfg :56 overrides the static range)
+    np.testing.assert_allclose(np.array(cfg.trunk_friction[:]), g["mat_ranges"][0], atol=1e-7)
+    np.testing.assert_allclose(np.array(cfg.trunk_restitution[:]), g["mat_ranges"][2], atol=1e-7)
+    for e in range(g["mat_u"].shape[0]):
+        out = (f32 * 3)()
+        lib.lt_oracle_material_u(_arr(cfg.trunk_friction[:]), _arr(g["mat_ranges"][1]), _arr(cfg.trunk_restitution[:]), _arr(g["mat_u"][e]), out)
+        np.testing.assert_allclose(np.array(out[:]), g["mat_out"][e], rtol=0, atol=1e-7)
+    assert (g["mat_out"][:, 1] <= g["mat_out"][:, 0]).all()  # make_consistent
+
+
+def test_reset_object_state_matches_reference_replay():
+    """World-axis offset, + cylinder height / 2, orientation = robot quat (x) euler, velocity = robot root velocity."""
+    g = np.load(GOLD)
+    lib, cfg = O.load(), _cfg()
+    pr = g["obj_pose_range"]
+    for i in range(3):
+        np.testing.assert_allclose(np.array(cfg.obj_reset_pos[i][:]), pr[i], atol=1e-7)
+        np.testing.assert_allclose(np.array(cfg.obj_reset_rpy[i][:]), pr[3 + i], atol=1e-6)
+    for e in range(g["obj_u_pose"].shape[0]):
+        rs = g["obj_root_state"][e].astype(np.float32)
+        pos, quat, lin, ang = (f32 * 3)(), (f32 * 4)(), (f32 * 3)(), (f32 * 3)()
+        lib.lt_oracle_reset_object_u(ctypes.byref(cfg), _arr(rs[0:3]), _arr(rs[3:7]), _arr(rs[7:10]), _arr(rs[10:13]),
+                                     float(g["obj_height"][e]), _arr(g["obj_u_pose"][e]), pos, quat, lin, ang)
+        np.testing.assert_allclose(np.array(pos[:]), g["obj_out_pose"][e, 0:3], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(np.array(quat[:]), g["obj_out_pose"][e, 3:7], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(np.array(lin[:] + ang[:]), g["obj_out_vel"][e], rtol=0, atol=1e-7)
+
+
+def test_noisy_object_state_observation_matches_reference_replay():
+    """Additive noise on position / velocities, euler noise right-multiplied onto the quaternion, the second draw for envs
+    that have not touched the plate yet, then the per-component scale."""
+    g = np.load(GOLD)
+    lib, cfg = O.load(), _cfg()
+    nmin, nmax = g["osn_n_min"], g["osn_n_max"]
+    np.testing.assert_allclose(-nmin, nmax)
+    np.testing.assert_allclose(np.array(cfg.obj_noise[:12]), nmax, atol=1e-7)
+    np.testing.assert_allclose(np.array(cfg.obj_scale[:]), g["osn_scale"], atol=1e-7)
+    T, n = g["osn_out"].shape[:2]
+    n_noncontact = 0
+    for t in range(T):
+        for e in range(n):
+            ti = O.TermIn()
+            r, o = g["osn_robot_root_state"][t, e], g["osn_obj_root_state"][t, e]
+            ti.root_pos[:], ti.root_quat[:], ti.root_lin[:], ti.root_ang[:] = r[0:3], r[3:7], r[7:10], r[10:13]
+            ti.obj_pos[:], ti.obj_quat[:], ti.obj_lin[:], ti.obj_ang[:] = o[0:3], o[3:7], o[7:10], o[10:13]
+            ti.obj_timers[1] = g["osn_obj_cur_contact"][t, e]
+            ti.obj_timers[3] = g["osn_obj_last_contact"][t, e]
+            n_noncontact += int(ti.obj_timers[1] < 1e-8 and ti.obj_timers[3] < 1e-8)
+            out = (f32 * 13)()
+            lib.lt_oracle_object_state_obs(ctypes.byref(cfg), ctypes.byref(ti), _arr(g["osn_u16"][t, e]), out)
+            np.testing.assert_allclose(np.array(out[:]), g["osn_out"][t, e], rtol=2e-5, atol=3e-6, err_msg=f"t {t} env {e}")
+    assert 0 < n_noncontact < T * n
