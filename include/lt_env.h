@@ -186,7 +186,11 @@ typedef struct lt_cfg {
   int32_t enable_corruption;      /* policy-group noise on/off */
   int32_t debug_terms;            /* 1: write unweighted reward terms to LT_F_REWARD_TERMS every step */
   int32_t max_episode_length;     /* ceil(episode_length_s / step_dt) = 1000 (kept integral: bit-exact time_out) */
-  int32_t reserved[5];
+  int32_t obj_reset_robot_frame;  /* 0: ResetObjectStateUniform (class; offset in world axes, mdp/events.py:85-109);
+                                   * 1: reset_object_state_uniform (function; offset rotated by the robot quat, :13-53) */
+  int32_t obj_size_explicit;      /* 1: per-env (radius, length) are taken from LT_F_OBJ_SIZES (written by the host before
+                                   * lt_env_reset_all) instead of the seeded draw from obj_radius / obj_length */
+  int32_t reserved[3];
 } lt_cfg;
 
 /* Fields of the state arena (zero-copy views for the manager-term data contract). */
@@ -228,6 +232,8 @@ enum lt_field {
   LT_F_TERM_BITS,       /* int32 [N] which termination terms fired this step */
   LT_F_CMD_PARAMS,      /* float [LT_CMD_PARAMS_LEN], device-resident command/curriculum block */
   LT_F_COUNTERS,        /* int64 [4]: (common_step_counter, _, arrival ticket of the step kernel's tail reduction, _) */
+  LT_F_OBJ_SIZES,       /* float [N][2]: explicit per-env cylinder (radius, length), read by lt_env_reset_all when
+                         * cfg.obj_size_explicit is set; lt_env_reset_all does not clear it */
   LT_F_END
 };
 
@@ -259,6 +265,12 @@ const char* lt_last_error(void);
 
 /* Fill `cfg` with the resolved task configuration.  `task` is an LT_TASK_* id. */
 int lt_cfg_default(int task, lt_cfg* cfg);
+/* Resolved configuration of a registered gym id (reference locotouch/config/locotouch/__init__.py:14-117), e.g.
+ * "Isaac-CylinderTransportTeacher-LocoTouch-Play-v1": the task kind's defaults plus that registration's overrides and its
+ * default num_envs.  LT_EINVAL for an unknown id.  lt_cfg_preset_id(i), i < lt_cfg_num_presets(), enumerates the ids. */
+int lt_cfg_preset(const char* gym_id, lt_cfg* cfg);
+int lt_cfg_num_presets(void);
+const char* lt_cfg_preset_id(int i);
 /* Observation width of a task (policy and critic groups are equally wide): 270 / 348. */
 int lt_cfg_obs_dim(const lt_cfg* cfg);
 

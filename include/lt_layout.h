@@ -48,9 +48,8 @@ typedef struct lt_layout {
   int32_t obs_dim;
   int64_t quad_off[LT_NUM_QUAD_FIELDS]; /* byte offsets */
   int64_t off_ep_len, off_obs_policy, off_obs_critic, off_reward, off_dones, off_terminated, off_time_out,
-      off_term_bits, off_cmd_params, off_counters, off_partials, off_dev_args;
+      off_term_bits, off_cmd_params, off_counters, off_partials, off_obj_sizes, off_dev_args;
   int64_t total_bytes;
-  int64_t reserved;  /* keeps sizeof(lt_dev_args) a multiple of 16 (the kernels stage it into LDS in 16-byte pieces) */
 } lt_layout;
 
 static inline int64_t lt_align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -75,9 +74,9 @@ static inline void lt_layout_init(lt_layout* L, int64_t num_envs, int32_t obs_di
   L->off_cmd_params = off;  off = lt_align256(off + LT_CMD_PARAMS_LEN * 4);
   L->off_counters = off;    off = lt_align256(off + 4 * 8);
   L->off_partials = off;    off = lt_align256(off + (L->npad / 16) * LT_PARTIAL_FLOATS * 4);
+  L->off_obj_sizes = off;   off = lt_align256(off + L->npad * 2 * 4); /* this and what follows survive lt_env_reset_all */
   L->off_dev_args = off;    off = lt_align256(off + LT_DEV_ARGS_BYTES);
   L->total_bytes = off;
-  L->reserved = 0;
 }
 
 /* float* of quad array `q` of quad field `f` */

@@ -96,6 +96,9 @@ def load() -> ctypes.CDLL:
     lib.lt_last_error.restype = ctypes.c_char_p
     lib.lt_cfg_default.argtypes = [ctypes.c_int, ctypes.POINTER(LtCfg)]
     lib.lt_cfg_obs_dim.argtypes = [ctypes.POINTER(LtCfg)]
+    lib.lt_cfg_preset.argtypes = [ctypes.c_char_p, ctypes.POINTER(LtCfg)]
+    lib.lt_cfg_preset_id.argtypes = [ctypes.c_int]
+    lib.lt_cfg_preset_id.restype = ctypes.c_char_p
     lib.lt_env_create.argtypes = [ctypes.POINTER(LtCfg), ctypes.POINTER(ctypes.c_void_p)]
     lib.lt_env_destroy.argtypes = [ctypes.c_void_p]
     lib.lt_env_state_bytes.argtypes = [ctypes.POINTER(LtCfg), ctypes.POINTER(ctypes.c_size_t)]
@@ -129,10 +132,28 @@ def load() -> ctypes.CDLL:
     return lib
 
 
-EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_obs_dim", "lt_env_create",
+EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_preset", "lt_cfg_num_presets", "lt_cfg_preset_id", "lt_cfg_obs_dim", "lt_env_create",
            "lt_env_destroy", "lt_env_state_bytes", "lt_env_bind", "lt_env_reset_all", "lt_env_step", "lt_env_step_profiled", "lt_env_eval_terms",
            "lt_env_curriculum_update", "lt_env_step_rows", "lt_env_step_rollout", "lt_env_get_view", "lt_env_set_command_ranges", "lt_rollout_act", "lt_rollout_record", "lt_mlp_packed_floats", "lt_mlp_pack", "lt_mlp_forward", "lt_rollout_policy", "lt_rollout_policy_value",
            "lt_env_kernel_name"]
+
+
+def preset_ids() -> list[str]:
+    lib = load()
+    return [lib.lt_cfg_preset_id(i).decode() for i in range(lib.lt_cfg_num_presets())]
+
+
+def preset_cfg(gym_id: str, num_envs: int | None = None, seed: int | None = None) -> LtCfg:
+    """Resolved lt_cfg of a registered gym id (lt_cfg_preset)."""
+    cfg = LtCfg()
+    rc = load().lt_cfg_preset(gym_id.encode(), ctypes.byref(cfg))
+    if rc != 0:
+        raise KeyError(f"unknown task {gym_id!r}; registered: {preset_ids()}")
+    if num_envs is not None:
+        cfg.num_envs = int(num_envs)
+    if seed is not None:
+        cfg.seed = int(seed)
+    return cfg
 
 
 def default_cfg(task: int, num_envs: int | None = None, seed: int | None = None) -> LtCfg:

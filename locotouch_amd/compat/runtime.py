@@ -109,18 +109,40 @@ class ManagedEnv:
         pass
 
 
+def translate_env_cfg(task_id: str, cfg):
+    """(lt_cfg, object_sizes | None) for the env-cfg tree the launch script built (and possibly edited): every manager term
+    is routed into lt_cfg by cfg_translate.translate, which raises on anything the fused kernels cannot honour.  Per-env
+    cylinders of a MultiAssetSpawnerCfg travel as an explicit size table.  `cfg is None`: the registration's preset."""
+    from .. import _abi
+    from . import cfg_translate
+
+    if cfg is None:
+        return _abi.preset_cfg(task_id), None
+    lt = cfg_translate.translate(cfg)
+    sizes = None
+    spawn = getattr(getattr(cfg.scene, "object", None), "spawn", None)
+    if spawn is not None and type(spawn).__name__ == "MultiAssetSpawnerCfg":
+        import torch
+
+        # MultiAssetSpawnerCfg(random_choice=False) deals the asset list to the envs in order, cyclically [DEP]; the -Play-
+        # registration builds 20 cylinders and then raises num_envs to 50 (rand_cylinder..._PLAY + smaller_scene_for_playing)
+        assets = spawn.assets_cfg
+        if getattr(spawn, "random_choice", False):
+            raise cfg_translate.UnsupportedCfg("MultiAssetSpawnerCfg(random_choice=True) is not implemented")
+        sizes = torch.tensor([[float(assets[i % len(assets)].radius), float(assets[i % len(assets)].height)] for i in range(lt.num_envs)],
+                             dtype=torch.float32)
+        lt.obj_size_explicit = 1
+    return lt, sizes
+
+
 def make_env(task_id: str, cfg):
-    num_envs = int(cfg.scene.num_envs) if cfg is not None else 4096
-    seed = getattr(cfg, "seed", None) if cfg is not None else None
     if _env_factory is not None:
         return ManagedEnv(task_id, cfg, _env_factory(task_id, cfg))
-    if task_id not in SUPPORTED_TASKS:
-        raise NotImplementedError(f"task {task_id!r} is registered by the reference but not implemented by this build; "
-                                  f"implemented: {SUPPORTED_TASKS}")
     from ..env import LocoTouchVecEnv
 
+    lt, sizes = translate_env_cfg(task_id, cfg)
     device = getattr(getattr(cfg, "sim", None), "device", None) or "cuda:0"
-    return ManagedEnv(task_id, cfg, LocoTouchVecEnv(task_id, num_envs=num_envs, device=device, seed=42 if seed is None else int(seed)))
+    return ManagedEnv(task_id, cfg, LocoTouchVecEnv(task_id, device=device, cfg=lt, object_sizes=sizes))
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -171,8 +171,8 @@ void transport_teacher(lt_cfg* c) {
   c->cur_enabled = 1;
   c->cur_bins[0] = c->cur_bins[1] = c->cur_bins[2] = 20;
   c->cur_len_threshold = 0.98f * 20.0f;                                // mdp/curriculums.py:194 (quirk Q4)
-  c->cur_reward_threshold[0] = std::exp(-0.08f / 0.25f) * 1.0f * 20.0f;  // :199
-  c->cur_reward_threshold[1] = std::exp(-0.1f / 0.25f) * 0.5f * 20.0f;   // :200
+  c->cur_reward_threshold[0] = (float)(std::exp(-0.08 / 0.25) * 1.0 * 20.0);  // :199
+  c->cur_reward_threshold[1] = (float)(std::exp(-0.1 / 0.25) * 0.5 * 20.0);   // :200
   c->cur_repeat_times[0] = c->cur_repeat_times[1] = 1;
   c->cur_max_distance_bins = 4;
   // rewards: object_transport_teacher_env_cfg.py:88-105, cylinder_transport_teacher_env_cfg.py:41-45
@@ -227,6 +227,48 @@ void transport_teacher(lt_cfg* c) {
   set2(c->push_obj_vel[4], -kPi / 20, kPi / 20);
   set2(c->push_obj_vel[5], -kPi / 5, kPi / 5);
 }
+// Isaac-LocomotionVelCur-LocoTouch-v1: locomotion + the MultiSampling command term and the velocity curriculum
+// (config/base/locomotion_vel_cur_base_env_cfg.py:14-50; maxima = the locomotion ranges)
+void locomotion_vel_cur(lt_cfg* c) {
+  set2(c->cmd_range_init[0], -0.2f, 0.2f);
+  set2(c->cmd_range_init[1], -0.1f, 0.1f);
+  set2(c->cmd_range_init[2], -kPi / 10, kPi / 10);
+  c->cmd_multi_sampling = 1;
+  c->cur_enabled = 1;
+  c->cur_bins[0] = c->cur_bins[1] = c->cur_bins[2] = 20;
+  c->cur_len_threshold = 0.98f * 20.0f;
+  c->cur_reward_threshold[0] = (float)(std::exp(-0.056 / 0.25) * 1.0 * 20.0);  // error_threshold_lin :38
+  c->cur_reward_threshold[1] = (float)(std::exp(-0.089 / 0.25) * 0.5 * 20.0);  // error_threshold_ang :39
+  c->cur_repeat_times[0] = c->cur_repeat_times[1] = 1;
+  c->cur_max_distance_bins = 4;
+}
+
+// Isaac-CylinderTransportTeacher-LocoTouch-v1: the transport teacher with ONE fixed cylinder
+// (config/locotouch/cylinder_transport_teacher_env_cfg.py:16-52; it keeps object_transport_teacher_env_cfg.py's material
+// ranges and the function variant of the object reset, which rand_cylinder_transport_teacher_env_cfg.py:52-56 replace)
+void cylinder_teacher(lt_cfg* c) {
+  set2(c->obj_radius, 0.05f, 0.05f);
+  set2(c->obj_length, 0.3f, 0.3f);
+  set2(c->trunk_friction, 0.1f, 0.8f);
+  set2(c->obj_friction, 0.1f, 0.8f);
+  c->obj_reset_robot_frame = 1;
+  c->cur_reward_threshold[0] = (float)(std::exp(-0.07 / 0.25) * 1.0 * 20.0);  // cylinder_...:37-38
+  c->cur_reward_threshold[1] = (float)(std::exp(-0.08 / 0.25) * 0.5 * 20.0);
+}
+
+struct Preset { const char* id; int task; void (*extra)(lt_cfg*); int num_envs; };
+// gym ids of the reference registry (locotouch/config/locotouch/__init__.py:14-117); -Play- variants differ in num_envs only
+// for the fused terms (locomotion_base_env_cfg.py:364-374 `smaller_scene_for_playing`: 50 envs; cylinder play cfgs: 20)
+const Preset kPresets[] = {
+    {"Isaac-Locomotion-LocoTouch-v1", LT_TASK_LOCOMOTION, nullptr, 4096},
+    {"Isaac-Locomotion-LocoTouch-Play-v1", LT_TASK_LOCOMOTION, nullptr, 50},
+    {"Isaac-LocomotionVelCur-LocoTouch-v1", LT_TASK_LOCOMOTION, locomotion_vel_cur, 4096},
+    {"Isaac-LocomotionVelCur-LocoTouch-Play-v1", LT_TASK_LOCOMOTION, locomotion_vel_cur, 50},
+    {"Isaac-CylinderTransportTeacher-LocoTouch-v1", LT_TASK_TRANSPORT_TEACHER, cylinder_teacher, 4096},
+    {"Isaac-CylinderTransportTeacher-LocoTouch-Play-v1", LT_TASK_TRANSPORT_TEACHER, cylinder_teacher, 50},
+    {"Isaac-RandCylinderTransportTeacher-LocoTouch-v1", LT_TASK_TRANSPORT_TEACHER, nullptr, 4096},
+    {"Isaac-RandCylinderTransportTeacher-LocoTouch-Play-v1", LT_TASK_TRANSPORT_TEACHER, nullptr, 50},
+};
 }  // namespace
 
 extern "C" {
@@ -244,6 +286,22 @@ int lt_cfg_default(int task, lt_cfg* cfg) {
   if (task == LT_TASK_TRANSPORT_TEACHER) transport_teacher(cfg);
   return LT_OK;
 }
+
+int lt_cfg_preset(const char* gym_id, lt_cfg* cfg) {
+  if (!gym_id || !cfg) return LT_EINVAL;
+  for (const Preset& p : kPresets) {
+    if (std::strcmp(p.id, gym_id) != 0) continue;
+    const int rc = lt_cfg_default(p.task, cfg);
+    if (rc != LT_OK) return rc;
+    if (p.extra) p.extra(cfg);
+    cfg->num_envs = p.num_envs;
+    return LT_OK;
+  }
+  return LT_EINVAL;
+}
+
+int lt_cfg_num_presets(void) { return (int)(sizeof(kPresets) / sizeof(kPresets[0])); }
+const char* lt_cfg_preset_id(int i) { return (i >= 0 && i < lt_cfg_num_presets()) ? kPresets[i].id : nullptr; }
 
 int lt_cfg_obs_dim(const lt_cfg* cfg) {
   if (!cfg) return LT_EINVAL;

@@ -710,6 +710,10 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     X.trunk_mass_add = lerp2(c.trunk_mass_add, u.a);
     O.rad = lerp2(c.obj_radius, u.b);
     O.len = lerp2(c.obj_length, u.c);
+    if (c.obj_size_explicit) {  // the cfg tree carried per-env cylinders (rand_cylinder_transport_teacher_env_cfg.py:26-38)
+      const float* sz = (const float*)(arena + L.off_obj_sizes) + env * 2;
+      O.rad = sz[0]; O.len = sz[1];
+    }
     const U4 uf = rng4(c.seed, (uint32_t)env, st, RS_STARTUP + 0x10 + leg);
     const float ms = lerp2(c.foot_friction, uf.a), md = lerp2(c.foot_friction, uf.b);
     G.mu = md < ms ? md : ms;
@@ -1022,8 +1026,11 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       X.obj_rest = lerp2(c.obj_restitution, u.d);
       u = rng4(c.seed, e32, step, RS_RESET_OBJ);                                                               // E6 (events.py:85-109)
       w4 = rng4(c.seed, e32, step, RS_RESET_OBJ + 1);
-      O.p = v3(B.p.x + lerp2(c.obj_reset_pos[0], u.a), B.p.y + lerp2(c.obj_reset_pos[1], u.b), B.p.z + lerp2(c.obj_reset_pos[2], u.c));
-      O.p.z += O.len / 2.f;
+      {
+        // class variant: offset in world axes (events.py:98-99); function variant: rotated by the robot quat (:43-44)
+        const V3 d = v3(lerp2(c.obj_reset_pos[0], u.a), lerp2(c.obj_reset_pos[1], u.b), lerp2(c.obj_reset_pos[2], u.c) + O.len / 2.f);
+        O.p = B.p + (c.obj_reset_robot_frame ? qapply(B.q, d) : d);
+      }
       O.q = qmul(B.q, q_from_euler(lerp2(c.obj_reset_rpy[0], w4.a), lerp2(c.obj_reset_rpy[1], w4.b), lerp2(c.obj_reset_rpy[2], w4.c)));
       O.u = B.u; O.w = B.w;
       O.mass = 1.0f + lerp2(c.obj_mass_add, w4.d);                                                             // E1
@@ -1344,7 +1351,7 @@ int lt_check_layout(const lt_layout* L) {
 
 int lt_launch_reset_all(const lt_env* env, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(env->arena, 0, (size_t)env->layout.total_bytes, s);
+  hipError_t e = hipMemsetAsync(env->arena, 0, (size_t)env->layout.off_obj_sizes, s);  // LT_F_OBJ_SIZES and the (cfg, layout) block survive
   if (e != hipSuccess) return (int)e;
   e = hipMemcpyAsync((char*)env->arena + env->layout.off_dev_args, &env->dev_args, sizeof(lt_dev_args), hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return (int)e;

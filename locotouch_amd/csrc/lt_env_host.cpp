@@ -104,6 +104,7 @@ int lt_env_get_view(lt_env* env, int field, lt_view* v) {
     case LT_F_TERM_BITS: plain(L.off_term_bits, 3, L.n, 0); break;
     case LT_F_CMD_PARAMS: plain(L.off_cmd_params, 0, LT_CMD_PARAMS_LEN, 0); break;
     case LT_F_COUNTERS: plain(L.off_counters, 1, 4, 0); break;
+    case LT_F_OBJ_SIZES: plain(L.off_obj_sizes, 0, L.n, 2); break;
     default: lt_set_error("lt_env_get_view: unknown field"); return LT_EINVAL;
   }
   return LT_OK;

@@ -24,11 +24,11 @@ from . import _abi
 C = _abi.CONSTS
 _TORCH_DTYPES = {0: torch.float32, 1: torch.int64, 2: torch.uint8, 3: torch.int32}
 
-TASK_IDS = {
-    # gym ids of the reference registry (locotouch/config/locotouch/__init__.py:14,99)
-    "Isaac-Locomotion-LocoTouch-v1": C["LT_TASK_LOCOMOTION"],
-    "Isaac-RandCylinderTransportTeacher-LocoTouch-v1": C["LT_TASK_TRANSPORT_TEACHER"],
-}
+def task_ids() -> list[str]:
+    """gym ids this build resolves (lt_cfg_preset): the reference registry of locotouch/config/locotouch/__init__.py."""
+    return _abi.preset_ids()
+
+
 REWARD_TERM_NAMES = [  # manager order == enum lt_reward_term
     "alive", "track_lin_vel_xy", "track_ang_vel_z", "foot_slip", "foot_dragging", "gait", "track_base_height",
     "base_z_velocity", "base_roll_pitch_angle", "base_roll_pitch_velocity", "joint_position_limit", "joint_position",
@@ -42,15 +42,25 @@ TERMINATION_NAMES = ["time_out", "base_orientation", "base_height_below_minimum"
 class LocoTouchVecEnv:
     """One process per GPU; `num_envs` environments sharded to this rank."""
 
-    def __init__(self, task: str | int = "Isaac-RandCylinderTransportTeacher-LocoTouch-v1", num_envs: int = 4096,
-                 device: str | torch.device = "cuda:0", seed: int = 42, cfg: _abi.LtCfg | None = None, **overrides):
+    def __init__(self, task: str | int = "Isaac-RandCylinderTransportTeacher-LocoTouch-v1", num_envs: int | None = None,
+                 device: str | torch.device = "cuda:0", seed: int = 42, cfg: _abi.LtCfg | None = None,
+                 object_sizes: torch.Tensor | None = None, **overrides):
+        """`task`: a registered gym id (its preset; `num_envs=None` keeps the registration's default, e.g. 50 for -Play-) or
+        an LT_TASK_* kind.  `cfg`: a complete lt_cfg instead (e.g. translated from a reference cfg tree,
+        locotouch_amd/compat/cfg_translate.py).  `object_sizes` [N][2]: explicit per-env cylinder (radius, length)."""
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("LocoTouchVecEnv needs a HIP device (there is no CPU path in the product; "
                                "the CPU oracle under oracle/ is test infrastructure only)")
         self._lib = _abi.load()
-        task_id = TASK_IDS[task] if isinstance(task, str) else int(task)
-        self.cfg = cfg.copy() if cfg is not None else _abi.default_cfg(task_id, num_envs=num_envs, seed=seed)
+        if cfg is not None:
+            self.cfg = cfg.copy()
+        elif isinstance(task, str):
+            self.cfg = _abi.preset_cfg(task, num_envs=num_envs, seed=seed)
+        else:
+            self.cfg = _abi.default_cfg(int(task), num_envs=4096 if num_envs is None else num_envs, seed=seed)
+        if object_sizes is not None:
+            self.cfg.obj_size_explicit = 1
         for k, v in overrides.items():
             if not hasattr(self.cfg, k):
                 raise AttributeError(f"lt_cfg has no field {k!r}")
@@ -84,6 +94,10 @@ class LocoTouchVecEnv:
         self.counters = self.view(C["LT_F_COUNTERS"])
         self.extras: dict = {}
         self._log_finished = None
+        if self.cfg.obj_size_explicit:
+            if object_sizes is None or tuple(object_sizes.shape) != (self.num_envs, 2):
+                raise ValueError("cfg.obj_size_explicit needs object_sizes [num_envs][2] (radius, length)")
+            self.view(C["LT_F_OBJ_SIZES"]).copy_(object_sizes.to(device=self.device, dtype=torch.float32))
         self.reset()
 
     # ---- zero-copy views -------------------------------------------------------------------------
@@ -225,12 +239,10 @@ class LocoTouchVecEnv:
             pass
 
 
-def make(task: str, num_envs: int = 4096, device: str = "cuda:0", seed: int = 42, **kw) -> LocoTouchVecEnv:
+def make(task: str, num_envs: int | None = None, device: str = "cuda:0", seed: int = 42, **kw) -> LocoTouchVecEnv:
     """`gym.make(task, cfg=...)` + `RslRlVecEnvWrapper(env)` equivalent (reference locotouch/scripts/train.py:98,116)."""
-    if task not in TASK_IDS:
-        raise KeyError(f"unknown task {task!r}; registered: {sorted(TASK_IDS)}")
     return LocoTouchVecEnv(task, num_envs=num_envs, device=device, seed=seed, **kw)
 
 
-__all__ = ["LocoTouchVecEnv", "make", "TASK_IDS", "REWARD_TERM_NAMES", "TERMINATION_NAMES"]
+__all__ = ["LocoTouchVecEnv", "make", "task_ids", "REWARD_TERM_NAMES", "TERMINATION_NAMES"]
 _ = math

@@ -54,6 +54,7 @@ class Layout:
             ("LT_F_CMD_PARAMS", C["LT_CMD_PARAMS_LEN"] * 4, np.float32, (C["LT_CMD_PARAMS_LEN"],)),
             ("LT_F_COUNTERS", 4 * 8, np.int64, (4,)),
             ("_PARTIALS", self.npad // 16 * 8 * 4, np.float32, (self.npad // 16, 8)),  # per-wave curriculum partials
+            ("LT_F_OBJ_SIZES", self.npad * 2 * 4, np.float32, (self.npad, 2)),
             ("_DEV_ARGS", 4096, np.uint8, (4096,)),  # device copy of (lt_cfg, lt_layout), include/lt_layout.h
         ]:
             self.plain[name] = (off, dtype, shape)

@@ -1273,7 +1273,7 @@ enum {
   RS_CMD_RESET = 0x230, RS_CMD_TIMER = 0x240, RS_PUSH_ROBOT = 0x250, RS_PUSH_OBJ = 0x260, RS_STARTUP = 0x300
 };
 
-static void startup_env(const lt_cfg* cfg, env_t* E, uint32_t env) {
+static void startup_env(const lt_cfg* cfg, env_t* E, uint32_t env, const float* sizes) {
   /* startup events: trunk mass (locomotion_base_env_cfg.py:224-232), foot material (:233-244 + teacher override),
    * and the per-env cylinder size (rand_cylinder_transport_teacher_env_cfg.py:21-27; seeded here, quirk Q2) */
   float u[4];
@@ -1282,6 +1282,7 @@ static void startup_env(const lt_cfg* cfg, env_t* E, uint32_t env) {
   E->trunk_mass_add = lt_lerp(cfg->trunk_mass_add, u[0]);
   E->obj_radius = lt_lerp(cfg->obj_radius, u[1]);
   E->obj_length = lt_lerp(cfg->obj_length, u[2]);
+  if (cfg->obj_size_explicit && sizes) { E->obj_radius = sizes[0]; E->obj_length = sizes[1]; }
   for (int l = 0; l < 4; ++l) {
     lt_rng4(cfg->seed, env, st, RS_STARTUP + 0x10 + l, u);
     real ms = lt_lerp(cfg->foot_friction, u[0]), md = lt_lerp(cfg->foot_friction, u[1]);
@@ -1301,12 +1302,17 @@ void lt_oracle_material_u(const float range_static[2], const float range_dynamic
 }
 /* E6 ResetObjectStateUniform.__call__ (events.py:85-109): offset added in WORLD axes (:98), + height/2 (:99), orientation
  * = robot quat (x) euler(roll, pitch, yaw) (:100-101), velocity = robot root velocity (+ zero-range samples) (:104-105).
+ * cfg->obj_reset_robot_frame selects the function variant reset_object_state_uniform (:13-53): offset rotated by the robot quat.
  * Explicit-uniform form, pinned by tests/golden/mdp_replay.npz. */
 void lt_oracle_reset_object_u(const lt_cfg* cfg, const float root_pos[3], const float root_quat[4], const float root_lin[3],
                               const float root_ang[3], float obj_length, const float u_pose[6], float pos[3], float quat[4],
                               float lin[3], float ang[3]) {
-  for (int c = 0; c < 3; ++c) pos[c] = root_pos[c] + lt_lerp(cfg->obj_reset_pos[c], u_pose[c]);
-  pos[2] += obj_length / 2;
+  real d[3], dw[3];
+  for (int c = 0; c < 3; ++c) d[c] = lt_lerp(cfg->obj_reset_pos[c], u_pose[c]);
+  d[2] += obj_length / 2;
+  if (cfg->obj_reset_robot_frame) quat_apply(dw, root_quat, d);  /* function variant, events.py:43-44 */
+  else v3_copy(dw, d);
+  for (int c = 0; c < 3; ++c) pos[c] = root_pos[c] + dw[c];
   real dq[4];
   quat_from_euler(dq, lt_lerp(cfg->obj_reset_rpy[0], u_pose[3]), lt_lerp(cfg->obj_reset_rpy[1], u_pose[4]), lt_lerp(cfg->obj_reset_rpy[2], u_pose[5]));
   quat_mul(quat, root_quat, dq);
@@ -1617,14 +1623,14 @@ static void post_step(const lt_cfg* cfg, void* arena, const lt_layout* L) {
 int lt_oracle_reset_all(const lt_cfg* cfg, void* arena) {
   lt_layout L;
   lt_layout_init(&L, cfg->num_envs, lt_oracle_obs_dim(cfg));
-  memset(arena, 0, (size_t)L.total_bytes);
+  memset(arena, 0, (size_t)L.off_obj_sizes);  /* LT_F_OBJ_SIZES (host input) survives */
   float* P = (float*)((char*)arena + L.off_cmd_params);
   lt_oracle_cmd_params_init(cfg, P);
   const int has_object = cfg->task != LT_TASK_LOCOMOTION;
   for (int64_t e = 0; e < L.n; ++e) {
     env_t E;
     gather(&E, arena, &L, e);
-    startup_env(cfg, &E, (uint32_t)e);
+    startup_env(cfg, &E, (uint32_t)e, (const float*)((char*)arena + L.off_obj_sizes) + e * 2);
     reset_env(cfg, P, &E, (uint32_t)e, 0, has_object);
     if (!has_object) E.obj_quat[0] = 1;
     /* ManagerBasedRLEnv.reset() does not run command_manager.compute(); only the zero-command window that

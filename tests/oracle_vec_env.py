@@ -12,15 +12,18 @@ from locotouch_amd import _abi
 from locotouch_amd.layout import Layout
 from tests import oracle_lib
 
-TASK_IDS = {"Isaac-Locomotion-LocoTouch-v1": "LT_TASK_LOCOMOTION", "Isaac-RandCylinderTransportTeacher-LocoTouch-v1": "LT_TASK_TRANSPORT_TEACHER"}
-
-
 class OracleVecEnv:
     num_actions = 12
 
-    def __init__(self, task_id: str, num_envs: int, seed: int = 42):
-        self.cfg = _abi.default_cfg(_abi.CONSTS[TASK_IDS[task_id]], num_envs=num_envs, seed=seed)
+    def __init__(self, task_id: str, num_envs: int | None = None, seed: int = 42, cfg: "_abi.LtCfg | None" = None, object_sizes=None):
+        """`cfg`: a complete lt_cfg (e.g. translated from the reference cfg tree) instead of the registration's preset."""
+        self.cfg = cfg.copy() if cfg is not None else _abi.preset_cfg(task_id, num_envs=num_envs, seed=seed)
+        num_envs = int(self.cfg.num_envs)
         self.o = oracle_lib.OracleEnv(self.cfg)
+        if object_sizes is not None:
+            self.cfg.obj_size_explicit = self.o.cfg.obj_size_explicit = 1
+            Layout(num_envs, int(oracle_lib.load().lt_oracle_obs_dim(self.o.cfg))).arr(self.o.arena, "LT_F_OBJ_SIZES")[:num_envs] = \
+                np.asarray(object_sizes, dtype=np.float32)
         self.o.reset_all()
         self.num_envs, self.device = num_envs, torch.device("cpu")
         self.num_obs = int(oracle_lib.load().lt_oracle_obs_dim(self.o.cfg))

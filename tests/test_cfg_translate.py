@@ -1,0 +1,115 @@
+"""cfg tree -> lt_cfg (VERDICT r01 missing #3/#5): the reference's RESOLVED env cfg of every registered
+LocoTouch teacher / locomotion id, built by the reference's own config classes, must translate to exactly the built-in
+preset (`lt_cfg_preset`) - which pins the presets to the reference - and an edit on the cfg tree must reach lt_cfg or raise.
+CPU only; needs the reference checkout (skipped on the GPU box)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from locotouch_amd import _abi
+
+REF = "/root/reference"
+C = _abi.CONSTS
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+
+IDS = ["Isaac-Locomotion-LocoTouch-v1", "Isaac-Locomotion-LocoTouch-Play-v1", "Isaac-LocomotionVelCur-LocoTouch-v1",
+       "Isaac-LocomotionVelCur-LocoTouch-Play-v1", "Isaac-CylinderTransportTeacher-LocoTouch-v1",
+       "Isaac-CylinderTransportTeacher-LocoTouch-Play-v1", "Isaac-RandCylinderTransportTeacher-LocoTouch-v1",
+       "Isaac-RandCylinderTransportTeacher-LocoTouch-Play-v1"]
+
+
+@pytest.fixture(scope="module")
+def rt():
+    sys.dont_write_bytecode = True
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import warnings
+
+    from locotouch_amd.compat import runtime
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        runtime.install()
+        import locotouch  # noqa: F401  (the reference's own gym.register calls)
+    return runtime
+
+
+def test_presets_cover_the_reference_registry(rt):
+    import gymnasium as gym
+
+    teacher_ids = sorted(k for k in gym.registry.keys() if "LocoTouch" in k and "Student" not in k)
+    assert teacher_ids == sorted(IDS)
+    assert set(IDS) <= set(_abi.preset_ids())
+
+
+@pytest.mark.parametrize("task", IDS)
+def test_resolved_reference_cfg_translates_to_the_preset(rt, task):
+    from locotouch_amd.compat import cfg_translate as T
+
+    cfg = rt.load_cfg_from_registry(task, "env_cfg_entry_point")
+    lt, sizes = rt.translate_env_cfg(task, cfg)
+    preset = _abi.preset_cfg(task)
+    assert lt.num_envs == preset.num_envs and lt.task == preset.task
+    skip = ("seed", "num_envs", "reserved", "debug_terms")
+    if "RandCylinder" in task:
+        # per-env cylinders (unseeded np.random at cfg time, quirk Q2) travel as an explicit table; the preset draws them
+        # (seeded) from the range those samples came from
+        assert lt.obj_size_explicit == 1 and sizes.shape == (lt.num_envs, 2)
+        s = sizes.numpy()
+        assert (s[:, 0] >= preset.obj_radius[0] - 1e-6).all() and (s[:, 0] <= preset.obj_radius[1] + 1e-6).all()
+        assert (s[:, 1] >= preset.obj_length[0] - 1e-6).all() and (s[:, 1] <= preset.obj_length[1] + 1e-6).all()
+        skip += ("obj_radius", "obj_length", "obj_size_explicit")
+    else:
+        assert sizes is None and lt.obj_size_explicit == 0
+    assert T.diff(lt, preset, skip=skip) == []
+
+
+def test_cfg_edits_reach_lt_cfg_or_raise(rt):
+    """What `env.rewards.<term>.weight=...` / post-init functions do to the tree must not be dropped silently."""
+    import locotouch.mdp as mdp
+    from locotouch_amd.compat import cfg_translate as T
+
+    task = "Isaac-CylinderTransportTeacher-LocoTouch-v1"
+    cfg = rt.load_cfg_from_registry(task, "env_cfg_entry_point")
+    cfg.scene.num_envs = 64
+    cfg.rewards.track_lin_vel_xy.weight = 2.5
+    cfg.rewards.foot_slip.params["threshold"] = 0.75
+    cfg.rewards.object_dangerous_state.params["x_max"] = 0.2
+    cfg.rewards.joint_torque = None                       # term removed
+    cfg.terminations.hip_contact = None
+    cfg.commands.base_velocity.ranges.lin_vel_x = (-0.3, 0.3)
+    cfg.events.push_robot.interval_range_s = (3.0, 4.0)
+    cfg.events.push_object = None
+    cfg.episode_length_s = 10.0
+    cfg.observations.policy.joint_vel.noise.n_min, cfg.observations.policy.joint_vel.noise.n_max = -0.5, 0.5
+    lt = T.translate(cfg, seed=9)
+    assert lt.num_envs == 64 and lt.seed == 9
+    assert abs(lt.reward_weight[C["LT_R_TRACK_LIN_VEL_XY"]] - 2.5) < 1e-7 and lt.reward_weight[C["LT_R_JOINT_TORQUE"]] == 0.0
+    assert abs(lt.foot_slip_threshold - 0.75) < 1e-7 and abs(lt.danger_x_max - 0.2) < 1e-7
+    assert lt.term_enabled[C["LT_T_HIP_CONTACT"]] == 0 and lt.term_enabled[C["LT_T_OBJECT_BAD_ROLL"]] == 1
+    np.testing.assert_allclose(lt.cmd_range_init[0][:], (-0.3, 0.3), atol=1e-7)
+    np.testing.assert_allclose(lt.push_robot_interval[:], (3.0, 4.0))
+    assert lt.push_obj_interval[0] > 1e8                   # no object pushes
+    assert lt.max_episode_length == 500 and abs(lt.cur_len_threshold - 9.8) < 1e-6
+    # the lin-vel curriculum threshold follows the edited reward weight (curriculums.py:199 reads it back from the cfg)
+    assert abs(lt.cur_reward_threshold[0] - np.exp(-0.07 / 0.25) * 2.5 * 10.0) < 1e-4
+    assert abs(lt.obs_noise_joint_vel - 0.5) < 1e-7
+
+    # ... and what the fused kernels cannot honour raises instead of training on something else
+    cfg = rt.load_cfg_from_registry(task, "env_cfg_entry_point")
+    cfg.rewards.track_lin_vel_xy.func = mdp.track_ang_vel_z_pst
+    with pytest.raises(T.UnsupportedCfg, match="track_lin_vel_xy"):
+        T.translate(cfg)
+    cfg = rt.load_cfg_from_registry(task, "env_cfg_entry_point")
+    cfg.rewards.my_new_term = cfg.rewards.alive
+    with pytest.raises(T.UnsupportedCfg, match="my_new_term"):
+        T.translate(cfg)
+    cfg = rt.load_cfg_from_registry(task, "env_cfg_entry_point")
+    cfg.commands.base_velocity.heading_command = True
+    with pytest.raises(T.UnsupportedCfg, match="heading"):
+        T.translate(cfg)
+    cfg = rt.load_cfg_from_registry("Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-v1", "env_cfg_entry_point")
+    with pytest.raises(T.UnsupportedCfg, match="tactile"):
+        T.translate(cfg)

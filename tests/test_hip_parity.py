@@ -47,6 +47,46 @@ def test_reset_all_matches_oracle(task, n):
         off += 6 * d
 
 
+def test_registered_presets_and_explicit_cylinders_match_oracle():
+    """The other registrations (fixed cylinder + robot-frame object reset, -Play- sizes, velocity-curriculum locomotion) and
+    the explicit per-env cylinder table a translated cfg tree carries: reset + steps against the oracle from identical bytes."""
+    import torch
+    from locotouch_amd.env import LocoTouchVecEnv, task_ids
+
+    assert len(task_ids()) >= 8
+    g = torch.Generator().manual_seed(9)
+    cases = [("Isaac-CylinderTransportTeacher-LocoTouch-v1", 48, None), ("Isaac-LocomotionVelCur-LocoTouch-Play-v1", None, None),
+             ("Isaac-RandCylinderTransportTeacher-LocoTouch-Play-v1", None, "sizes")]
+    for task, n, sizes in cases:
+        kw = {}
+        if sizes:
+            kw["object_sizes"] = torch.stack([0.03 + 0.04 * torch.rand(50, generator=g), 0.1 + 0.3 * torch.rand(50, generator=g)], 1)
+        env = LocoTouchVecEnv(task, num_envs=n, device="cuda:0", seed=5, debug_terms=1, **kw)
+        n = env.num_envs
+        assert n == (48 if "CylinderTransportTeacher-LocoTouch-v1" in task and "Rand" not in task else 50)
+        ora = O.OracleEnv(env.cfg)
+        L = Layout(n, env.num_obs)
+        if sizes:
+            L.arr(ora.arena, "LT_F_OBJ_SIZES")[:n] = kw["object_sizes"].numpy()
+        ora.reset_all()
+        torch.cuda.synchronize()
+        compare_arenas(env, ora, what=f"reset_all {task}")
+        if sizes:
+            np.testing.assert_array_equal(L.vec(ora.arena, "LT_F_OBJ_PARAMS")[:, :2], kw["object_sizes"].numpy())
+        if "CylinderTransportTeacher-LocoTouch-v1" in task and "Rand" not in task:
+            assert env.cfg.obj_reset_robot_frame == 1 and (L.vec(ora.arena, "LT_F_OBJ_PARAMS")[:, 0] == np.float32(0.05)).all()
+        tally = Tally(n)
+        for t in range(30):
+            act = (0.4 if t > 5 else 0.0) * torch.randn(n, 12, generator=g)
+            env._arena_aligned.copy_(torch.from_numpy(ora.arena))
+            env.step(act.cuda())
+            ora.step(act.numpy())
+            torch.cuda.synchronize()
+            tally.add(compare_arenas(env, ora, what=f"{task} step {t}", max_flip_frac=0.05, max_event_frac=2.0 / n))
+        print(tally.line(task))
+        assert tally.flips <= 0.01 * n * 30 and tally.events <= 0.005 * n * 30
+
+
 @pytest.mark.parametrize("task,n,steps,phys,pre", [
     ("teacher", 64, 160, 1, 0), ("locomotion", 64, 120, 1, 0), ("teacher", 32, 40, 2, 0),
     # > 8192 envs: launch_step picks the register-path (PREFETCH=false) history variant, which shifts the rows in place

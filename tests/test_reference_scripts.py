@@ -1,8 +1,9 @@
 """The reference's launch script runs UNMODIFIED against this package's import surface.
 
 `locotouch/scripts/train.py` is executed from the read-only reference checkout with locotouch_amd.compat.runtime installed:
-its own argparse / config classes / gym registrations / call sequence run as they are; `gym.make` is pointed at the CPU oracle
-(test infrastructure) because this container has no GPU, and `from loco_rl.runners import OnPolicyRunner` resolves to this
+its own argparse / config classes / gym registrations / call sequence run as they are; the env-cfg tree it builds is
+translated into lt_cfg by the product's own compat/cfg_translate.py; `gym.make` is pointed at the CPU oracle (test
+infrastructure) because this container has no GPU, and `from loco_rl.runners import OnPolicyRunner` resolves to this
 package's trainer.  Skipped where the reference checkout does not exist (the GPU box).
 """
 import glob
@@ -24,14 +25,18 @@ sys.path.insert(0, os.path.dirname(script))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(script))))
 from locotouch_amd.compat import runtime
 from tests.oracle_vec_env import OracleVecEnv
-runtime.install(env_factory=lambda task_id, cfg: OracleVecEnv(task_id, int(cfg.scene.num_envs), seed=int(cfg.seed)))
+def factory(task_id, cfg):  # the product's own cfg-tree translation (compat/cfg_translate.py), fed to the CPU oracle env
+    lt, sizes = runtime.translate_env_cfg(task_id, cfg)
+    return OracleVecEnv(task_id, cfg=lt, object_sizes=sizes)
+runtime.install(env_factory=factory)
 sys.argv = [script] + sys.argv[3:]
 runpy.run_path(script, run_name="__main__")
 """
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
-@pytest.mark.parametrize("task", ["Isaac-RandCylinderTransportTeacher-LocoTouch-v1", "Isaac-Locomotion-LocoTouch-v1"])
+@pytest.mark.parametrize("task", ["Isaac-RandCylinderTransportTeacher-LocoTouch-v1", "Isaac-Locomotion-LocoTouch-v1",
+                                  "Isaac-CylinderTransportTeacher-LocoTouch-v1"])
 def test_reference_train_script_runs_unmodified(tmp_path, task):
     script = os.path.join(REF, "locotouch", "scripts", "train.py")
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="2")
