@@ -21,10 +21,15 @@ _BASE = {
                   "schedule": "adaptive", "gamma": 0.99, "lam": 0.95, "desired_kl": 0.01, "max_grad_norm": 1.0},
 }
 
-TRAIN_CFGS = {
-    "Isaac-Locomotion-LocoTouch-v1": dict(_BASE, experiment_name="locotouch_locomotion"),
-    "Isaac-RandCylinderTransportTeacher-LocoTouch-v1": dict(_BASE, experiment_name="locotouch_rand_cylinder_transport_teacher"),
+# experiment names: agents/rsl_rl_ppo_cfg.py:31,41,57,64 (-Play- registrations share their task's agent cfg,
+# locotouch/config/locotouch/__init__.py:19-114)
+_EXPERIMENTS = {
+    "Isaac-Locomotion-LocoTouch": "locotouch_locomotion",
+    "Isaac-LocomotionVelCur-LocoTouch": "locotouch_vel_cur",
+    "Isaac-CylinderTransportTeacher-LocoTouch": "locotouch_cylinder_transport_teacher",
+    "Isaac-RandCylinderTransportTeacher-LocoTouch": "locotouch_rand_cylinder_transport_teacher",
 }
+TRAIN_CFGS = {f"{k}{suffix}": dict(_BASE, experiment_name=v) for k, v in _EXPERIMENTS.items() for suffix in ("-v1", "-Play-v1")}
 
 
 def train_cfg(task: str) -> dict:

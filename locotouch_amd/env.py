@@ -219,6 +219,7 @@ class LocoTouchVecEnv:
                     log[f"Episode_Termination/{name}"] = float(((bits >> b) & 1).float().sum())
             log["Episode/length"] = float(info[mask, 1].mean())
             log["Episode/reward"] = float(sums[:, : len(REWARD_TERM_NAMES)].sum(1).mean())
+        log.update(self.command_metrics())
         p = self.cmd_params
         log["Metrics/base_velocity/lin_vel_x"] = float(p[1])
         log["Metrics/base_velocity/lin_vel_y"] = float(p[3])
@@ -226,6 +227,37 @@ class LocoTouchVecEnv:
         log["Metrics/base_velocity/initial_zero_command_steps"] = float(p[15])
         log["Metrics/base_velocity/rel_standing_envs"] = float(p[16])
         return log
+
+    def command_metrics(self) -> dict:
+        """The command term's `Metrics/base_velocity/*` (reference mdp/commands.py:392-417 + the stock base-class errors):
+        instantaneous quantities of the current state.  The reference logs their mean over the envs that reset in a step;
+        here they are sampled over ALL envs when the log is read (once per training iteration) - logging, not control."""
+        f = self.field
+        q = f("LT_F_ROOT_QUAT")[:, 0, :]
+        w, v = q[:, :1], q[:, 1:]
+
+        def to_body(u):  # quat_apply_inverse
+            t = 2.0 * torch.cross(v, u, dim=1)
+            return u - w * t + torch.cross(v, t, dim=1)
+
+        lin_b = to_body(f("LT_F_ROOT_LIN_VEL_W")[:, 0, :3])
+        ang_b = to_body(f("LT_F_ROOT_ANG_VEL_W")[:, 0, :3])
+        cmd = f("LT_F_CMD")[:, 0, :3]
+        out = {"Metrics/base_velocity/error_vel_xy": float((cmd[:, :2] - lin_b[:, :2]).norm(dim=1).mean()),
+               "Metrics/base_velocity/error_vel_yaw": float((cmd[:, 2] - ang_b[:, 2]).abs().mean()),
+               "Metrics/base_velocity/foot_air_time_variance": float(f("LT_F_FOOT_LAST_AIR")[:, 0, :].var(dim=1).mean())}
+        valid = f("LT_F_GAIT_VALID_LAST_AIR")[:, 0, :][:, [0, 3, 1, 2]]  # gait-class column order [FR, RL, FL, RR]
+        ok = (valid > 1.0e-6).all(dim=1)
+        stats = {"foot_step_frequency": 0.0, "pair_1_step_frequency": 0.0, "pair_2_step_frequency": 0.0,
+                 "step_air_time": 0.0, "pair_1_air_time": 0.0, "pair_2_air_time": 0.0}
+        if bool(ok.any()):
+            m = valid[ok]
+            for name, cols in (("", slice(None)), ("pair_1_", [0, 1]), ("pair_2_", [2, 3])):
+                t = float(m[:, cols].mean())
+                stats[("foot_step_frequency" if not name else name + "step_frequency")] = (0.5 / t) if t > 0 else 0.0
+                stats[("step_air_time" if not name else name + "air_time")] = t if t > 0 else 0.0
+        out.update({f"Metrics/base_velocity/{k}": v_ for k, v_ in stats.items()})
+        return out
 
     def close(self) -> None:
         if getattr(self, "_handle", None):

@@ -2,8 +2,11 @@
 from .dist import Dist
 from .fused import FusedRollout
 from .modules import ActorCritic
+from .normalizer import EmpiricalNormalization
 from .ppo import PPO
 from .runner import OnPolicyRunner
 from .storage import RolloutStorage
+from .trajectories import split_and_pad_trajectories, unpad_trajectories
 
-__all__ = ["Dist", "FusedRollout", "ActorCritic", "PPO", "OnPolicyRunner", "RolloutStorage"]
+__all__ = ["Dist", "FusedRollout", "ActorCritic", "EmpiricalNormalization", "PPO", "OnPolicyRunner", "RolloutStorage",
+           "split_and_pad_trajectories", "unpad_trajectories"]

@@ -18,6 +18,7 @@ import torch
 
 from .dist import Dist
 from .modules import ActorCritic
+from .normalizer import EmpiricalNormalization
 from .ppo import PPO
 
 
@@ -37,19 +38,38 @@ class OnPolicyRunner:
         self.num_steps_per_env = int(self.cfg["num_steps_per_env"])
         self.save_interval = int(self.cfg.get("save_interval", 50))
         self.alg.init_storage(env.num_envs, self.num_steps_per_env, [num_obs], [num_critic_obs], [env.num_actions])
+        # observation normalisers (on_policy_runner.py:85-95); identity unless `empirical_normalization` is set
+        self.empirical_normalization = bool(self.cfg.get("empirical_normalization", False))
+        if self.empirical_normalization:
+            self.obs_normalizer = EmpiricalNormalization(shape=[num_obs], until=1.0e8).to(device)
+            self.critic_obs_normalizer = EmpiricalNormalization(shape=[num_critic_obs], until=1.0e8).to(device)
+        else:
+            self.obs_normalizer = self.critic_obs_normalizer = torch.nn.Identity().to(device)
         self.log_dir = log_dir if self.dist.is_main else None
+        self.writer = None
+        self.logger_type = str(self.cfg.get("logger", "tensorboard")).lower()
         self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0.0, 0
         self.history: list[dict] = []
         self.git_status_repos: list[str] = []
 
     def learn(self, num_learning_iterations: int, init_at_random_ep_len: bool = False) -> None:
         env, alg = self.env, self.alg
+        if self.log_dir is not None and self.writer is None:  # on_policy_runner.py:98-118
+            if self.logger_type == "tensorboard":
+                from .tb_writer import SummaryWriter
+
+                self.writer = SummaryWriter(self.log_dir, flush_secs=10)
+            elif self.logger_type in ("wandb", "neptune"):
+                raise NotImplementedError(f"logger {self.logger_type!r} needs a network service; use --logger tensorboard (quirk Q9: the "
+                                          "reference's agent cfgs default to wandb)")
+            else:
+                raise ValueError("Logger type not found. Please choose 'neptune', 'wandb' or 'tensorboard'.")
         if init_at_random_ep_len:  # on_policy_runner.py:121-124
             env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
         obs, extras = env.get_observations()
         critic_obs = extras["observations"].get("critic", obs)
         obs, critic_obs = obs.to(self.device), critic_obs.to(self.device)
-        alg.train_mode()
+        self.train_mode()
         n = env.num_envs
         fused = self._make_fused()
         rew_acc = torch.zeros(n, device=self.device)
@@ -66,11 +86,14 @@ class OnPolicyRunner:
                     alg.compute_returns(env.obs_critic)
             else:
               with torch.inference_mode():
+                if it == start:
+                    obs, critic_obs = self.obs_normalizer(obs), self.critic_obs_normalizer(critic_obs)
                 for _ in range(self.num_steps_per_env):
                     actions = alg.act(obs, critic_obs)
                     obs, rewards, dones, infos = env.step(actions.to(env.device))
                     obs, rewards, dones = obs.to(self.device), rewards.to(self.device), dones.to(self.device)
-                    critic_obs = infos["observations"].get("critic", obs).to(self.device)
+                    obs = self.obs_normalizer(obs)                                                    # on_policy_runner.py:163-169
+                    critic_obs = self.critic_obs_normalizer(infos["observations"]["critic"].to(self.device)) if "critic" in infos["observations"] else obs
                     alg.process_env_step(rewards, dones, infos)
                     rew_acc += rewards
                     len_acc += 1
@@ -110,11 +133,21 @@ class OnPolicyRunner:
                 os.makedirs(self.log_dir, exist_ok=True)
                 with open(os.path.join(self.log_dir, "progress.jsonl"), "a") as f:
                     f.write(json.dumps(rec) + "\n")
+                if self.writer is not None:  # the reference's scalar tags (on_policy_runner.py:268-309), same x axis
+                    for k, v in rec.items():
+                        if k != "iter" and isinstance(v, (int, float)):
+                            self.writer.add_scalar(k, v, it)
+                    if rec.get("Train/mean_reward") is not None:
+                        self.writer.add_scalar("Train/mean_reward/time", rec["Train/mean_reward"], int(self.tot_time))
+                        self.writer.add_scalar("Train/mean_episode_length/time", rec["Train/mean_episode_length"], int(self.tot_time))
                 if it % self.save_interval == 0:
                     self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
-        self.current_learning_iteration = start + num_learning_iterations
+        # the final model, under the number of the LAST iteration run - the reference's naming (on_policy_runner.py:221,243-245):
+        # `current_learning_iteration` is that iteration, and a resumed run starts again from it
         if self.log_dir is not None:
             self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+            if self.writer is not None:
+                self.writer.flush()
 
     def _make_fused(self):
         """FusedRollout when the env is the HIP env on a GPU and the policy is the plain feed-forward ActorCritic."""
@@ -127,15 +160,21 @@ class OnPolicyRunner:
             return None
         if getattr(self.alg.actor_critic, "noise_std_type", "scalar") != "scalar":
             return None
+        if self.empirical_normalization:  # the fused rollout feeds raw observation rows to the MLP kernel
+            return None
         return FusedRollout(self.env, self.alg)
 
     # ---- checkpoints (reference on_policy_runner.py:369-422) -------------------------------------------
     def save(self, path: str, infos=None) -> None:
         if not self.dist.is_main:
             return
-        torch.save({"model_state_dict": self.alg.actor_critic.state_dict(),
-                    "optimizer_state_dict": self.alg.optimizer.state_dict(),
-                    "iter": self.current_learning_iteration, "infos": infos}, path)
+        saved = {"model_state_dict": self.alg.actor_critic.state_dict(),
+                 "optimizer_state_dict": self.alg.optimizer.state_dict(),
+                 "iter": self.current_learning_iteration, "infos": infos}
+        if self.empirical_normalization:  # on_policy_runner.py:376-379
+            saved["obs_norm_state_dict"] = self.obs_normalizer.state_dict()
+            saved["critic_obs_norm_state_dict"] = self.critic_obs_normalizer.state_dict()
+        torch.save(saved, path)
 
     def load(self, path: str, load_optimizer: bool = True, pretrained: bool = False):
         loaded = torch.load(path, map_location=self.device, weights_only=True)
@@ -146,6 +185,9 @@ class OnPolicyRunner:
             self.alg.actor_critic.reset_init_std()
         else:
             self.alg.actor_critic.load_state_dict(sd)
+            if self.empirical_normalization:  # on_policy_runner.py:413-415
+                self.obs_normalizer.load_state_dict(loaded["obs_norm_state_dict"])
+                self.critic_obs_normalizer.load_state_dict(loaded["critic_obs_norm_state_dict"])
             if load_optimizer:
                 self.alg.optimizer.load_state_dict(loaded["optimizer_state_dict"])
             self.current_learning_iteration = loaded["iter"]
@@ -155,9 +197,15 @@ class OnPolicyRunner:
 
     def train_mode(self) -> None:  # reference on_policy_runner.py:466-475
         self.alg.train_mode()
+        if self.empirical_normalization:
+            self.obs_normalizer.train()
+            self.critic_obs_normalizer.train()
 
     def eval_mode(self) -> None:  # reference on_policy_runner.py:477-486
         self.alg.test_mode()
+        if self.empirical_normalization:
+            self.obs_normalizer.eval()
+            self.critic_obs_normalizer.eval()
 
     def add_git_repo_to_log(self, repo_file_path: str) -> None:
         """Reference on_policy_runner.py:488-489: remembers code locations whose git state goes into the log directory.  There is
@@ -168,8 +216,13 @@ class OnPolicyRunner:
             with open(os.path.join(self.log_dir, "git", "repos.txt"), "a") as f:
                 f.write(str(repo_file_path) + "\n")
 
-    def get_inference_policy(self, device=None):
-        self.alg.test_mode()
+    def get_inference_policy(self, device=None):  # reference on_policy_runner.py:424-436
+        self.eval_mode()
         if device is not None:
             self.alg.actor_critic.to(device)
-        return self.alg.actor_critic.act_inference
+        policy = self.alg.actor_critic.act_inference
+        if self.empirical_normalization:
+            if device is not None:
+                self.obs_normalizer.to(device)
+            policy = lambda x: self.alg.actor_critic.act_inference(self.obs_normalizer(x))  # noqa: E731
+        return policy

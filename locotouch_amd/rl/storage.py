@@ -97,6 +97,39 @@ class RolloutStorage:
                 idx = perm[i * mb:(i + 1) * mb]
                 yield Batch(*[x[idx] for x in flat])
 
+    def recurrent_mini_batches(self, num_mini_batches: int, num_epochs: int = 8, hidden_states_a=None, hidden_states_c=None):
+        """Minibatches of whole trajectories for recurrent policies (reference rollout_storage.py:246-318): envs are dealt to
+        minibatches in contiguous blocks; a block's padded trajectories (and the hidden states saved at their first steps)
+        form the batch.  `hidden_states_*`: lists of (T, layers, N, H) tensors saved during the rollout, or None.
+        Yields (obs, critic_obs, actions, values, advantages, returns, log_prob, mu, sigma, (hid_a, hid_c), masks)."""
+        from .trajectories import split_and_pad_trajectories
+
+        obs_traj, masks = split_and_pad_trajectories(self.observations, self.dones)
+        critic_traj, _ = split_and_pad_trajectories(self.privileged_observations, self.dones)
+        per = self.num_envs // num_mini_batches
+        d = self.dones.squeeze(-1).bool()
+        starts = torch.ones_like(d)          # a trajectory starts at t = 0 and right after every done
+        starts[1:] = d[:-1]
+        traj_per_env = starts.sum(0)         # (N,)
+        first_of_env = torch.cumsum(traj_per_env, 0) - traj_per_env
+        starts_env_major = starts.t()        # (N, T)
+
+        def hidden(saved, lo, hi):
+            if saved is None:
+                return None
+            out = [h.permute(2, 0, 1, 3)[starts_env_major][lo:hi].transpose(1, 0).contiguous() for h in saved]
+            return out[0] if len(out) == 1 else out
+
+        for _ in range(num_epochs):
+            for i in range(num_mini_batches):
+                e0, e1 = i * per, (i + 1) * per
+                lo = int(first_of_env[e0])
+                hi = lo + int(traj_per_env[e0:e1].sum())
+                sl = (slice(None), slice(e0, e1))
+                yield (obs_traj[:, lo:hi], critic_traj[:, lo:hi], self.actions[sl], self.values[sl], self.advantages[sl],
+                       self.returns[sl], self.actions_log_prob[sl], self.mu[sl], self.sigma[sl],
+                       (hidden(hidden_states_a, lo, hi), hidden(hidden_states_c, lo, hi)), masks[:, lo:hi])
+
     def get_statistics(self):
         done = self.dones.clone()
         done[-1] = 1

@@ -37,6 +37,7 @@ def main() -> None:
 
     dist = Dist.from_env()
     cfg = train_cfg(args.task)
+    cfg["logger"] = args.logger
     if args.seed is not None:
         cfg["seed"] = args.seed
     if args.max_iterations is not None:
@@ -47,8 +48,13 @@ def main() -> None:
     env = make(args.task, num_envs=args.num_envs, device=device, seed=cfg["seed"] + dist.rank)
     log_dir = os.path.join(args.log_root, cfg["experiment_name"], datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S"))
     runner = OnPolicyRunner(env, cfg, log_dir=log_dir, device=device, dist=dist)
-    if args.resume and args.checkpoint:
-        runner.load(args.checkpoint)
+    if args.resume:  # train.py:131-137 of the reference: newest matching run / checkpoint under the experiment's log root
+        from locotouch_amd.compat.runtime import get_checkpoint_path
+
+        ckpt = args.checkpoint if (args.checkpoint and os.path.isfile(args.checkpoint)) else get_checkpoint_path(
+            os.path.join(args.log_root, cfg["experiment_name"]), args.load_run or ".*", args.checkpoint or "model_.*.pt")
+        print(f"[INFO]: Loading model checkpoint from: {ckpt}")
+        runner.load(ckpt)
     if dist.is_main:
         os.makedirs(os.path.join(log_dir, "params"), exist_ok=True)
         import yaml

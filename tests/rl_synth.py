@@ -24,3 +24,22 @@ def synth_rollout(seed: int = 123):
     last_critic_obs = torch.randn(N_ENVS, N_OBS, generator=g)
     return dict(obs=obs, critic_obs=critic_obs, rewards=rewards, dones=dones.long(), time_outs=time_outs,
                 last_critic_obs=last_critic_obs)
+
+
+def extra_inputs(seed: int = 77):
+    """Seeded inputs for tools/gen_golden_rl_extra.py / tests/test_rl_extra.py (normaliser, trajectories, recurrent generator)."""
+    g = torch.Generator().manual_seed(seed)
+    T, N, D, A, H = 12, 8, 5, 3, 4
+    dones = (torch.rand(T, N, 1, generator=g) < 0.2).to(torch.uint8)
+    dones[:, 3] = 0                                   # an env without any done inside the window
+    dones[5, 0] = 1; dones[6, 0] = 1                  # back-to-back dones: a length-1 trajectory
+    x = dict(T=T, N=N, D=D, A=A, H=H, num_mini_batches=2,
+             norm_batches=torch.randn(6, 16, 7, generator=g) * torch.tensor([1, 2, 0.5, 3, 1, 10, 0.1]) + torch.tensor([0, 1, -1, 5, 0, 2, 0.3]),
+             norm_until=70,
+             traj_tensor=torch.randn(T, N, D, generator=g), traj_dones=dones.clone(),
+             obs=torch.randn(T, N, D, generator=g), cobs=torch.randn(T, N, D, generator=g), actions=torch.randn(T, N, A, generator=g),
+             rewards=torch.randn(T, N, generator=g), dones=dones.squeeze(-1).clone(), values=torch.randn(T, N, 1, generator=g),
+             logp=torch.randn(T, N, generator=g), mu=torch.randn(T, N, A, generator=g), sigma=torch.rand(T, N, A, generator=g) + 0.1,
+             hid_a=torch.randn(T, 1, N, H, generator=g), hid_c=torch.randn(T, 1, N, H, generator=g),
+             last_values=torch.randn(N, 1, generator=g))
+    return x

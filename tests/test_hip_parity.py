@@ -444,8 +444,8 @@ def test_training_loop_runs_and_checkpoints(tmp_path):
     h = runner.history
     assert len(h) == 3 and all(np.isfinite(r["Loss/value_function"]) and np.isfinite(r["Loss/surrogate"]) for r in h)
     assert h[-1]["Perf/total_fps"] > 0 and "Metrics/base_velocity/lin_vel_x" in h[-1]
-    ck = os.path.join(str(tmp_path), "model_3.pt")
-    assert os.path.exists(ck)
+    ck = os.path.join(str(tmp_path), "model_2.pt")  # iterations 0..2: the final save carries the last iteration's number
+    assert os.path.exists(ck) and "Metrics/base_velocity/error_vel_xy" in h[-1]
     loaded = torch.load(ck, weights_only=True)
     assert set(loaded) == {"model_state_dict", "optimizer_state_dict", "iter", "infos"}  # on_policy_runner.py:369-385
     runner2 = OnPolicyRunner(make(task, num_envs=512, device="cuda:0", seed=2), cfg, log_dir=None, device="cuda:0")

@@ -60,11 +60,19 @@ def test_reference_train_script_runs_unmodified(tmp_path, task):
     with open(os.path.join(run, "params", "agent.pkl"), "rb") as f:  # written by this process' own code: a plain dict
         assert pickle.load(f)["num_steps_per_env"] == 24
     models = sorted(os.path.basename(p) for p in glob.glob(os.path.join(run, "model_*.pt")))
-    assert "model_2.pt" in models, models  # final checkpoint of a 2-iteration run (on_policy_runner.py:243-245 naming)
+    # iterations 0 and 1: model_0.pt from the save interval, model_1.pt = the final save under the LAST iteration's number
+    # (on_policy_runner.py:221,243-245)
+    assert models == ["model_0.pt", "model_1.pt"], models
     import torch
 
-    ck = torch.load(os.path.join(run, "model_2.pt"), weights_only=True)
-    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "iter", "infos"}
+    ck = torch.load(os.path.join(run, "model_1.pt"), weights_only=True)
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "iter", "infos"} and ck["iter"] == 1
+    from locotouch_amd.rl.tb_writer import read_events
+
+    ev = read_events(glob.glob(os.path.join(run, "events.out.tfevents.*"))[0])  # --logger tensorboard: the reference's scalar tags
+    tags = {t for _, t, _ in ev}
+    assert {"Loss/value_function", "Loss/surrogate", "Loss/entropy", "Loss/learning_rate", "Policy/mean_noise_std", "Perf/total_fps",
+            "Perf/collection time", "Perf/learning_time"} <= tags and {s_ for s_, _, _ in ev} == {0, 1}
     obs_dim = 348 if "Transport" in task else 270
     assert ck["model_state_dict"]["actor.0.weight"].shape == (512, obs_dim)
 
