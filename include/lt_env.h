@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 3
+#define LT_ABI_VERSION 4
 
 /* error codes */
 #define LT_OK 0
@@ -44,7 +44,11 @@ extern "C" {
 
 /* tasks (gym ids: reference locotouch/config/locotouch/__init__.py:14,99) */
 #define LT_TASK_LOCOMOTION 0        /* Isaac-Locomotion-LocoTouch-v1 */
-#define LT_TASK_TRANSPORT_TEACHER 1 /* Isaac-RandCylinderTransportTeacher-LocoTouch-v1 */
+#define LT_TASK_TRANSPORT_TEACHER 1 /* Isaac-RandCylinderTransportTeacher-LocoTouch-v1 (and, with cfg.tactile_enabled, the
+                                     * student tasks: same scene + the 17 x 13 taxel sensor on the carrying plate) */
+#define LT_TACTILE_ROWS 17          /* taxel grid: rows along x (front -> back), columns along y (left -> right);        */
+#define LT_TACTILE_COLS 13          /* reference utils/urdf_processor/go1/generate_locotouch_urdf.py:4-8,59-72          */
+#define LT_TACTILE_DIM 442          /* BinaryTactileSignals: two identical channels of the 17 x 13 contact map (mdp/observations.py:307-308) */
 
 /* reward terms, in manager order (reference config/base/locomotion_base_env_cfg.py:139-218 then
  * config/locotouch/object_transport_teacher_env_cfg.py:88-105).  Zero-weight terms are not evaluated. */
@@ -190,7 +194,15 @@ typedef struct lt_cfg {
                                    * 1: reset_object_state_uniform (function; offset rotated by the robot quat, :13-53) */
   int32_t obj_size_explicit;      /* 1: per-env (radius, length) are taken from LT_F_OBJ_SIZES (written by the host before
                                    * lt_env_reset_all) instead of the seeded draw from obj_radius / obj_length */
-  int32_t reserved[3];
+  /* tactile sensor + BinaryTactileSignals (student tasks): reference mdp/observations.py:95-308, cfg
+   * config/locotouch/object_transport_student_env_cfg.py:13-43 (term params), :195-201 (sensor, 40 Hz) */
+  int32_t tactile_enabled;
+  float tactile_update_period;    /* 0.025 s: the taxel forces refresh every 5th sim step since the env's reset [DEP ContactSensor] */
+  float tactile_threshold;        /* contact_threshold 0.05 N */
+  float tactile_threshold_noise;  /* +- half-width of the per-(env, taxel) threshold offset drawn once: 0.05 * 0.2 */
+  float tactile_dropout_prob;     /* contact_dropout_prob 0.005 */
+  float tactile_addition_prob;    /* contact_addition_prob 0.005 */
+  int32_t reserved[4];
 } lt_cfg;
 
 /* Fields of the state arena (zero-copy views for the manager-term data contract). */
@@ -220,6 +232,8 @@ enum lt_field {
                          * (reset_lin, len_lin, sum_lin, reset_ang); (len_ang, sum_ang, _, _).  The trackers lag the
                          * reference's by one pass: LT_F_CMD_PARAMS[27..30] holds the operations still to be applied */
   LT_F_REWARD_TERMS,    /* 7 quad arrays: unweighted term values of the last step (diagnostics / parity) */
+  LT_F_PLATE_SAMPLES,   /* 3 quad arrays (lane = plate sample): contact point x, y in the trunk frame and normal force of the
+                         * cylinder-on-plate contact at the last tactile refresh (zero after a reset); tactile tasks only */
   LT_NUM_QUAD_FIELDS,
   /* plain (non-quad) arrays */
   LT_F_EP_LEN = 64,     /* int64 [N] */
@@ -232,6 +246,9 @@ enum lt_field {
   LT_F_TERM_BITS,       /* int32 [N] which termination terms fired this step */
   LT_F_CMD_PARAMS,      /* float [LT_CMD_PARAMS_LEN], device-resident command/curriculum block */
   LT_F_COUNTERS,        /* int64 [4]: (common_step_counter, _, arrival ticket of the step kernel's tail reduction, _) */
+  LT_F_OBS_TACTILE,     /* float [N][442]: observation group `tactile` (tactile tasks; no history) */
+  LT_F_OBS_OBJECT_STATE,/* float [N][78] (row stride obs_dim): observation group `object_state` = the object-state block of the
+                         * policy rows (same term, same parameters; the reference draws its noise separately) */
   LT_F_OBJ_SIZES,       /* float [N][2]: explicit per-env cylinder (radius, length), read by lt_env_reset_all when
                          * cfg.obj_size_explicit is set; lt_env_reset_all does not clear it */
   LT_F_END
@@ -298,6 +315,10 @@ int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_pol
 /* Profiling variant of lt_env_step: HIP events bracket the step kernel on `stream`; the call WAITS for them (host
  * sync - never use it inside a captured region) and returns the step kernel's duration in milliseconds. */
 int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float* step_kernel_ms);
+/* Tactile observation pass (tactile tasks): taxel forces from LT_F_PLATE_SAMPLES -> thresholds -> dropout / addition ->
+ * LT_F_OBS_TACTILE.  lt_env_step runs it after the step kernel; drivers that launch lt_env_step_rows / _rollout call it
+ * themselves.  No-op (LT_OK) when cfg.tactile_enabled is 0. */
+int lt_env_tactile_update(lt_env* env, void* stream);
 /* Reward / termination / observation terms on the CURRENT arena contents, without physics, reset or
  * command update (parity-test hook: lets a test write a golden state into the views and read the terms).
  * `terminated_in` (uint8[N], device, may be NULL) feeds the `alive` term. */

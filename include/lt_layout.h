@@ -28,7 +28,7 @@ static inline int lt_field_quads(int f) {
       return 3;
     case LT_F_FORCE_HIST: return 12;
     case LT_F_EPISODE_SUMS: case LT_F_LAST_EPISODE_SUMS: case LT_F_REWARD_TERMS: return 7;
-    case LT_F_CURRICULUM: return 3;
+    case LT_F_CURRICULUM: case LT_F_PLATE_SAMPLES: return 3;
     default: return 1;
   }
 }
@@ -48,20 +48,22 @@ typedef struct lt_layout {
   int32_t obs_dim;
   int64_t quad_off[LT_NUM_QUAD_FIELDS]; /* byte offsets */
   int64_t off_ep_len, off_obs_policy, off_obs_critic, off_reward, off_dones, off_terminated, off_time_out,
-      off_term_bits, off_cmd_params, off_counters, off_partials, off_obj_sizes, off_dev_args;
+      off_term_bits, off_cmd_params, off_counters, off_partials, off_obs_tactile, off_obj_sizes, off_dev_args;
   int64_t total_bytes;
+  int32_t tactile, reserved;
 } lt_layout;
 
 static inline int64_t lt_align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
-static inline void lt_layout_init(lt_layout* L, int64_t num_envs, int32_t obs_dim) {
+/* `tactile`: cfg.tactile_enabled - the plate-sample field and the tactile rows take no space otherwise */
+static inline void lt_layout_init(lt_layout* L, int64_t num_envs, int32_t obs_dim, int32_t tactile) {
   int64_t off = 0;
   L->n = num_envs;
   L->npad = (num_envs + 15) / 16 * 16;
   L->obs_dim = obs_dim;
   for (int f = 0; f < LT_NUM_QUAD_FIELDS; ++f) {
     L->quad_off[f] = off;
-    off = lt_align256(off + (int64_t)lt_field_quads(f) * L->npad * 4 * 4);
+    off = lt_align256(off + (int64_t)((f == LT_F_PLATE_SAMPLES && !tactile) ? 0 : lt_field_quads(f)) * L->npad * 4 * 4);
   }
   L->off_ep_len = off;      off = lt_align256(off + L->npad * 8);
   L->off_obs_policy = off;  off = lt_align256(off + L->npad * (int64_t)obs_dim * 4);
@@ -74,9 +76,11 @@ static inline void lt_layout_init(lt_layout* L, int64_t num_envs, int32_t obs_di
   L->off_cmd_params = off;  off = lt_align256(off + LT_CMD_PARAMS_LEN * 4);
   L->off_counters = off;    off = lt_align256(off + 4 * 8);
   L->off_partials = off;    off = lt_align256(off + (L->npad / 16) * LT_PARTIAL_FLOATS * 4);
+  L->off_obs_tactile = off; off = lt_align256(off + (tactile ? L->npad * (int64_t)LT_TACTILE_DIM * 4 : 0));
   L->off_obj_sizes = off;   off = lt_align256(off + L->npad * 2 * 4); /* this and what follows survive lt_env_reset_all */
   L->off_dev_args = off;    off = lt_align256(off + LT_DEV_ARGS_BYTES);
   L->total_bytes = off;
+  L->tactile = tactile; L->reserved = 0;
 }
 
 /* float* of quad array `q` of quad field `f` */
@@ -84,7 +88,8 @@ static inline float* lt_quad(void* arena, const lt_layout* L, int f, int q) {
   return (float*)((char*)arena + L->quad_off[f]) + (int64_t)q * L->npad * 4;
 }
 
-typedef struct lt_dev_args {
+/* device-resident (cfg, layout) block; 16-byte sized so that the kernels stage it with whole 16-byte loads */
+typedef struct __attribute__((aligned(16))) lt_dev_args {
   lt_cfg cfg;
   lt_layout layout;
 } lt_dev_args;

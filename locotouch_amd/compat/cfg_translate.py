@@ -227,8 +227,10 @@ def translate(env_cfg, seed: int | None = None) -> "_abi.LtCfg":
 
     # ---- observations (policy group: noisy; critic: same terms, corruption off) ----
     groups = _terms(env_cfg.observations)
-    extra = set(groups) - {"policy", "critic"}
-    _need(not extra, f"observation groups {sorted(extra)} have no fused implementation (student/tactile path)")
+    extra = set(groups) - {"policy", "critic", "tactile", "object_state"}
+    _need(not extra, f"observation groups {sorted(extra)} have no fused implementation "
+                     "(only the binary tactile map and the object-state group of the student tasks do)")
+    _need(("tactile" in groups) == ("object_state" in groups), "the student tasks carry the tactile and object_state groups together")
     pol = groups["policy"]
     cfg.enable_corruption = 1 if pol.enable_corruption else 0
     hist = {int(v.history_length) for v in vars(pol).values() if hasattr(v, "func") and v is not None and v.history_length is not None}
@@ -271,6 +273,8 @@ def translate(env_cfg, seed: int | None = None) -> "_abi.LtCfg":
         sc = op["scale"]
         for i in range(13):
             cfg.obj_scale[i] = float(sc[i]) if not isinstance(sc, float) else float(sc)
+    if "tactile" in groups:
+        _translate_student_groups(env_cfg, cfg, groups, pterms)
     cri = groups["critic"]
     _need(not cri.enable_corruption, "critic group: corruption off")
     _need([k for k, v in vars(cri).items() if hasattr(v, "func")] == order, "critic group must hold the policy group's terms")
@@ -375,6 +379,51 @@ def translate(env_cfg, seed: int | None = None) -> "_abi.LtCfg":
         cfg.cur_repeat_times[0], cfg.cur_repeat_times[1] = int(p["repeat_times_lin"]), int(p["repeat_times_ang"])
         cfg.cur_max_distance_bins = int(p["max_distance_bins"])
     return cfg
+
+
+def _translate_student_groups(env_cfg, cfg, groups, pterms) -> None:
+    """`tactile` (BinaryTactileSignals on the 17 x 13 taxel sensor) and `object_state` groups of the student tasks
+    (reference config/locotouch/object_transport_student_env_cfg.py:13-43,161-201)."""
+    _need(cfg.task == C["LT_TASK_TRANSPORT_TEACHER"], "tactile observations need the transport scene")
+    tac = groups["tactile"]
+    tterms = {k: v for k, v in vars(tac).items() if hasattr(v, "func") and v is not None}
+    _need(list(tterms) == ["tactile_signals"], f"tactile group terms {list(tterms)} != ['tactile_signals']")
+    t = tterms["tactile_signals"]
+    _need(_name(t.func) == "BinaryTactileSignals", f"tactile term {_name(t.func)}: only the binary map is implemented "
+                                                   "(the reference evaluates no other format, object_transport_student_env_cfg.py:45)")
+    _need(tac.enable_corruption and tac.concatenate_terms and not t.history_length and t.noise is None and _close(t.scale, 1.0)
+          and t.clip is None and not t.modifiers, "tactile group: corruption on, concatenated, no history / manager noise / scale / clip")
+    p = t.params
+    _need(tuple(p["tactile_signal_shape"]) == (C["LT_TACTILE_ROWS"], C["LT_TACTILE_COLS"]), "taxel grid must be 17 x 13")
+    _need(not float(p.get("add_continuous_artifact", 0.0)) > 0.5, "continuous tactile artifacts are not implemented")
+    sensor = getattr(env_cfg.scene, "tactile_contact_sensor", None)
+    _need(sensor is not None and sensor.prim_path.endswith("/Robot/sensor_.*"), "scene.tactile_contact_sensor on the taxel bodies")
+    cfg.tactile_enabled = 1
+    cfg.tactile_update_period = float(sensor.update_period)
+    cfg.tactile_threshold = float(p["contact_threshold"])
+    if p["add_threshold_noise"]:
+        _need(_close(-float(p["threshold_n_min"]), float(p["threshold_n_max"])), "tactile threshold noise must be symmetric")
+        cfg.tactile_threshold_noise = float(p["threshold_n_max"])
+    else:
+        cfg.tactile_threshold_noise = 0.0
+    cfg.tactile_dropout_prob = float(p["contact_dropout_prob"])
+    cfg.tactile_addition_prob = float(p["contact_addition_prob"])
+    # object_state group: served as a window of the policy rows, so it must be the policy group's own object_state term
+    og = groups["object_state"]
+    oterms = {k: v for k, v in vars(og).items() if hasattr(v, "func") and v is not None}
+    _need(list(oterms) == ["object_state"] and og.enable_corruption and og.concatenate_terms, "object_state group: one noisy term")
+    a, b = oterms["object_state"], pterms["object_state"]
+    _need(_name(a.func) == _name(b.func) and int(a.history_length or 0) == int(cfg.obs_history)
+          and all(_same(a.params.get(k), b.params.get(k)) for k in set(a.params) | set(b.params) if not k.endswith("_cfg")),
+          "object_state group must repeat the policy group's object_state term (it is served as a window of the policy rows)")
+
+
+def _same(x, y) -> bool:
+    if isinstance(x, (list, tuple)) and isinstance(y, (list, tuple)):
+        return len(x) == len(y) and all(_same(a, b) for a, b in zip(x, y))
+    if isinstance(x, (int, float)) and isinstance(y, (int, float)):
+        return _close(x, y)
+    return x == y
 
 
 def diff(a: "_abi.LtCfg", b: "_abi.LtCfg", rtol: float = 1e-6, skip=("seed", "num_envs", "reserved", "debug_terms")) -> list[str]:

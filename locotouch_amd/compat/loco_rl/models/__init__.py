@@ -23,4 +23,6 @@ class ModelCfg:
     cnn_normlayer: object = None
 
 
-__all__ = ["ModelCfg"]
+from locotouch_amd.rl.models import MLP, RNN, CNN2d, CNN2dHead, Memory, generate_model  # noqa: E402
+
+__all__ = ["ModelCfg", "MLP", "RNN", "CNN2d", "CNN2dHead", "Memory", "generate_model"]

@@ -256,6 +256,26 @@ void cylinder_teacher(lt_cfg* c) {
   c->cur_reward_threshold[1] = (float)(std::exp(-0.08 / 0.25) * 0.5 * 20.0);
 }
 
+// Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-v1: the rand-cylinder teacher env in its final
+// ("play") setup plus the tactile sensor (config/locotouch/object_transport_student_env_cfg.py:161-201)
+void student_binary_tac(lt_cfg* c) {
+  c->episode_length_s = 10.0f;                                       // :172
+  c->max_episode_length = 500;                                       // ceil(10.0 / 0.02)
+  for (int i = 0; i < 3; ++i) set2(c->cmd_range_init[i], -c->cmd_range_max[i], c->cmd_range_max[i]);  // :179-182
+  c->cmd_zero_steps = c->cmd_zero_steps_final;                       // :183
+  c->cmd_rel_standing = c->cmd_rel_standing_final;                   // :184
+  // the curriculum term stays registered; its thresholds scale with max_episode_length_s (mdp/curriculums.py:194-200)
+  c->cur_len_threshold = 0.98f * 10.0f;
+  c->cur_reward_threshold[0] = (float)(std::exp(-0.08 / 0.25) * 1.0 * 10.0);
+  c->cur_reward_threshold[1] = (float)(std::exp(-0.1 / 0.25) * 0.5 * 10.0);
+  c->tactile_enabled = 1;                                            // :195-201, term params :16-37
+  c->tactile_update_period = 0.025f;
+  c->tactile_threshold = 0.05f;
+  c->tactile_threshold_noise = 0.05f * 0.2f;
+  c->tactile_dropout_prob = 0.005f;
+  c->tactile_addition_prob = 0.005f;
+}
+
 struct Preset { const char* id; int task; void (*extra)(lt_cfg*); int num_envs; };
 // gym ids of the reference registry (locotouch/config/locotouch/__init__.py:14-117); -Play- variants differ in num_envs only
 // for the fused terms (locomotion_base_env_cfg.py:364-374 `smaller_scene_for_playing`: 50 envs; cylinder play cfgs: 20)
@@ -268,6 +288,8 @@ const Preset kPresets[] = {
     {"Isaac-CylinderTransportTeacher-LocoTouch-Play-v1", LT_TASK_TRANSPORT_TEACHER, cylinder_teacher, 50},
     {"Isaac-RandCylinderTransportTeacher-LocoTouch-v1", LT_TASK_TRANSPORT_TEACHER, nullptr, 4096},
     {"Isaac-RandCylinderTransportTeacher-LocoTouch-Play-v1", LT_TASK_TRANSPORT_TEACHER, nullptr, 50},
+    {"Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-v1", LT_TASK_TRANSPORT_TEACHER, student_binary_tac, 405},
+    {"Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-Play-v1", LT_TASK_TRANSPORT_TEACHER, student_binary_tac, 20},
 };
 }  // namespace
 

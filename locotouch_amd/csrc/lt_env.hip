@@ -34,6 +34,7 @@ struct KArgs {
   const lt_dev_args* __restrict__ d;
   char* arena;
   const float* actions;
+  const long long* ep_len;  // == arena + layout.off_ep_len (the tactile refresh phase is needed before the layout block is staged)
   long long npad;  // == d->layout.npad: lets the state loads be issued before the (cfg, layout) block has been staged
   // observation rows [npad][OBS] of the two groups: previous rows (read) and new rows (written).  Equal pointers =
   // in-place update of the arena rows (lt_env_step); distinct = rollout-storage slots t / t+1 (lt_env_step_rows).
@@ -53,7 +54,7 @@ static_assert(sizeof(lt_dev_args) <= LT_DEV_ARGS_BYTES, "lt_dev_args outgrew its
 struct CumQ { int v[LT_NUM_QUAD_FIELDS + 1]; };
 constexpr int field_quads_c(int f) {
   return (f == LT_F_JOINT_POS || f == LT_F_JOINT_VEL || f == LT_F_JOINT_ACC || f == LT_F_APPLIED_TORQUE || f == LT_F_ACT_RAW ||
-          f == LT_F_ACT_PREV_RAW || f == LT_F_ACT_PREV_PREV_RAW || f == LT_F_FOOT_POS_W || f == LT_F_FOOT_VEL_W || f == LT_F_CURRICULUM)
+          f == LT_F_ACT_PREV_RAW || f == LT_F_ACT_PREV_PREV_RAW || f == LT_F_FOOT_POS_W || f == LT_F_FOOT_VEL_W || f == LT_F_CURRICULUM || f == LT_F_PLATE_SAMPLES)
              ? 3
              : (f == LT_F_FORCE_HIST ? 12 : ((f == LT_F_EPISODE_SUMS || f == LT_F_LAST_EPISODE_SUMS || f == LT_F_REWARD_TERMS) ? 7 : 1));
 }
@@ -88,8 +89,13 @@ __device__ constexpr float k_trunk_half[3] = LT_TRUNK_BOX_HALF_INIT;
 enum {
   RS_NOISE_JPOS = 0x100, RS_NOISE_JVEL = 0x110, RS_NOISE_BASE = 0x120, RS_NOISE_OBJ = 0x130,
   RS_RESET_ROOT = 0x200, RS_RESET_JOINT = 0x210, RS_RESET_MAT = 0x220, RS_RESET_OBJ = 0x221, RS_RESET_EVENT = 0x223,
-  RS_CMD_RESET = 0x230, RS_CMD_TIMER = 0x240, RS_PUSH_ROBOT = 0x250, RS_PUSH_OBJ = 0x260, RS_STARTUP = 0x300
+  RS_CMD_RESET = 0x230, RS_CMD_TIMER = 0x240, RS_PUSH_ROBOT = 0x250, RS_PUSH_OBJ = 0x260, RS_STARTUP = 0x300,
+  RS_TACTILE_THR = 0x400,  // + taxel / 4 (startup stream): the per-(env, taxel) threshold offsets, drawn once
+  RS_TACTILE = 0x500       // + taxel / 2 (step stream): (dropout, addition) uniforms of two taxels per call
 };
+// kernel-template task index of the transport task WITH the tactile sensor (cfg.task stays LT_TASK_TRANSPORT_TEACHER, the
+// student registrations derive from the teacher's env cfg: object_transport_student_env_cfg.py:161-168)
+constexpr int K_TASK_TACTILE = 2;
 
 // observation history tables: for output column `col` of a group row, where does the value come from?
 //   src[col] >= 0 : old row, column src[col] (one slot newer);  src[col] < 0 : newest frame, element -src-1
@@ -175,6 +181,7 @@ struct Report {  // contact forces of the last physics substep (world frame)
   V3 body[4];    // hip, thigh, calf, foot of this lane's leg
   V3 trunk_part; // this lane's share of the trunk force (corners + plate reactions)
   V3 obj_part;   // this lane's share of the object force
+  V3 plate;      // tactile tasks: this lane's plate sample - contact point (x, y) in the trunk frame, normal force on the plate
 };
 
 // ---- contact law (DESIGN.md "contact model"; executable spec: oracle/lt_oracle.c contact_eval) ----------
@@ -541,6 +548,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
 #endif
   LT_STAMP(0);
   constexpr bool HAS_OBJ = TASK != LT_TASK_LOCOMOTION;
+  constexpr bool TAC = TASK == K_TASK_TACTILE;
   constexpr int FRAME = HAS_OBJ ? 58 : 45;
   constexpr int OBS = FRAME * 6;
   const int lane = threadIdx.x & 63;
@@ -566,7 +574,9 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   struct {
     float root_pos, root_quat, root_lin, root_ang, obj_pos, obj_quat, obj_lin, obj_ang, obj_timers, obj_params, env_params, trunk_fh;
     float q[3], qd[3], raw[3], fh[12], cur_air, cur_con, last_air, last_con, mu;
+    long long ep0;
   } hot;
+  hot.ep0 = 0;
   if (wave == 0) {
     stg0 = stg_src[lane < STG ? lane : 0]; stg1 = stg_src[lane + 64 < STG ? lane + 64 : 0];
     hot.root_pos = *F(LT_F_ROOT_POS, 0); hot.root_quat = *F(LT_F_ROOT_QUAT, 0);
@@ -582,6 +592,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     hot.cur_air = *F(LT_F_FOOT_CUR_AIR, 0); hot.cur_con = *F(LT_F_FOOT_CUR_CONTACT, 0);
     hot.last_air = *F(LT_F_FOOT_LAST_AIR, 0); hot.last_con = *F(LT_F_FOOT_LAST_CONTACT, 0);
     hot.mu = *F(LT_F_FOOT_FRICTION, 0);
+    if (TAC && MODE == MODE_STEP) hot.ep0 = a.ep_len[env];
     uint4* dst = (uint4*)&s_d;
     if (lane < STG) dst[lane] = stg0;
     if (lane + 64 < STG) dst[lane + 64] = stg1;
@@ -724,6 +735,9 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   // =================================================================================================
   // stages 1-3: action term, decimation x (PD, physics, sensors), counters
   // =================================================================================================
+  // tactile refresh of this step (TAC): this lane's plate sample at the sim step where the sensor's period elapses
+  V3 tac = v3(0, 0, 0);
+  bool tac_new = false;
   if (MODE == MODE_STEP) {
     // 1. JointPositionActionPrevPrev.process_actions (reference mdp/actions.py:30-44); action index = type*4 + leg
 #pragma unroll
@@ -735,6 +749,10 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     }
     // 2. decimation loop
     const float h = c.sim_dt / (float)c.phys_substeps;
+    // ContactSensor cadence [DEP]: the taxel forces refresh at the first sim step after a reset and then whenever
+    // update_period (0.025 s = 5 sim steps) has elapsed: sim-step indices 0, 5, 10, ... counted from the reset
+    const int tac_every = TAC ? (int)(c.tactile_update_period / c.sim_dt + 0.5f) : 1;
+    int tac_phase = TAC ? (int)((hot.ep0 * (long long)c.decimation) % (long long)(tac_every > 0 ? tac_every : 1)) : 0;
     for (int d = 0; d < c.decimation; ++d) {
       float qd0[3];
 #pragma unroll
@@ -743,7 +761,11 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
         G.tau[k] = dc_motor(c, qdef[k] + G.raw[k], G.q[k], G.qd[k]);
       }
       Report rep;
-      for (int s = 0; s < c.phys_substeps; ++s) physics_substep<HAS_OBJ>(c, h, leg, sgn, B, G, O, X, rep);
+      for (int s = 0; s < c.phys_substeps; ++s) physics_substep<HAS_OBJ, TAC>(c, h, leg, sgn, B, G, O, X, rep);
+      if (TAC) {
+        if (tac_phase == 0) { tac = rep.plate; tac_new = true; }
+        tac_phase = tac_phase + 1 >= tac_every ? 0 : tac_phase + 1;
+      }
 #pragma unroll
       for (int k = 0; k < 3; ++k) G.qdd[k] = (G.qd[k] - qd0[k]) / c.sim_dt;  // Articulation.data.joint_acc [DEP]
       // K3 sensors: |F| history (newest first) + timers, at the sensor period = sim dt (locomotion_base_env_cfg.py:358-359)
@@ -1043,6 +1065,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     X.push_robot_left = lerp2(c.push_robot_interval, u.a);
     X.push_obj_left = lerp2(c.push_obj_interval, u.b);
     X.ep_len = 0;
+    if (TAC) { tac = v3(0, 0, 0); tac_new = true; }  // ContactSensor.reset [DEP]: the reset envs' net forces are zeroed
     foot_kinematics(sgn, B, G);
     if (MODE == MODE_RESET_ALL && c.cmd_multi_sampling && 0 < (int)P[15]) X.cmd = v3(0, 0, 0);                 // commands.py:559
   }
@@ -1216,6 +1239,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     *F(LT_F_EVENT_TIMERS, 0) = sel4(leg, X.push_robot_left, X.push_obj_left, 0.f, 0.f);
     *F(LT_F_GAIT_CMD, 0) = sel4(leg, X.gait_cmd.x, X.gait_cmd.y, X.gait_cmd.z, X.gait_step);
     if (leg == 0) ((long long*)(arena + L.off_ep_len))[env] = X.ep_len;
+    if (TAC && tac_new) { *F(LT_F_PLATE_SAMPLES, 0) = tac.x; *F(LT_F_PLATE_SAMPLES, 1) = tac.y; *F(LT_F_PLATE_SAMPLES, 2) = tac.z; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       *F(LT_F_JOINT_POS, k) = G.q[k]; *F(LT_F_JOINT_VEL, k) = G.qd[k];
@@ -1308,6 +1332,7 @@ KArgs make_args(const lt_env* env, const float* actions) {
   k.d = (const lt_dev_args*)((const char*)env->arena + env->layout.off_dev_args);
   k.arena = (char*)env->arena;
   k.actions = actions;
+  k.ep_len = (const long long*)((const char*)env->arena + env->layout.off_ep_len);
   k.npad = env->layout.npad;
   float* const rp = (float*)((char*)env->arena + env->layout.off_obs_policy);
   float* const rc = (float*)((char*)env->arena + env->layout.off_obs_critic);
@@ -1334,6 +1359,9 @@ int launch_step(const lt_env* env, const float* actions, hipStream_t s, const fl
   if (env->cfg.task == LT_TASK_LOCOMOTION) {
     if (helpers) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, MODE == MODE_STEP>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, false>), grid, dim3(64), 0, s, k);
+  } else if (env->cfg.tactile_enabled) {
+    if (helpers) hipLaunchKernelGGL((lt_step_kernel<K_TASK_TACTILE, MODE, MODE == MODE_STEP>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((lt_step_kernel<K_TASK_TACTILE, MODE, false>), grid, dim3(64), 0, s, k);
   } else {
     if (helpers) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE, MODE == MODE_STEP>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE, false>), grid, dim3(64), 0, s, k);

@@ -19,6 +19,7 @@ bool cfg_valid(const lt_cfg* c) {
   if (c->decimation < 1 || c->decimation > 64 || c->phys_substeps < 1 || c->phys_substeps > 16) return false;
   if (c->obs_history != 6) return false;  // the kernels are specialised for the reference's history length
   if (!(c->sim_dt > 0.f) || c->max_episode_length <= 0) return false;
+  if (c->tactile_enabled && (c->task != LT_TASK_TRANSPORT_TEACHER || !(c->tactile_update_period >= c->sim_dt))) return false;
   return true;
 }
 }  // namespace
@@ -32,7 +33,7 @@ const char* lt_last_error(void) { return g_last_error.c_str(); }
 int lt_env_state_bytes(const lt_cfg* cfg, size_t* bytes) {
   if (!cfg_valid(cfg) || !bytes) { lt_set_error("lt_env_state_bytes: invalid cfg"); return LT_EINVAL; }
   lt_layout L;
-  lt_layout_init(&L, cfg->num_envs, lt_cfg_obs_dim(cfg));
+  lt_layout_init(&L, cfg->num_envs, lt_cfg_obs_dim(cfg), cfg->tactile_enabled);
   *bytes = (size_t)L.total_bytes;
   return LT_OK;
 }
@@ -44,7 +45,7 @@ int lt_env_create(const lt_cfg* cfg, lt_env** out) {
   lt_env* e = new (std::nothrow) lt_env();
   if (!e) return LT_ENOMEM;
   e->cfg = *cfg;
-  lt_layout_init(&e->layout, cfg->num_envs, lt_cfg_obs_dim(cfg));
+  lt_layout_init(&e->layout, cfg->num_envs, lt_cfg_obs_dim(cfg), cfg->tactile_enabled);
   if (!lt_check_layout(&e->layout)) {
     delete e;
     lt_set_error("lt_env_create: lt_layout_init and the kernels' compile-time field offsets disagree (library built from mixed sources)");
@@ -77,6 +78,10 @@ int lt_env_get_view(lt_env* env, int field, lt_view* v) {
   const lt_layout& L = env->layout;
   char* base = (char*)env->arena;  // may be null: offsets are then relative to 0 (layout queries before bind)
   std::memset(v, 0, sizeof(*v));
+  if ((field == LT_F_PLATE_SAMPLES || field == LT_F_OBS_TACTILE) && !L.tactile) {
+    lt_set_error("lt_env_get_view: the tactile fields exist only with cfg.tactile_enabled");
+    return LT_EINVAL;
+  }
   if (field >= 0 && field < LT_NUM_QUAD_FIELDS) {
     const int q = lt_field_quads(field);
     v->ptr = base + L.quad_off[field];
@@ -105,6 +110,12 @@ int lt_env_get_view(lt_env* env, int field, lt_view* v) {
     case LT_F_CMD_PARAMS: plain(L.off_cmd_params, 0, LT_CMD_PARAMS_LEN, 0); break;
     case LT_F_COUNTERS: plain(L.off_counters, 1, 4, 0); break;
     case LT_F_OBJ_SIZES: plain(L.off_obj_sizes, 0, L.n, 2); break;
+    case LT_F_OBS_TACTILE: plain(L.off_obs_tactile, 0, L.n, LT_TACTILE_DIM); break;
+    case LT_F_OBS_OBJECT_STATE:  // the object-state term block (13 x 6) closes the policy rows of the transport tasks
+      if (env->cfg.task != LT_TASK_TRANSPORT_TEACHER) { lt_set_error("lt_env_get_view: no object in this task"); return LT_EINVAL; }
+      plain(L.off_obs_policy + (int64_t)(L.obs_dim - 13 * env->cfg.obs_history) * 4, 0, L.n, 13 * env->cfg.obs_history);
+      v->stride[0] = L.obs_dim;
+      break;
     default: lt_set_error("lt_env_get_view: unknown field"); return LT_EINVAL;
   }
   return LT_OK;
@@ -120,13 +131,24 @@ static int finish(int hip_err, const char* what) {
 int lt_env_reset_all(lt_env* env, void* stream) {
   if (!env) return LT_EINVAL;
   if (!env->arena) { lt_set_error("lt_env_reset_all: arena not bound"); return LT_EFAULT; }
-  return finish(lt_launch_reset_all(env, stream), "lt_env_reset_all");
+  const int rc = finish(lt_launch_reset_all(env, stream), "lt_env_reset_all");
+  if (rc != LT_OK || !env->cfg.tactile_enabled) return rc;
+  return finish(lt_launch_tactile(env, stream), "lt_env_reset_all (tactile)");
+}
+
+int lt_env_tactile_update(lt_env* env, void* stream) {
+  if (!env) return LT_EINVAL;
+  if (!env->cfg.tactile_enabled) return LT_OK;
+  if (!env->arena) { lt_set_error("lt_env_tactile_update: arena not bound"); return LT_EFAULT; }
+  return finish(lt_launch_tactile(env, stream), "lt_env_tactile_update");
 }
 
 int lt_env_step(lt_env* env, const float* actions, void* stream) {
   if (!env || !actions) return LT_EINVAL;
   if (!env->arena) { lt_set_error("lt_env_step: arena not bound"); return LT_EFAULT; }
-  return finish(lt_launch_step(env, actions, stream), "lt_env_step");
+  const int rc = finish(lt_launch_step(env, actions, stream), "lt_env_step");
+  if (rc != LT_OK || !env->cfg.tactile_enabled) return rc;
+  return finish(lt_launch_tactile(env, stream), "lt_env_step (tactile)");
 }
 
 int lt_env_step_rows(lt_env* env, const float* actions, const float* prev_policy, const float* prev_critic, float* next_policy,

@@ -154,7 +154,7 @@ __device__ __forceinline__ RC leg_contact(const lt_cfg& c, float h, V3 r, float 
 // K2 physics: one integrator substep of length h (torques held).  Reference: PhysX (closed source) - this is the
 // engine's own model; executable spec: oracle/lt_oracle.c physics_substep; description: DESIGN.md "Physics model".
 // =====================================================================================================
-template <bool HAS_OBJ>
+template <bool HAS_OBJ, bool TAC = false>
 __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int leg, const float (&sgn)[4], Base& B, Leg& G, Obj& O,
                                                 const Misc& X, Report& rep) {
   const float g = c.gravity;
@@ -216,6 +216,7 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
     Law lp; lp.active = false; lp.fx = lp.fy = lp.fn = lp.cte = lp.Bn = 0.f;
     V3 Pw_p = v3(0, 0, 0), rho_p = v3(0, 0, 0), F0_p = v3(0, 0, 0);
     const V3 nw = col(R0, 2);
+    if (TAC) rep.plate = v3(0, 0, 0);
     if (ok) {
       const float nza = at.z;
       const V3 up = v3(-nza * at.x, -nza * at.y, 1.f - nza * at.z);
@@ -224,6 +225,7 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
       const float sk = s0 + (s1 - s0) * (float)leg / 3.f;
       const V3 Pt = v3(ct.x + sk * at.x - rad * up.x * inv, ct.y + sk * at.y - rad * up.y * inv, ct.z + sk * at.z - rad * up.z * inv);
       const float d = zp - Pt.z;
+      if (TAC) { rep.plate.x = Pt.x; rep.plate.y = Pt.y; }
       if (d > 0.f) {
         Pw_p = B.p + mul(R0, Pt);
         rho_p = Pw_p - O.p;
@@ -277,6 +279,7 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
       const float an = dot(nw, ap);
       const V3 F = F0_p - h * (lp.cte * ap + ((lp.Bn - lp.cte) * an) * nw);
       rep.obj_part += F;
+      if (TAC) rep.plate.z = dot(nw, F);  // the cylinder presses the taxels with the plate-normal part of its contact force
       const V3 Fn = -F;
       const V3 rb = tmul(R0, Pw_p - B.p), fb = tmul(R0, Fn);
       pb.n -= cross(rb, fb);

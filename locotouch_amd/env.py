@@ -92,6 +92,11 @@ class LocoTouchVecEnv:
         self._ep_len = self.view(C["LT_F_EP_LEN"])
         self.cmd_params = self.view(C["LT_F_CMD_PARAMS"])
         self.counters = self.view(C["LT_F_COUNTERS"])
+        # student tasks (cfg.tactile_enabled): observation groups `tactile` [N][442] and `object_state` [N][78]
+        # (reference object_transport_student_env_cfg.py:165-166; the distillation reads them, distillation.py:57-59,159-162)
+        self.tactile = bool(self.cfg.tactile_enabled)
+        self.obs_tactile = self.view(C["LT_F_OBS_TACTILE"]) if self.tactile else None
+        self.obs_object_state = self.view(C["LT_F_OBS_OBJECT_STATE"]) if self.cfg.task == C["LT_TASK_TRANSPORT_TEACHER"] else None
         self.extras: dict = {}
         self._log_finished = None
         if self.cfg.obj_size_explicit:
@@ -142,7 +147,15 @@ class LocoTouchVecEnv:
         return self.get_observations()
 
     def _extras(self) -> dict:
-        return {"observations": {"policy": self.obs_policy, "critic": self.obs_critic}, "time_outs": self.time_out_buf.bool()}
+        groups = {"policy": self.obs_policy, "critic": self.obs_critic}
+        if self.tactile:
+            groups["tactile"] = self.obs_tactile
+            groups["object_state"] = self.obs_object_state
+        return {"observations": groups, "time_outs": self.time_out_buf.bool()}
+
+    def tactile_update(self) -> None:
+        """lt_env_tactile_update: for drivers of the launch-only row/rollout entry points (lt_env_step runs it itself)."""
+        _abi.check(self._lib.lt_env_tactile_update(self._handle, self._stream()), "lt_env_tactile_update")
 
     def get_observations(self):
         return self.obs_policy, self._extras()

@@ -12,7 +12,7 @@ from . import _abi
 C = _abi.CONSTS
 
 _QUADS3 = {"LT_F_JOINT_POS", "LT_F_JOINT_VEL", "LT_F_JOINT_ACC", "LT_F_APPLIED_TORQUE", "LT_F_ACT_RAW", "LT_F_ACT_PREV_RAW",
-           "LT_F_ACT_PREV_PREV_RAW", "LT_F_FOOT_POS_W", "LT_F_FOOT_VEL_W", "LT_F_CURRICULUM"}
+           "LT_F_ACT_PREV_PREV_RAW", "LT_F_FOOT_POS_W", "LT_F_FOOT_VEL_W", "LT_F_CURRICULUM", "LT_F_PLATE_SAMPLES"}
 _QUADS7 = {"LT_F_EPISODE_SUMS", "LT_F_LAST_EPISODE_SUMS", "LT_F_REWARD_TERMS"}
 QUAD_FIELDS = [k for k, v in sorted(C.items(), key=lambda kv: kv[1]) if k.startswith("LT_F_") and v < C["LT_NUM_QUAD_FIELDS"]]
 
@@ -32,15 +32,17 @@ def _align(x: int) -> int:
 
 
 class Layout:
-    def __init__(self, num_envs: int, obs_dim: int):
+    def __init__(self, num_envs: int, obs_dim: int, tactile: int = 0):
         self.n = num_envs
+        self.tactile = int(bool(tactile))
         self.npad = (num_envs + 15) // 16 * 16
         self.obs_dim = obs_dim
         off = 0
         self.quad_off = {}
         for name in QUAD_FIELDS:
             self.quad_off[name] = off
-            off = _align(off + field_quads(name) * self.npad * 16)
+            quads = 0 if (name == "LT_F_PLATE_SAMPLES" and not self.tactile) else field_quads(name)
+            off = _align(off + quads * self.npad * 16)
         self.plain = {}
         for name, nbytes, dtype, shape in [
             ("LT_F_EP_LEN", self.npad * 8, np.int64, (self.npad,)),
@@ -54,6 +56,7 @@ class Layout:
             ("LT_F_CMD_PARAMS", C["LT_CMD_PARAMS_LEN"] * 4, np.float32, (C["LT_CMD_PARAMS_LEN"],)),
             ("LT_F_COUNTERS", 4 * 8, np.int64, (4,)),
             ("_PARTIALS", self.npad // 16 * 8 * 4, np.float32, (self.npad // 16, 8)),  # per-wave curriculum partials
+            ("LT_F_OBS_TACTILE", self.npad * C["LT_TACTILE_DIM"] * 4 * self.tactile, np.float32, (self.npad * self.tactile, C["LT_TACTILE_DIM"])),
             ("LT_F_OBJ_SIZES", self.npad * 2 * 4, np.float32, (self.npad, 2)),
             ("_DEV_ARGS", 4096, np.uint8, (4096,)),  # device copy of (lt_cfg, lt_layout), include/lt_layout.h
         ]:

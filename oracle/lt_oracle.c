@@ -90,6 +90,7 @@ typedef struct {
   real episodes_finished, last_ep_len, last_term_bits;
   real cur_step[4], cur_track[8];
   real terms[LT_REWARD_SLOTS];
+  real plate[4][3];      /* tactile tasks: plate samples of the last sensor refresh (x, y in the trunk frame, normal force) */
   int64_t ep_len;
 } env_t;
 
@@ -149,6 +150,8 @@ static void gather(env_t* E, void* arena, const lt_layout* L, int64_t e) {
     E->last_sums[i] = Q(LT_F_LAST_EPISODE_SUMS, i / 4, i % 4);
     E->terms[i] = Q(LT_F_REWARD_TERMS, i / 4, i % 4);
   }
+  for (int k = 0; k < 4; ++k)
+    for (int c = 0; c < 3; ++c) E->plate[k][c] = L->tactile ? Q(LT_F_PLATE_SAMPLES, c, k) : 0;
   E->ep_len = ((int64_t*)((char*)arena + L->off_ep_len))[e];
 }
 
@@ -207,6 +210,9 @@ static void scatter(const env_t* E, void* arena, const lt_layout* L, int64_t e) 
     Q(LT_F_LAST_EPISODE_SUMS, i / 4, i % 4) = E->last_sums[i];
     Q(LT_F_REWARD_TERMS, i / 4, i % 4) = E->terms[i];
   }
+  if (L->tactile)
+    for (int k = 0; k < 4; ++k)
+      for (int c = 0; c < 3; ++c) Q(LT_F_PLATE_SAMPLES, c, k) = E->plate[k][c];
   ((int64_t*)((char*)arena + L->off_ep_len))[e] = E->ep_len;
 #undef Q
 }
@@ -379,6 +385,7 @@ typedef struct {
   real obj_force[3];            /* net contact force on the object (world) */
   real body_force[5][4][3];     /* [sensor type hip,thigh,calf,foot,trunk][leg] net contact force (world) */
   real trunk_force[3];
+  real plate[4][3];             /* tactile tasks: plate sample k -> contact point (x, y) in the trunk frame, normal force on the plate */
 } contact_report;
 
 /* one integrator substep of length h; tau held constant */
@@ -471,6 +478,7 @@ static void physics_substep(const lt_cfg* cfg, env_t* E, real h, int has_object,
         real Pt[3] = {ct_[0] + s * at_[0] - rad * up[0] * inv, ct_[1] + s * at_[1] - rad * up[1] * inv,
                       ct_[2] + s * at_[2] - rad * up[2] * inv};
         real d = zp - Pt[2];
+        rep->plate[k][0] = Pt[0]; rep->plate[k][1] = Pt[1];
         ocontact* c = &oc[nc++];
         real Pw[3], t[3], vo[3], vtk[3], vrel[3], vrel_n[3], rt[3];
         m3_mulv(t, Rw[0], Pt);
@@ -567,6 +575,7 @@ static void physics_substep(const lt_cfg* cfg, env_t* E, real h, int has_object,
         for (int i = 0; i < 3; ++i) F[i] = oc[k].F0[i] - h * t[i];
         v3_add(rep->obj_force, rep->obj_force, F);
         if (k < 4) { /* plate contact: -F on the trunk at P */
+          rep->plate[k][2] = F[0] * Rw[0][2] + F[1] * Rw[0][5] + F[2] * Rw[0][8]; /* plate normal = trunk z axis in world */
           real rb[3], fb[3], nb[3], dpos[3], Fn[3] = {-F[0], -F[1], -F[2]};
           v3_sub(dpos, oc[k].P, pw[0]);
           m3_tmulv(rb, Rw[0], dpos);
@@ -1249,7 +1258,7 @@ static void curriculum_decide(const lt_cfg* cfg, void* arena, const lt_layout* L
 /* HIP-hook twin (lt_env_curriculum_update): one pass on caller-supplied records, no step-counter increment */
 int lt_oracle_curriculum_update(const lt_cfg* cfg, void* arena, const float* records) {
   lt_layout L;
-  lt_layout_init(&L, cfg->num_envs, (cfg->task == LT_TASK_LOCOMOTION ? 45 : 58) * cfg->obs_history);
+  lt_layout_init(&L, cfg->num_envs, (cfg->task == LT_TASK_LOCOMOTION ? 45 : 58) * cfg->obs_history, cfg->tactile_enabled);
   curriculum_apply_pending(arena, &L);
   float* rec = lt_quad(arena, &L, LT_F_CURRICULUM, 0);
   for (int64_t e = 0; e < L.n; ++e)
@@ -1270,7 +1279,9 @@ int lt_oracle_curriculum_update(const lt_cfg* cfg, void* arena, const float* rec
 enum {
   RS_NOISE_JPOS = 0x100, RS_NOISE_JVEL = 0x110, RS_NOISE_BASE = 0x120, RS_NOISE_OBJ = 0x130,
   RS_RESET_ROOT = 0x200, RS_RESET_JOINT = 0x210, RS_RESET_MAT = 0x220, RS_RESET_OBJ = 0x221, RS_RESET_EVENT = 0x223,
-  RS_CMD_RESET = 0x230, RS_CMD_TIMER = 0x240, RS_PUSH_ROBOT = 0x250, RS_PUSH_OBJ = 0x260, RS_STARTUP = 0x300
+  RS_CMD_RESET = 0x230, RS_CMD_TIMER = 0x240, RS_PUSH_ROBOT = 0x250, RS_PUSH_OBJ = 0x260, RS_STARTUP = 0x300,
+  RS_TACTILE_THR = 0x400, /* + taxel / 4 (startup stream): per-(env, taxel) threshold offsets, drawn once */
+  RS_TACTILE = 0x500      /* + taxel / 2 (step stream): (dropout, addition) uniforms of two taxels per call */
 };
 
 static void startup_env(const lt_cfg* cfg, env_t* E, uint32_t env, const float* sizes) {
@@ -1503,6 +1514,11 @@ static void step_one(const lt_cfg* cfg, void* arena, const lt_layout* L, const f
     lt_oracle_process_action(cfg, actions + e * 12, raw, prev, prev2);
     for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) { E.act_raw[l][k] = raw[k * 4 + l]; E.act_prev[l][k] = prev[k * 4 + l]; E.act_prev2[l][k] = prev2[k * 4 + l]; }
     /* 2. decimation x (PD -> physics -> sensors) */
+    /* tactile ContactSensor cadence [DEP] (update_period 0.025 s, object_transport_student_env_cfg.py:195-201): the taxel
+     * forces refresh at the first sim step after a reset and then whenever the period has elapsed - sim-step indices
+     * 0, 5, 10, ... counted from the reset (the episode step counter supplies the index) */
+    const int tac_every = cfg->tactile_enabled ? (int)(cfg->tactile_update_period / cfg->sim_dt + 0.5f) : 1;
+    int tac_phase = cfg->tactile_enabled ? (int)((E.ep_len * (int64_t)cfg->decimation) % (int64_t)(tac_every > 0 ? tac_every : 1)) : 0;
     for (int d = 0; d < cfg->decimation; ++d) {
       real qd0[4][3];
       memcpy(qd0, E.qd, sizeof(qd0));
@@ -1512,6 +1528,10 @@ static void step_one(const lt_cfg* cfg, void* arena, const lt_layout* L, const f
       for (int s = 0; s < cfg->phys_substeps; ++s) physics_substep(cfg, &E, h, has_object, &rep);
       for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) E.qdd[l][k] = (E.qd[l][k] - qd0[l][k]) / cfg->sim_dt; /* Articulation.data.joint_acc [DEP] */
       sensors_update(cfg, &E, &rep, has_object);
+      if (cfg->tactile_enabled) {
+        if (tac_phase == 0) memcpy(E.plate, rep.plate, sizeof(E.plate));
+        tac_phase = tac_phase + 1 >= tac_every ? 0 : tac_phase + 1;
+      }
     }
     foot_kinematics(&E);
     /* 3. counters */
@@ -1557,6 +1577,7 @@ static void step_one(const lt_cfg* cfg, void* arena, const lt_layout* L, const f
       for (int i = 0; i < LT_REWARD_SLOTS; ++i) E.last_sums[i] = E.sums[i];
       E.episodes_finished += 1; E.last_ep_len = (real)E.ep_len; E.last_term_bits = (real)bits;
       reset_env(cfg, P, &E, (uint32_t)e, step, has_object);
+      memset(E.plate, 0, sizeof(E.plate)); /* ContactSensor.reset [DEP]: the reset envs' net forces are zeroed */
     }
     /* 7. command term compute */
     E.cmd_time_left -= step_dt;
@@ -1613,6 +1634,95 @@ static int any_nonzero(void* arena, const lt_layout* L) {
   return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* K10: tactile observation (student tasks)                                                          */
+/* ------------------------------------------------------------------------------------------------ */
+/* cumulative integral of the piecewise-linear line pressure from the first sample to arc length s */
+static float pressure_integral(const float p[4], float dl, float s) {
+  float acc = 0;
+  for (int k = 0; k < 3; ++k) {
+    float t = s - (float)k * dl;
+    t = t < 0 ? 0 : (t > dl ? dl : t);
+    acc += t * (p[k] + (p[k + 1] - p[k]) * t / (2 * dl));
+  }
+  return acc;
+}
+
+/* Taxel normal forces [17 x 13] from the four plate samples (x[4], y[4], f[4]).  The reference reads one net contact force
+ * per taxel body from PhysX [DEP] (mdp/observations.py:154-158); the restated engine carries the cylinder-on-plate contact
+ * as a 4-sample line, so a taxel's force is the integral, over the part of the contact line inside the taxel's collision box
+ * (generate_locotouch_urdf.py:4-8, locotouch.urdf:816-821), of the piecewise-linear line pressure whose cell integrals are
+ * the sample forces (end cells are half cells).  Engine restatement: parity unpinned (no PhysX taxel-force fixture exists). */
+void lt_oracle_taxel_forces(const float x[4], const float y[4], const float f_in[4], float* out) {
+  float f[4];
+  for (int k = 0; k < 4; ++k) f[k] = f_in[k] > 0 ? f_in[k] : 0;
+  const float dx = x[3] - x[0], dy = y[3] - y[0];
+  const float len = sqrtf(dx * dx + dy * dy);
+  const float ftot = f[0] + f[1] + f[2] + f[3];
+  for (int t = 0; t < LT_TAXEL_ROWS * LT_TAXEL_COLS; ++t) {
+    const int row = t / LT_TAXEL_COLS, col = t - row * LT_TAXEL_COLS;
+    const float cx = LT_TAXEL_X0 - LT_TAXEL_DX * (float)row, cy = LT_TAXEL_Y0 - LT_TAXEL_DY * (float)col;
+    out[t] = 0;
+    if (!(ftot > 0)) continue;
+    if (len < 1e-6f) {
+      if (fabsf(x[0] - cx) <= LT_TAXEL_HALF_X && fabsf(y[0] - cy) <= LT_TAXEL_HALF_Y) out[t] = ftot;
+      continue;
+    }
+    float t0 = 0, t1 = 1;
+    const float pp[2] = {x[0] - cx, y[0] - cy}, dd[2] = {dx, dy}, hh[2] = {LT_TAXEL_HALF_X, LT_TAXEL_HALF_Y};
+    int miss = 0;
+    for (int ax = 0; ax < 2 && !miss; ++ax) {
+      if (fabsf(dd[ax]) < 1e-9f) { if (fabsf(pp[ax]) > hh[ax]) miss = 1; }
+      else {
+        float ta = (-hh[ax] - pp[ax]) / dd[ax], tb = (hh[ax] - pp[ax]) / dd[ax];
+        if (ta > tb) { float tt = ta; ta = tb; tb = tt; }
+        if (ta > t0) t0 = ta;
+        if (tb < t1) t1 = tb;
+      }
+    }
+    if (miss || !(t1 > t0)) continue;
+    const float dl = len / 3;
+    const float p[4] = {f[0] / (0.5f * dl), f[1] / dl, f[2] / dl, f[3] / (0.5f * dl)};
+    out[t] = pressure_integral(p, dl, t1 * len) - pressure_integral(p, dl, t0 * len);
+  }
+}
+
+/* BinaryTactileSignals with explicit uniforms (reference mdp/observations.py:121-126 thresholds, :154-158 contact map,
+ * :166-184 dropout then addition, :307-308 two identical channels).  forces / u_*: [221]; out: [442]. */
+void lt_oracle_tactile_signals_u(const lt_cfg* cfg, const float* forces, const float* u_thr, const float* u_drop, const float* u_add,
+                                 float* out) {
+  const int nt = LT_TAXEL_ROWS * LT_TAXEL_COLS;
+  for (int t = 0; t < nt; ++t) {
+    const float n_min = -cfg->tactile_threshold_noise, n_max = cfg->tactile_threshold_noise;
+    const float thr = cfg->tactile_threshold + (u_thr[t] * (n_max - n_min) + n_min);   /* :126 */
+    int contact = forces[t] > thr;                                                       /* :158 */
+    if (cfg->tactile_dropout_prob > 0 && contact && u_drop[t] < cfg->tactile_dropout_prob) contact = 0;   /* :170-175 */
+    if (cfg->tactile_addition_prob > 0 && !contact && u_add[t] < cfg->tactile_addition_prob) contact = 1; /* :179-184 */
+    out[t] = out[nt + t] = contact ? 1.0f : 0.0f;
+  }
+}
+
+static void tactile_pass(const lt_cfg* cfg, void* arena, const lt_layout* L) {
+  const int nt = LT_TAXEL_ROWS * LT_TAXEL_COLS;
+  const uint64_t step = (uint64_t)((int64_t*)((char*)arena + L->off_counters))[0];
+  for (int64_t e = 0; e < L->n; ++e) {
+    float x[4], y[4], f[4], forces[LT_TAXEL_ROWS * LT_TAXEL_COLS], ut[LT_TAXEL_ROWS * LT_TAXEL_COLS + 4],
+        ud[LT_TAXEL_ROWS * LT_TAXEL_COLS + 2], ua[LT_TAXEL_ROWS * LT_TAXEL_COLS + 2], u[4];
+    for (int k = 0; k < 4; ++k) {
+      x[k] = lt_quad(arena, L, LT_F_PLATE_SAMPLES, 0)[e * 4 + k];
+      y[k] = lt_quad(arena, L, LT_F_PLATE_SAMPLES, 1)[e * 4 + k];
+      f[k] = lt_quad(arena, L, LT_F_PLATE_SAMPLES, 2)[e * 4 + k];
+    }
+    lt_oracle_taxel_forces(x, y, f, forces);
+    for (int t = 0; t < nt; t += 4) { lt_rng4(cfg->seed, (uint32_t)e, ~(uint64_t)0, RS_TACTILE_THR + (uint32_t)(t >> 2), u); memcpy(ut + t, u, sizeof(u)); }
+    for (int t = 0; t < nt; t += 2) {
+      lt_rng4(cfg->seed, (uint32_t)e, step, RS_TACTILE + (uint32_t)(t >> 1), u);
+      ud[t] = u[0]; ua[t] = u[1]; ud[t + 1] = u[2]; ua[t + 1] = u[3];
+    }
+    lt_oracle_tactile_signals_u(cfg, forces, ut, ud, ua, (float*)((char*)arena + L->off_obs_tactile) + e * LT_TACTILE_DIM);
+  }
+}
+
 static void post_step(const lt_cfg* cfg, void* arena, const lt_layout* L) {
   float* P = (float*)((char*)arena + L->off_cmd_params);
   curriculum_decide(cfg, arena, L);
@@ -1622,7 +1732,7 @@ static void post_step(const lt_cfg* cfg, void* arena, const lt_layout* L) {
 
 int lt_oracle_reset_all(const lt_cfg* cfg, void* arena) {
   lt_layout L;
-  lt_layout_init(&L, cfg->num_envs, lt_oracle_obs_dim(cfg));
+  lt_layout_init(&L, cfg->num_envs, lt_oracle_obs_dim(cfg), cfg->tactile_enabled);
   memset(arena, 0, (size_t)L.off_obj_sizes);  /* LT_F_OBJ_SIZES (host input) survives */
   float* P = (float*)((char*)arena + L.off_cmd_params);
   lt_oracle_cmd_params_init(cfg, P);
@@ -1642,6 +1752,7 @@ int lt_oracle_reset_all(const lt_cfg* cfg, void* arena) {
   if (cfg->cur_enabled) { P[24] = 1; P[25] = 1; }
   P[26] = 1;
   counters(arena, &L)[0] = 1;
+  if (cfg->tactile_enabled) tactile_pass(cfg, arena, &L);
   {
     lt_dev_args da;  /* byte-identical to what the HIP library uploads (tests copy whole arenas between the two) */
     memset(&da, 0, sizeof(da));
@@ -1654,7 +1765,7 @@ int lt_oracle_reset_all(const lt_cfg* cfg, void* arena) {
 
 int lt_oracle_step(const lt_cfg* cfg, void* arena, const float* actions, int nthreads) {
   lt_layout L;
-  lt_layout_init(&L, cfg->num_envs, lt_oracle_obs_dim(cfg));
+  lt_layout_init(&L, cfg->num_envs, lt_oracle_obs_dim(cfg), cfg->tactile_enabled);
   uint64_t step = (uint64_t)counters(arena, &L)[0];
   int nz = ((const float*)((char*)arena + L.off_cmd_params))[26] != 0;
   int64_t n = L.n;
@@ -1665,12 +1776,13 @@ int lt_oracle_step(const lt_cfg* cfg, void* arena, const float* actions, int nth
 #endif
   for (int64_t e = 0; e < n; ++e) step_one(cfg, arena, &L, actions, e, step, nz, LT_ORACLE_MODE_STEP);
   post_step(cfg, arena, &L);
+  if (cfg->tactile_enabled) tactile_pass(cfg, arena, &L);
   return 0;
 }
 
 int lt_oracle_eval_terms(const lt_cfg* cfg, void* arena) {
   lt_layout L;
-  lt_layout_init(&L, cfg->num_envs, lt_oracle_obs_dim(cfg));
+  lt_layout_init(&L, cfg->num_envs, lt_oracle_obs_dim(cfg), cfg->tactile_enabled);
   uint64_t step = (uint64_t)counters(arena, &L)[0];
   int nz = any_nonzero(arena, &L);
   for (int64_t e = 0; e < L.n; ++e) step_one(cfg, arena, &L, NULL, e, step, nz, LT_ORACLE_MODE_TERMS);
@@ -1679,6 +1791,6 @@ int lt_oracle_eval_terms(const lt_cfg* cfg, void* arena) {
 
 int64_t lt_oracle_state_bytes(const lt_cfg* cfg) {
   lt_layout L;
-  lt_layout_init(&L, cfg->num_envs, lt_oracle_obs_dim(cfg));
+  lt_layout_init(&L, cfg->num_envs, lt_oracle_obs_dim(cfg), cfg->tactile_enabled);
   return L.total_bytes;
 }

@@ -65,6 +65,11 @@ void lt_oracle_command_update(int64_t ep_len, int zero_steps, const float buf[3]
  * reference's own code; the oracle's step path calls these very functions with Philox uniforms) */
 void lt_oracle_command_resample_u(const lt_cfg* cfg, const float* P, const float ub[3], const float uv[3], float ustand, float utime,
                                   float cmd[3], float cmd_buf[3], float* standing, float* time_left);
+/* K10 tactile (student tasks): taxel forces [221] from the four plate samples; BinaryTactileSignals [442] from taxel forces
+ * and explicit uniforms (reference mdp/observations.py:121-126,154-184,307-308) */
+void lt_oracle_taxel_forces(const float x[4], const float y[4], const float f[4], float* out);
+void lt_oracle_tactile_signals_u(const lt_cfg* cfg, const float* forces, const float* u_thr, const float* u_drop, const float* u_add,
+                                 float* out);
 void lt_oracle_material_u(const float range_static[2], const float range_dynamic[2], const float range_restitution[2],
                           const float u[3], float out[3]);
 void lt_oracle_reset_object_u(const lt_cfg* cfg, const float root_pos[3], const float root_quat[4], const float root_lin[3],

@@ -22,13 +22,13 @@ class OracleVecEnv:
         self.o = oracle_lib.OracleEnv(self.cfg)
         if object_sizes is not None:
             self.cfg.obj_size_explicit = self.o.cfg.obj_size_explicit = 1
-            Layout(num_envs, int(oracle_lib.load().lt_oracle_obs_dim(self.o.cfg))).arr(self.o.arena, "LT_F_OBJ_SIZES")[:num_envs] = \
+            Layout(num_envs, int(oracle_lib.load().lt_oracle_obs_dim(self.o.cfg)), int(self.cfg.tactile_enabled)).arr(self.o.arena, "LT_F_OBJ_SIZES")[:num_envs] = \
                 np.asarray(object_sizes, dtype=np.float32)
         self.o.reset_all()
         self.num_envs, self.device = num_envs, torch.device("cpu")
         self.num_obs = int(oracle_lib.load().lt_oracle_obs_dim(self.o.cfg))
         self.num_privileged_obs = self.num_obs
-        self.layout = Layout(num_envs, self.num_obs)
+        self.layout = Layout(num_envs, self.num_obs, int(self.cfg.tactile_enabled))
         self.max_episode_length = int(self.cfg.max_episode_length)
         self.step_dt = float(self.cfg.sim_dt) * int(self.cfg.decimation)
 
@@ -49,7 +49,11 @@ class OracleVecEnv:
 
     def get_observations(self):
         obs = torch.from_numpy(self._arr("LT_F_OBS_POLICY"))
-        return obs, {"observations": {"policy": obs, "critic": torch.from_numpy(self._arr("LT_F_OBS_CRITIC"))}}
+        groups = {"policy": obs, "critic": torch.from_numpy(self._arr("LT_F_OBS_CRITIC"))}
+        if self.cfg.tactile_enabled:  # student tasks: same groups as LocoTouchVecEnv (object_state = the policy rows' object block)
+            groups["tactile"] = torch.from_numpy(self._arr("LT_F_OBS_TACTILE"))
+            groups["object_state"] = obs[:, self.num_obs - 13 * int(self.cfg.obs_history):]
+        return obs, {"observations": groups}
 
     def reset(self):
         return self.get_observations()

@@ -24,7 +24,13 @@ TOL = {
     "LT_F_FOOT_VEL_W": (2e-3, 1e-3),
     "LT_F_EPISODE_SUMS": (2e-4, 2e-4), "LT_F_LAST_EPISODE_SUMS": (2e-4, 2e-4), "LT_F_REWARD_TERMS": (2e-3, 5e-4),
     "LT_F_CURRICULUM": (2e-4, 2e-4),
+    # tactile plate samples: contact point (x, y) in the trunk frame [position band], normal force [force band]
+    "LT_F_PLATE_SAMPLES": (5e-5, 5e-5),
 }
+PLATE_FORCE_TOL = (5e-2, 2e-3)
+# binary taxel map: a taxel whose force sits within fp32 noise of its threshold may flip; more than this many differing
+# taxels in one env is a failure, not a flip
+MAX_TAXEL_FLIPS_PER_ENV = 4
 # per-term overrides inside LT_F_REWARD_TERMS (unweighted terms): the L2 norms of joint acc / vel / torque inherit the
 # tolerance of their inputs
 TERM_TOL = {C["LT_R_JOINT_ACCELERATION"]: (2.0, 2e-3), C["LT_R_JOINT_VELOCITY"]: (5e-3, 5e-4), C["LT_R_JOINT_TORQUE"]: (5e-3, 5e-4),
@@ -46,11 +52,11 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
     deciding quantity sat within rounding of its threshold.  Callers bound the total over a run as well."""
     n = int(cfg.num_envs)
     obs_dim = (45 if cfg.task == C["LT_TASK_LOCOMOTION"] else 58) * int(cfg.obs_history)
-    L = Layout(n, obs_dim)
+    L = Layout(n, obs_dim, int(cfg.tactile_enabled))
     assert dev.shape == ref.shape == (L.total_bytes,), (dev.shape, ref.shape, L.total_bytes)
     report, failures, flip_envs, event_envs, soft_envs = [], [], set(), set(), {}
     for name in QUAD_FIELDS:
-        if name in skip:
+        if name in skip or (name == "LT_F_PLATE_SAMPLES" and not L.tactile):
             continue
         a, b = L.vec(dev, name), L.vec(ref, name)
         if name == "LT_F_GAIT_FLAGS":
@@ -63,6 +69,9 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
                 rtol = np.full(a.shape[1], rtol, np.float32)
                 for col, (ta, tr) in TERM_TOL.items():
                     atol[col], rtol[col] = ta, tr
+            if name == "LT_F_PLATE_SAMPLES":  # columns 8..11 = normal force of the four samples
+                atol = np.array([atol] * 8 + [PLATE_FORCE_TOL[0]] * 4, np.float32)
+                rtol = np.array([rtol] * 8 + [PLATE_FORCE_TOL[1]] * 4, np.float32)
             with np.errstate(invalid="ignore"):
                 badm = ~(np.abs(a - b) <= atol + rtol * np.abs(b))
             badm |= ~np.isfinite(a)
@@ -80,6 +89,20 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
         if name in skip or name.startswith("_"):
             continue
         a, b = L.arr(dev, name), L.arr(ref, name)
+        if name == "LT_F_OBS_TACTILE":
+            if not L.tactile:
+                continue
+            a, b = a[:n], b[:n]
+            assert np.isin(a, (0.0, 1.0)).all(), "tactile rows must be binary"
+            per_env = (a != b).sum(axis=1) // 2  # two identical channels
+            bad = per_env > 0
+            err = float(per_env.max()) if n else 0.0
+            if (per_env > MAX_TAXEL_FLIPS_PER_ENV).any():
+                hard.append((name, err, np.nonzero(per_env > MAX_TAXEL_FLIPS_PER_ENV)[0][:5].tolist()))
+            else:
+                flip_envs |= set(np.nonzero(bad)[0].tolist())
+            report.append((name, err, int(bad.sum())))
+            continue
         if name in ("LT_F_OBS_POLICY", "LT_F_OBS_CRITIC", "LT_F_REWARD"):
             a, b = a[:n], b[:n]
             atol, rtol = obs_tol

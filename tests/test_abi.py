@@ -38,27 +38,40 @@ def test_cfg_struct_mirror_and_defaults():
     assert lib.lt_cfg_default(7, ctypes.byref(loco)) == C["LT_EINVAL"]
 
 
-@pytest.mark.parametrize("task,n", [(0, 4096), (1, 4096), (1, 100), (1, 17)])
-def test_layout_mirror_matches_c(task, n):
+@pytest.mark.parametrize("task,n,tactile", [(0, 4096, 0), (1, 4096, 0), (1, 100, 0), (1, 17, 0), (1, 405, 1), (1, 20, 1)])
+def test_layout_mirror_matches_c(task, n, tactile):
     lib = _abi.load()
     cfg = _abi.default_cfg(task, num_envs=n)
+    cfg.tactile_enabled = tactile
+    cfg.tactile_update_period = 0.025
     h = ctypes.c_void_p()
     assert lib.lt_env_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
     nbytes = ctypes.c_size_t()
     assert lib.lt_env_state_bytes(ctypes.byref(cfg), ctypes.byref(nbytes)) == 0
-    L = Layout(n, lib.lt_cfg_obs_dim(ctypes.byref(cfg)))
+    L = Layout(n, lib.lt_cfg_obs_dim(ctypes.byref(cfg)), tactile)
     assert L.total_bytes == nbytes.value
     v = _abi.LtView()
     for name in QUAD_FIELDS:
+        if name == "LT_F_PLATE_SAMPLES" and not tactile:  # the tactile fields exist only with cfg.tactile_enabled
+            assert lib.lt_env_get_view(h, C[name], ctypes.byref(v)) == C["LT_EINVAL"]
+            continue
         assert lib.lt_env_get_view(h, C[name], ctypes.byref(v)) == 0
         assert (v.ptr or 0) == L.quad_off[name], name
         assert list(v.shape) == [n, field_quads(name), 4] and list(v.stride) == [4, L.npad * 4, 1]
     for name, (off, dtype, shape) in L.plain.items():
         if name.startswith("_"):
             continue  # internal regions (device args block) have no public view
+        if name == "LT_F_OBS_TACTILE" and not tactile:
+            assert lib.lt_env_get_view(h, C[name], ctypes.byref(v)) == C["LT_EINVAL"]
+            continue
         assert lib.lt_env_get_view(h, C[name], ctypes.byref(v)) == 0
         assert (v.ptr or 0) == off, name
     assert lib.lt_env_get_view(h, 63, ctypes.byref(v)) == C["LT_EINVAL"]
+    rc = lib.lt_env_get_view(h, C["LT_F_OBS_OBJECT_STATE"], ctypes.byref(v))  # a strided window of the policy rows
+    if task == 1:
+        assert rc == 0 and (v.ptr or 0) == L.plain["LT_F_OBS_POLICY"][0] + 270 * 4 and list(v.shape)[:2] == [n, 78] and list(v.stride)[:2] == [348, 1]
+    else:
+        assert rc == C["LT_EINVAL"]
     # error behaviour: stepping / resetting without a bound arena fails loudly, never silently
     assert lib.lt_env_reset_all(h, None) == C["LT_EFAULT"]
     dummy = (ctypes.c_float * 12)()

@@ -13,7 +13,8 @@ from tests.parity_util import Tally, compare_arenas, compare_host_arenas, device
 pytestmark = pytest.mark.gpu
 C = _abi.CONSTS
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TASKS = {"teacher": "Isaac-RandCylinderTransportTeacher-LocoTouch-v1", "locomotion": "Isaac-Locomotion-LocoTouch-v1"}
+TASKS = {"teacher": "Isaac-RandCylinderTransportTeacher-LocoTouch-v1", "locomotion": "Isaac-Locomotion-LocoTouch-v1",
+         "student": "Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-v1"}
 
 
 def make_env(task, n, seed=11, **kw):
@@ -25,21 +26,21 @@ def make_env(task, n, seed=11, **kw):
     return env
 
 
-@pytest.mark.parametrize("task,n", [("teacher", 64), ("teacher", 37), ("locomotion", 48)])
+@pytest.mark.parametrize("task,n", [("teacher", 64), ("teacher", 37), ("locomotion", 48), ("student", 53)])
 def test_reset_all_matches_oracle(task, n):
     """Startup + reset events (counter-based Philox: same draws on both sides) and the first observation."""
     env = make_env(task, n)
     ora = O.OracleEnv(env.cfg)
     ora.reset_all()
     compare_arenas(env, ora, what=f"reset_all {task}")
-    L = Layout(n, env.num_obs)
+    L = Layout(n, env.num_obs, int(env.cfg.tactile_enabled))
     a = device_arena_to_host(env)
     assert (L.arr(a, "LT_F_EP_LEN")[:n] == 0).all() and L.arr(a, "LT_F_COUNTERS")[0] == 1
     obs = L.arr(a, "LT_F_OBS_POLICY")[:n]
     frame = env.num_obs // 6
     assert frame in (45, 58)
     # first push after reset fills all 6 history slots: every term block repeats its newest frame
-    dims = [3, 3, 3, 12, 12, 12] + ([13] if task == "teacher" else [])
+    dims = [3, 3, 3, 12, 12, 12] + ([13] if task != "locomotion" else [])
     off = 0
     for d in dims:
         blk = obs[:, off:off + 6 * d].reshape(n, 6, d)
@@ -89,6 +90,8 @@ def test_registered_presets_and_explicit_cylinders_match_oracle():
 
 @pytest.mark.parametrize("task,n,steps,phys,pre", [
     ("teacher", 64, 160, 1, 0), ("locomotion", 64, 120, 1, 0), ("teacher", 32, 40, 2, 0),
+    # student task: + tactile refresh cadence, plate samples, lt_tactile_kernel rows (405 = the registration's env count)
+    ("student", 405, 100, 1, 0),
     # > 8192 envs: launch_step picks the register-path (PREFETCH=false) history variant, which shifts the rows in place
     ("teacher", 8208, 16, 1, 45), ("locomotion", 8208, 12, 1, 45)])
 def test_step_parity_resynced(task, n, steps, phys, pre):
@@ -103,9 +106,9 @@ def test_step_parity_resynced(task, n, steps, phys, pre):
     g = torch.Generator().manual_seed(3)
     for _ in range(pre):
         ora.step((0.6 * torch.randn(n, 12, generator=g)).numpy(), nthreads=8)
-    n_reset, n_shift = 0, 0
+    n_reset, n_shift, lit = 0, 0, 0
     tally = Tally(n)
-    L = Layout(n, env.num_obs)
+    L = Layout(n, env.num_obs, int(env.cfg.tactile_enabled))
     for t in range(steps):
         scale = 1.0 if pre else (0.0 if t < 10 else (0.3 if t < steps // 2 else 1.0))
         act = scale * torch.randn(n, 12, generator=g)
@@ -120,7 +123,15 @@ def test_step_parity_resynced(task, n, steps, phys, pre):
         d = L.arr(ora.arena, "LT_F_DONES")[:n]
         n_reset += int(d.sum())
         n_shift += int((d == 0).sum())
+        if task == "student":
+            ex = env.get_observations()[1]["observations"]
+            assert set(ex) == {"policy", "critic", "tactile", "object_state"}
+            assert ex["tactile"].shape == (n, 442) and ex["object_state"].shape == (n, 78)
+            assert torch.equal(ex["object_state"], ex["policy"][:, 270:])  # a zero-copy window of the policy rows
+            lit += int(ex["tactile"][:, :221].sum())
     print(tally.line(f"{task} n={n} phys={phys}"))
+    if task == "student":
+        assert lit > 3 * n * steps // 2, "the carried cylinders must light taxels"
     assert n_reset > 0, "the sequence must include resets"
     assert n_shift > n_reset, "most rows must really shift (not fill)"
     assert tally.flips <= 0.01 * n * steps, f"too many thresholded-contact flips: {tally.flips}"

@@ -4,6 +4,7 @@ explicit-uniform entry points - which its step path calls with Philox uniforms -
 uniforms with lt_cfg_default's parameters.  CPU only.
 
   C4 commands.py:517-559   E3 events.py:160-196   E6 events.py:85-109   O1 (noise) observations.py:71-83
+  K10 observations.py:121-126,154-184,281-308 (BinaryTactileSignals of the student task)
 """
 import ctypes
 import os
@@ -114,3 +115,31 @@ def test_noisy_object_state_observation_matches_reference_replay():
             lib.lt_oracle_object_state_obs(ctypes.byref(cfg), ctypes.byref(ti), _arr(g["osn_u16"][t, e]), out)
             np.testing.assert_allclose(np.array(out[:]), g["osn_out"][t, e], rtol=2e-5, atol=3e-6, err_msg=f"t {t} env {e}")
     assert 0 < n_noncontact < T * n
+
+
+def test_binary_tactile_matches_reference_replay():
+    """Thresholds (+ per-taxel offset drawn once), contact map, dropout THEN addition (a dropped taxel can be re-added), two
+    identical channels - with the student preset's parameters, which the golden's resolved term params pin."""
+    g = np.load(GOLD)
+    lib = O.load()
+    cfg = _abi.preset_cfg("Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-v1", num_envs=16)
+    thr, nmin, nmax, pdrop, padd = g["tac_params"]
+    assert abs(cfg.tactile_threshold - thr) < 1e-7 and abs(cfg.tactile_threshold_noise - nmax) < 1e-7 and abs(nmin + nmax) < 1e-12
+    assert abs(cfg.tactile_dropout_prob - pdrop) < 1e-9 and abs(cfg.tactile_addition_prob - padd) < 1e-9
+    T, n, nt = g["tac_forces_local"].shape
+    assert nt == C["LT_TACTILE_ROWS"] * C["LT_TACTILE_COLS"] and 2 * nt == C["LT_TACTILE_DIM"]
+    dropped = added = readded = 0
+    for t in range(T):
+        for e in range(n):
+            f = np.ascontiguousarray(g["tac_forces_local"][t, e], np.float32)
+            ut = np.ascontiguousarray(g["tac_u_thr"][e], np.float32)
+            ud = np.ascontiguousarray(g["tac_u_drop"][t, e], np.float32)
+            ua = np.ascontiguousarray(g["tac_u_add"][t, e], np.float32)
+            out = np.zeros(2 * nt, np.float32)
+            lib.lt_oracle_tactile_signals_u(ctypes.byref(cfg), O.fptr(f), O.fptr(ut), O.fptr(ud), O.fptr(ua), O.fptr(out))
+            assert np.array_equal(out, g["tac_out"][t, e]), (t, e, np.nonzero(out != g["tac_out"][t, e]))
+            raw = f > np.float32(thr) + (ut * np.float32(nmax - nmin) + np.float32(nmin))
+            dropped += int((raw & (ud < pdrop)).sum())
+            added += int((~raw & (ua < padd)).sum())
+            readded += int((raw & (ud < pdrop) & (ua < padd)).sum())
+    assert dropped >= 5 and added >= 20  # the vectors exercise both corruption branches

@@ -1,0 +1,113 @@
+"""Tactile path of the CPU oracle (student tasks): the taxel-force restatement's own properties and the sensor cadence.
+The binary-map pipeline itself is pinned to the reference by tests/test_oracle_replay.py; the taxel forces are an engine
+restatement (the reference reads them from PhysX), so what is checked here is what the model promises: the line pressure
+integrates to the sample forces, a taxel receives pressure x (length of the contact line inside its box), boxes overlap as in
+the URDF, and the samples refresh at the ContactSensor's 40 Hz cadence.  CPU only."""
+import ctypes
+
+import numpy as np
+
+from locotouch_amd import _abi
+from locotouch_amd.layout import Layout
+from tests import oracle_lib as O
+
+C = _abi.CONSTS
+STUDENT = "Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-v1"
+ROWS, COLS = C["LT_TACTILE_ROWS"], C["LT_TACTILE_COLS"]
+X0, Y0, DX, DY, HX, HY = 0.1144, 0.0768, 0.0143, 0.0128, 0.00915, 0.00875  # include/lt_go1_model.h LT_TAXEL_*
+
+
+def taxel_forces(x, y, f):
+    out = np.zeros(ROWS * COLS, np.float32)
+    a = [np.ascontiguousarray(v, np.float32) for v in (x, y, f)]
+    O.load().lt_oracle_taxel_forces(O.fptr(a[0]), O.fptr(a[1]), O.fptr(a[2]), O.fptr(out))
+    return out.reshape(ROWS, COLS)
+
+
+def test_uniform_line_pressure_times_length_inside_each_box():
+    """A uniformly loaded line along y through a taxel row's centres: every taxel gets F / L x |line inside its box|."""
+    F, row = 6.0, 5
+    xs = X0 - DX * row
+    ya, yb = -0.0631, 0.0417
+    x = [xs] * 4
+    y = list(np.linspace(ya, yb, 4))
+    f = [F / 6, F / 3, F / 3, F / 6]  # cell integrals of a constant pressure (end cells are half cells)
+    tf = taxel_forces(x, y, f)
+    L = yb - ya
+    for col in range(COLS):
+        cy = Y0 - DY * col
+        inside = max(0.0, min(yb, cy + HY) - max(ya, cy - HY))
+        assert abs(tf[row, col] - F / L * inside) < 2e-5, (col, tf[row, col], F / L * inside)
+    assert (np.delete(tf, row, axis=0) == 0).all()  # boxes of neighbouring ROWS end 5.15 mm short of this line
+    # boxes overlap by 2 * HY - DY along y: the row sum exceeds the applied force by exactly the doubly covered length
+    cover = sum(max(0.0, min(yb, Y0 - DY * c + HY) - max(ya, Y0 - DY * c - HY)) for c in range(COLS))
+    assert abs(tf.sum() - F / L * cover) < 1e-4 and tf.sum() > F
+
+
+def test_oblique_line_and_linear_pressure_conserve_the_sample_forces():
+    """Any line inside the grid: summing taxel forces over a PARTITION of the plane (each point counted once) gives back the
+    summed sample forces; with overlapping boxes the sum can only be larger, and never exceeds the 4-fold cover."""
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        p0 = np.array([rng.uniform(-0.09, 0.09), rng.uniform(-0.06, 0.06)])
+        p3 = np.array([rng.uniform(-0.09, 0.09), rng.uniform(-0.06, 0.06)])
+        pts = np.linspace(p0, p3, 4)
+        f = rng.uniform(0.0, 2.0, 4)
+        tf = taxel_forces(pts[:, 0], pts[:, 1], f)
+        assert (tf >= -1e-6).all()
+        assert f.sum() * (1 - 1e-4) - 1e-5 <= tf.sum() <= 4 * f.sum() + 1e-5
+    # swapping the line's direction changes nothing
+    tf_a = taxel_forces([0.05, 0.02, -0.01, -0.04], [0.03, 0.01, -0.01, -0.03], [0.2, 0.9, 0.4, 0.1])
+    tf_b = taxel_forces([-0.04, -0.01, 0.02, 0.05], [-0.03, -0.01, 0.01, 0.03], [0.1, 0.4, 0.9, 0.2])
+    np.testing.assert_allclose(tf_a, tf_b, atol=2e-6)
+
+
+def test_degenerate_and_unloaded_lines():
+    assert (taxel_forces([0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]) == 0).all()
+    # negative (adhesive) sample forces are not sensor load
+    assert (taxel_forces([0.01, 0.02, 0.03, 0.04], [0, 0, 0, 0], [-1, -1, -1, -1]) == 0).all()
+    # a line collapsed to a point loads the taxel(s) whose box holds it with the whole force
+    cx, cy = X0 - DX * 8, Y0 - DY * 6
+    tf = taxel_forces([cx] * 4, [cy] * 4, [0.5, 0.5, 0.5, 0.5])
+    assert tf[8, 6] == 2.0 and tf.sum() == 2.0
+    # off the sensor: nothing
+    assert (taxel_forces([0.2] * 4, [0.0, 0.01, 0.02, 0.03], [1, 1, 1, 1]) == 0).all()
+
+
+def test_student_env_tactile_rows_and_sensor_cadence():
+    """Reset + steps of the student task on the oracle: binary two-channel rows; zero forces right after a reset (only
+    `addition` noise can light a taxel); the plate samples refresh on sim steps 0, 5, 10, ... since the reset - so an env
+    step whose four sim steps hold no multiple of 5 (ep_len % 5 == 4 before the step) leaves them untouched."""
+    n = 24
+    cfg = _abi.preset_cfg(STUDENT, num_envs=n, seed=5)
+    assert cfg.tactile_enabled == 1 and cfg.max_episode_length == 500 and cfg.num_envs == n
+    ora = O.OracleEnv(cfg)
+    ora.reset_all()
+    L = Layout(n, 348, 1)
+    tac = L.arr(ora.arena, "LT_F_OBS_TACTILE")[:n]
+    assert tac.shape == (n, 442) and np.isin(tac, (0.0, 1.0)).all() and (tac[:, :221] == tac[:, 221:]).all()
+    assert tac.mean() < 0.03  # all forces zero after the reset: only the 0.5 % additions
+    assert (L.vec(ora.arena, "LT_F_PLATE_SAMPLES") == 0).all()
+    lit, stale_steps = [], 0
+    for t in range(40):
+        ep0 = L.arr(ora.arena, "LT_F_EP_LEN")[:n].copy()
+        before = L.vec(ora.arena, "LT_F_PLATE_SAMPLES").copy()
+        ora.step(np.zeros((n, 12), np.float32))
+        after = L.vec(ora.arena, "LT_F_PLATE_SAMPLES")
+        done = L.arr(ora.arena, "LT_F_DONES")[:n] != 0
+        stale = (ep0 % 5 == 4) & ~done
+        assert (after[stale] == before[stale]).all()
+        stale_steps += int(stale.sum())
+        fresh = (ep0 % 5 != 4) & ~done & (t > 12)  # the cylinder has landed: a refresh sees a loaded, moving contact line
+        if fresh.any():  # (an env whose cylinder has rolled off the plate keeps all-zero samples)
+            assert (np.abs(after[fresh] - before[fresh]).sum(axis=1) > 0).mean() > 0.7
+        assert (after[done] == 0).all()
+        tac = L.arr(ora.arena, "LT_F_OBS_TACTILE")[:n]
+        assert np.isin(tac, (0.0, 1.0)).all() and (tac[:, :221] == tac[:, 221:]).all()
+        lit.append(tac[:, :221].sum(axis=1))
+    assert stale_steps > 0
+    lit = np.array(lit)
+    # a carried cylinder of length 0.1 .. 0.4 m presses a band of taxels: some, never most of the 221
+    assert np.median(lit[15:30]) >= 3 and lit.max() < 120, (np.median(lit[15:30]), lit.max())
+    # object_state group = the object block of the policy rows
+    assert L.arr(ora.arena, "LT_F_OBS_POLICY").shape[1] == 348

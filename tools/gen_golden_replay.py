@@ -11,6 +11,7 @@ Philox uniforms, which is what the HIP kernels are compared with.
   E3  randomize_friction_restitution.__call__                            locotouch/mdp/events.py:160-196
   E6  ResetObjectStateUniform.__call__                                   locotouch/mdp/events.py:85-109
   O1  object_state_in_robot_frame, add_uniform_noise branch              locotouch/mdp/observations.py:71-83
+  K10 BinaryTactileSignals (thresholds, dropout, addition)               locotouch/mdp/observations.py:121-126,154-184,281-308
 
 Runs ONLY in the build container (imports /root/reference read-only on the throw-away isaaclab stand-in); writes data only:
 tests/golden/mdp_replay.npz.  Parameters come from the reference's RESOLVED task config
@@ -305,6 +306,64 @@ def gen_object_state_noise(cfg, out, n=96, T=3, seed=51):
     out["osn_scale"] = np.array(oc.params["scale"], np.float64)
 
 
+def gen_binary_tactile(out, n=40, T=4, seed=61):
+    """K10: BinaryTactileSignals of the student task, resolved term params (object_transport_student_env_cfg.py:13-43):
+    per-(env, taxel) thresholds drawn at construction, dropout then addition per call; the force-noise draws that follow
+    do not reach the binary map.  Taxel forces are synthetic (a pressed band + scattered near-threshold taxels)."""
+    from isaaclab.managers import ObservationTermCfg, SceneEntityCfg
+
+    scfg = runtime.load_cfg_from_registry("Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-v1", "env_cfg_entry_point")
+    tc = scfg.observations.tactile.tactile_signals
+    assert tc.func is mdp.BinaryTactileSignals
+    R, Cc = tc.params["tactile_signal_shape"]
+    nt = R * Cc
+    names = ["trunk"] + [f"sensor_{r + 1:02d}_{c + 1:02d}" for r in range(R) for c in range(Cc)]
+    env = FakeEnv(n)
+    env.scene["robot"] = GG.FakeAsset(names)
+    env.scene.sensors["tactile_contact_sensor"] = GG.FakeAsset(names)
+    params = dict(tc.params)
+    ac, sc = SceneEntityCfg("robot", body_names="sensor_.*"), SceneEntityCfg("tactile_contact_sensor", body_names="sensor_.*")
+    ac.body_ids = sc.body_ids = list(range(1, 1 + nt))
+    params["asset_cfg"], params["sensor_cfg"] = ac, sc
+    tape = Tape(seed)
+    with replay(tape):
+        term = mdp.BinaryTactileSignals(ObservationTermCfg(func=mdp.BinaryTactileSignals, params=params), env)
+    assert tape.log == [("rand_like", n * nt, 0)]
+    u_thr = tape.u[:n * nt].reshape(n, nt).clone()
+    g = torch.Generator().manual_seed(seed + 1)
+    rec = {k: [] for k in ("forces_local", "u_drop", "u_add", "out")}
+    for t in range(T):
+        quat = rand_quat(g, n, rp=0.3)
+        f_local = torch.zeros(n, R, Cc)
+        for e in range(n):  # a band of pressed taxels (a cylinder lying across the plate) ...
+            r0, w = int(torch.randint(0, R - 2, (1,), generator=g)), int(torch.randint(1, 3, (1,), generator=g))
+            c0, c1 = sorted(int(x) for x in torch.randint(0, Cc, (2,), generator=g))
+            f_local[e, r0:r0 + w, c0:c1 + 1] = U(g, (w, c1 + 1 - c0), 0.0, 0.6)
+        near = torch.rand(n, R, Cc, generator=g) < 0.15  # ... and taxels within the threshold-noise band 0.04 .. 0.06 N
+        f_local = torch.where(near, U(g, (n, R, Cc), 0.035, 0.065), f_local)
+        f_body = torch.cat([U(g, (n, nt, 2), -0.2, 0.2), -f_local.reshape(n, nt, 1)], dim=2)  # force ON the taxel, sensor frame
+        q = quat[:, None, :].expand(n, nt, 4)
+        env.scene["robot"].data.body_quat_w = torch.cat([quat[:, None, :], q], dim=1)
+        env.scene.sensors["tactile_contact_sensor"].data.net_forces_w = torch.cat(
+            [torch.zeros(n, 1, 3), M.quat_apply(q.reshape(-1, 4), f_body.reshape(-1, 3)).reshape(n, nt, 3)], dim=1)
+        tape = Tape(seed + 10 + t)
+        with replay(tape):
+            obs = term(env, **params)
+        kinds = [(k, c) for k, c, _ in tape.log]
+        assert kinds[0] == ("rand_like", n * nt) and kinds[2] == ("rand_like", n * nt), kinds[:4]
+        u_drop = tape.u[:n * nt].reshape(n, nt)
+        p2 = tape.log[2][2]
+        u_add = tape.u[p2:p2 + n * nt].reshape(n, nt)
+        rec["forces_local"].append(term.original_normal_forces.reshape(n, nt).clone())  # computed by the reference itself (:154-157)
+        rec["u_drop"].append(u_drop.clone()), rec["u_add"].append(u_add.clone()), rec["out"].append(obs.clone())
+        assert obs.shape == (n, 2 * nt)
+    for kk, v in rec.items():
+        out["tac_" + kk] = torch.stack(v).numpy()
+    out["tac_u_thr"] = u_thr.numpy()
+    out["tac_params"] = np.array([params["contact_threshold"], params["threshold_n_min"], params["threshold_n_max"],
+                                  params["contact_dropout_prob"], params["contact_addition_prob"]], np.float64)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -314,6 +373,7 @@ if __name__ == "__main__":
     gen_material(cfg, out)
     gen_reset_object(cfg, out)
     gen_object_state_noise(cfg, out)
+    gen_binary_tactile(out)
     np.savez_compressed(os.path.join(OUT, "mdp_replay.npz"), **out)
     print("mdp_replay.npz", {k: v.shape for k, v in out.items()})
     _ = GG
