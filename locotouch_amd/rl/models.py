@@ -68,9 +68,9 @@ class Memory(nn.Module):
         if dones is None:
             self.hidden_states = None
             return
-        mask = dones.reshape(-1) != 0
+        keep = (dones.reshape(-1) == 0)
         for state in (self.hidden_states if isinstance(self.hidden_states, tuple) else (self.hidden_states,)):
-            state[:, mask, :] = 0.0
+            state.mul_(keep.to(state.dtype)[None, :, None])  # masked multiply: no host sync (a bool-mask index_put has one)
 
     def get_hidden_states(self):
         return self.hidden_states
