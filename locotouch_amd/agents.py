@@ -30,6 +30,11 @@ _EXPERIMENTS = {
     "Isaac-RandCylinderTransportTeacher-LocoTouch": "locotouch_rand_cylinder_transport_teacher",
 }
 TRAIN_CFGS = {f"{k}{suffix}": dict(_BASE, experiment_name=v) for k, v in _EXPERIMENTS.items() for suffix in ("-v1", "-Play-v1")}
+# the student registrations carry the rand-cylinder TEACHER's runner cfg (config/locotouch/__init__.py:133,143): it names the
+# experiment the teacher checkpoint is loaded from
+for _suffix in ("-v1", "-Play-v1"):
+    TRAIN_CFGS[f"Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch{_suffix}"] = dict(
+        _BASE, experiment_name="locotouch_rand_cylinder_transport_teacher")
 
 
 def train_cfg(task: str) -> dict:

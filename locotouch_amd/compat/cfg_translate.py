@@ -92,7 +92,14 @@ def task_kind(env_cfg) -> int:
     return C["LT_TASK_TRANSPORT_TEACHER"] if getattr(env_cfg.scene, "object", None) is not None else C["LT_TASK_LOCOMOTION"]
 
 
-def translate(env_cfg, seed: int | None = None) -> "_abi.LtCfg":
+# Observation groups of the student -Play- registration that exist for visualisation only: all tactile formats side by side
+# (object_transport_student_env_cfg.py:171-177), read by nothing but the ROS publisher block the reference keeps switched off
+# (distillation.py:141 `self.publish_tactile_ros_topic = False`, :190-199).  `translate(..., omit_groups=...)` leaves exactly
+# these out - by name, with a warning - and still raises on any other unknown group.
+VISUALISATION_ONLY_GROUPS = ("original_tactile", "processed_tactile")
+
+
+def translate(env_cfg, seed: int | None = None, omit_groups: tuple = ()) -> "_abi.LtCfg":
     kind = task_kind(env_cfg)
     has_obj = kind != C["LT_TASK_LOCOMOTION"]
     cfg = _abi.default_cfg(kind, num_envs=int(env_cfg.scene.num_envs), seed=int(seed if seed is not None else (getattr(env_cfg, "seed", None) or 42)))
@@ -227,6 +234,12 @@ def translate(env_cfg, seed: int | None = None) -> "_abi.LtCfg":
 
     # ---- observations (policy group: noisy; critic: same terms, corruption off) ----
     groups = _terms(env_cfg.observations)
+    omitted = sorted(set(groups) & set(omit_groups))
+    if omitted:
+        import warnings
+
+        warnings.warn(f"observation groups {omitted} are visualisation-only in the reference and are not computed by this env")
+        groups = {k: v for k, v in groups.items() if k not in omitted}
     extra = set(groups) - {"policy", "critic", "tactile", "object_state"}
     _need(not extra, f"observation groups {sorted(extra)} have no fused implementation "
                      "(only the binary tactile map and the object-state group of the student tasks do)")

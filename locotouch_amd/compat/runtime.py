@@ -118,7 +118,7 @@ def translate_env_cfg(task_id: str, cfg):
 
     if cfg is None:
         return _abi.preset_cfg(task_id), None
-    lt = cfg_translate.translate(cfg)
+    lt = cfg_translate.translate(cfg, omit_groups=cfg_translate.VISUALISATION_ONLY_GROUPS)
     sizes = None
     spawn = getattr(getattr(cfg.scene, "object", None), "spawn", None)
     if spawn is not None and type(spawn).__name__ == "MultiAssetSpawnerCfg":
@@ -149,8 +149,16 @@ def make_env(task_id: str, cfg):
 # isaaclab.app, isaaclab_tasks.utils, isaaclab_rl.rsl_rl
 # ---------------------------------------------------------------------------------------------------------
 class _App:
+    """`simulation_app`: there is no window to close, so the play loops (`while simulation_app.is_running()`, play.py:139,
+    distillation.py:181) end after LT_APP_MAX_STEPS polls when that variable is set (unset = run until interrupted)."""
+
+    def __init__(self):
+        self._polls = 0
+        self._limit = int(os.environ["LT_APP_MAX_STEPS"]) if os.environ.get("LT_APP_MAX_STEPS") else None
+
     def is_running(self) -> bool:
-        return True
+        self._polls += 1
+        return self._limit is None or self._polls <= self._limit
 
     def close(self) -> None:
         pass
@@ -188,7 +196,21 @@ def load_cfg_from_registry(task_name: str, entry_point_key: str):
                 return yaml.safe_load(f)
         mod, attr = entry.split(":")
         entry = getattr(importlib.import_module(mod), attr)
-    return entry() if callable(entry) else entry
+    cfg = entry() if callable(entry) else entry
+    # LT_CFG_OVERRIDES='{"distillation_cfg_entry_point": {"bc_data_steps": 2000, "num_iterations": 2}}': dotted-path edits per
+    # entry point, for the cfgs the reference scripts offer no command-line override for (distill.py has no Hydra hook)
+    ov = os.environ.get("LT_CFG_OVERRIDES")
+    if ov:
+        import json
+
+        for dotted, value in json.loads(ov).get(entry_point_key, {}).items():
+            obj, parts = cfg, dotted.split(".")
+            for p_ in parts[:-1]:
+                obj = getattr(obj, p_)
+            if not hasattr(obj, parts[-1]):
+                raise AttributeError(f"LT_CFG_OVERRIDES: {entry_point_key} has no field {dotted!r}")
+            setattr(obj, parts[-1], value)
+    return cfg
 
 
 def parse_env_cfg(task_name: str, device: str = "cuda:0", num_envs: int | None = None, use_fabric: bool | None = None):
@@ -296,6 +318,58 @@ def _rsl_rl_cfgs():
     return RslRlPpoActorCriticCfg, RslRlPpoAlgorithmCfg, RslRlOnPolicyRunnerCfg
 
 
+class ObsGroups(tuple):
+    """What `get_observations()` returns.  The reference is written against TWO generations of the IsaacLab wrapper (quirk Q1):
+    its runner / play.py / ReplayBuffer.evaluate unpack `obs, extras = env.get_observations()` (on_policy_runner.py:158,
+    play.py:122, replay_buffer.py:137) while its distillation code indexes a group mapping - `env_obs["policy"]`,
+    `env_obs.items()` (distillation.py:51-54, replay_buffer.py:37-39).  This object is the 2-tuple AND the mapping."""
+
+    def __new__(cls, obs, extras):
+        return super().__new__(cls, (obs, extras))
+
+    @property
+    def groups(self) -> dict:
+        return tuple.__getitem__(self, 1)["observations"]
+
+    def __getitem__(self, k):
+        return self.groups[k] if isinstance(k, str) else tuple.__getitem__(self, k)
+
+    def __contains__(self, k):
+        return k in self.groups if isinstance(k, str) else tuple.__contains__(self, k)
+
+    def keys(self):
+        return self.groups.keys()
+
+    def values(self):
+        return self.groups.values()
+
+    def items(self):
+        return self.groups.items()
+
+
+class ObsTensor(torch.Tensor):
+    """First element of `step()`: the policy rows (what the runner / play.py feed to the policy) that can also be indexed by
+    group name and iterated with `.items()` (what the distillation code does with `next_obs`, replay_buffer.py:52-54).
+    Shares the policy rows' storage; every torch operation on it returns a plain Tensor."""
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @staticmethod
+    def wrap(obs: torch.Tensor, groups: dict) -> "ObsTensor":
+        t = torch.Tensor._make_subclass(ObsTensor, obs)
+        t._groups = groups
+        return t
+
+    def __getitem__(self, k):
+        return self._groups[k] if isinstance(k, str) else torch.Tensor.__getitem__(self.as_subclass(torch.Tensor), k)
+
+    def keys(self):
+        return self._groups.keys()
+
+    def items(self):
+        return self._groups.items()
+
+
 class RslRlVecEnvWrapper:
     """`RslRlVecEnvWrapper(env)`: the VecEnv protocol of loco_rl/loco_rl/env/vec_env.py:12-101 over what gym.make returned.
     The HIP env already speaks that protocol, so this only forwards (and performs the reset the IsaacLab wrapper does)."""
@@ -326,15 +400,18 @@ class RslRlVecEnvWrapper:
         self.env.unwrapped.episode_length_buf = value
 
     def get_observations(self):
-        return self.env.unwrapped.get_observations()
+        obs, extras = self.env.unwrapped.get_observations()
+        return ObsGroups(obs, extras)
 
     def reset(self):
-        return self.env.unwrapped.reset()
+        obs, extras = self.env.unwrapped.reset()
+        return ObsGroups(obs, extras)
 
     def step(self, actions: torch.Tensor):
         if self.clip_actions is not None:
             actions = torch.clamp(actions, -self.clip_actions, self.clip_actions)
-        return self.env.unwrapped.step(actions)
+        obs, rew, dones, extras = self.env.unwrapped.step(actions)
+        return ObsTensor.wrap(obs, extras["observations"]), rew, dones, extras
 
     def seed(self, seed: int = -1) -> int:
         return seed
@@ -346,8 +423,46 @@ class RslRlVecEnvWrapper:
         return getattr(self.env.unwrapped, name)
 
 
-def _export_unavailable(*args, **kwargs):
-    raise NotImplementedError("policy export (jit/onnx) is outside this build's scope; torch.save the ActorCritic instead")
+class _PolicyExport(torch.nn.Module):
+    """Deployment module of `export_policy_as_jit` / `_onnx` [DEP isaaclab_rl.rsl_rl.exporter]: normaliser -> actor."""
+
+    def __init__(self, actor_critic, normalizer=None):
+        super().__init__()
+        import copy
+
+        if getattr(actor_critic, "is_recurrent", False):
+            raise NotImplementedError("recurrent actor export is not implemented (no registered LocoTouch task trains one)")
+        self.actor = copy.deepcopy(actor_critic.actor).cpu()
+        self.normalizer = copy.deepcopy(normalizer).cpu() if normalizer is not None else torch.nn.Identity()
+
+    def forward(self, x):
+        return self.actor(self.normalizer(x))
+
+
+def export_policy_as_jit(actor_critic, normalizer=None, path: str = ".", filename: str = "policy.pt") -> str:
+    """TorchScript file `path/filename` of obs -> mean action (what the robot-side runtime loads)."""
+    os.makedirs(path, exist_ok=True)
+    mod = _PolicyExport(actor_critic, normalizer).eval()
+    out = os.path.join(path, filename)
+    torch.jit.script(mod).save(out)
+    return out
+
+
+def export_policy_as_onnx(actor_critic, path: str = ".", normalizer=None, filename: str = "policy.onnx", verbose: bool = False) -> str:
+    """ONNX file (inputs `obs`, outputs `actions`, opset 11, as the IsaacLab exporter writes it).  torch's exporter needs the
+    `onnx` package, which this image does not ship: the ImportError says so instead of writing nothing."""
+    try:
+        import onnx  # noqa: F401
+    except ImportError as e:
+        raise ImportError("export_policy_as_onnx needs the `onnx` package (torch.onnx.export serialises through it); "
+                          "export_policy_as_jit writes the same network as TorchScript") from e
+    os.makedirs(path, exist_ok=True)
+    mod = _PolicyExport(actor_critic, normalizer).eval()
+    out = os.path.join(path, filename)
+    n_in = mod.actor[0].in_features
+    torch.onnx.export(mod, torch.zeros(1, n_in), out, export_params=True, opset_version=11, verbose=verbose, input_names=["obs"],
+                      output_names=["actions"], dynamic_axes={})
+    return out
 
 
 _STOCK_MDP = ["generated_commands", "base_ang_vel", "base_lin_vel", "projected_gravity", "joint_pos_rel", "joint_vel_rel", "last_action",
@@ -417,7 +532,13 @@ def install(env_factory=None) -> None:
     ac, alg, runner = _rsl_rl_cfgs()
     _module("isaaclab_rl")
     _module("isaaclab_rl.rsl_rl", RslRlVecEnvWrapper=RslRlVecEnvWrapper, RslRlOnPolicyRunnerCfg=runner, RslRlPpoActorCriticCfg=ac,
-            RslRlPpoAlgorithmCfg=alg, export_policy_as_jit=_export_unavailable, export_policy_as_onnx=_export_unavailable)
+            RslRlPpoAlgorithmCfg=alg, export_policy_as_jit=export_policy_as_jit, export_policy_as_onnx=export_policy_as_onnx)
+    try:  # `from torch.utils.tensorboard import SummaryWriter` (distillation.py:85): the real one needs the tensorboard package
+        importlib.import_module("torch.utils.tensorboard")
+    except ImportError:
+        from ..rl import tb_writer
+
+        _module("torch.utils.tensorboard", SummaryWriter=tb_writer.SummaryWriter)
     # loco_rl -> this package's trainer
     from . import loco_rl as alias
 

@@ -216,6 +216,20 @@ class OnPolicyRunner:
             with open(os.path.join(self.log_dir, "git", "repos.txt"), "a") as f:
                 f.write(str(repo_file_path) + "\n")
 
+    def get_inference_encoder(self, device=None):  # reference on_policy_runner.py:435-448: None unless the policy has an encoder
+        self.eval_mode()
+        ac = self.alg.actor_critic
+        if device is not None:
+            ac.to(device)
+        if callable(getattr(ac, "act_encoder_inference", None)):
+            if self.empirical_normalization:
+                return lambda x: ac.act_encoder_inference(self.obs_normalizer(x))
+            return ac.act_encoder_inference
+        return None
+
+    def get_backbone_weights(self):  # :463-464 (RMA distillation: the teacher's actor becomes the student's frozen backbone)
+        return self.alg.actor_critic.actor.state_dict()
+
     def get_inference_policy(self, device=None):  # reference on_policy_runner.py:424-436
         self.eval_mode()
         if device is not None:

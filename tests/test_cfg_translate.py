@@ -19,9 +19,9 @@ IDS = ["Isaac-Locomotion-LocoTouch-v1", "Isaac-Locomotion-LocoTouch-Play-v1", "I
        "Isaac-CylinderTransportTeacher-LocoTouch-Play-v1", "Isaac-RandCylinderTransportTeacher-LocoTouch-v1",
        "Isaac-RandCylinderTransportTeacher-LocoTouch-Play-v1",
        "Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-v1"]
-# the student -Play- registration adds two evaluation-only observation groups (all tactile formats side by side,
-# object_transport_student_env_cfg.py:171-177) that have no fused implementation: its cfg tree must be REFUSED, while the
-# preset of the same id serves the play env without them
+# the student -Play- registration adds two visualisation-only observation groups (all tactile formats side by side,
+# object_transport_student_env_cfg.py:171-177; read only by the ROS publisher the reference keeps switched off): the strict
+# translation REFUSES them, gym.make's translation leaves exactly these two out with a warning
 STUDENT_PLAY = "Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-Play-v1"
 
 
@@ -49,14 +49,18 @@ def test_presets_cover_the_reference_registry(rt):
     assert set(ids) == set(_abi.preset_ids())
 
 
-def test_student_play_groups_are_refused_not_dropped(rt):
+def test_student_play_groups_are_refused_or_omitted_by_name(rt):
     from locotouch_amd.compat import cfg_translate as T
 
     cfg = rt.load_cfg_from_registry(STUDENT_PLAY, "env_cfg_entry_point")
     with pytest.raises(T.UnsupportedCfg, match="original_tactile"):
+        T.translate(cfg)
+    cfg.observations.my_group = cfg.observations.original_tactile
+    with pytest.raises(T.UnsupportedCfg, match="my_group"):  # only the two known names may be left out
         rt.translate_env_cfg(STUDENT_PLAY, cfg)
-    del cfg.observations.original_tactile, cfg.observations.processed_tactile
-    lt, sizes = rt.translate_env_cfg(STUDENT_PLAY, cfg)
+    del cfg.observations.my_group
+    with pytest.warns(UserWarning, match="visualisation-only"):
+        lt, sizes = rt.translate_env_cfg(STUDENT_PLAY, cfg)
     preset = _abi.preset_cfg(STUDENT_PLAY)
     assert lt.num_envs == preset.num_envs == 20 and lt.tactile_enabled == 1
     assert T.diff(lt, preset, skip=("seed", "num_envs", "reserved", "debug_terms", "obj_radius", "obj_length", "obj_size_explicit")) == []

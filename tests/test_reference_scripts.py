@@ -77,6 +77,52 @@ def test_reference_train_script_runs_unmodified(tmp_path, task):
     assert ck["model_state_dict"]["actor.0.weight"].shape == (512, obs_dim)
 
 
+def _run(tmp_path, script, args, extra_env=None, timeout=900):
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="2", **(extra_env or {}))
+    cmd = [sys.executable, "-c", DRIVER, REPO, os.path.join(REF, "locotouch", "scripts", script)] + args
+    out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    return out
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_reference_play_and_distill_scripts_run_unmodified(tmp_path):
+    """train.py (teacher, 2 iterations) -> play.py (loads the checkpoint, steps the policy) -> distill.py --training (the
+    reference's OWN Distillation / ReplayBuffer / Student / TactileRecorder classes on this package's import surface: student
+    env with tactile + object_state groups, both observation call forms, loco_rl.models, runner getters) -> distill.py (play)."""
+    import json
+
+    teacher, student = "Isaac-RandCylinderTransportTeacher-LocoTouch-v1", "Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-v1"
+    _run(tmp_path, "train.py", ["--task", teacher, "--num_envs", "16", "--max_iterations", "2", "--headless", "--device", "cpu",
+                                "--logger", "tensorboard", "--seed", "3", "agent.device=cpu"])
+    out = _run(tmp_path, "play.py", ["--task", teacher.replace("-v1", "-Play-v1"), "--num_envs", "8", "--headless", "--device", "cpu"],
+               extra_env={"LT_APP_MAX_STEPS": "6", "LT_CFG_OVERRIDES": json.dumps({"rsl_rl_cfg_entry_point": {"device": "cpu"}})})
+    assert "Loading model checkpoint from" in out.stdout and "model_1.pt" in out.stdout
+    ov = {"rsl_rl_cfg_entry_point": {"device": "cpu"},
+          "distillation_cfg_entry_point": {"num_iterations": 2, "bc_data_steps": 60, "dagger_data_steps": 40, "initial_epoches": 3,
+                                           "incremental_epoches": 1, "batch_steps": 50, "evaluation_trajs_num": 3}}
+    out = _run(tmp_path, "distill.py", ["--task", student, "--num_envs", "12", "--headless", "--device", "cpu", "--training",
+                                        "--logger", "tensorboard"], extra_env={"LT_CFG_OVERRIDES": json.dumps(ov)})
+    assert "Tactile signal dim: 442, Proprioception dim: 270" in out.stdout
+    assert "[Distillation iteration 1] Action MSE" in out.stdout and "Collected" in out.stdout
+    runs = glob.glob(os.path.join(str(tmp_path), "logs", "distillation", "rand_cylinder", "*"))
+    assert len(runs) == 1 and sorted(os.path.basename(p) for p in glob.glob(os.path.join(runs[0], "model_*.pt"))) == ["model_0.pt", "model_1.pt"]
+    import torch
+
+    sd = torch.load(os.path.join(runs[0], "model_1.pt"), weights_only=True)  # the reference Student's state_dict
+    from locotouch_amd.distill import Student, distillation_cfg
+
+    cfg = distillation_cfg(student)
+    cfg.device, cfg.log_dir = "cpu", str(tmp_path)
+    mine = Student(cfg, 270, 442, 12, verbose=False)
+    mine.load_state_dict(sd)  # same names and shapes: a reference-trained student loads into this package's class
+    # play mode: the student checkpoint drives the env on delayed tactile rows
+    out = _run(tmp_path, "distill.py", ["--task", student.replace("-v1", "-Play-v1"), "--num_envs", "6", "--headless", "--device", "cpu",
+                                        "--log_dir_distill", os.path.basename(runs[0]), "--checkpoint_distill", "model_1.pt"],
+               extra_env={"LT_APP_MAX_STEPS": "5"})
+    assert "Loading student policy checkpoint from" in out.stdout
+
+
 def test_checkpoint_path_regex_semantics(tmp_path):
     """`get_checkpoint_path(root, run_regex, ckpt_regex)`: latest matching run, numerically latest matching checkpoint."""
     from locotouch_amd.compat.runtime import get_checkpoint_path
