@@ -131,7 +131,10 @@ def main() -> None:
     dev = torch.device(f"cuda:{os.environ.get('LT_FORCE_DEVICE', dist.local_rank)}")  # LT_FORCE_DEVICE: multi-rank rehearsal on one GPU
     torch.cuda.set_device(dev)
     n = args.envs
-    env = LocoTouchVecEnv(TASKS[args.task], num_envs=n, device=dev, seed=42 + dist.rank)
+    # one population over all ranks: same seed, RNG streams keyed by the global env index; with more than one rank the
+    # curriculum gate is decided on cross-rank sums, one 1-KiB all-reduce per rollout
+    env = LocoTouchVecEnv(TASKS[args.task], num_envs=n, device=dev, seed=42, env_index_offset=dist.rank * n,
+                          cur_gate_external=1 if dist.world_size > 1 else 0)
     torch.manual_seed(1234)  # identical random-init policy on every rank
     ac = ActorCritic(env.num_obs, env.num_obs, 12, **POLICY_CFG)
     alg = PPO(ac, device=dev, dist=dist, **PPO_CFG)
@@ -250,6 +253,7 @@ def main() -> None:
                 graphs[ROLLOUT].replay()
             else:
                 rollout_steps(ROLLOUT)
+            env.curriculum_sync(dist, ROLLOUT)
             with torch.inference_mode():
                 alg.compute_returns(critic_obs)
             alg.update()
@@ -275,7 +279,7 @@ def main() -> None:
                "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{TASKS[args.task]} rollout (policy act + env step + storage), {n} envs/GPU, "
-                                      f"random-init ActorCritic [512,256,128], seed 42+rank",
+                                      f"random-init ActorCritic [512,256,128], seed 42, env RNG keyed by global env index",
                           "envs_per_gpu": n, "rollout_len": ROLLOUT, "hipgraph_replayed": launched["graph"] > 0 and launched["eager"] == 0,
                           "steps_replayed_from_graphs": launched["graph"], "steps_launched_eagerly": launched["eager"],
                           "fused_rollout": fused is not None, "launches_per_step": fused.launches_per_step if fused is not None else None},

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 4
+#define LT_ABI_VERSION 5
 
 /* error codes */
 #define LT_OK 0
@@ -49,6 +49,7 @@ extern "C" {
 #define LT_TACTILE_ROWS 17          /* taxel grid: rows along x (front -> back), columns along y (left -> right);        */
 #define LT_TACTILE_COLS 13          /* reference utils/urdf_processor/go1/generate_locotouch_urdf.py:4-8,59-72          */
 #define LT_TACTILE_DIM 442          /* BinaryTactileSignals: two identical channels of the 17 x 13 contact map (mdp/observations.py:307-308) */
+#define LT_GATE_RING 32             /* passes kept in LT_F_GATE_RING (>= steps per rollout between two global gate evaluations) */
 
 /* reward terms, in manager order (reference config/base/locomotion_base_env_cfg.py:139-218 then
  * config/locotouch/object_transport_teacher_env_cfg.py:88-105).  Zero-weight terms are not evaluated. */
@@ -202,7 +203,13 @@ typedef struct lt_cfg {
   float tactile_threshold_noise;  /* +- half-width of the per-(env, taxel) threshold offset drawn once: 0.05 * 0.2 */
   float tactile_dropout_prob;     /* contact_dropout_prob 0.005 */
   float tactile_addition_prob;    /* contact_addition_prob 0.005 */
-  int32_t reserved[4];
+  /* multi-rank runs (one process per GPU) */
+  int32_t cur_gate_external;      /* 1: the step kernel keeps the per-env curriculum trackers and publishes its population sums
+                                   * into LT_F_GATE_RING, but leaves the success test / widening (mdp/curriculums.py:224-238,
+                                   * 245-259) to lt_env_curriculum_apply_global on sums all-reduced over the ranks */
+  int32_t env_index_offset;       /* global index of this shard's env 0: the RNG streams are keyed (seed, offset + env, step,
+                                   * stream), so R ranks with offsets r * N draw exactly what one R * N-env population draws */
+  int32_t reserved[2];
 } lt_cfg;
 
 /* Fields of the state arena (zero-copy views for the manager-term data contract). */
@@ -245,7 +252,11 @@ enum lt_field {
   LT_F_TIME_OUT,        /* uint8 [N] */
   LT_F_TERM_BITS,       /* int32 [N] which termination terms fired this step */
   LT_F_CMD_PARAMS,      /* float [LT_CMD_PARAMS_LEN], device-resident command/curriculum block */
-  LT_F_COUNTERS,        /* int64 [4]: (common_step_counter, _, arrival ticket of the step kernel's tail reduction, _) */
+  LT_F_COUNTERS,        /* int64 [4]: (common_step_counter, _, arrival ticket of the step kernel's tail reduction,
+                         *             number of curriculum passes so far = next LT_F_GATE_RING slot, mod LT_GATE_RING) */
+  LT_F_GATE_RING,       /* float [LT_GATE_RING][8]: the population sums of the last curriculum passes, one row per pass:
+                         * (envs with a non-zero command, envs reset this step, lin trackers not all reset, sum ep_len lin,
+                         *  sum reward lin, ang trackers not all reset, sum ep_len ang, sum reward ang) */
   LT_F_OBS_TACTILE,     /* float [N][442]: observation group `tactile` (tactile tasks; no history) */
   LT_F_OBS_OBJECT_STATE,/* float [N][78] (row stride obs_dim): observation group `object_state` = the object-state block of the
                          * policy rows (same term, same parameters; the reference draws its noise separately) */
@@ -328,6 +339,11 @@ int lt_env_eval_terms(lt_env* env, void* stream);
  * kernel derives per env) instead of a physics step; does not advance the step counter.  Parity-test hook for the
  * reference's curriculum sequence (mdp/curriculums.py:184-275). */
 int lt_env_curriculum_update(lt_env* env, const float* records, void* stream);
+/* Multi-rank curriculum gate (cfg.cur_gate_external): `ring_sums` (device, float[LT_GATE_RING][8]) = LT_F_GATE_RING summed
+ * over all ranks; replays the reference's decision sequence on the last `nsteps` passes with `n_total` envs and, at the first
+ * pass that succeeds (per lin / ang), widens the command ranges and schedules the tracker clear for the next step.  Every
+ * rank calls it with identical sums, so every rank widens on the same step.  Lags the reference by < nsteps steps. */
+int lt_env_curriculum_apply_global(lt_env* env, const float* ring_sums, int nsteps, int64_t n_total, void* stream);
 int lt_env_get_view(lt_env* env, int field, lt_view* view);
 /* Host-side override of the command block (what `set_ranges` does in the reference; resume workflows). */
 int lt_env_set_command_ranges(lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream);

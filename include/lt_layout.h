@@ -48,7 +48,7 @@ typedef struct lt_layout {
   int32_t obs_dim;
   int64_t quad_off[LT_NUM_QUAD_FIELDS]; /* byte offsets */
   int64_t off_ep_len, off_obs_policy, off_obs_critic, off_reward, off_dones, off_terminated, off_time_out,
-      off_term_bits, off_cmd_params, off_counters, off_partials, off_obs_tactile, off_obj_sizes, off_dev_args;
+      off_term_bits, off_cmd_params, off_counters, off_gate_ring, off_partials, off_obs_tactile, off_obj_sizes, off_dev_args;
   int64_t total_bytes;
   int32_t tactile, reserved;
 } lt_layout;
@@ -75,6 +75,7 @@ static inline void lt_layout_init(lt_layout* L, int64_t num_envs, int32_t obs_di
   L->off_term_bits = off;   off = lt_align256(off + L->npad * 4);
   L->off_cmd_params = off;  off = lt_align256(off + LT_CMD_PARAMS_LEN * 4);
   L->off_counters = off;    off = lt_align256(off + 4 * 8);
+  L->off_gate_ring = off;   off = lt_align256(off + LT_GATE_RING * LT_PARTIAL_FLOATS * 4);
   L->off_partials = off;    off = lt_align256(off + (L->npad / 16) * LT_PARTIAL_FLOATS * 4);
   L->off_obs_tactile = off; off = lt_align256(off + (tactile ? L->npad * (int64_t)LT_TACTILE_DIM * 4 : 0));
   L->off_obj_sizes = off;   off = lt_align256(off + L->npad * 2 * 4); /* this and what follows survive lt_env_reset_all */

@@ -612,6 +612,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   const float* P = (const float*)(arena + L.off_cmd_params);
   const uint64_t step = MODE == MODE_RESET_ALL ? 0ull : (uint64_t)((const long long*)(arena + L.off_counters))[0];
   const float step_dt = c.sim_dt * (float)c.decimation;
+  const uint32_t ekey = (uint32_t)env + (uint32_t)c.env_index_offset;  // RNG stream key of this env (global index over all ranks)
 
   if (HELPERS && wave != 0) {
     if (wave == 3) {
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   // ---- startup events (reset-all only): reference locomotion_base_env_cfg.py:224-244, rand_cylinder_...:21-27 ----
   if (MODE == MODE_RESET_ALL) {
     const uint64_t st = ~0ull;
-    const U4 u = rng4(c.seed, (uint32_t)env, st, RS_STARTUP);
+    const U4 u = rng4(c.seed, ekey, st, RS_STARTUP);
     X.trunk_mass_add = lerp2(c.trunk_mass_add, u.a);
     O.rad = lerp2(c.obj_radius, u.b);
     O.len = lerp2(c.obj_length, u.c);
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       const float* sz = (const float*)(arena + L.off_obj_sizes) + env * 2;
       O.rad = sz[0]; O.len = sz[1];
     }
-    const U4 uf = rng4(c.seed, (uint32_t)env, st, RS_STARTUP + 0x10 + leg);
+    const U4 uf = rng4(c.seed, ekey, st, RS_STARTUP + 0x10 + leg);
     const float ms = lerp2(c.foot_friction, uf.a), md = lerp2(c.foot_friction, uf.b);
     G.mu = md < ms ? md : ms;
     O.mass = 1.0f; O.mu = 1.0f; X.trunk_mu = 1.0f; X.trunk_rest = 0.f; X.obj_rest = 0.f;
@@ -1009,7 +1010,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     }
   }
   if ((MODE == MODE_STEP && reset) || MODE == MODE_RESET_ALL) {
-    const uint32_t e32 = (uint32_t)env;
+    const uint32_t e32 = ekey;
     // E4 reset_root_state_uniform [DEP] (params locomotion_base_env_cfg.py:249-267 / object_transport_teacher...:144-160)
     U4 u = rng4(c.seed, e32, step, RS_RESET_ROOT);
     B.p = v3(lerp2(c.reset_root_pos[0], u.a), lerp2(c.reset_root_pos[1], u.b), LT_ROOT_INIT_HEIGHT + lerp2(c.reset_root_pos[2], u.c));
@@ -1072,7 +1073,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   if (MODE == MODE_STEP) {
     // 7. CommandTerm.compute [DEP] + MultiSampling._update_command (commands.py:561-576)
     X.cmd_time_left -= step_dt;
-    if (X.cmd_time_left <= 0.f) command_resample(c, P, (uint32_t)env, step, RS_CMD_TIMER, X);
+    if (X.cmd_time_left <= 0.f) command_resample(c, P, ekey, step, RS_CMD_TIMER, X);
     if (c.cmd_multi_sampling) {
       const long long zs = (long long)(int)P[15];
       if (X.ep_len < zs) X.cmd = 0.0f * X.cmd_buf;
@@ -1082,7 +1083,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     // 8. interval events: push_by_setting_velocity [DEP] (cfg locomotion_base_env_cfg.py:279-292, teacher :189-209)
     X.push_robot_left -= step_dt;
     if (X.push_robot_left < 1e-6f) {
-      const U4 u = rng4(c.seed, (uint32_t)env, step, RS_PUSH_ROBOT), w4 = rng4(c.seed, (uint32_t)env, step, RS_PUSH_ROBOT + 1);
+      const U4 u = rng4(c.seed, ekey, step, RS_PUSH_ROBOT), w4 = rng4(c.seed, ekey, step, RS_PUSH_ROBOT + 1);
       X.push_robot_left = lerp2(c.push_robot_interval, u.d);
       B.u += v3(lerp2(c.push_robot_vel[0], u.a), lerp2(c.push_robot_vel[1], u.b), lerp2(c.push_robot_vel[2], u.c));
       B.w += v3(lerp2(c.push_robot_vel[3], w4.a), lerp2(c.push_robot_vel[4], w4.b), lerp2(c.push_robot_vel[5], w4.c));
@@ -1090,7 +1091,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     if (HAS_OBJ) {
       X.push_obj_left -= step_dt;
       if (X.push_obj_left < 1e-6f) {
-        const U4 u = rng4(c.seed, (uint32_t)env, step, RS_PUSH_OBJ), w4 = rng4(c.seed, (uint32_t)env, step, RS_PUSH_OBJ + 1);
+        const U4 u = rng4(c.seed, ekey, step, RS_PUSH_OBJ), w4 = rng4(c.seed, ekey, step, RS_PUSH_OBJ + 1);
         X.push_obj_left = lerp2(c.push_obj_interval, u.d);
         O.u += v3(lerp2(c.push_obj_vel[0], u.a), lerp2(c.push_obj_vel[1], u.b), lerp2(c.push_obj_vel[2], u.c));
         O.w += v3(lerp2(c.push_obj_vel[3], w4.a), lerp2(c.push_obj_vel[4], w4.b), lerp2(c.push_obj_vel[5], w4.c));
@@ -1118,7 +1119,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
     const V3 wb = tmul(R0, B.w), gb = -row(R0, 2);
     const bool noisy = c.enable_corruption != 0;
-    const U4 uj = rng4(c.seed, (uint32_t)env, step, RS_NOISE_JPOS + leg), uvv = rng4(c.seed, (uint32_t)env, step, RS_NOISE_JVEL + leg);
+    const U4 uj = rng4(c.seed, ekey, step, RS_NOISE_JPOS + leg), uvv = rng4(c.seed, ekey, step, RS_NOISE_JVEL + leg);
     const float nj[3] = {uj.a, uj.b, uj.c}, nv[3] = {uvv.a, uvv.b, uvv.c};
     float* fp = s_frame[0][el];
     float* fc = s_frame[1][el];
@@ -1134,7 +1135,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       fp[33 + k * 4 + leg] = G.raw[k];
     }
     if (leg == 0) {
-      const U4 ua = rng4(c.seed, (uint32_t)env, step, RS_NOISE_BASE), ug = rng4(c.seed, (uint32_t)env, step, RS_NOISE_BASE + 1);
+      const U4 ua = rng4(c.seed, ekey, step, RS_NOISE_BASE), ug = rng4(c.seed, ekey, step, RS_NOISE_BASE + 1);
       const float na[3] = {ua.a, ua.b, ua.c}, ng[3] = {ug.a, ug.b, ug.c};
       const float cm[3] = {X.cmd.x, X.cmd.y, X.cmd.z}, wv[3] = {wb.x, wb.y, wb.z}, gv[3] = {gb.x, gb.y, gb.z};
 #pragma unroll
@@ -1151,7 +1152,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       float u16[16];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const U4 t = rng4(c.seed, (uint32_t)env, step, RS_NOISE_OBJ + b);
+        const U4 t = rng4(c.seed, ekey, step, RS_NOISE_OBJ + b);
         u16[4 * b] = t.a; u16[4 * b + 1] = t.b; u16[4 * b + 2] = t.c; u16[4 * b + 3] = t.d;
       }
       float o[13];
@@ -1286,6 +1287,10 @@ __global__ __launch_bounds__(64) void lt_curriculum_kernel(const KArgs a, const 
   const float cm = ((const float*)(a.arena + L.quad_off[LT_F_CMD]))[gid];
   in.cmd_nonzero = qor((leg < 3 && cm != 0.f) ? 1 : 0) != 0;
   if (curriculum_publish(L, a.arena, gid, leg, in)) curriculum_decide(c, L, a.arena, 0);
+}
+// multi-rank curriculum gate on cross-rank sums (lt_post.h curriculum_apply_global); one wave
+__global__ __launch_bounds__(64) void lt_gate_apply_kernel(const KArgs a, const float* __restrict__ ring_sums, int nsteps, float inv_n_total) {
+  curriculum_apply_global(a.d->cfg, a.d->layout, a.arena, ring_sums, nsteps, inv_n_total);
 }
 // population gate of rewards.py:190 from the commands currently in the arena (lt_env_eval_terms; one block)
 __global__ __launch_bounds__(1024) void lt_gate_kernel(const KArgs a) {
@@ -1435,6 +1440,12 @@ int lt_launch_eval_terms(const lt_env* env, void* stream) {
 int lt_launch_curriculum(const lt_env* env, const float* records, void* stream) {
   const KArgs k = make_args(env, nullptr);
   hipLaunchKernelGGL(lt_curriculum_kernel, dim3((unsigned)(env->layout.npad / 16)), dim3(64), 0, (hipStream_t)stream, k, records);
+  return (int)hipGetLastError();
+}
+
+int lt_launch_curriculum_apply_global(const lt_env* env, const float* ring_sums, int nsteps, long long n_total, void* stream) {
+  const KArgs k = make_args(env, nullptr);
+  hipLaunchKernelGGL(lt_gate_apply_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, ring_sums, nsteps, 1.f / (float)n_total);
   return (int)hipGetLastError();
 }
 

@@ -110,6 +110,7 @@ int lt_env_get_view(lt_env* env, int field, lt_view* v) {
     case LT_F_CMD_PARAMS: plain(L.off_cmd_params, 0, LT_CMD_PARAMS_LEN, 0); break;
     case LT_F_COUNTERS: plain(L.off_counters, 1, 4, 0); break;
     case LT_F_OBJ_SIZES: plain(L.off_obj_sizes, 0, L.n, 2); break;
+    case LT_F_GATE_RING: plain(L.off_gate_ring, 0, LT_GATE_RING, LT_PARTIAL_FLOATS); break;
     case LT_F_OBS_TACTILE: plain(L.off_obs_tactile, 0, L.n, LT_TACTILE_DIM); break;
     case LT_F_OBS_OBJECT_STATE:  // the object-state term block (13 x 6) closes the policy rows of the transport tasks
       if (env->cfg.task != LT_TASK_TRANSPORT_TEACHER) { lt_set_error("lt_env_get_view: no object in this task"); return LT_EINVAL; }
@@ -134,6 +135,16 @@ int lt_env_reset_all(lt_env* env, void* stream) {
   const int rc = finish(lt_launch_reset_all(env, stream), "lt_env_reset_all");
   if (rc != LT_OK || !env->cfg.tactile_enabled) return rc;
   return finish(lt_launch_tactile(env, stream), "lt_env_reset_all (tactile)");
+}
+
+int lt_env_curriculum_apply_global(lt_env* env, const float* ring_sums, int nsteps, int64_t n_total, void* stream) {
+  if (!env || !ring_sums || nsteps < 1 || nsteps > LT_GATE_RING || n_total < 1) return LT_EINVAL;
+  if (!env->arena) { lt_set_error("lt_env_curriculum_apply_global: arena not bound"); return LT_EFAULT; }
+  if (!env->cfg.cur_gate_external) {
+    lt_set_error("lt_env_curriculum_apply_global: cfg.cur_gate_external is 0 (the step kernel decides by itself)");
+    return LT_EINVAL;
+  }
+  return finish(lt_launch_curriculum_apply_global(env, ring_sums, nsteps, (long long)n_total, stream), "lt_env_curriculum_apply_global");
 }
 
 int lt_env_tactile_update(lt_env* env, void* stream) {

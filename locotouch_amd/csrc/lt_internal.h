@@ -28,6 +28,7 @@ int lt_launch_eval_terms(const lt_env* env, void* stream);
 void lt_release_events(lt_env* env);
 int lt_launch_curriculum(const lt_env* env, const float* records, void* stream);
 int lt_launch_set_command_ranges(const lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream);
+int lt_launch_curriculum_apply_global(const lt_env* env, const float* ring_sums, int nsteps, long long n_total, void* stream);
 int lt_launch_tactile(const lt_env* env, void* stream);  // lt_tactile.hip
 const char* lt_hip_error_string(int err);
 

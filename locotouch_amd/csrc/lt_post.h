@@ -100,6 +100,79 @@ __device__ __forceinline__ bool curriculum_publish(const lt_layout& L, char* con
   return ticket == nwaves - 1;
 }
 
+// The reference's decision sequence on one pass's population sums `r` (lin gate -> maybe widen -> ang gate -> maybe widen);
+// updates the command block copy `Pl` in place.  `allow_*`: whether a success may be declared for that group here.
+struct GateOut { bool run, lin_open, lin_pass, ang_open, ang_pass; };
+__device__ __forceinline__ GateOut gate_decision(const lt_cfg& c, float (&Pl)[31], const float (&r)[LT_PARTIAL_FLOATS], float inv_n,
+                                                 bool allow_lin, bool allow_ang) {
+  GateOut g;
+  const float* mx = c.cmd_range_max;
+  g.run = c.cur_enabled != 0 && r[1] > 0.f;  // _reset_idx (and the curriculum with it) only runs when some env reset this step
+  g.lin_open = g.run && (Pl[1] != mx[0] || Pl[12] == 0.f || Pl[3] != mx[1] || Pl[13] == 0.f) &&
+               (Pl[17] - Pl[18] <= (float)c.cur_max_distance_bins);                                        // curriculums.py:218-220
+  g.lin_pass = false;
+  if (g.lin_open && allow_lin) {
+    g.lin_pass = r[2] == 0.f && r[3] * inv_n > c.cur_len_threshold && r[4] * inv_n > c.cur_reward_threshold[0];  // :224
+    if (g.lin_pass) {
+      Pl[19] += 1.f;
+      if ((int)Pl[19] == c.cur_repeat_times[0]) {                                                          // :226-235
+        const float lx = clampf(Pl[0] - Pl[21], -mx[0], 0.f), ly = clampf(Pl[2] - Pl[22], -mx[1], 0.f);
+        set_range(Pl, 0, lx, -lx);
+        set_range(Pl, 1, ly, -ly);
+        if (Pl[12] != 0.f && Pl[13] != 0.f && Pl[14] != 0.f) { Pl[15] = (float)c.cmd_zero_steps_final; Pl[16] = c.cmd_rel_standing_final; }
+        Pl[19] = 0.f; Pl[17] += 1.f;
+      }
+    }
+  }
+  // the ang gate is evaluated after the lin update, as in the reference's call order (:239-240)
+  g.ang_open = g.run && (Pl[5] != mx[2] || Pl[14] == 0.f) && (Pl[18] - Pl[17] <= (float)c.cur_max_distance_bins);
+  g.ang_pass = false;
+  if (g.ang_open && allow_ang) {
+    g.ang_pass = r[5] == 0.f && r[6] * inv_n > c.cur_len_threshold && r[7] * inv_n > c.cur_reward_threshold[1];
+    if (g.ang_pass) {
+      Pl[20] += 1.f;
+      if ((int)Pl[20] == c.cur_repeat_times[1]) {
+        const float lz = clampf(Pl[4] - Pl[23], -mx[2], 0.f);
+        set_range(Pl, 2, lz, -lz);
+        if (Pl[12] != 0.f && Pl[13] != 0.f && Pl[14] != 0.f) { Pl[15] = (float)c.cmd_zero_steps_final; Pl[16] = c.cmd_rel_standing_final; }
+        Pl[20] = 0.f; Pl[18] += 1.f;
+      }
+    }
+  }
+  return g;
+}
+
+// Multi-rank gate (cfg.cur_gate_external), one wave: the decision sequence replayed over the last `nsteps` passes on sums
+// all-reduced over the ranks.  After a group's first success the later rows of this window are stale for it (their sums
+// were formed from trackers the success clears), so the group is closed for the rest of the window and the clear is
+// scheduled (P[29] / P[30]) for the next step's tracker pass.
+__device__ __forceinline__ void curriculum_apply_global(const lt_cfg& c, const lt_layout& L, char* const arena, const float* ring_sums,
+                                                        int nsteps, float inv_n_total) {
+  float* const P = (float*)(arena + L.off_cmd_params);
+  const long long pos = ((const long long*)(arena + L.off_counters))[3];
+  float Pl[31];
+#pragma unroll
+  for (int i = 0; i < 31; ++i) Pl[i] = P[i];
+  bool lin_done = false, ang_done = false;
+  for (int k = 0; k < nsteps; ++k) {
+    const long long pass = pos - nsteps + k;
+    if (pass < 0) continue;
+    const float* row = ring_sums + (pass % LT_GATE_RING) * LT_PARTIAL_FLOATS;
+    float r[LT_PARTIAL_FLOATS];
+#pragma unroll
+    for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] = row[i];
+    const GateOut g = gate_decision(c, Pl, r, inv_n_total, !lin_done, !ang_done);
+    lin_done |= g.lin_pass;
+    ang_done |= g.ang_pass;
+  }
+  if (lin_done) Pl[29] = 1.f;
+  if (ang_done) Pl[30] = 1.f;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 31; ++i) P[i] = Pl[i];
+  }
+}
+
 // Step 4, last arriver only: fixed-order reduction of the slots, then the reference's decision sequence.
 __device__ __forceinline__ void curriculum_decide(const lt_cfg& c, const lt_layout& L, char* const arena, int bump_counter) {
   float* const P = (float*)(arena + L.off_cmd_params);
@@ -119,46 +192,19 @@ __device__ __forceinline__ void curriculum_decide(const lt_cfg& c, const lt_layo
   float Pl[31];
 #pragma unroll
   for (int i = 0; i < 31; ++i) Pl[i] = P[i];
-  const float* mx = c.cmd_range_max;
-  const bool cur = c.cur_enabled != 0;
-  const bool any = r[1] > 0.f;
-  const bool run = cur && any;  // _reset_idx (and the curriculum with it) only runs when some env reset this step
-  const float inv_n = 1.f / (float)L.n;
-  const bool lin_open = run && (Pl[1] != mx[0] || Pl[12] == 0.f || Pl[3] != mx[1] || Pl[13] == 0.f) &&
-                        (Pl[17] - Pl[18] <= (float)c.cur_max_distance_bins);                               // curriculums.py:218-220
-  bool lin_pass = false;
-  if (lin_open) {
-    lin_pass = r[2] == 0.f && r[3] * inv_n > c.cur_len_threshold && r[4] * inv_n > c.cur_reward_threshold[0];  // :224
-    if (lin_pass) {
-      Pl[19] += 1.f;
-      if ((int)Pl[19] == c.cur_repeat_times[0]) {                                                          // :226-235
-        const float lx = clampf(Pl[0] - Pl[21], -mx[0], 0.f), ly = clampf(Pl[2] - Pl[22], -mx[1], 0.f);
-        set_range(Pl, 0, lx, -lx);
-        set_range(Pl, 1, ly, -ly);
-        if (Pl[12] != 0.f && Pl[13] != 0.f && Pl[14] != 0.f) { Pl[15] = (float)c.cmd_zero_steps_final; Pl[16] = c.cmd_rel_standing_final; }
-        Pl[19] = 0.f; Pl[17] += 1.f;
-      }
-    }
-  }
-  // the ang gate is evaluated after the lin update, as in the reference's call order (:239-240)
-  const bool ang_open = run && (Pl[5] != mx[2] || Pl[14] == 0.f) && (Pl[18] - Pl[17] <= (float)c.cur_max_distance_bins);
-  bool ang_pass = false;
-  if (ang_open) {
-    ang_pass = r[5] == 0.f && r[6] * inv_n > c.cur_len_threshold && r[7] * inv_n > c.cur_reward_threshold[1];
-    if (ang_pass) {
-      Pl[20] += 1.f;
-      if ((int)Pl[20] == c.cur_repeat_times[1]) {
-        const float lz = clampf(Pl[4] - Pl[23], -mx[2], 0.f);
-        set_range(Pl, 2, lz, -lz);
-        if (Pl[12] != 0.f && Pl[13] != 0.f && Pl[14] != 0.f) { Pl[15] = (float)c.cmd_zero_steps_final; Pl[16] = c.cmd_rel_standing_final; }
-        Pl[20] = 0.f; Pl[18] += 1.f;
-      }
-    }
-  }
-  if (run) { Pl[24] = lin_open ? 1.f : 0.f; Pl[25] = ang_open ? 1.f : 0.f; }
+  const bool ext = c.cur_gate_external != 0;  // multi-rank: the success test runs on cross-rank sums (curriculum_apply_global)
+  GateOut g = gate_decision(c, Pl, r, 1.f / (float)L.n, !ext, !ext);
+  if (g.run) { Pl[24] = g.lin_open ? 1.f : 0.f; Pl[25] = g.ang_open ? 1.f : 0.f; }
   Pl[26] = r[0] > 0.f ? 1.f : 0.f;
-  Pl[27] = lin_open ? 1.f : 0.f; Pl[28] = ang_open ? 1.f : 0.f;  // tracker operations for the next pass
-  Pl[29] = lin_pass ? 1.f : 0.f; Pl[30] = ang_pass ? 1.f : 0.f;
+  Pl[27] = g.lin_open ? 1.f : 0.f; Pl[28] = g.ang_open ? 1.f : 0.f;  // tracker operations for the next pass
+  Pl[29] = g.lin_pass ? 1.f : 0.f; Pl[30] = g.ang_pass ? 1.f : 0.f;
+  if (lane == 0) {  // this pass's population sums, for a cross-rank gate
+    long long* const cnt = (long long*)(arena + L.off_counters);
+    float* const ring = (float*)(arena + L.off_gate_ring) + (cnt[3] % LT_GATE_RING) * LT_PARTIAL_FLOATS;
+#pragma unroll
+    for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) ring[i] = r[i];
+    cnt[3] += 1;
+  }
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 31; ++i) P[i] = Pl[i];

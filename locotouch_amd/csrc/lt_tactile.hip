@@ -82,14 +82,15 @@ __global__ __launch_bounds__(256) void lt_tactile_kernel(const lt_dev_args* __re
   const int row = t / LT_TAXEL_COLS, col = t - row * LT_TAXEL_COLS;
   const float cx = LT_TAXEL_X0 - LT_TAXEL_DX * (float)row, cy = LT_TAXEL_Y0 - LT_TAXEL_DY * (float)col;
   const float force = taxel_force(x, y, f, cx, cy);
+  const uint32_t ekey = (uint32_t)env + (uint32_t)c.env_index_offset;
   // observations.py:121-126: threshold + U(n_min, n_max) per (env, taxel), drawn once at construction
-  const U4 ut = rng4(c.seed, (uint32_t)env, ~0ull, RS_TACTILE_THR + (uint32_t)(t >> 2));
+  const U4 ut = rng4(c.seed, ekey, ~0ull, RS_TACTILE_THR + (uint32_t)(t >> 2));
   const float u_thr = (t & 3) == 0 ? ut.a : ((t & 3) == 1 ? ut.b : ((t & 3) == 2 ? ut.c : ut.d));
   const float n_min = -c.tactile_threshold_noise, n_max = c.tactile_threshold_noise;
   const float thr = c.tactile_threshold + (u_thr * (n_max - n_min) + n_min);
   bool contact = force > thr;                                                                    // :158
   const uint64_t step = (uint64_t)((const long long*)(arena + L.off_counters))[0];
-  const U4 un = rng4(c.seed, (uint32_t)env, step, RS_TACTILE + (uint32_t)(t >> 1));
+  const U4 un = rng4(c.seed, ekey, step, RS_TACTILE + (uint32_t)(t >> 1));
   const float u_drop = (t & 1) ? un.c : un.a, u_add = (t & 1) ? un.d : un.b;
   if (contact && u_drop < c.tactile_dropout_prob) contact = false;                              // :171-175
   if (!contact && u_add < c.tactile_addition_prob) contact = true;                              // :179-184 (after the dropout)

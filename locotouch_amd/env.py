@@ -206,6 +206,19 @@ class LocoTouchVecEnv:
         _abi.check(self._lib.lt_env_curriculum_update(self._handle, ctypes.c_void_p(records.data_ptr()), self._stream()),
                    "lt_env_curriculum_update")
 
+    def curriculum_sync(self, dist, nsteps: int) -> None:
+        """Multi-rank curriculum gate (cfg.cur_gate_external): all-reduce the population sums of the last
+        `nsteps` curriculum passes over the ranks and replay the reference's decision sequence on them - every rank widens the
+        command ranges on the same step.  One 1-KiB all-reduce per rollout; no host sync."""
+        if not self.cfg.cur_gate_external:
+            return
+        ring = self.view(C["LT_F_GATE_RING"]).clone()
+        dist.all_reduce_sum_(ring)
+        _abi.check(self._lib.lt_env_curriculum_apply_global(self._handle, ctypes.c_void_p(ring.data_ptr()), int(nsteps),
+                                                            int(self.num_envs) * int(dist.world_size), self._stream()),
+                   "lt_env_curriculum_apply_global")
+        self._gate_ring_keepalive = ring  # the kernel reads it asynchronously
+
     def set_command_ranges(self, ranges, zero_steps: int, rel_standing: float) -> None:
         arr = (ctypes.c_float * 6)(*[float(x) for x in ranges])
         _abi.check(self._lib.lt_env_set_command_ranges(self._handle, arr, int(zero_steps), float(rel_standing), self._stream()),

@@ -55,6 +55,7 @@ class Layout:
             ("LT_F_TERM_BITS", self.npad * 4, np.int32, (self.npad,)),
             ("LT_F_CMD_PARAMS", C["LT_CMD_PARAMS_LEN"] * 4, np.float32, (C["LT_CMD_PARAMS_LEN"],)),
             ("LT_F_COUNTERS", 4 * 8, np.int64, (4,)),
+            ("LT_F_GATE_RING", C["LT_GATE_RING"] * 8 * 4, np.float32, (C["LT_GATE_RING"], 8)),
             ("_PARTIALS", self.npad // 16 * 8 * 4, np.float32, (self.npad // 16, 8)),  # per-wave curriculum partials
             ("LT_F_OBS_TACTILE", self.npad * C["LT_TACTILE_DIM"] * 4 * self.tactile, np.float32, (self.npad * self.tactile, C["LT_TACTILE_DIM"])),
             ("LT_F_OBJ_SIZES", self.npad * 2 * 4, np.float32, (self.npad, 2)),

@@ -103,6 +103,8 @@ class OnPolicyRunner:
                     rew_acc = torch.where(d, torch.zeros_like(rew_acc), rew_acc)
                     len_acc = torch.where(d, torch.zeros_like(len_acc), len_acc)
                 alg.compute_returns(critic_obs)
+            if hasattr(env, "curriculum_sync"):  # multi-rank: one all-reduce of the curriculum sums per rollout
+                env.curriculum_sync(self.dist, self.num_steps_per_env)
             t1 = time.time()
             value_loss, surrogate_loss, entropy, _, _ = alg.update()
             t2 = time.time()

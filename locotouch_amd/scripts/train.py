@@ -45,7 +45,10 @@ def main() -> None:
     device = f"cuda:{dist.local_rank}"
     torch.cuda.set_device(device)
     torch.manual_seed(cfg["seed"])
-    env = make(args.task, num_envs=args.num_envs, device=device, seed=cfg["seed"] + dist.rank)
+    # one population over all ranks: same seed, RNG streams keyed by the GLOBAL env index (rank r owns envs [r*N, (r+1)*N)),
+    # and - with more than one rank - the curriculum gate decided on cross-rank sums
+    env = make(args.task, num_envs=args.num_envs, device=device, seed=cfg["seed"], env_index_offset=dist.rank * args.num_envs,
+               cur_gate_external=1 if dist.world_size > 1 else 0)
     log_dir = os.path.join(args.log_root, cfg["experiment_name"], datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S"))
     runner = OnPolicyRunner(env, cfg, log_dir=log_dir, device=device, dist=dist)
     if args.resume:  # train.py:131-137 of the reference: newest matching run / checkpoint under the experiment's log root

@@ -1237,6 +1237,69 @@ static void curriculum_apply_pending(void* arena, const lt_layout* L) {
     if (P[30] != 0) { t1[e * 4 + 3] = 0; t2[e * 4 + 0] = 0; t2[e * 4 + 1] = 0; }
   }
 }
+/* The decision sequence of curriculum_core on POPULATION SUMS instead of per-env arrays (what a multi-rank run has after its
+ * all-reduce): r = (groups with a non-zero command, groups with a reset, groups whose lin trackers are not all reset, sum ep_len
+ * lin, sum reward lin, same three for ang), trackers already merged.  tests/test_oracle_gate.py checks it against
+ * curriculum_core on the same population.  out = (run, lin_open, lin_pass, ang_open, ang_pass). */
+void lt_oracle_gate_on_sums(const lt_cfg* cfg, float* P, const float r[8], float inv_n, int allow_lin, int allow_ang, int out[5]) {
+  const float* mx = cfg->cmd_range_max;
+  out[0] = cfg->cur_enabled != 0 && r[1] > 0;
+  out[1] = out[0] && (P[1] != mx[0] || P[12] == 0 || P[3] != mx[1] || P[13] == 0) && (P[17] - P[18] <= (float)cfg->cur_max_distance_bins);
+  out[2] = 0;
+  if (out[1] && allow_lin) {
+    out[2] = r[2] == 0 && r[3] * inv_n > cfg->cur_len_threshold && r[4] * inv_n > cfg->cur_reward_threshold[0];
+    if (out[2]) {
+      P[19] += 1;
+      if ((int)P[19] == cfg->cur_repeat_times[0]) {
+        float lx = clipf(P[0] - P[21], -mx[0], 0.f), ly = clipf(P[2] - P[22], -mx[1], 0.f);
+        set_range(cfg, P, 0, lx, -lx);
+        set_range(cfg, P, 1, ly, -ly);
+        set_ranges_done(cfg, P);
+        P[19] = 0; P[17] += 1;
+      }
+    }
+  }
+  out[3] = out[0] && (P[5] != mx[2] || P[14] == 0) && (P[18] - P[17] <= (float)cfg->cur_max_distance_bins);
+  out[4] = 0;
+  if (out[3] && allow_ang) {
+    out[4] = r[5] == 0 && r[6] * inv_n > cfg->cur_len_threshold && r[7] * inv_n > cfg->cur_reward_threshold[1];
+    if (out[4]) {
+      P[20] += 1;
+      if ((int)P[20] == cfg->cur_repeat_times[1]) {
+        float lz = clipf(P[4] - P[23], -mx[2], 0.f);
+        set_range(cfg, P, 2, lz, -lz);
+        set_ranges_done(cfg, P);
+        P[20] = 0; P[18] += 1;
+      }
+    }
+  }
+}
+
+/* population sums of one pass, per 16-env group as the HIP kernel's waves form them (trackers with this step's records merged) */
+static void curriculum_sums(void* arena, const lt_layout* L, float r[8]) {
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const float* rec = lt_quad(arena, L, LT_F_CURRICULUM, 0);
+  const float* t1 = lt_quad(arena, L, LT_F_CURRICULUM, 1);
+  const float* t2 = lt_quad(arena, L, LT_F_CURRICULUM, 2);
+  for (int64_t g0 = 0; g0 < L->npad; g0 += 16) {
+    int nz = 0, any = 0, nl = 0, na = 0;
+    for (int64_t e = g0; e < g0 + 16 && e < L->n; ++e) {
+      const float* cm = lt_quad(arena, L, LT_F_CMD, 0) + e * 4;
+      const int reset = rec[e * 4] != 0;
+      nz |= cm[0] != 0 || cm[1] != 0 || cm[2] != 0;
+      any |= reset;
+      nl |= !(reset || t1[e * 4 + 0] != 0);
+      na |= !(reset || t1[e * 4 + 3] != 0);
+      acc[3] += reset ? rec[e * 4 + 1] : t1[e * 4 + 1];
+      acc[4] += reset ? rec[e * 4 + 2] : t1[e * 4 + 2];
+      acc[6] += reset ? rec[e * 4 + 1] : t2[e * 4 + 0];
+      acc[7] += reset ? rec[e * 4 + 3] : t2[e * 4 + 1];
+    }
+    acc[0] += nz; acc[1] += any; acc[2] += nl; acc[5] += na;
+  }
+  for (int i = 0; i < 8; ++i) r[i] = (float)acc[i];
+}
+
 /* the pass proper on the (now up-to-date) trackers and this step's records: decisions into P, tracker operations deferred */
 static void curriculum_decide(const lt_cfg* cfg, void* arena, const lt_layout* L) {
   float* P = (float*)((char*)arena + L->off_cmd_params);
@@ -1251,9 +1314,41 @@ static void curriculum_decide(const lt_cfg* cfg, void* arena, const lt_layout* L
       trk[e * 8 + 4 + c] = lt_quad(arena, L, LT_F_CURRICULUM, 2)[e * 4 + c];
     }
   int ops[4];
-  curriculum_core(cfg, P, n, rec, trk, ops);  /* works on the copy: the arena's trackers are updated by the next pass */
+  if (cfg->cur_gate_external) {  /* multi-rank: trackers merge as usual, the success test waits for the cross-rank sums */
+    lt_cfg never = *cfg;
+    never.cur_len_threshold = INFINITY;
+    curriculum_core(&never, P, n, rec, trk, ops);
+  } else {
+    curriculum_core(cfg, P, n, rec, trk, ops);  /* works on the copy: the arena's trackers are updated by the next pass */
+  }
   P[27] = (float)ops[0]; P[28] = (float)ops[1]; P[29] = (float)ops[2]; P[30] = (float)ops[3];
   free(rec); free(trk);
+  {
+    int64_t* cnt = (int64_t*)((char*)arena + L->off_counters);
+    curriculum_sums(arena, L, (float*)((char*)arena + L->off_gate_ring) + (cnt[3] % LT_GATE_RING) * LT_PARTIAL_FLOATS);
+    cnt[3] += 1;
+  }
+}
+/* multi-rank gate (HIP twin: lt_env_curriculum_apply_global): the decision sequence over the last `nsteps` passes on sums
+ * all-reduced over the ranks; a group is closed after its first success in the window and its tracker clear is scheduled */
+int lt_oracle_curriculum_apply_global(const lt_cfg* cfg, void* arena, const float* ring_sums, int nsteps, int64_t n_total) {
+  lt_layout L;
+  lt_layout_init(&L, cfg->num_envs, (cfg->task == LT_TASK_LOCOMOTION ? 45 : 58) * cfg->obs_history, cfg->tactile_enabled);
+  float* P = (float*)((char*)arena + L.off_cmd_params);
+  const int64_t pos = ((int64_t*)((char*)arena + L.off_counters))[3];
+  const float inv_n = 1.0f / (float)n_total;
+  int lin_done = 0, ang_done = 0;
+  for (int k = 0; k < nsteps; ++k) {
+    const int64_t pass = pos - nsteps + k;
+    if (pass < 0) continue;
+    int out[5];
+    lt_oracle_gate_on_sums(cfg, P, ring_sums + (pass % LT_GATE_RING) * LT_PARTIAL_FLOATS, inv_n, !lin_done, !ang_done, out);
+    lin_done |= out[2];
+    ang_done |= out[4];
+  }
+  if (lin_done) P[29] = 1;
+  if (ang_done) P[30] = 1;
+  return 0;
 }
 /* HIP-hook twin (lt_env_curriculum_update): one pass on caller-supplied records, no step-counter increment */
 int lt_oracle_curriculum_update(const lt_cfg* cfg, void* arena, const float* records) {
@@ -1283,6 +1378,9 @@ enum {
   RS_TACTILE_THR = 0x400, /* + taxel / 4 (startup stream): per-(env, taxel) threshold offsets, drawn once */
   RS_TACTILE = 0x500      /* + taxel / 2 (step stream): (dropout, addition) uniforms of two taxels per call */
 };
+
+/* RNG stream key of env e: its global index over all ranks (cfg.env_index_offset = index of this shard's env 0) */
+#define EKEY(cfg, e) ((uint32_t)(e) + (uint32_t)(cfg)->env_index_offset)
 
 static void startup_env(const lt_cfg* cfg, env_t* E, uint32_t env, const float* sizes) {
   /* startup events: trunk mass (locomotion_base_env_cfg.py:224-232), foot material (:233-244 + teacher override),
@@ -1576,13 +1674,13 @@ static void step_one(const lt_cfg* cfg, void* arena, const lt_layout* L, const f
     if (reset) {
       for (int i = 0; i < LT_REWARD_SLOTS; ++i) E.last_sums[i] = E.sums[i];
       E.episodes_finished += 1; E.last_ep_len = (real)E.ep_len; E.last_term_bits = (real)bits;
-      reset_env(cfg, P, &E, (uint32_t)e, step, has_object);
+      reset_env(cfg, P, &E, EKEY(cfg, e), step, has_object);
       memset(E.plate, 0, sizeof(E.plate)); /* ContactSensor.reset [DEP]: the reset envs' net forces are zeroed */
     }
     /* 7. command term compute */
     E.cmd_time_left -= step_dt;
     if (E.cmd_time_left <= 0)
-      command_resample(cfg, P, cfg->seed, (uint32_t)e, step, RS_CMD_TIMER, E.cmd, E.cmd_buf, &E.cmd_standing, &E.cmd_time_left);
+      command_resample(cfg, P, cfg->seed, EKEY(cfg, e), step, RS_CMD_TIMER, E.cmd, E.cmd_buf, &E.cmd_standing, &E.cmd_time_left);
     {
       float c[3] = {E.cmd[0], E.cmd[1], E.cmd[2]}, b[3] = {E.cmd_buf[0], E.cmd_buf[1], E.cmd_buf[2]};
       if (cfg->cmd_multi_sampling) lt_oracle_command_update(E.ep_len, (int)P[15], b, E.cmd_standing != 0, c);
@@ -1593,16 +1691,16 @@ static void step_one(const lt_cfg* cfg, void* arena, const lt_layout* L, const f
     float u[4], w[4];
     E.push_robot_left -= step_dt;
     if (E.push_robot_left < (real)1e-6) {
-      lt_rng4(cfg->seed, (uint32_t)e, step, RS_PUSH_ROBOT, u);
-      lt_rng4(cfg->seed, (uint32_t)e, step, RS_PUSH_ROBOT + 1, w);
+      lt_rng4(cfg->seed, EKEY(cfg, e), step, RS_PUSH_ROBOT, u);
+      lt_rng4(cfg->seed, EKEY(cfg, e), step, RS_PUSH_ROBOT + 1, w);
       E.push_robot_left = lt_lerp(cfg->push_robot_interval, u[3]);
       for (int c = 0; c < 3; ++c) { E.root_lin[c] += lt_lerp(cfg->push_robot_vel[c], u[c]); E.root_ang[c] += lt_lerp(cfg->push_robot_vel[3 + c], w[c]); }
     }
     if (has_object) {
       E.push_obj_left -= step_dt;
       if (E.push_obj_left < (real)1e-6) {
-        lt_rng4(cfg->seed, (uint32_t)e, step, RS_PUSH_OBJ, u);
-        lt_rng4(cfg->seed, (uint32_t)e, step, RS_PUSH_OBJ + 1, w);
+        lt_rng4(cfg->seed, EKEY(cfg, e), step, RS_PUSH_OBJ, u);
+        lt_rng4(cfg->seed, EKEY(cfg, e), step, RS_PUSH_OBJ + 1, w);
         E.push_obj_left = lt_lerp(cfg->push_obj_interval, u[3]);
         for (int c = 0; c < 3; ++c) { E.obj_lin[c] += lt_lerp(cfg->push_obj_vel[c], u[c]); E.obj_ang[c] += lt_lerp(cfg->push_obj_vel[3 + c], w[c]); }
       }
@@ -1612,7 +1710,7 @@ static void step_one(const lt_cfg* cfg, void* arena, const lt_layout* L, const f
   float pol[64], cri[64];
   int dims[8];
   int nt = task_term_dims(cfg, dims);
-  obs_frame(cfg, &E, (uint32_t)e, step, has_object, pol, cri);
+  obs_frame(cfg, &E, EKEY(cfg, e), step, has_object, pol, cri);
   float* rp = (float*)((char*)arena + L->off_obs_policy) + e * L->obs_dim;
   float* rc = (float*)((char*)arena + L->off_obs_critic) + e * L->obs_dim;
   int fill = reset || mode != LT_ORACLE_MODE_STEP;
@@ -1714,9 +1812,9 @@ static void tactile_pass(const lt_cfg* cfg, void* arena, const lt_layout* L) {
       f[k] = lt_quad(arena, L, LT_F_PLATE_SAMPLES, 2)[e * 4 + k];
     }
     lt_oracle_taxel_forces(x, y, f, forces);
-    for (int t = 0; t < nt; t += 4) { lt_rng4(cfg->seed, (uint32_t)e, ~(uint64_t)0, RS_TACTILE_THR + (uint32_t)(t >> 2), u); memcpy(ut + t, u, sizeof(u)); }
+    for (int t = 0; t < nt; t += 4) { lt_rng4(cfg->seed, EKEY(cfg, e), ~(uint64_t)0, RS_TACTILE_THR + (uint32_t)(t >> 2), u); memcpy(ut + t, u, sizeof(u)); }
     for (int t = 0; t < nt; t += 2) {
-      lt_rng4(cfg->seed, (uint32_t)e, step, RS_TACTILE + (uint32_t)(t >> 1), u);
+      lt_rng4(cfg->seed, EKEY(cfg, e), step, RS_TACTILE + (uint32_t)(t >> 1), u);
       ud[t] = u[0]; ua[t] = u[1]; ud[t + 1] = u[2]; ua[t + 1] = u[3];
     }
     lt_oracle_tactile_signals_u(cfg, forces, ut, ud, ua, (float*)((char*)arena + L->off_obs_tactile) + e * LT_TACTILE_DIM);
@@ -1740,8 +1838,8 @@ int lt_oracle_reset_all(const lt_cfg* cfg, void* arena) {
   for (int64_t e = 0; e < L.n; ++e) {
     env_t E;
     gather(&E, arena, &L, e);
-    startup_env(cfg, &E, (uint32_t)e, (const float*)((char*)arena + L.off_obj_sizes) + e * 2);
-    reset_env(cfg, P, &E, (uint32_t)e, 0, has_object);
+    startup_env(cfg, &E, EKEY(cfg, e), (const float*)((char*)arena + L.off_obj_sizes) + e * 2);
+    reset_env(cfg, P, &E, EKEY(cfg, e), 0, has_object);
     if (!has_object) E.obj_quat[0] = 1;
     /* ManagerBasedRLEnv.reset() does not run command_manager.compute(); only the zero-command window that
      * _resample_command applies itself (commands.py:559) is visible in the first observation */

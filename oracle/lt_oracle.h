@@ -79,6 +79,10 @@ void lt_oracle_cmd_params_init(const lt_cfg* cfg, float* P);
 void lt_oracle_curriculum(const lt_cfg* cfg, float* P, int64_t n, const float* rec, float* trk);
 /* arena twin of lt_env_curriculum_update: one curriculum pass on caller-supplied records [n][4] (trackers lag by one pass) */
 int lt_oracle_curriculum_update(const lt_cfg* cfg, void* arena, const float* records);
+/* multi-rank gate: the decision sequence on population sums (cross-checked against lt_oracle_curriculum in tests), and the
+ * arena twin of lt_env_curriculum_apply_global */
+void lt_oracle_gate_on_sums(const lt_cfg* cfg, float* P, const float r[8], float inv_n, int allow_lin, int allow_ang, int out[5]);
+int lt_oracle_curriculum_apply_global(const lt_cfg* cfg, void* arena, const float* ring_sums, int nsteps, int64_t n_total);
 void lt_oracle_obs_push(const int* term_dims, int nterms, int hist, const float* frame, int fill, float* row);
 
 #ifdef __cplusplus

@@ -69,6 +69,8 @@ def load() -> ctypes.CDLL:
     lib.lt_oracle_tactile_signals_u.argtypes = [P(_abi.LtCfg)] + [P(f32)] * 5
     lib.lt_oracle_reset_object_u.argtypes = [P(_abi.LtCfg)] + [P(f32)] * 4 + [f32] + [P(f32)] * 5
     lib.lt_oracle_curriculum_update.argtypes = [P(_abi.LtCfg), ctypes.c_void_p, P(f32)]
+    lib.lt_oracle_gate_on_sums.argtypes = [P(_abi.LtCfg), P(f32), P(f32), f32, ctypes.c_int, ctypes.c_int, P(i32)]
+    lib.lt_oracle_curriculum_apply_global.argtypes = [P(_abi.LtCfg), ctypes.c_void_p, P(f32), ctypes.c_int, ctypes.c_int64]
     lib.lt_oracle_obs_push.argtypes = [P(i32), ctypes.c_int, ctypes.c_int, P(f32), ctypes.c_int, P(f32)]
     _lib = lib
     return lib
@@ -102,6 +104,10 @@ class OracleEnv:
     def curriculum_update(self, records: np.ndarray):
         r = np.ascontiguousarray(records, dtype=np.float32)
         self.lib.lt_oracle_curriculum_update(ctypes.byref(self.cfg), self.ptr, fptr(r))
+
+    def curriculum_apply_global(self, ring_sums: np.ndarray, nsteps: int, n_total: int):
+        r = np.ascontiguousarray(ring_sums, dtype=np.float32)
+        self.lib.lt_oracle_curriculum_apply_global(ctypes.byref(self.cfg), self.ptr, fptr(r), int(nsteps), int(n_total))
 
     def eval_terms(self):
         self.lib.lt_oracle_eval_terms(ctypes.byref(self.cfg), self.ptr)

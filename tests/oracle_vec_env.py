@@ -58,6 +58,14 @@ class OracleVecEnv:
     def reset(self):
         return self.get_observations()
 
+    def curriculum_sync(self, dist, nsteps: int) -> None:
+        """LocoTouchVecEnv.curriculum_sync on the host arena."""
+        if not self.cfg.cur_gate_external:
+            return
+        ring = torch.from_numpy(self.layout.arr(self.o.arena, "LT_F_GATE_RING").copy())
+        dist.all_reduce_sum_(ring)
+        self.o.curriculum_apply_global(ring.numpy(), nsteps, self.num_envs * dist.world_size)
+
     def step(self, actions: torch.Tensor):
         self.o.step(actions.detach().cpu().numpy().astype(np.float32))
         obs, extras = self.get_observations()

@@ -111,13 +111,18 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
             err = float(np.abs(a - b).max())
             if bad.any():
                 soft_envs[name] = (err, set(np.nonzero(bad)[0].tolist()))
+        elif name == "LT_F_GATE_RING":  # population sums of the last passes: float sums formed in a different order on each side
+            bad = np.array([not np.allclose(a, b, rtol=2e-5, atol=2e-4)])
+            err = float(np.abs(a - b).max())
+            if bad.any():
+                hard.append((name, err, []))
         elif name == "LT_F_CMD_PARAMS":
             bad = np.array([not np.allclose(a, b, atol=1e-6)])
             err = float(np.abs(a - b).max())
             if bad.any():
                 hard.append((name, err, []))
         elif name == "LT_F_COUNTERS":
-            bad = np.array([a[0] != b[0]])
+            bad = np.array([a[0] != b[0] or a[3] != b[3]])
             err = float(abs(int(a[0]) - int(b[0])))
             if bad.any():
                 hard.append((name, err, []))

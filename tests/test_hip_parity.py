@@ -138,6 +138,49 @@ def test_step_parity_resynced(task, n, steps, phys, pre):
     assert tally.events <= 0.003 * n * steps, f"too many discontinuous-event divergences: {tally.events}"
 
 
+def test_global_gate_kernel_matches_oracle():
+    """Multi-rank curriculum gate (cfg.cur_gate_external): the step kernel publishes its population sums into LT_F_GATE_RING and
+    leaves the widening to lt_env_curriculum_apply_global; HIP and oracle, fed the same (here: single-rank) sums, must keep
+    identical command blocks, and the ranges must really widen."""
+    import torch
+    from locotouch_amd.rl import Dist
+
+    n, rollout = 64, 8
+    from locotouch_amd.env import LocoTouchVecEnv
+
+    cfg = _abi.preset_cfg(TASKS["teacher"], num_envs=n, seed=11)
+    cfg.cur_gate_external, cfg.env_index_offset, cfg.debug_terms = 1, 4096, 1
+    cfg.max_episode_length, cfg.cur_len_threshold = 12, 2.0  # every env times out often: whole populations pass the gate quickly
+    cfg.cur_reward_threshold[0] = cfg.cur_reward_threshold[1] = -1.0e3
+    env = LocoTouchVecEnv(TASKS["teacher"], device="cuda:0", cfg=cfg)
+    ora = O.OracleEnv(env.cfg)
+    ora.reset_all()
+    torch.cuda.synchronize()
+    compare_arenas(env, ora, what="reset_all (offset RNG keys)")
+    L = Layout(n, env.num_obs)
+    g = torch.Generator().manual_seed(5)
+    dist = Dist()
+    bins = []
+    for it in range(30):
+        for t in range(rollout):
+            act = 0.3 * torch.randn(n, 12, generator=g)
+            env._arena_aligned.copy_(torch.from_numpy(ora.arena))
+            env.step(act.cuda())
+            ora.step(act.numpy())
+            torch.cuda.synchronize()
+            compare_arenas(env, ora, what=f"external gate it {it} step {t}", max_flip_frac=0.05, max_event_frac=2.0 / n)
+        env._arena_aligned.copy_(torch.from_numpy(ora.arena))
+        env.curriculum_sync(dist, rollout)
+        ring = L.arr(ora.arena, "LT_F_GATE_RING").copy()
+        ora.curriculum_apply_global(ring, rollout, n)
+        torch.cuda.synchronize()
+        Pd = device_arena_to_host(env)
+        np.testing.assert_array_equal(L.arr(Pd, "LT_F_CMD_PARAMS"), L.arr(ora.arena, "LT_F_CMD_PARAMS"))
+        bins.append(float(L.arr(ora.arena, "LT_F_CMD_PARAMS")[17] + L.arr(ora.arena, "LT_F_CMD_PARAMS")[18]))
+    assert bins[-1] >= 3, bins
+    assert int(L.arr(ora.arena, "LT_F_COUNTERS")[3]) == 30 * rollout
+
+
 def test_free_running_statistics_teacher():
     """Without re-syncing, chaotic contact dynamics decorrelate trajectories; episode statistics must still agree."""
     import torch
