@@ -540,10 +540,56 @@ __device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P
 #ifndef LT_STEP_MIN_WAVES_LARGE
 #define LT_STEP_MIN_WAVES_LARGE 1
 #endif
+// ---- helper form: the physics of one 16-env tile runs on three waves.  Wave 0 keeps the leg dynamics; per substep it
+//      publishes (cos q, sin q, base state), wave 1 returns the CRBA part and wave 2 - which owns the object's state for the
+//      whole step - the object part, through LDS mailboxes [slot][lane] (same lane = env * 4 + leg mapping in all waves, so
+//      every slot row is one conflict-free 256-B line).  Two workgroup barriers per substep order the exchange:
+//        A: wave 0's inputs are in LDS          (helpers start)
+//        B: the helpers' results are in LDS     (wave 0 has meanwhile done FK / RNEA / contacts / the backward pass)
+//      `s_waitcnt lgkmcnt(0); s_barrier` only: no vmcnt drain (the history waves' DMA and wave 0's stores stay in flight).
+constexpr int MB_IN = 19, MB_CRBA = 34, MB_OBJ = 15, MB_OFIN = 13;
+__device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifdef LT_STAMPS
+#define LT_TIMED_BARRIER(acc) do { unsigned long long t0_, t1_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); \
+    wg_barrier_lds(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory"); *(acc) += t1_ - t0_; } while (0)
+#else
+#define LT_TIMED_BARRIER(acc) wg_barrier_lds()
+#endif
+struct HelperParts {
+  static constexpr bool external = true;
+  float (*in)[64]; float (*crba)[64]; float (*obj)[64];
+  int lane;
+  unsigned long long* wait;  // LT_STAMPS builds: cycles spent in barriers A ([0]) and B ([1])
+  __device__ __forceinline__ void publish(const float (&cq)[3], const float (&sq)[3], const Base& B) const {
+    const float v[MB_IN] = {cq[0], cq[1], cq[2], sq[0], sq[1], sq[2], B.p.x, B.p.y, B.p.z, B.q.w, B.q.x, B.q.y, B.q.z,
+                            B.u.x, B.u.y, B.u.z, B.w.x, B.w.y, B.w.z};
+#pragma unroll
+    for (int i = 0; i < MB_IN; ++i) in[i][lane] = v[i];
+    LT_TIMED_BARRIER(wait);  // A
+  }
+  __device__ __forceinline__ void fetch(PhysExt& e) const {
+    LT_TIMED_BARRIER(wait + 1);  // B
+    float c[MB_CRBA], o[MB_OBJ];
+#pragma unroll
+    for (int i = 0; i < MB_CRBA; ++i) c[i] = crba[i][lane];
+#pragma unroll
+    for (int i = 0; i < MB_OBJ; ++i) o[i] = obj[i][lane];
+    CrbaOut& r = e.crba;
+    r.h00 = c[0]; r.h01 = c[1]; r.h02 = c[2]; r.h11 = c[3]; r.h12 = c[4]; r.h22 = c[5];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { r.bn[j] = v3(c[6 + 3 * j], c[7 + 3 * j], c[8 + 3 * j]); r.bl[j] = v3(c[15 + 3 * j], c[16 + 3 * j], c[17 + 3 * j]); }
+    r.Io.xx = c[24]; r.Io.xy = c[25]; r.Io.xz = c[26]; r.Io.yy = c[27]; r.Io.yz = c[28]; r.Io.zz = c[29];
+    r.mc = v3(c[30], c[31], c[32]); r.m = c[33];
+    ObjOut& q = e.obj;
+    q.pb_n = v3(o[0], o[1], o[2]); q.pb_f = v3(o[3], o[4], o[5]); q.obj_part = v3(o[6], o[7], o[8]);
+    q.trunk_part = v3(o[9], o[10], o[11]); q.plate = v3(o[12], o[13], o[14]);
+  }
+};
+
 template <int TASK, int MODE, bool HELPERS>
 __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES_LARGE) void lt_step_kernel(const KArgs a) {
 #ifdef LT_STAMPS
-  unsigned long long stamps_[8];
+  unsigned long long stamps_[8], bar_wait_[2] = {0, 0};
   for (int i = 0; i < 8; ++i) stamps_[i] = 0;
 #endif
   LT_STAMP(0);
@@ -596,12 +642,19 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     uint4* dst = (uint4*)&s_d;
     if (lane < STG) dst[lane] = stg0;
     if (lane + 64 < STG) dst[lane + 64] = stg1;
+  } else if (HELPERS && HAS_OBJ && wave == 2) {  // the object helper owns the object's state during the physics
+    hot.obj_pos = *F(LT_F_OBJ_POS, 0); hot.obj_quat = *F(LT_F_OBJ_QUAT, 0);
+    hot.obj_lin = *F(LT_F_OBJ_LIN_VEL_W, 0); hot.obj_ang = *F(LT_F_OBJ_ANG_VEL_W, 0);
+    hot.obj_params = *F(LT_F_OBJ_PARAMS, 0); hot.env_params = *F(LT_F_ENV_PARAMS, 0);
   }
   __shared__ float s_frame[2][16][64];
   __shared__ int s_fill[16];
   __shared__ short s_tab[HELPERS ? 2 : 1][704];  // observation history tables (src[352] | frame[352]), one copy per history wave
   __shared__ __attribute__((aligned(16))) float s_old[HELPERS ? 2 * 16 * OBS : 4];
   __shared__ float s_cur[HELPERS ? 64 * 5 : 1];  // wave 0 -> wave 3: this step's curriculum record per lane
+  __shared__ float s_mb_in[HELPERS ? MB_IN : 1][64], s_mb_crba[HELPERS ? MB_CRBA : 1][64], s_mb_obj[HELPERS ? MB_OBJ : 1][64],
+      s_mb_ofin[HELPERS ? MB_OFIN : 1][64];  // physics mailboxes (HelperParts)
+  __shared__ float s_mb_rng[HELPERS ? 16 : 1][64];  // wave 3 -> wave 0: this step's observation-noise uniforms
   if (!HELPERS) {
     const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
     for (int i = lane; i < 352; i += 64) { s_tab[0][i] = tab.src[i]; s_tab[0][352 + i] = tab.frame[i]; }
@@ -615,8 +668,71 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   const uint32_t ekey = (uint32_t)env + (uint32_t)c.env_index_offset;  // RNG stream key of this env (global index over all ranks)
 
   if (HELPERS && wave != 0) {
+    // ---- physics helpers: as many (A, B) barrier pairs as wave 0 runs substeps ----
+    {
+      const int nsub = c.decimation * c.phys_substeps;
+      const float hs = c.sim_dt / (float)c.phys_substeps;
+      const float sxh = leg < 2 ? 1.f : -1.f, syh = (leg & 1) ? 1.f : -1.f;
+      const float sgnh[4] = {1.f, sxh, syh, sxh * syh};
+      Obj Oh;
+      float trunk_mu = 0.f;
+      if (HAS_OBJ && wave == 2) {
+        float t;
+        t = hot.obj_pos; Oh.p = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+        t = hot.obj_quat; Oh.q.w = qbcast<0>(t); Oh.q.x = qbcast<1>(t); Oh.q.y = qbcast<2>(t); Oh.q.z = qbcast<3>(t);
+        t = hot.obj_lin; Oh.u = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+        t = hot.obj_ang; Oh.w = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
+        t = hot.obj_params; Oh.rad = qbcast<0>(t); Oh.len = qbcast<1>(t); Oh.mass = qbcast<2>(t); Oh.mu = qbcast<3>(t);
+        Oh.cur_air = Oh.cur_con = Oh.last_air = Oh.last_con = 0.f;
+        trunk_mu = qbcast<1>(hot.env_params);
+      }
+      for (int it = 0; it < nsub; ++it) {
+        wg_barrier_lds();  // A
+        if (wave == 1) {
+          const float cqh[3] = {s_mb_in[0][lane], s_mb_in[1][lane], s_mb_in[2][lane]};
+          const float sqh[3] = {s_mb_in[3][lane], s_mb_in[4][lane], s_mb_in[5][lane]};
+          const CrbaOut r = crba_part(sgnh, cqh, sqh);
+          const float v[MB_CRBA] = {r.h00, r.h01, r.h02, r.h11, r.h12, r.h22,
+                                    r.bn[0].x, r.bn[0].y, r.bn[0].z, r.bn[1].x, r.bn[1].y, r.bn[1].z, r.bn[2].x, r.bn[2].y, r.bn[2].z,
+                                    r.bl[0].x, r.bl[0].y, r.bl[0].z, r.bl[1].x, r.bl[1].y, r.bl[1].z, r.bl[2].x, r.bl[2].y, r.bl[2].z,
+                                    r.Io.xx, r.Io.xy, r.Io.xz, r.Io.yy, r.Io.yz, r.Io.zz, r.mc.x, r.mc.y, r.mc.z, r.m};
+#pragma unroll
+          for (int i = 0; i < MB_CRBA; ++i) s_mb_crba[i][lane] = v[i];
+        } else if (HAS_OBJ && wave == 2) {
+          Base Bh;
+          Bh.p = v3(s_mb_in[6][lane], s_mb_in[7][lane], s_mb_in[8][lane]);
+          Bh.q.w = s_mb_in[9][lane]; Bh.q.x = s_mb_in[10][lane]; Bh.q.y = s_mb_in[11][lane]; Bh.q.z = s_mb_in[12][lane];
+          Bh.u = v3(s_mb_in[13][lane], s_mb_in[14][lane], s_mb_in[15][lane]);
+          Bh.w = v3(s_mb_in[16][lane], s_mb_in[17][lane], s_mb_in[18][lane]);
+          const ObjOut o = object_part<TAC>(c, hs, leg, Bh, Oh, trunk_mu);
+          const float v[MB_OBJ] = {o.pb_n.x, o.pb_n.y, o.pb_n.z, o.pb_f.x, o.pb_f.y, o.pb_f.z, o.obj_part.x, o.obj_part.y, o.obj_part.z,
+                                   o.trunk_part.x, o.trunk_part.y, o.trunk_part.z, o.plate.x, o.plate.y, o.plate.z};
+#pragma unroll
+          for (int i = 0; i < MB_OBJ; ++i) s_mb_obj[i][lane] = v[i];
+          if (it == nsub - 1) {  // the object's state after the last substep, for wave 0's terminations / rewards / observations
+            const float w[MB_OFIN] = {Oh.p.x, Oh.p.y, Oh.p.z, Oh.q.w, Oh.q.x, Oh.q.y, Oh.q.z, Oh.u.x, Oh.u.y, Oh.u.z, Oh.w.x, Oh.w.y, Oh.w.z};
+#pragma unroll
+            for (int i = 0; i < MB_OFIN; ++i) s_mb_ofin[i][lane] = w[i];
+          }
+        }
+        wg_barrier_lds();  // B
+      }
+    }
     if (wave == 3) {
-      // ---- wave 3: curriculum / population gate / step counter (lt_post.h) on the record wave 0 leaves in LDS ----
+      // ---- wave 3, beside wave 0's terminations / rewards: the observation-noise uniforms of this step (Philox is ~1 k
+      //      cycles per call - quarter-rate integer multiplies - and wave 0 would run its 8 calls serially through divergent
+      //      branches).  Per lane: joint-pos and joint-vel noise of its leg, object-noise block `leg`, base-noise block
+      //      (legs 2, 3 -> RS_NOISE_BASE, + 1).  Same streams and keys as the inline form: bit-identical draws. ----
+      {
+        const U4 uj = rng4(c.seed, ekey, step, RS_NOISE_JPOS + leg), uv = rng4(c.seed, ekey, step, RS_NOISE_JVEL + leg);
+        const U4 uo = rng4(c.seed, ekey, step, RS_NOISE_OBJ + leg);
+        const U4 ub = rng4(c.seed, ekey, step, RS_NOISE_BASE + (leg == 3 ? 1 : 0));
+        const float v[16] = {uj.a, uj.b, uj.c, uj.d, uv.a, uv.b, uv.c, uv.d, uo.a, uo.b, uo.c, uo.d, ub.a, ub.b, ub.c, ub.d};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_mb_rng[i][lane] = v[i];
+      }
+      wg_barrier_lds();  // C: the uniforms are in LDS
+      // ---- curriculum / population gate / step counter (lt_post.h) on the record wave 0 leaves in LDS ----
       __syncthreads();  // B1
       CurIn in;
       in.valid = env < L.n;
@@ -664,6 +780,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
         if (col < OBS && src[i] >= 0) rows[r * OBS + col] = old[r * OBS + src[i]];
       }
     }
+    wg_barrier_lds();  // C (wave 3's noise uniforms -> wave 0)
     __syncthreads();  // B1: newest frame + reset flags are in LDS
     for (int r = 0; r < 16; ++r) {
       const bool fill = s_fill[r] != 0;  // first push after a reset fills all 6 slots
@@ -762,7 +879,18 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
         G.tau[k] = dc_motor(c, qdef[k] + G.raw[k], G.q[k], G.qd[k]);
       }
       Report rep;
-      for (int s = 0; s < c.phys_substeps; ++s) physics_substep<HAS_OBJ, TAC>(c, h, leg, sgn, B, G, O, X, rep);
+      if (HELPERS) {
+        HelperParts hp;
+        hp.in = s_mb_in; hp.crba = s_mb_crba; hp.obj = s_mb_obj; hp.lane = lane;
+#ifdef LT_STAMPS
+        hp.wait = bar_wait_;
+#else
+        hp.wait = nullptr;
+#endif
+        for (int s = 0; s < c.phys_substeps; ++s) physics_substep<HAS_OBJ, TAC, HelperParts>(c, h, leg, sgn, B, G, O, X, rep, hp);
+      } else {
+        for (int s = 0; s < c.phys_substeps; ++s) physics_substep<HAS_OBJ, TAC>(c, h, leg, sgn, B, G, O, X, rep);
+      }
       if (TAC) {
         if (tac_phase == 0) { tac = rep.plate; tac_new = true; }
         tac_phase = tac_phase + 1 >= tac_every ? 0 : tac_phase + 1;
@@ -780,6 +908,12 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       X.trunk_fh[2] = X.trunk_fh[1]; X.trunk_fh[1] = X.trunk_fh[0];
       X.trunk_fh[0] = norm(qsum(rep.trunk_part));
       if (HAS_OBJ) timers_update(O.cur_air, O.cur_con, O.last_air, O.last_con, norm(qsum(rep.obj_part)) > c.contact_force_threshold, c.sim_dt);
+    }
+    if (HELPERS && HAS_OBJ) {  // the object as its helper wave left it (written before the last barrier B)
+      O.p = v3(s_mb_ofin[0][lane], s_mb_ofin[1][lane], s_mb_ofin[2][lane]);
+      O.q.w = s_mb_ofin[3][lane]; O.q.x = s_mb_ofin[4][lane]; O.q.y = s_mb_ofin[5][lane]; O.q.z = s_mb_ofin[6][lane];
+      O.u = v3(s_mb_ofin[7][lane], s_mb_ofin[8][lane], s_mb_ofin[9][lane]);
+      O.w = v3(s_mb_ofin[10][lane], s_mb_ofin[11][lane], s_mb_ofin[12][lane]);
     }
     foot_kinematics(sgn, B, G);
   }
@@ -1119,7 +1253,15 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
     const V3 wb = tmul(R0, B.w), gb = -row(R0, 2);
     const bool noisy = c.enable_corruption != 0;
-    const U4 uj = rng4(c.seed, ekey, step, RS_NOISE_JPOS + leg), uvv = rng4(c.seed, ekey, step, RS_NOISE_JVEL + leg);
+    U4 uj, uvv;
+    if (HELPERS) {
+      wg_barrier_lds();  // C: wave 3's uniforms are in LDS
+      uj.a = s_mb_rng[0][lane]; uj.b = s_mb_rng[1][lane]; uj.c = s_mb_rng[2][lane]; uj.d = 0.f;
+      uvv.a = s_mb_rng[4][lane]; uvv.b = s_mb_rng[5][lane]; uvv.c = s_mb_rng[6][lane]; uvv.d = 0.f;
+    } else {
+      uj = rng4(c.seed, ekey, step, RS_NOISE_JPOS + leg);
+      uvv = rng4(c.seed, ekey, step, RS_NOISE_JVEL + leg);
+    }
     const float nj[3] = {uj.a, uj.b, uj.c}, nv[3] = {uvv.a, uvv.b, uvv.c};
     float* fp = s_frame[0][el];
     float* fc = s_frame[1][el];
@@ -1135,7 +1277,14 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       fp[33 + k * 4 + leg] = G.raw[k];
     }
     if (leg == 0) {
-      const U4 ua = rng4(c.seed, ekey, step, RS_NOISE_BASE), ug = rng4(c.seed, ekey, step, RS_NOISE_BASE + 1);
+      U4 ua, ug;
+      if (HELPERS) {  // lanes 2 and 3 of the quad hold the two base-noise blocks
+        ua.a = s_mb_rng[12][lane + 2]; ua.b = s_mb_rng[13][lane + 2]; ua.c = s_mb_rng[14][lane + 2]; ua.d = 0.f;
+        ug.a = s_mb_rng[12][lane + 3]; ug.b = s_mb_rng[13][lane + 3]; ug.c = s_mb_rng[14][lane + 3]; ug.d = 0.f;
+      } else {
+        ua = rng4(c.seed, ekey, step, RS_NOISE_BASE);
+        ug = rng4(c.seed, ekey, step, RS_NOISE_BASE + 1);
+      }
       const float na[3] = {ua.a, ua.b, ua.c}, ng[3] = {ug.a, ug.b, ug.c};
       const float cm[3] = {X.cmd.x, X.cmd.y, X.cmd.z}, wv[3] = {wb.x, wb.y, wb.z}, gv[3] = {gb.x, gb.y, gb.z};
 #pragma unroll
@@ -1152,7 +1301,13 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       float u16[16];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const U4 t = rng4(c.seed, ekey, step, RS_NOISE_OBJ + b);
+        U4 t;
+        if (HELPERS) {  // block b was drawn by lane b of the quad (this is lane 1)
+          const int l = lane - 1 + b;
+          t.a = s_mb_rng[8][l]; t.b = s_mb_rng[9][l]; t.c = s_mb_rng[10][l]; t.d = s_mb_rng[11][l];
+        } else {
+          t = rng4(c.seed, ekey, step, RS_NOISE_OBJ + b);
+        }
         u16[4 * b] = t.a; u16[4 * b + 1] = t.b; u16[4 * b + 2] = t.c; u16[4 * b + 3] = t.d;
       }
       float o[13];
@@ -1267,6 +1422,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   LT_STAMP(7);
   if (lane == 0)
     for (int q = 0; q < 7; ++q) *F(LT_F_LAST_EPISODE_SUMS, q) = (float)(long long)(stamps_[q + 1] - stamps_[q]);
+  if (lane == 0) { *F(LT_F_REWARD_TERMS, 0) = (float)(long long)bar_wait_[0]; *F(LT_F_REWARD_TERMS, 1) = (float)(long long)bar_wait_[1]; }
 #endif
 }
 

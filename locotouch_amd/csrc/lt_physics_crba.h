@@ -150,47 +150,72 @@ __device__ __forceinline__ RC leg_contact(const lt_cfg& c, float h, V3 r, float 
   return out;
 }
 
-// =====================================================================================================
-// K2 physics: one integrator substep of length h (torques held).  Reference: PhysX (closed source) - this is the
-// engine's own model; executable spec: oracle/lt_oracle.c physics_substep; description: DESIGN.md "Physics model".
-// =====================================================================================================
-template <bool HAS_OBJ, bool TAC = false>
-__device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int leg, const float (&sgn)[4], Base& B, Leg& G, Obj& O,
-                                                const Misc& X, Report& rep) {
-  const float g = c.gravity;
+// ---- CRBA on rigid composites: this leg's joint-space inertia, its coupling to the base and its rigid share of the base
+//      block.  A function of the joint angles alone, so a helper wave can run it beside the leg dynamics. ----
+struct CrbaOut {
+  float h00, h01, h02, h11, h12, h22;
+  V3 bn[3], bl[3];
+  S3 Io; V3 mc; float m;  // composite of the whole leg about the base origin
+};
+__device__ __forceinline__ CrbaOut crba_part(const float (&sgn)[4], const float (&cq)[3], const float (&sq)[3]) {
+  CrbaOut o;
   const LinkC LC[3] = {make_link<0>(sgn), make_link<1>(sgn), make_link<2>(sgn)};
-  float cq[3], sq[3];
+  Rigid RB[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { sq[k] = __sinf(G.q[k]); cq[k] = __cosf(G.q[k]); }  // v_sin/v_cos: |err| ~1e-6 on |q| < 4.6 rad
+  for (int k = 0; k < 3; ++k) { RB[k].m = LC[k].m; RB[k].mc = LC[k].mc; RB[k].Io = LC[k].Io; }
+  {
+    const Rigid C3 = RB[2];
+    const Rigid C2 = rigid_add(RB[1], rigid_to_parent<1>(C3, cq[2], sq[2], LC[2].r));
+    const Rigid C1 = rigid_add(RB[0], rigid_to_parent<1>(C2, cq[1], sq[1], LC[1].r));
+    const Rigid Cb = rigid_to_parent<0>(C1, cq[0], sq[0], LC[0].r);
+    // joint 2 (calf, axis y)
+    const F6 F3 = rigid_col<1>(C3);
+    o.h22 = C3.Io.yy;
+    const F6 F32 = force_to_parent<1>(F3, cq[2], sq[2], LC[2].r);
+    o.h12 = F32.n.y;
+    const F6 F31 = force_to_parent<1>(F32, cq[1], sq[1], LC[1].r);
+    o.h02 = F31.n.x;
+    const F6 F30 = force_to_parent<0>(F31, cq[0], sq[0], LC[0].r);
+    o.bn[2] = F30.n; o.bl[2] = F30.f;
+    // joint 1 (thigh, axis y)
+    const F6 F2 = rigid_col<1>(C2);
+    o.h11 = C2.Io.yy;
+    const F6 F21 = force_to_parent<1>(F2, cq[1], sq[1], LC[1].r);
+    o.h01 = F21.n.x;
+    const F6 F20 = force_to_parent<0>(F21, cq[0], sq[0], LC[0].r);
+    o.bn[1] = F20.n; o.bl[1] = F20.f;
+    // joint 0 (hip, axis x)
+    const F6 F1 = rigid_col<0>(C1);
+    o.h00 = C1.Io.xx;
+    const F6 F10 = force_to_parent<0>(F1, cq[0], sq[0], LC[0].r);
+    o.bn[0] = F10.n; o.bl[0] = F10.f;
+    o.Io = Cb.Io; o.mc = Cb.mc; o.m = Cb.m;  // rigid share of the base block
+  }
+  return o;
+}
+
+// ---- the carried cylinder's share of a substep: its contacts with the plate (sample = lane) and the ground, its own 6x6
+//      solve, and its integration.  Couples to the robot only through the base STATE at the substep start (the plate
+//      reaction is an explicit wrench on the trunk), so a helper wave can run it beside the leg dynamics. ----
+struct ObjOut {
+  V3 pb_n, pb_f;      // this lane's share of the base bias wrench (reaction of its plate sample)
+  V3 obj_part;        // ... of the net contact force on the object (world)
+  V3 trunk_part;      // ... of the net contact force on the trunk (world), plate part
+  V3 plate;           // tactile tasks: this lane's plate sample (x, y in the trunk frame, normal force)
+};
+template <bool TAC>
+__device__ __forceinline__ ObjOut object_part(const lt_cfg& c, float h, int leg, const Base& B, Obj& O, float trunk_mu) {
+  ObjOut out;
+  out.pb_n = v3(0, 0, 0); out.pb_f = v3(0, 0, 0); out.obj_part = v3(0, 0, 0); out.trunk_part = v3(0, 0, 0); out.plate = v3(0, 0, 0);
+  const float g = c.gravity;
   const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
-  const V3 wb = tmul(R0, B.w), vb = tmul(R0, B.u);
-  V3 om[3], vl[3], pw[3], ca[3], cl[3];
-  M3 Rw[3];
-  joint_fk<0>(wb, vb, R0, B.p, LC[0].r, cq[0], sq[0], G.qd[0], om[0], vl[0], Rw[0], pw[0], ca[0], cl[0]);
-  joint_fk<1>(om[0], vl[0], Rw[0], pw[0], LC[1].r, cq[1], sq[1], G.qd[1], om[1], vl[1], Rw[1], pw[1], ca[1], cl[1]);
-  joint_fk<1>(om[1], vl[1], Rw[1], pw[1], LC[2].r, cq[2], sq[2], G.qd[2], om[2], vl[2], Rw[2], pw[2], ca[2], cl[2]);
-  // velocity-product spatial accelerations (base and joint accelerations zero)
-  V3 aa[3], al[3];
-  aa[0] = ca[0]; al[0] = cl[0];
-  aa[1] = rot_inv<1>(cq[1], sq[1], aa[0]) + ca[1];
-  al[1] = rot_inv<1>(cq[1], sq[1], al[0] + cross(aa[0], LC[1].r)) + cl[1];
-  aa[2] = rot_inv<1>(cq[2], sq[2], aa[1]) + ca[2];
-  al[2] = rot_inv<1>(cq[2], sq[2], al[1] + cross(aa[1], LC[2].r)) + cl[2];
-  const V3 axw[3] = {col(Rw[0], 0), col(Rw[1], 1), col(Rw[2], 1)};  // joint axes in world
-
-  // this lane's share of the base block / base bias wrench
-  I6 Mbb; Mbb.A = m3_zero(); Mbb.B = m3_zero(); Mbb.C = m3_zero();
-  F6 pb; pb.n = v3(0, 0, 0); pb.f = v3(0, 0, 0);
-  rep.trunk_part = v3(0, 0, 0);
-  rep.obj_part = v3(0, 0, 0);
-
   // ---- carried cylinder: free body, implicit contacts with the plate (sample = lane) and the ground ----
   V3 obj_aa = v3(0, 0, 0), obj_al = v3(0, 0, 0);
-  if (HAS_OBJ) {
+  {
     const M3 Ro = quat_to_mat(O.q.w, O.q.x, O.q.y, O.q.z);
     const V3 ay = col(Ro, 1);
     const float rad = O.rad, half = 0.5f * O.len;
-    const float mu_plate = 0.5f * (X.trunk_mu + O.mu);
+    const float mu_plate = 0.5f * (trunk_mu + O.mu);
     const V3 ct = tmul(R0, O.p - B.p), at = tmul(R0, ay);
     const float hx = LT_BACK_HALF_X, hy = LT_RAIL_Y + LT_RAIL_RADIUS, zp = LT_BACK_TOP_Z;
     float s0 = -half, s1 = half;
@@ -216,7 +241,7 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
     Law lp; lp.active = false; lp.fx = lp.fy = lp.fn = lp.cte = lp.Bn = 0.f;
     V3 Pw_p = v3(0, 0, 0), rho_p = v3(0, 0, 0), F0_p = v3(0, 0, 0);
     const V3 nw = col(R0, 2);
-    if (TAC) rep.plate = v3(0, 0, 0);
+    out.plate = v3(0, 0, 0);
     if (ok) {
       const float nza = at.z;
       const V3 up = v3(-nza * at.x, -nza * at.y, 1.f - nza * at.z);
@@ -225,7 +250,7 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
       const float sk = s0 + (s1 - s0) * (float)leg / 3.f;
       const V3 Pt = v3(ct.x + sk * at.x - rad * up.x * inv, ct.y + sk * at.y - rad * up.y * inv, ct.z + sk * at.z - rad * up.z * inv);
       const float d = zp - Pt.z;
-      if (TAC) { rep.plate.x = Pt.x; rep.plate.y = Pt.y; }
+      if (TAC) { out.plate.x = Pt.x; out.plate.y = Pt.y; }
       if (d > 0.f) {
         Pw_p = B.p + mul(R0, Pt);
         rho_p = Pw_p - O.p;
@@ -278,19 +303,70 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
       const V3 ap = obj_al + cross(obj_aa, rho_p);
       const float an = dot(nw, ap);
       const V3 F = F0_p - h * (lp.cte * ap + ((lp.Bn - lp.cte) * an) * nw);
-      rep.obj_part += F;
-      if (TAC) rep.plate.z = dot(nw, F);  // the cylinder presses the taxels with the plate-normal part of its contact force
+      out.obj_part += F;
+      if (TAC) out.plate.z = dot(nw, F);  // the cylinder presses the taxels with the plate-normal part of its contact force
       const V3 Fn = -F;
       const V3 rb = tmul(R0, Pw_p - B.p), fb = tmul(R0, Fn);
-      pb.n -= cross(rb, fb);
-      pb.f -= fb;
-      rep.trunk_part += Fn;
+      out.pb_n -= cross(rb, fb);
+      out.pb_f -= fb;
+      out.trunk_part += Fn;
     }
     if (lg.active) {
       const V3 ap = obj_al + cross(obj_aa, rho_g);
-      rep.obj_part += v3(F0_g.x - h * lg.cte * ap.x, F0_g.y - h * lg.cte * ap.y, F0_g.z - h * lg.Bn * ap.z);
+      out.obj_part += v3(F0_g.x - h * lg.cte * ap.x, F0_g.y - h * lg.cte * ap.y, F0_g.z - h * lg.Bn * ap.z);
     }
   }
+
+  O.w += h * obj_aa;
+  O.u += h * obj_al;
+  O.p += h * O.u;
+  O.q = q_integrate(O.q, O.w, h);
+  return out;
+}
+
+// =====================================================================================================
+// K2 physics: one integrator substep of length h (torques held).  Reference: PhysX (closed source) - this is the
+// engine's own model; executable spec: oracle/lt_oracle.c physics_substep; description: DESIGN.md "Physics model".
+// =====================================================================================================
+// `Ext` decides where the CRBA and object parts run.  InlineParts: here, in this wave.  The step kernel's helper form passes
+// a policy whose publish() hands (cos q, sin q, base state) to two helper waves and whose fetch() waits for their results
+// (lt_env.hip): the object is then owned by its helper wave and `O` is not touched here.
+struct PhysExt { CrbaOut crba; ObjOut obj; };
+struct InlineParts {
+  static constexpr bool external = false;
+  __device__ __forceinline__ void publish(const float (&)[3], const float (&)[3], const Base&) const {}
+  __device__ __forceinline__ void fetch(PhysExt&) const {}
+};
+template <bool HAS_OBJ, bool TAC = false, class Ext = InlineParts>
+__device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int leg, const float (&sgn)[4], Base& B, Leg& G, Obj& O,
+                                                const Misc& X, Report& rep, const Ext& ext = Ext()) {
+  const float g = c.gravity;
+  const LinkC LC[3] = {make_link<0>(sgn), make_link<1>(sgn), make_link<2>(sgn)};
+  float cq[3], sq[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { sq[k] = __sinf(G.q[k]); cq[k] = __cosf(G.q[k]); }  // v_sin/v_cos: |err| ~1e-6 on |q| < 4.6 rad
+  ext.publish(cq, sq, B);
+  const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
+  const V3 wb = tmul(R0, B.w), vb = tmul(R0, B.u);
+  V3 om[3], vl[3], pw[3], ca[3], cl[3];
+  M3 Rw[3];
+  joint_fk<0>(wb, vb, R0, B.p, LC[0].r, cq[0], sq[0], G.qd[0], om[0], vl[0], Rw[0], pw[0], ca[0], cl[0]);
+  joint_fk<1>(om[0], vl[0], Rw[0], pw[0], LC[1].r, cq[1], sq[1], G.qd[1], om[1], vl[1], Rw[1], pw[1], ca[1], cl[1]);
+  joint_fk<1>(om[1], vl[1], Rw[1], pw[1], LC[2].r, cq[2], sq[2], G.qd[2], om[2], vl[2], Rw[2], pw[2], ca[2], cl[2]);
+  // velocity-product spatial accelerations (base and joint accelerations zero)
+  V3 aa[3], al[3];
+  aa[0] = ca[0]; al[0] = cl[0];
+  aa[1] = rot_inv<1>(cq[1], sq[1], aa[0]) + ca[1];
+  al[1] = rot_inv<1>(cq[1], sq[1], al[0] + cross(aa[0], LC[1].r)) + cl[1];
+  aa[2] = rot_inv<1>(cq[2], sq[2], aa[1]) + ca[2];
+  al[2] = rot_inv<1>(cq[2], sq[2], al[1] + cross(aa[1], LC[2].r)) + cl[2];
+  const V3 axw[3] = {col(Rw[0], 0), col(Rw[1], 1), col(Rw[2], 1)};  // joint axes in world
+
+  // this lane's share of the base block / base bias wrench
+  I6 Mbb; Mbb.A = m3_zero(); Mbb.B = m3_zero(); Mbb.C = m3_zero();
+  F6 pb; pb.n = v3(0, 0, 0); pb.f = v3(0, 0, 0);
+  rep.trunk_part = v3(0, 0, 0);
+  rep.obj_part = v3(0, 0, 0);
 
   // ---- RNEA forces of this leg's links (zero accelerations) + contacts ----
   Rigid RB[3];
@@ -333,39 +409,31 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
   S.rhs[1] = G.tau[1] - f[1].n.y;
   S.rhs[2] = G.tau[2] - f[2].n.y;
 
-  // ---- CRBA on rigid composites ----
+  // ---- the two parts that do not depend on this lane's leg dynamics: the carried cylinder (object_part) and the CRBA
+  //      (crba_part) - computed here, or fetched from the helper waves that ran them beside the code above ----
+  PhysExt pe;
+  if (Ext::external) {
+    ext.fetch(pe);
+  } else {
+    if (HAS_OBJ) pe.obj = object_part<TAC>(c, h, leg, B, O, X.trunk_mu);
+    pe.crba = crba_part(sgn, cq, sq);
+  }
+  if (HAS_OBJ) {
+    pb.n += pe.obj.pb_n; pb.f += pe.obj.pb_f;
+    rep.obj_part = pe.obj.obj_part;
+    rep.trunk_part += pe.obj.trunk_part;
+    if (TAC) rep.plate = pe.obj.plate;
+  }
   {
-    const Rigid C3 = RB[2];
-    const Rigid C2 = rigid_add(RB[1], rigid_to_parent<1>(C3, cq[2], sq[2], LC[2].r));
-    const Rigid C1 = rigid_add(RB[0], rigid_to_parent<1>(C2, cq[1], sq[1], LC[1].r));
-    const Rigid Cb = rigid_to_parent<0>(C1, cq[0], sq[0], LC[0].r);
-    // joint 2 (calf, axis y)
-    const F6 F3 = rigid_col<1>(C3);
-    S.h22 += C3.Io.yy;
-    const F6 F32 = force_to_parent<1>(F3, cq[2], sq[2], LC[2].r);
-    S.h12 += F32.n.y;
-    const F6 F31 = force_to_parent<1>(F32, cq[1], sq[1], LC[1].r);
-    S.h02 += F31.n.x;
-    const F6 F30 = force_to_parent<0>(F31, cq[0], sq[0], LC[0].r);
-    S.bn[2] += F30.n; S.bl[2] += F30.f;
-    // joint 1 (thigh, axis y)
-    const F6 F2 = rigid_col<1>(C2);
-    S.h11 += C2.Io.yy;
-    const F6 F21 = force_to_parent<1>(F2, cq[1], sq[1], LC[1].r);
-    S.h01 += F21.n.x;
-    const F6 F20 = force_to_parent<0>(F21, cq[0], sq[0], LC[0].r);
-    S.bn[1] += F20.n; S.bl[1] += F20.f;
-    // joint 0 (hip, axis x)
-    const F6 F1 = rigid_col<0>(C1);
-    S.h00 += C1.Io.xx;
-    const F6 F10 = force_to_parent<0>(F1, cq[0], sq[0], LC[0].r);
-    S.bn[0] += F10.n; S.bl[0] += F10.f;
-    // rigid share of the base block
-    Mbb.A.m[0] += Cb.Io.xx; Mbb.A.m[1] += Cb.Io.xy; Mbb.A.m[2] += Cb.Io.xz;
-    Mbb.A.m[3] += Cb.Io.xy; Mbb.A.m[4] += Cb.Io.yy; Mbb.A.m[5] += Cb.Io.yz;
-    Mbb.A.m[6] += Cb.Io.xz; Mbb.A.m[7] += Cb.Io.yz; Mbb.A.m[8] += Cb.Io.zz;
-    Mbb.B += skew_of(Cb.mc);
-    Mbb.C.m[0] += Cb.m; Mbb.C.m[4] += Cb.m; Mbb.C.m[8] += Cb.m;
+    const CrbaOut& cr = pe.crba;
+    S.h00 += cr.h00; S.h01 += cr.h01; S.h02 += cr.h02; S.h11 += cr.h11; S.h12 += cr.h12; S.h22 += cr.h22;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { S.bn[j] += cr.bn[j]; S.bl[j] += cr.bl[j]; }
+    Mbb.A.m[0] += cr.Io.xx; Mbb.A.m[1] += cr.Io.xy; Mbb.A.m[2] += cr.Io.xz;
+    Mbb.A.m[3] += cr.Io.xy; Mbb.A.m[4] += cr.Io.yy; Mbb.A.m[5] += cr.Io.yz;
+    Mbb.A.m[6] += cr.Io.xz; Mbb.A.m[7] += cr.Io.yz; Mbb.A.m[8] += cr.Io.zz;
+    Mbb.B += skew_of(cr.mc);
+    Mbb.C.m[0] += cr.m; Mbb.C.m[4] += cr.m; Mbb.C.m[8] += cr.m;
   }
 
   // ---- eliminate this leg's joints: H = L L^T (3x3), Y = L^-1 H_lb, z = L^-1 rhs ----
@@ -455,11 +523,5 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
     B.w += h * mul(R0, a0a);
     B.p += h * B.u;
     B.q = q_integrate(B.q, B.w, h);
-  }
-  if (HAS_OBJ) {
-    O.w += h * obj_aa;
-    O.u += h * obj_al;
-    O.p += h * O.u;
-    O.q = q_integrate(O.q, O.w, h);
   }
 }

@@ -14,4 +14,6 @@ names = ["load hot state", "physics (4 substeps)", "late loads + terms + rewards
 tot = st.sum(1).mean()
 for i, nm in enumerate(names):
     print(f"{nm:32s} mean {st[:, i].mean():10.0f} ticks  ({100 * st[:, i].mean() / tot:5.1f} %)   max {st[:, i].max():10.0f}")
+bw = env.field("LT_F_REWARD_TERMS")[::16, :2, 0].cpu()
+print(f"wave 0 waiting in physics barriers: A {bw[:, 0].mean():.0f} ticks, B {bw[:, 1].mean():.0f} ticks (4 substeps)")
 print("total ticks", float(tot), "(s_memtime ticks at 100 MHz => us:", float(tot) / 100.0, ")")
