@@ -11,6 +11,8 @@ import torch
 import torch.nn as nn
 from torch.distributions import Normal
 
+from .linear import Linear
+
 _ACTIVATIONS = {"elu": nn.ELU, "relu": nn.ReLU, "selu": nn.SELU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid,
                 "lrelu": nn.LeakyReLU, "identity": nn.Identity}
 
@@ -21,8 +23,8 @@ def build_mlp(in_dim: int, hidden: list[int], out_dim: int, activation: str) -> 
     sizes = [in_dim, *hidden]
     layers: list[nn.Module] = []
     for a, b in zip(sizes[:-1], sizes[1:]):
-        layers += [nn.Linear(a, b), act()]
-    layers.append(nn.Linear(sizes[-1], out_dim))
+        layers += [Linear(a, b), act()]
+    layers.append(Linear(sizes[-1], out_dim))
     return nn.Sequential(*layers)
 
 
