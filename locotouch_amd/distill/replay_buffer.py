@@ -154,17 +154,28 @@ class ReplayBuffer:
                               torch.tensor(self._traj_len, dtype=torch.int64, device=self._device))
         return self._flat, self._traj_dev
 
-    def to_recurrent_generator(self, batch_size: int):
+    def to_recurrent_generator(self, batch_size: int, static_shapes: bool = True):
+        """`static_shapes`: every batch is padded to the SAME (longest trajectory in the buffer, batch_size) shape - masked
+        rows / columns, so losses and gradients are those of the tight padding.  On ROCm every new (L * B) costs MIOpen a
+        solver search for the student's convolutions (110-300 ms per new shape, tools/shape_probe.py; once 151 s for a
+        kernel compile), which at ~10 differently shaped batches per epoch was 85 % of the BC wall clock."""
         num_trajs = len(self._traj_first)
         order = np.random.permutation(np.arange(num_trajs))  # replay_buffer.py:86-87
+        pad = (max(self._traj_len), batch_size) if static_shapes and num_trajs else None
         for s in range(0, num_trajs, batch_size):
-            yield self._prepare_padded_sequence(order[s:min(s + batch_size, num_trajs)])
+            yield self._prepare_padded_sequence(order[s:min(s + batch_size, num_trajs)], pad_to=pad)
 
-    def _prepare_padded_sequence(self, traj_indices):
+    def _prepare_padded_sequence(self, traj_indices, pad_to=None):
         (policy, tactile), (first, length) = self._materialise()
         idx = torch.as_tensor(np.asarray(traj_indices), dtype=torch.int64, device=self._device)
         f, ln = first[idx], length[idx]
         max_len = int(max(self._traj_len[i] for i in traj_indices))
+        if pad_to is not None:
+            max_len = max(max_len, int(pad_to[0]))
+            extra = int(pad_to[1]) - len(traj_indices)
+            if extra > 0:  # empty trajectories: length 0, every step masked
+                f = torch.cat([f, f.new_zeros(extra)])
+                ln = torch.cat([ln, ln.new_zeros(extra)])
         tt = torch.arange(max_len, device=self._device).unsqueeze(1)            # (L, 1)
         masks = tt < ln.unsqueeze(0)                                            # (L, B)
         rows = torch.where(masks, f.unsqueeze(0) + tt * self._num_envs, torch.zeros_like(tt))

@@ -15,6 +15,8 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from .gru import gru_sequence
+
 _ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "crelu": nn.ReLU, "lrelu": nn.LeakyReLU, "tanh": nn.Tanh,
                 "sigmoid": nn.Sigmoid}
 
@@ -54,9 +56,13 @@ class Memory(nn.Module):
         cls = nn.GRU if memory_type.lower() == "gru" else nn.LSTM
         self.rnn = cls(input_size=input_dim, hidden_size=hidden_size, num_layers=num_layers)
         self.hidden_states = None
+        self.use_miopen_sequence = False  # True: whole-trajectory batches through nn.GRU's own (MIOpen) path
 
     def forward(self, input, hidden_states=None):
         if input.dim() == 3:
+            if input.is_cuda and isinstance(self.rnn, nn.GRU) and self.rnn.num_layers == 1 and not self.use_miopen_sequence:
+                out, _ = gru_sequence(self.rnn, input, hidden_states)  # rl/gru.py: ~15x MIOpen's RNN path at L ~ 500, B ~ 47
+                return out
             out, _ = self.rnn(input, hidden_states)
             return out
         if isinstance(self.rnn, nn.GRU) and self.rnn.num_layers == 1:

@@ -132,6 +132,19 @@ def test_replay_buffer_keeps_the_reference_trajectories(gold, check_every):
         assert rb._traj_len == gold["rb2_traj_lengths"].tolist()
         seen = sum(len(b_["masks"][0]) for b_ in rb.to_recurrent_generator(batch_size=4))
         assert seen == rb.num_trajs
+    # static shapes: same masked content, padded to (longest trajectory, batch size)
+    torch.manual_seed(0)
+    import numpy as _np
+    _np.random.seed(3)
+    tight = list(rb.to_recurrent_generator(batch_size=4, static_shapes=False))
+    _np.random.seed(3)
+    fixed = list(rb.to_recurrent_generator(batch_size=4, static_shapes=True))
+    Lmax = max(rb._traj_len)
+    for a, b_ in zip(tight, fixed):
+        assert b_["masks"].shape == (Lmax, 4) and int(b_["masks"].sum()) == int(a["masks"].sum())
+        l, w = a["masks"].shape
+        assert torch.equal(b_["masks"][:l, :w], a["masks"]) and not b_["masks"][l:].any() and not b_["masks"][:, w:].any()
+        assert torch.equal(b_["tactile_signals"][:l, :w], a["tactile_signals"]) and (b_["proprioceptions"][l:] == 0).all()
     rb.clear_buffer()
     assert rb.num_trajs == 0 and rb.num_steps == 0
 
