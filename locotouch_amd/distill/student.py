@@ -54,7 +54,14 @@ class Student(nn.Module):
         self.batch_steps = cfg.batch_steps
         self._criterion = nn.MSELoss(reduction="none")
         self._distill_lr = cfg.distill_lr
-        self._optimizer = torch.optim.AdamW(self.parameters(), lr=self._distill_lr)
+        on_gpu = torch.device(self.device).type == "cuda"
+        self._optimizer = torch.optim.AdamW(self.parameters(), lr=self._distill_lr, capturable=on_gpu)
+        # hipGraph replay of the whole training step (forward, backward, AdamW) per batch shape; the replay buffer pads every
+        # batch to one shape, so one capture serves an iteration.  The GRU's 2 x L-step time loop is ~2 k tiny launches:
+        # replayed from a graph they cost their ~10 us of GPU time each instead of ~45 us of Python + dispatch.
+        self.graph_training = on_gpu and bool(getattr(cfg, "graph_training", True))
+        self._graphs: dict = {}
+        self._eager_seen: dict = {}
         self.clip_actions, self.clip_range = cfg.clip_actions, cfg.clip_range
         self.action_scale_within_env = cfg.action_scale_within_env
         self.last_stats: dict = {}
@@ -118,6 +125,50 @@ class Student(nn.Module):
             action_mae = ((sa - ta).abs().mean(dim=-1) * masks).sum() / denom * self.action_scale_within_env
         return loss, action_mse, action_mae
 
+    def _eager_step(self, batch):
+        self._optimizer.zero_grad(set_to_none=True)
+        loss, mse, mae = self.batch_loss(batch)
+        loss.backward()
+        self._optimizer.step()
+        return loss.detach(), mse, mae
+
+    def training_step(self, batch):
+        """One optimizer step on a padded batch; (loss, action_mse | None, action_mae) as device scalars."""
+        if not self.graph_training:
+            return self._eager_step(batch)
+        key = tuple(batch["masks"].shape)
+        entry = self._graphs.get(key)
+        if entry is None:
+            seen = self._eager_seen.get(key, 0)
+            if seen < 2:  # the first two batches of a shape train eagerly on a side stream: they are the capture's warm-up
+                self._eager_seen[key] = seen + 1
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    out = self._eager_step(batch)
+                torch.cuda.current_stream().wait_stream(side)
+                return out
+            try:
+                static = {k: v.clone() for k, v in batch.items()}
+                graph = torch.cuda.CUDAGraph()
+                self._optimizer.zero_grad(set_to_none=True)
+                with torch.cuda.graph(graph):
+                    loss, mse, mae = self.batch_loss(static)
+                    loss.backward()
+                    self._optimizer.step()
+                entry = (graph, static, (loss.detach(), mse, mae))
+                self._graphs = {key: entry}  # one live capture: an older shape's pool (activations of a whole batch) is released
+            except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back loudly, keep training)
+                print(f"[WARN] hipGraph capture of the student's training step failed ({type(e).__name__}: {e}); training eagerly")
+                self.graph_training = False
+                torch.cuda.synchronize()
+                return self._eager_step(batch)
+        graph, static, outs = entry
+        for k, v in batch.items():
+            static[k].copy_(v)
+        graph.replay()
+        return tuple(None if o is None else o.clone() for o in outs)
+
     def num_epoches(self, num_iter: int) -> int:
         n = self.initial_epoches + self.incremental_epoches * num_iter
         return n + (self.final_epoches if num_iter == self.max_iterations - 1 else 0)
@@ -129,11 +180,8 @@ class Student(nn.Module):
         for epoch in range(self.num_epoches(num_iter)):
             losses, mses, maes = [], [], []
             for batch in replay_buffer.to_recurrent_generator(batch_size=batch_trajs):
-                self._optimizer.zero_grad(set_to_none=True)
-                loss, mse, mae = self.batch_loss(batch)
-                loss.backward()
-                self._optimizer.step()
-                losses.append(loss.detach()), maes.append(mae)
+                loss, mse, mae = self.training_step(batch)
+                losses.append(loss), maes.append(mae)
                 if mse is not None:
                     mses.append(mse)
             stats = {"loss": float(torch.stack(losses).mean()), "action_mae": float(torch.stack(maes).mean())}
@@ -151,6 +199,8 @@ class Student(nn.Module):
                     self.logger.log(scalars)
             if progress:
                 print(f"[Distillation iteration {num_iter}] epoch {epoch}: avg loss {stats['loss']:.4f}", flush=True)
+        self._graphs.clear()  # the next iteration's buffer has another longest trajectory / batch width
+        self._eager_seen.clear()
         self.last_stats = stats
         if stats:
             print(f"[Distillation iteration {num_iter}] Action MSE: {stats['action_mse']}")

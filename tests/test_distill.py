@@ -130,7 +130,7 @@ def test_replay_buffer_keeps_the_reference_trajectories(gold, check_every):
         _, lengths2 = rb.collect_data(teacher_policy=teacher, student_policy=None, num_steps=30)
         assert lengths2 == gold["rb2_lengths"].tolist() and rb.num_trajs == int(gold["rb2_num_trajs"]) and rb.num_steps == int(gold["rb2_num_steps"])
         assert rb._traj_len == gold["rb2_traj_lengths"].tolist()
-        seen = sum(len(b_["masks"][0]) for b_ in rb.to_recurrent_generator(batch_size=4))
+        seen = sum(int(b_["masks"][0].sum()) for b_ in rb.to_recurrent_generator(batch_size=4))  # every trajectory exactly once
         assert seen == rb.num_trajs
     # static shapes: same masked content, padded to (longest trajectory, batch size)
     torch.manual_seed(0)
