@@ -1,6 +1,8 @@
-"""Single-launch fp32 MLP inference on the HIP library (locotouch_amd/csrc/lt_mlp.hip) for an `nn.Sequential` of
-Linear layers with one activation between them - the actor / critic of the reference's ActorCritic
-(loco_rl/loco_rl/modules/actor_critic.py:41-67 builds exactly such stacks).
+"""Single-launch MLP inference on the HIP library (locotouch_amd/csrc/lt_mlp.hip) for an `nn.Sequential` of Linear layers
+with one activation between them - the actor / critic of the reference's ActorCritic
+(loco_rl/loco_rl/modules/actor_critic.py:41-67 builds exactly such stacks).  Arithmetic: f32-equivalent - both operands
+are split into fp16 (hi, lo) pairs and multiplied on the fp16 MFMA with an f32 error-compensation term (three MFMAs per
+tile, DESIGN.md "MLP kernel"); parameters and results are f32, the error is below an f32 GEMM's own rounding.
 
 The packed parameter buffer is refreshed from the live `nn.Linear` parameters by `pack()` (a few small launches; call it
 whenever the optimizer has stepped, e.g. at the start of every rollout - it is stream-ordered and graph-capturable).
