@@ -16,6 +16,7 @@
 //
 // Reference citations use paths relative to the reference repo (locotouch/...).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "lt_device_math.h"
 #include "lt_internal.h"
@@ -1516,7 +1517,16 @@ int launch_step(const lt_env* env, const float* actions, hipStream_t s, const fl
   }
   const dim3 grid((unsigned)(env->layout.npad / 16));
   // the 4-wave (helper) form only where the grid leaves SIMDs idle: up to two 16-env tiles per CU
-  const bool helpers = MODE == MODE_STEP && grid.x <= 2 * 256;
+  // The 4-wave helper form needs a whole CU per 16-env tile (one ~310-register wave on each SIMD): it pays while every tile
+  // gets its own CU, i.e. up to one workgroup per CU (4096 envs on an MI355X).  Beyond that a second round of tiles would wait
+  // for the first (measured at 8192 envs: 85 us against 69 us for the one-wave form).  LT_STEP_HELPERS_MAX_WG overrides.
+  static const unsigned helpers_max = [] {
+    if (const char* e = getenv("LT_STEP_HELPERS_MAX_WG")) return (unsigned)atoi(e);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return (unsigned)cus;
+  }();
+  const bool helpers = MODE == MODE_STEP && grid.x <= helpers_max;
   if (env->cfg.task == LT_TASK_LOCOMOTION) {
     if (helpers) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, MODE == MODE_STEP>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, false>), grid, dim3(64), 0, s, k);

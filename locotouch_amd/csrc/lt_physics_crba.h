@@ -346,6 +346,8 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
 #pragma unroll
   for (int k = 0; k < 3; ++k) { sq[k] = __sinf(G.q[k]); cq[k] = __cosf(G.q[k]); }  // v_sin/v_cos: |err| ~1e-6 on |q| < 4.6 rad
   ext.publish(cq, sq, B);
+  PhysExt pe;
+  if (!Ext::external && HAS_OBJ) pe.obj = object_part<TAC>(c, h, leg, B, O, X.trunk_mu);  // first: nothing else is live yet
   const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
   const V3 wb = tmul(R0, B.w), vb = tmul(R0, B.u);
   V3 om[3], vl[3], pw[3], ca[3], cl[3];
@@ -411,11 +413,9 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
 
   // ---- the two parts that do not depend on this lane's leg dynamics: the carried cylinder (object_part) and the CRBA
   //      (crba_part) - computed here, or fetched from the helper waves that ran them beside the code above ----
-  PhysExt pe;
   if (Ext::external) {
     ext.fetch(pe);
   } else {
-    if (HAS_OBJ) pe.obj = object_part<TAC>(c, h, leg, B, O, X.trunk_mu);
     pe.crba = crba_part(sgn, cq, sq);
   }
   if (HAS_OBJ) {
