@@ -160,3 +160,43 @@ def test_two_ranks_widen_on_the_same_step_as_one_population():
     _run_rank(env, Dist(), actions, log1)
     b1 = np.stack(log1)[:, 17] + np.stack(log1)[:, 18]
     assert b1[-1] >= bins[-1] and (b1 >= bins).all()
+
+
+# ---- the trainer's hook: OnPolicyRunner.learn() calls env.curriculum_sync(dist, steps) after every rollout --------------------
+def _runner_worker(rank, world, port, outdir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from locotouch_amd.agents import train_cfg
+    from locotouch_amd.rl import Dist, OnPolicyRunner
+    from tests.oracle_vec_env import OracleVecEnv
+
+    dist = Dist.from_env(backend="gloo")
+    env = OracleVecEnv(TASK, cfg=_gate_cfg(N_RANK, rank * N_RANK, 1))
+    calls = []
+    sync = env.curriculum_sync
+    env.curriculum_sync = lambda d, n: (calls.append((d.world_size, n)), sync(d, n))[1]
+    cfg = train_cfg(TASK)
+    cfg["num_steps_per_env"], cfg["algorithm"]["num_learning_epochs"], cfg["algorithm"]["num_mini_batches"] = 8, 1, 1
+    torch.manual_seed(0)
+    runner = OnPolicyRunner(env, cfg, log_dir=None, device="cpu", dist=dist)
+    runner.learn(6)
+    P = env.layout.arr(env.o.arena, "LT_F_CMD_PARAMS")[:24].copy()
+    np.save(os.path.join(outdir, f"runner_P_rank{rank}.npy"), P)
+    np.save(os.path.join(outdir, f"runner_calls_rank{rank}.npy"), np.array(calls))
+    sd = torch.cat([p.detach().flatten() for p in runner.alg.actor_critic.parameters()])
+    np.save(os.path.join(outdir, f"runner_w_rank{rank}.npy"), sd.numpy())
+    dist.shutdown()
+
+
+def test_runner_syncs_the_gate_after_every_rollout_on_all_ranks():
+    outdir = tempfile.mkdtemp()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_runner_worker, args=(2, port, outdir), nprocs=2, join=True)
+    P0, P1 = np.load(os.path.join(outdir, "runner_P_rank0.npy")), np.load(os.path.join(outdir, "runner_P_rank1.npy"))
+    np.testing.assert_array_equal(P0, P1)
+    assert P0[17] + P0[18] >= 1, "the ranges must have widened at least once in 48 steps"
+    for r in range(2):
+        assert np.load(os.path.join(outdir, f"runner_calls_rank{r}.npy")).tolist() == [[2, 8]] * 6
+    np.testing.assert_array_equal(np.load(os.path.join(outdir, "runner_w_rank0.npy")), np.load(os.path.join(outdir, "runner_w_rank1.npy")))
