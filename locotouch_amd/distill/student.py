@@ -55,11 +55,13 @@ class Student(nn.Module):
         self._criterion = nn.MSELoss(reduction="none")
         self._distill_lr = cfg.distill_lr
         on_gpu = torch.device(self.device).type == "cuda"
-        self._optimizer = torch.optim.AdamW(self.parameters(), lr=self._distill_lr, capturable=on_gpu)
-        # hipGraph replay of the whole training step (forward, backward, AdamW) per batch shape; the replay buffer pads every
-        # batch to one shape, so one capture serves an iteration.  The GRU's 2 x L-step time loop is ~2 k tiny launches:
-        # replayed from a graph they cost their ~10 us of GPU time each instead of ~45 us of Python + dispatch.
-        self.graph_training = on_gpu and bool(getattr(cfg, "graph_training", True))
+        # Optional (cfg.graph_training, default off): hipGraph replay of the whole training step (forward, backward, AdamW) per
+        # batch shape - the replay buffer pads every batch to one shape, so one capture serves an iteration.  Measured +6 %
+        # (239 k -> 254 k steps/s: the GRU's chain of ~2 k small launches is bound by their GPU latency, not by dispatch), equal
+        # to eager steps in tests/test_hip_distill.py; off because graph replays of captured backward passes showed
+        # order-dependent results elsewhere on this stack (rl/ppo.py).
+        self.graph_training = on_gpu and bool(getattr(cfg, "graph_training", False))
+        self._optimizer = torch.optim.AdamW(self.parameters(), lr=self._distill_lr, capturable=self.graph_training)
         self._graphs: dict = {}
         self._eager_seen: dict = {}
         self.clip_actions, self.clip_range = cfg.clip_actions, cfg.clip_range
@@ -142,20 +144,27 @@ class Student(nn.Module):
             seen = self._eager_seen.get(key, 0)
             if seen < 2:  # the first two batches of a shape train eagerly on a side stream: they are the capture's warm-up
                 self._eager_seen[key] = seen + 1
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
+                if getattr(self, "_g_stream", None) is None:
+                    self._g_stream = torch.cuda.Stream()  # the same stream captures later (no AccumulateGrad stream mismatch)
+                self._g_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._g_stream):
                     out = self._eager_step(batch)
-                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.current_stream().wait_stream(self._g_stream)
                 return out
             try:
                 static = {k: v.clone() for k, v in batch.items()}
                 graph = torch.cuda.CUDAGraph()
                 self._optimizer.zero_grad(set_to_none=True)
-                with torch.cuda.graph(graph):
-                    loss, mse, mae = self.batch_loss(static)
-                    loss.backward()
-                    self._optimizer.step()
+                from ..rl.linear import Linear
+
+                Linear.force_split_k = True  # stock weight-gradient GEMMs are not replay-safe at every shape (rl/linear.py)
+                try:
+                    with torch.cuda.graph(graph, stream=self._g_stream):
+                        loss, mse, mae = self.batch_loss(static)
+                        loss.backward()
+                        self._optimizer.step()
+                finally:
+                    Linear.force_split_k = False
                 entry = (graph, static, (loss.detach(), mse, mae))
                 self._graphs = {key: entry}  # one live capture: an older shape's pool (activations of a whole batch) is released
             except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back loudly, keep training)
@@ -167,7 +176,9 @@ class Student(nn.Module):
         for k, v in batch.items():
             static[k].copy_(v)
         graph.replay()
-        return tuple(None if o is None else o.clone() for o in outs)
+        outs = tuple(None if o is None else o.clone() for o in outs)
+        torch.cuda.synchronize()  # back-to-back replays of a captured backward are not stream-ordered on this stack (rl/ppo.py)
+        return outs
 
     def num_epoches(self, num_iter: int) -> int:
         n = self.initial_epoches + self.incremental_epoches * num_iter

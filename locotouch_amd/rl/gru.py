@@ -46,11 +46,14 @@ def _cell_backward(dh, ws, hidden):
     return torch.cat([dr_pre, dz_pre, dn_pre], 1), torch.cat([dr_pre, dz_pre, dn_pre * r], 1), dh * z
 
 
-def _wgrad(dy2d, x2d, splits: int = 8):
-    """dy^T @ x with a long reduction: split-K as a batched GEMM + sum (see rl/linear.py)."""
+def _wgrad(dy2d, x2d):
+    """dy^T @ x with a long reduction: split-K as a batched GEMM + sum (see rl/linear.py; also what is safe under graph replay)."""
+    from .linear import pick_splits
+
     m = dy2d.shape[0]
-    if m >= 4096 and m % splits == 0:
-        return torch.bmm(dy2d.view(splits, m // splits, -1).transpose(1, 2), x2d.view(splits, m // splits, -1)).sum(0)
+    s = pick_splits(m) if dy2d.is_cuda else 1
+    if s > 1:
+        return torch.bmm(dy2d.view(s, m // s, -1).transpose(1, 2), x2d.view(s, m // s, -1)).sum(0)
     return dy2d.t() @ x2d
 
 

@@ -37,14 +37,27 @@ class _SplitKLinear(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def pick_splits(m: int) -> int:
+    """Row blocks for the split-K weight gradient: the largest of a few small factors of m that leaves >= 64 rows per block."""
+    for s in (8, 4, 5, 2, 3, 7):
+        if m % s == 0 and m // s >= 64:
+            return s
+    return 1
+
+
 class Linear(nn.Linear):
-    """Drop-in `nn.Linear`; 2-D inputs with at least `split_k_min_rows` rows take the split-K weight-gradient path."""
+    """Drop-in `nn.Linear`; 2-D CUDA inputs with at least `split_k_min_rows` rows take the split-K weight-gradient path.
+
+    `force_split_k`: take that path for every row count.  Set while a training step is being captured into a hipGraph: the
+    stock weight-gradient GEMM (`dY^T @ X` as one hipBLASLt stream-K kernel) returns wrong results when REPLAYED from a graph
+    at some shapes on this stack (3072 x 348 x 512: tools/ppo_graph_probe.py, SPLITK_MIN=1000000), the batched form does not.
+    """
 
     split_k_min_rows = 4096
-    split_k = 8
+    force_split_k = False
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if (x.dim() == 2 and x.shape[0] >= self.split_k_min_rows and x.shape[0] % self.split_k == 0 and x.is_contiguous()
+        if (x.dim() == 2 and x.is_cuda and (Linear.force_split_k or x.shape[0] >= self.split_k_min_rows) and x.is_contiguous()
                 and torch.is_grad_enabled() and self.weight.requires_grad):
-            return _SplitKLinear.apply(x, self.weight, self.bias, self.split_k)
+            return _SplitKLinear.apply(x, self.weight, self.bias, pick_splits(x.shape[0]))
         return F.linear(x, self.weight, self.bias)

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from .gru import gru_sequence
+from .linear import Linear
 
 _ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "crelu": nn.ReLU, "lrelu": nn.LeakyReLU, "tanh": nn.Tanh,
                 "sigmoid": nn.Sigmoid}
@@ -34,8 +35,8 @@ class MLP(nn.Module):
         dims = [input_dim] + list(hidden_dims or [])
         layers: list[nn.Module] = []
         for a, b in zip(dims[:-1], dims[1:]):
-            layers += [nn.Linear(a, b), act]
-        layers.append(nn.Linear(dims[-1], output_dim))
+            layers += [Linear(a, b), act]
+        layers.append(Linear(dims[-1], output_dim))
         if final_layer_activation is not None:
             layers.append(get_activation(final_layer_activation))
         self.model = nn.Sequential(*layers)

@@ -170,8 +170,12 @@ class OnPolicyRunner:
     def save(self, path: str, infos=None) -> None:
         if not self.dist.is_main:
             return
+        opt_sd = self.alg.optimizer.state_dict()
+        for g in opt_sd["param_groups"]:  # the graph-replayed update keeps the learning rate in a device scalar: save a float
+            if torch.is_tensor(g.get("lr")):
+                g["lr"] = float(g["lr"])
         saved = {"model_state_dict": self.alg.actor_critic.state_dict(),
-                 "optimizer_state_dict": self.alg.optimizer.state_dict(),
+                 "optimizer_state_dict": opt_sd,
                  "iter": self.current_learning_iteration, "infos": infos}
         if self.empirical_normalization:  # on_policy_runner.py:376-379
             saved["obs_norm_state_dict"] = self.obs_normalizer.state_dict()

@@ -111,7 +111,8 @@ def test_export_policy_as_jit_matches_actor(tmp_path):
             export_policy_as_onnx(runner.alg.actor_critic, path=str(tmp_path / "exported"))
 
 
-def test_graph_replayed_training_step_equals_eager(tmp_path):
+@pytest.mark.parametrize("L,B", [(60, 9), (500, 101)])
+def test_graph_replayed_training_step_equals_eager(tmp_path, L, B):
     """The hipGraph-captured training step (forward, backward, AdamW) leaves the student where eager steps leave it."""
     import torch
 
@@ -125,7 +126,6 @@ def test_graph_replayed_training_step_equals_eager(tmp_path):
         return Student(cfg, 270, 442, 12, teacher_policy_inference=lambda o: o @ W, verbose=False).train()
 
     g = torch.Generator(device="cuda:0").manual_seed(1)
-    L, B = 60, 9
     masks = torch.arange(L, device="cuda:0").unsqueeze(1) < torch.randint(20, L + 1, (B,), device="cuda:0", generator=g).unsqueeze(0)
     batches = [dict(proprioceptions=torch.randn(L, B, 270, device="cuda:0", generator=g) * masks.unsqueeze(-1),
                     teacher_encoder_obses=torch.randn(L, B, 78, device="cuda:0", generator=g) * masks.unsqueeze(-1),
@@ -137,5 +137,7 @@ def test_graph_replayed_training_step_equals_eager(tmp_path):
     assert a.graph_training and len(a._graphs) == 1, "the step must really have been captured and replayed"
     assert all(abs(x - y) <= 2e-4 * max(1.0, abs(y)) for x, y in zip(la, lb)), (la, lb)
     assert lb[-1] < lb[0]
-    for pa, pb in zip(a.parameters(), b.parameters()):
-        torch.testing.assert_close(pa, pb, rtol=2e-3, atol=2e-4)
+    # parameters: AdamW moves an entry with a near-zero gradient by +-lr per step whatever its size, so rounding differences
+    # (split-K weight gradients inside the capture) show up as a few entries off by some lr = 5e-4; the bulk must agree
+    diff = torch.cat([(pa - pb).abs().flatten() for pa, pb in zip(a.parameters(), b.parameters())])
+    assert float((diff > 1e-3).float().mean()) < 0.01 and float(diff.max()) < 6 * 5e-4 + 1e-4, (float(diff.max()), float((diff > 1e-3).float().mean()))
