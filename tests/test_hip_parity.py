@@ -572,3 +572,43 @@ def test_fused_policy_kernel_matches_act_kernel():
     assert not torch.equal(a.actions[1] - a.mu[1], a.actions[0] - a.mu[0])  # fresh noise per step (counter + t keying)
     z_a, z_b = (a.actions[2] - a.mu[2]), (b.actions[2] - b.mu[2])
     torch.testing.assert_close(z_a, z_b, rtol=1e-4, atol=1e-5)  # same Philox draws at step 2 in both paths
+
+
+def test_back_to_back_graph_replays_of_the_rollout_equal_eager_rollouts():
+    """bench.py and the trainer replay the captured 24-step rollout graph several times in a row with nothing in between.
+    Replays must be ordered by the stream (replay k+1 reads the arena replay k wrote): three back-to-back replays of a 6-step
+    rollout graph must leave the env and the storage exactly where 18 eagerly launched steps leave a twin."""
+    import copy
+
+    import torch
+    from locotouch_amd.rl import PPO, ActorCritic, FusedRollout
+    from tests.rl_synth import POLICY_CFG, PPO_CFG
+
+    n, T = 4096, 6
+    envs = [make_env("teacher", n), make_env("teacher", n)]
+    torch.manual_seed(3)
+    ac = ActorCritic(348, 348, 12, **POLICY_CFG)
+    algs = [PPO(copy.deepcopy(ac), device="cuda:0", **PPO_CFG) for _ in range(2)]
+    frs = []
+    for env, alg in zip(envs, algs):
+        alg.init_storage(n, T, [348], [348], [12])
+        frs.append(FusedRollout(env, alg))
+    # A: capture once (warm-up on a side stream advances the env: the twin does the same rollout eagerly), then 3 replays
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        frs[0].rollout(T)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        frs[0].rollout(T)
+    for _ in range(3):
+        g.replay()
+    # B: the same 4 rollouts, launched eagerly
+    for _ in range(4):
+        frs[1].rollout(T)
+    torch.cuda.synchronize()
+    assert torch.equal(envs[0].counters[:1], envs[1].counters[:1]) and int(envs[0].counters[0]) == 1 + 4 * T
+    assert torch.equal(envs[0]._arena_aligned, envs[1]._arena_aligned), "arena differs: replays were not ordered"
+    for name in ("observations", "privileged_observations", "actions", "rewards", "dones", "values", "actions_log_prob", "mu"):
+        assert torch.equal(getattr(algs[0].storage, name), getattr(algs[1].storage, name)), name
