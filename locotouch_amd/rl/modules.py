@@ -100,3 +100,128 @@ class ActorCritic(nn.Module):
 
     def forward(self):
         raise NotImplementedError("use act / evaluate")
+
+
+class PolicyMemory(nn.Module):
+    """`Memory` of the reference's recurrent policy (loco_rl/loco_rl/modules/actor_critic_recurrent.py:66-94): batch mode (masks
+    given) runs padded trajectories from their saved first hidden states and returns the outputs in (T, envs) layout; inference
+    mode carries the module's own state.  Parameter names `rnn.*`."""
+
+    def __init__(self, input_size, type="lstm", num_layers=1, hidden_size=256):
+        super().__init__()
+        self.rnn = (nn.GRU if type.lower() == "gru" else nn.LSTM)(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers)
+        self.hidden_states = None
+
+    def forward(self, input, masks=None, hidden_states=None):
+        from .trajectories import unpad_trajectories
+
+        if masks is not None:
+            if hidden_states is None:
+                raise ValueError("Hidden states not passed to memory module during policy update")
+            out, _ = self.rnn(input, hidden_states)
+            return unpad_trajectories(out, masks)
+        out, self.hidden_states = self.rnn(input.unsqueeze(0), self.hidden_states)
+        return out
+
+    def reset(self, dones=None):
+        if self.hidden_states is None:
+            return
+        keep = None if dones is None else (dones.reshape(-1) != 1)
+        for h in (self.hidden_states if isinstance(self.hidden_states, tuple) else (self.hidden_states,)):
+            if keep is None:
+                h.zero_()
+            else:
+                h.mul_(keep.to(h.dtype)[None, :, None])
+
+
+class ActorCriticRecurrent(ActorCritic):
+    """Reference loco_rl/loco_rl/modules/actor_critic_recurrent.py:8-63: an RNN per network in front of the MLPs."""
+
+    is_recurrent = True
+
+    def __init__(self, num_actor_obs, num_critic_obs, num_actions, actor_hidden_dims=(256, 256, 256), critic_hidden_dims=(256, 256, 256),
+                 activation="elu", rnn_type="lstm", rnn_hidden_size=256, rnn_num_layers=1, init_noise_std=1.0, **unused):
+        super().__init__(num_actor_obs=rnn_hidden_size, num_critic_obs=rnn_hidden_size, num_actions=num_actions,
+                         actor_hidden_dims=actor_hidden_dims, critic_hidden_dims=critic_hidden_dims, activation=activation,
+                         init_noise_std=init_noise_std)
+        self.memory_a = PolicyMemory(num_actor_obs, type=rnn_type, num_layers=rnn_num_layers, hidden_size=rnn_hidden_size)
+        self.memory_c = PolicyMemory(num_critic_obs, type=rnn_type, num_layers=rnn_num_layers, hidden_size=rnn_hidden_size)
+
+    def reset(self, dones=None):
+        self.memory_a.reset(dones)
+        self.memory_c.reset(dones)
+
+    def act(self, observations, masks=None, hidden_states=None):
+        return super().act(self.memory_a(observations, masks, hidden_states).squeeze(0))
+
+    def update_distribution_recurrent(self, observations, masks, hidden_states):
+        super().update_distribution(self.memory_a(observations, masks, hidden_states).squeeze(0))
+
+    def act_inference(self, observations):
+        return super().act_inference(self.memory_a(observations).squeeze(0))
+
+    def evaluate(self, critic_observations, masks=None, hidden_states=None):
+        return super().evaluate(self.memory_c(critic_observations, masks, hidden_states).squeeze(0))
+
+    def get_hidden_states(self):
+        return self.memory_a.hidden_states, self.memory_c.hidden_states
+
+
+class ActorCriticEncoder(ActorCritic):
+    """Reference loco_rl/loco_rl/modules/actor_critic_encoder.py:7-117: the tail of the observation row goes through an MLP
+    encoder whose embedding is concatenated with the head of the row (the teacher form of RMA-style distillation:
+    `act_encoder_inference` / `act_backbone_inference` are what `Distillation` asks the runner for)."""
+
+    is_recurrent = False
+
+    def __init__(self, actor_obs_dim, critic_obs_dim, num_actions, actor_flatten_obs_end_idx, actor_encoder_obs_start_idx,
+                 actor_encoder_hidden_dims, actor_encoder_embedding_dim, actor_hidden_dims, critic_flatten_obs_end_idx=None,
+                 critic_encoder_obs_start_idx=None, critic_encoder_hidden_dims=None, critic_encoder_embedding_dim=None,
+                 critic_hidden_dims=(256, 256, 256), encoder_activation="elu", encoder_final_activation=None, activation="elu",
+                 init_noise_std=1.0, **unused):
+        from .models import MLP
+
+        enc_dim = abs(actor_encoder_obs_start_idx) if actor_encoder_obs_start_idx < 0 else actor_obs_dim - actor_encoder_obs_start_idx
+        flat_dim = actor_flatten_obs_end_idx if actor_flatten_obs_end_idx > 0 else actor_obs_dim - abs(actor_flatten_obs_end_idx)
+        with_c = critic_encoder_hidden_dims is not None
+        c_enc = c_flat = 0
+        if with_c:
+            assert None not in (critic_flatten_obs_end_idx, critic_encoder_obs_start_idx, critic_encoder_embedding_dim)
+            c_enc = abs(critic_encoder_obs_start_idx) if critic_encoder_obs_start_idx < 0 else critic_obs_dim - critic_encoder_obs_start_idx
+            c_flat = critic_flatten_obs_end_idx if critic_flatten_obs_end_idx > 0 else critic_obs_dim - abs(critic_flatten_obs_end_idx)
+        super().__init__(num_actor_obs=flat_dim + actor_encoder_embedding_dim,
+                         num_critic_obs=(c_enc + critic_encoder_embedding_dim) if with_c else critic_obs_dim,  # (sic, :49)
+                         num_actions=num_actions, actor_hidden_dims=actor_hidden_dims, critic_hidden_dims=critic_hidden_dims,
+                         activation=activation, init_noise_std=init_noise_std)
+        self.actor_encoder_obs_dim, self.actor_flatten_obs_dim = enc_dim, flat_dim
+        self.critic_with_encoder, self.critic_encoder_obs_dim, self.critic_flatten_obs_dim = with_c, c_enc, c_flat
+        self.actor_encoder = MLP(enc_dim, actor_encoder_hidden_dims, actor_encoder_embedding_dim, activation=encoder_activation,
+                                 final_layer_activation=encoder_final_activation)
+        if with_c:
+            self.critic_encoder = MLP(c_enc, critic_encoder_hidden_dims, critic_encoder_embedding_dim, activation=encoder_activation,
+                                      final_layer_activation=encoder_final_activation)
+
+    def _actor_input(self, obs):
+        return torch.cat([obs[..., :self.actor_flatten_obs_dim], self.actor_encoder(obs[..., -self.actor_encoder_obs_dim:])], dim=-1)
+
+    def update_distribution(self, observations):
+        super().update_distribution(self._actor_input(observations))
+
+    def act_inference(self, obs):
+        return super().act_inference(self._actor_input(obs))
+
+    def act_encoder_inference(self, encoder_obs):
+        return self.actor_encoder(encoder_obs)
+
+    def act_backbone_inference(self, flatten_obs, embedding):
+        return super().act_inference(torch.cat([flatten_obs, embedding], dim=-1))
+
+    def evaluate(self, obs, **kwargs):
+        if self.critic_with_encoder:
+            obs = torch.cat([obs[..., :self.critic_flatten_obs_dim], self.critic_encoder(obs[..., -self.critic_encoder_obs_dim:])], dim=-1)
+        return super().evaluate(obs)
+
+    def get_actor_critic_obs_from_obs_dict(self, obs_dict):
+        actor_obs, enc = obs_dict["policy"], obs_dict["encoder"]
+        critic_obs = obs_dict.get("critic", actor_obs)
+        return torch.cat((actor_obs, enc), dim=1), (torch.cat((critic_obs, enc), dim=1) if self.critic_with_encoder else critic_obs)

@@ -86,6 +86,9 @@ class PPO:
 
     def act(self, obs: torch.Tensor, critic_obs: torch.Tensor) -> torch.Tensor:
         ac, t = self.actor_critic, self._t
+        if getattr(ac, "is_recurrent", False):  # the state the memories hold BEFORE this step (ppo.py:130-131)
+            t["hidden"] = tuple(None if h is None else (tuple(x.clone() for x in h) if isinstance(h, tuple) else h.clone())
+                                for h in ac.get_hidden_states())
         t["actions"] = ac.act(obs).detach()
         t["values"] = ac.evaluate(critic_obs).detach()
         t["log_prob"] = ac.get_actions_log_prob(t["actions"]).detach()
@@ -99,7 +102,8 @@ class PPO:
         rew = rewards.clone()
         if "time_outs" in infos:  # bootstrap the value through time-limit terminations (ppo.py:162-165)
             rew += self.gamma * torch.squeeze(t["values"] * infos["time_outs"].unsqueeze(1).to(self.device), 1)
-        self.storage.add(t["obs"], t["critic_obs"], t["actions"], rew, dones, t["values"], t["log_prob"], t["mu"], t["sigma"])
+        self.storage.add(t["obs"], t["critic_obs"], t["actions"], rew, dones, t["values"], t["log_prob"], t["mu"], t["sigma"],
+                         hidden_states=t.get("hidden"))
         self._t = {}
         self.actor_critic.reset(dones)
 
@@ -288,14 +292,28 @@ class PPO:
     def _eager_update(self):
         ac = self.actor_critic
         sum_value = sum_surr = sum_ent = 0.0
-        for b in self.storage.mini_batches(self.num_mini_batches, self.num_learning_epochs):
+        recurrent = getattr(ac, "is_recurrent", False)
+        batches = (self.storage.recurrent_mini_batches(self.num_mini_batches, self.num_learning_epochs) if recurrent
+                   else self.storage.mini_batches(self.num_mini_batches, self.num_learning_epochs))
+        for raw in batches:
+            if recurrent:  # padded whole trajectories + the hidden states saved at their first steps (ppo.py:195-196,251-256)
+                from .storage import Batch
+
+                b, (hid_a, hid_c), masks = Batch(*raw[:9]), raw[9], raw[10]
+            else:
+                b, hid_a, hid_c, masks = raw, None, None, None
             adv = b.advantages
             if self.normalize_advantage_per_mini_batch:
                 with torch.no_grad():
                     adv = (adv - adv.mean()) / (adv.std() + 1e-8)
-            ac.act(b.obs)
-            log_prob = ac.get_actions_log_prob(b.actions)
-            value = ac.evaluate(b.critic_obs)
+            if recurrent:
+                ac.act(b.obs, masks=masks, hidden_states=hid_a)
+                log_prob = ac.get_actions_log_prob(b.actions)
+                value = ac.evaluate(b.critic_obs, masks=masks, hidden_states=hid_c)
+            else:
+                ac.act(b.obs)
+                log_prob = ac.get_actions_log_prob(b.actions)
+                value = ac.evaluate(b.critic_obs)
             mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
             if self.desired_kl is not None and self.schedule == "adaptive":
                 self._adapt_learning_rate(mu, sigma, b.mu, b.sigma)

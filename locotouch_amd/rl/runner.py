@@ -31,9 +31,13 @@ class OnPolicyRunner:
         obs, extras = env.get_observations()
         num_obs = obs.shape[1]
         num_critic_obs = extras["observations"]["critic"].shape[1] if "critic" in extras["observations"] else num_obs
-        self.policy_cfg.pop("class_name", None)
+        from . import modules as _m
+
+        cls_name = self.policy_cfg.pop("class_name", "ActorCritic")  # on_policy_runner.py:42 (`eval(class_name)`)
+        if cls_name not in ("ActorCritic", "ActorCriticRecurrent", "ActorCriticEncoder"):
+            raise NotImplementedError(f"policy class {cls_name!r} is not implemented (ActorCritic, ActorCriticRecurrent, ActorCriticEncoder are)")
         self.alg_cfg.pop("class_name", None)
-        ac = ActorCritic(num_obs, num_critic_obs, env.num_actions, **self.policy_cfg).to(device)
+        ac = getattr(_m, cls_name)(num_obs, num_critic_obs, env.num_actions, **self.policy_cfg).to(device)
         self.alg = PPO(ac, device=device, dist=self.dist, **self.alg_cfg)
         self.num_steps_per_env = int(self.cfg["num_steps_per_env"])
         self.save_interval = int(self.cfg.get("save_interval", 50))
@@ -160,8 +164,8 @@ class OnPolicyRunner:
             return None
         if not isinstance(self.env, LocoTouchVecEnv) or self.cfg.get("fused_rollout", True) is False:
             return None
-        if getattr(self.alg.actor_critic, "noise_std_type", "scalar") != "scalar":
-            return None
+        if getattr(self.alg.actor_critic, "noise_std_type", "scalar") != "scalar" or type(self.alg.actor_critic) is not ActorCritic:
+            return None  # the fused rollout packs the plain feed-forward actor / critic MLPs
         if self.empirical_normalization:  # the fused rollout feeds raw observation rows to the MLP kernel
             return None
         return FusedRollout(self.env, self.alg)

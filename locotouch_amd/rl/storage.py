@@ -42,12 +42,25 @@ class RolloutStorage:
         self.returns = z(num_steps, num_envs, 1)
         self.advantages = z(num_steps, num_envs, 1)
         self.actions_log_prob = z(num_steps, num_envs, 1)
+        self.saved_hidden_states_a = self.saved_hidden_states_c = None  # recurrent policies: lists of (T, layers, N, H)
         self.step = 0
 
-    def add(self, obs, critic_obs, actions, rewards, dones, values, log_prob, mu, sigma) -> None:
+    def add(self, obs, critic_obs, actions, rewards, dones, values, log_prob, mu, sigma, hidden_states=None) -> None:
         t = self.step
         if t >= self.num_steps:
             raise OverflowError("rollout buffer is full: call clear() before adding transitions")
+        if hidden_states is not None and hidden_states != (None, None):  # rollout_storage.py:109-146
+            hid_a = hidden_states[0] if isinstance(hidden_states[0], tuple) else (hidden_states[0],)
+            hid_c = None if hidden_states[1] is None else (hidden_states[1] if isinstance(hidden_states[1], tuple) else (hidden_states[1],))
+            if self.saved_hidden_states_a is None:
+                self.saved_hidden_states_a = [torch.zeros(self.num_steps, *h.shape, device=self.device) for h in hid_a]
+                if hid_c is not None:
+                    self.saved_hidden_states_c = [torch.zeros(self.num_steps, *h.shape, device=self.device) for h in hid_c]
+            for i, h in enumerate(hid_a):
+                self.saved_hidden_states_a[i][t].copy_(h)
+            if hid_c is not None:
+                for i, h in enumerate(hid_c):
+                    self.saved_hidden_states_c[i][t].copy_(h)
         self.observations[t].copy_(obs)
         self.privileged_observations[t].copy_(critic_obs)
         self.actions[t].copy_(actions)
@@ -97,13 +110,17 @@ class RolloutStorage:
                 idx = perm[i * mb:(i + 1) * mb]
                 yield Batch(*[x[idx] for x in flat])
 
-    def recurrent_mini_batches(self, num_mini_batches: int, num_epochs: int = 8, hidden_states_a=None, hidden_states_c=None):
+    def recurrent_mini_batches(self, num_mini_batches: int, num_epochs: int = 8, hidden_states_a="saved", hidden_states_c="saved"):
         """Minibatches of whole trajectories for recurrent policies (reference rollout_storage.py:246-318): envs are dealt to
         minibatches in contiguous blocks; a block's padded trajectories (and the hidden states saved at their first steps)
         form the batch.  `hidden_states_*`: lists of (T, layers, N, H) tensors saved during the rollout, or None.
         Yields (obs, critic_obs, actions, values, advantages, returns, log_prob, mu, sigma, (hid_a, hid_c), masks)."""
         from .trajectories import split_and_pad_trajectories
 
+        if isinstance(hidden_states_a, str):
+            hidden_states_a = self.saved_hidden_states_a
+        if isinstance(hidden_states_c, str):
+            hidden_states_c = self.saved_hidden_states_c
         obs_traj, masks = split_and_pad_trajectories(self.observations, self.dones)
         critic_traj, _ = split_and_pad_trajectories(self.privileged_observations, self.dones)
         per = self.num_envs // num_mini_batches

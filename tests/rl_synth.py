@@ -43,3 +43,30 @@ def extra_inputs(seed: int = 77):
              hid_a=torch.randn(T, 1, N, H, generator=g), hid_c=torch.randn(T, 1, N, H, generator=g),
              last_values=torch.randn(N, 1, generator=g))
     return x
+
+
+def policy_case(kind: str, seed: int = 321):
+    """Seeded inputs for tools/gen_golden_rl_policies.py / tests/test_rl_policies.py: a small rollout for the recurrent (GRU) and
+    the encoder policy classes.  `args` / `kwargs` are the constructor arguments (same for the reference and this package)."""
+    g = torch.Generator().manual_seed(seed + (0 if kind == "recurrent" else 1))
+    N, T, A = 8, 10, 4
+    D = 14
+    dones = (torch.rand(T, N, generator=g) < 0.15).long()
+    dones[:, 2] = 0
+    case = dict(N=N, T=T, D=D, A=A, seed=seed, obs=torch.randn(T, N, D, generator=g), rewards=torch.randn(T, N, generator=g), dones=dones,
+                last_cobs=torch.randn(N, D, generator=g))
+    case["cobs"] = case["obs"] + 0.05 * torch.randn(T, N, D, generator=g)
+    case["ppo"] = dict(value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2, entropy_coef=0.01, num_learning_epochs=2,
+                       num_mini_batches=2, learning_rate=1.0e-3, schedule="adaptive", gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0)
+    if kind == "recurrent":
+        case["args"] = (D, D, A)
+        case["kwargs"] = dict(actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], activation="elu", rnn_type="gru", rnn_hidden_size=24,
+                              rnn_num_layers=1, init_noise_std=1.0)
+    else:
+        case["args"] = (D, D, A)
+        case["kwargs"] = dict(actor_flatten_obs_end_idx=9, actor_encoder_obs_start_idx=-5, actor_encoder_hidden_dims=[16, 8],
+                              actor_encoder_embedding_dim=6, actor_hidden_dims=[32, 16], critic_flatten_obs_end_idx=None,
+                              critic_encoder_obs_start_idx=None, critic_encoder_hidden_dims=None, critic_encoder_embedding_dim=None,
+                              critic_hidden_dims=[32, 16], encoder_activation="elu", encoder_final_activation=None, activation="elu",
+                              init_noise_std=1.0)
+    return case
