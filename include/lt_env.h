@@ -326,6 +326,17 @@ int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_pol
 /* Profiling variant of lt_env_step: HIP events bracket the step kernel on `stream`; the call WAITS for them (host
  * sync - never use it inside a captured region) and returns the step kernel's duration in milliseconds. */
 int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float* step_kernel_ms);
+/* GRU recurrence of the student's tactile encoder over a padded batch of whole trajectories (reference
+ * loco_rl/loco_rl/models/memory_module.py:10-14 -> nn.GRU, single layer; locotouch/distill/student.py:119-123 trains it on
+ * (L, B, .) batches).  One launch per time step whose grid covers the chip (csrc/lt_gru.hip); the time loop runs here.
+ *   forward : ig [L][B][3H] = X W_ih^T (no bias), h0 [B][H]  ->  out [L][B][H], ws [L][B][4H] (r, z, n, W_hn h + b_hn)
+ *   backward: dout [L][B][H], dhn [B][H] | NULL  ->  dig, dhg [L][B][3H] (gate gradients, input / hidden side), dh0 [B][H];
+ *             scratch [3][B][H].  The caller forms dW_hh = dhg^T H_prev, dW_ih = dig^T X, dX = dig W_ih and the bias sums.
+ * Gate order and formulas are PyTorch's (r, z, n).  H must be a multiple of 64.  Device pointers, f32. */
+int lt_gru_forward(const float* ig, const float* h0, const float* w_hh, const float* b_ih, const float* b_hh, int L, int B, int H,
+                   float* out, float* ws, void* stream);
+int lt_gru_backward(const float* dout, const float* dhn, const float* out, const float* ws, const float* h0, const float* w_hh, int L, int B,
+                    int H, float* dig, float* dhg, float* scratch, float* dh0, void* stream);
 /* Tactile observation pass (tactile tasks): taxel forces from LT_F_PLATE_SAMPLES -> thresholds -> dropout / addition ->
  * LT_F_OBS_TACTILE.  lt_env_step runs it after the step kernel; drivers that launch lt_env_step_rows / _rollout call it
  * themselves.  No-op (LT_OK) when cfg.tactile_enabled is 0. */

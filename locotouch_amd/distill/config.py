@@ -54,7 +54,6 @@ class DistillationCfg:
     action_scale_within_env: float = 0.25
     min_delay: int = 1
     max_delay: int = 2
-    graph_training: bool = False  # (not a reference field) hipGraph replay of the student's training step
 
     def to_dict(self) -> dict:
         return asdict(self)

@@ -54,16 +54,7 @@ class Student(nn.Module):
         self.batch_steps = cfg.batch_steps
         self._criterion = nn.MSELoss(reduction="none")
         self._distill_lr = cfg.distill_lr
-        on_gpu = torch.device(self.device).type == "cuda"
-        # Optional (cfg.graph_training, default off): hipGraph replay of the whole training step (forward, backward, AdamW) per
-        # batch shape - the replay buffer pads every batch to one shape, so one capture serves an iteration.  Measured +6 %
-        # (239 k -> 254 k steps/s: the GRU's chain of ~2 k small launches is bound by their GPU latency, not by dispatch), equal
-        # to eager steps in tests/test_hip_distill.py; off because graph replays of captured backward passes showed
-        # order-dependent results elsewhere on this stack (rl/ppo.py).
-        self.graph_training = on_gpu and bool(getattr(cfg, "graph_training", False))
-        self._optimizer = torch.optim.AdamW(self.parameters(), lr=self._distill_lr, capturable=self.graph_training)
-        self._graphs: dict = {}
-        self._eager_seen: dict = {}
+        self._optimizer = torch.optim.AdamW(self.parameters(), lr=self._distill_lr)
         self.clip_actions, self.clip_range = cfg.clip_actions, cfg.clip_range
         self.action_scale_within_env = cfg.action_scale_within_env
         self.last_stats: dict = {}
@@ -135,50 +126,10 @@ class Student(nn.Module):
         return loss.detach(), mse, mae
 
     def training_step(self, batch):
-        """One optimizer step on a padded batch; (loss, action_mse | None, action_mae) as device scalars."""
-        if not self.graph_training:
-            return self._eager_step(batch)
-        key = tuple(batch["masks"].shape)
-        entry = self._graphs.get(key)
-        if entry is None:
-            seen = self._eager_seen.get(key, 0)
-            if seen < 2:  # the first two batches of a shape train eagerly on a side stream: they are the capture's warm-up
-                self._eager_seen[key] = seen + 1
-                if getattr(self, "_g_stream", None) is None:
-                    self._g_stream = torch.cuda.Stream()  # the same stream captures later (no AccumulateGrad stream mismatch)
-                self._g_stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self._g_stream):
-                    out = self._eager_step(batch)
-                torch.cuda.current_stream().wait_stream(self._g_stream)
-                return out
-            try:
-                static = {k: v.clone() for k, v in batch.items()}
-                graph = torch.cuda.CUDAGraph()
-                self._optimizer.zero_grad(set_to_none=True)
-                from ..rl.linear import Linear
-
-                Linear.force_split_k = True  # stock weight-gradient GEMMs are not replay-safe at every shape (rl/linear.py)
-                try:
-                    with torch.cuda.graph(graph, stream=self._g_stream):
-                        loss, mse, mae = self.batch_loss(static)
-                        loss.backward()
-                        self._optimizer.step()
-                finally:
-                    Linear.force_split_k = False
-                entry = (graph, static, (loss.detach(), mse, mae))
-                self._graphs = {key: entry}  # one live capture: an older shape's pool (activations of a whole batch) is released
-            except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back loudly, keep training)
-                print(f"[WARN] hipGraph capture of the student's training step failed ({type(e).__name__}: {e}); training eagerly")
-                self.graph_training = False
-                torch.cuda.synchronize()
-                return self._eager_step(batch)
-        graph, static, outs = entry
-        for k, v in batch.items():
-            static[k].copy_(v)
-        graph.replay()
-        outs = tuple(None if o is None else o.clone() for o in outs)
-        torch.cuda.synchronize()  # back-to-back replays of a captured backward are not stream-ordered on this stack (rl/ppo.py)
-        return outs
+        """One optimizer step on a padded batch; (loss, action_mse | None, action_mae) as device scalars.
+        (A hipGraph replay of this step was tried: +6 %, and capture of the ~3 k-launch step segfaulted in `capture_end` on
+        this stack once the GRU's HIP time loop was inside - removed.)"""
+        return self._eager_step(batch)
 
     def num_epoches(self, num_iter: int) -> int:
         n = self.initial_epoches + self.incremental_epoches * num_iter
@@ -210,8 +161,6 @@ class Student(nn.Module):
                     self.logger.log(scalars)
             if progress:
                 print(f"[Distillation iteration {num_iter}] epoch {epoch}: avg loss {stats['loss']:.4f}", flush=True)
-        self._graphs.clear()  # the next iteration's buffer has another longest trajectory / batch width
-        self._eager_seen.clear()
         self.last_stats = stats
         if stats:
             print(f"[Distillation iteration {num_iter}] Action MSE: {stats['action_mse']}")

@@ -58,6 +58,8 @@ def _wgrad(dy2d, x2d):
 
 
 class _GRUSequence(torch.autograd.Function):
+    """Time loop in PyTorch ops (CPU, and the GPU when the HIP kernels do not apply)."""
+
     @staticmethod
     def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh):
         L, B, _ = x.shape
@@ -87,17 +89,75 @@ class _GRUSequence(torch.autograd.Function):
             dig[t] = a
             dhg[t] = b
             dh = torch.addmm(dhx, b, w_hh)
-        dig2, dhg2 = dig.view(L * B, 3 * H), dhg.view(L * B, 3 * H)
-        h_prev = torch.cat([h0.unsqueeze(0), out[:-1]], dim=0).view(L * B, H)
-        dw_hh = _wgrad(dhg2, h_prev)
-        dw_ih = _wgrad(dig2, x.reshape(L * B, -1))
-        dx = (dig2 @ w_ih).view_as(x) if ctx.needs_input_grad[0] else None
-        return dx, dh, dw_ih, dw_hh, dig2.sum(0), dhg2.sum(0)
+        return _finish_backward(ctx, x, h0, w_ih, out, dig, dhg, dh)
+
+
+def _finish_backward(ctx, x, h0, w_ih, out, dig, dhg, dh0):
+    """Everything of the backward pass that is not sequential: one GEMM each."""
+    L, B, _ = x.shape
+    H = out.shape[2]
+    dig2, dhg2 = dig.view(L * B, 3 * H), dhg.view(L * B, 3 * H)
+    h_prev = torch.cat([h0.unsqueeze(0), out[:-1]], dim=0).view(L * B, H)
+    dw_hh = _wgrad(dhg2, h_prev)
+    dw_ih = _wgrad(dig2, x.reshape(L * B, -1))
+    dx = (dig2 @ w_ih).view_as(x) if ctx.needs_input_grad[0] else None
+    return dx, dh0, dw_ih, dw_hh, dig2.sum(0), dhg2.sum(0)
+
+
+class _GRUSequenceHip(torch.autograd.Function):
+    """Time loop in csrc/lt_gru.hip: one launch per step forward, two backward, issued from C (`lt_gru_forward/_backward`)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh):
+        import ctypes
+
+        from .. import _abi
+
+        lib = _abi.load()
+        L, B, _ = x.shape
+        H = w_hh.shape[1]
+        ig = (x.reshape(L * B, -1) @ w_ih.t()).view(L, B, 3 * H)
+        h0c, w_hh_c = h0.contiguous(), w_hh.contiguous()
+        out = x.new_empty(L, B, H)
+        ws = x.new_empty(L, B, 4 * H)
+        vp = ctypes.c_void_p
+        stream = vp(torch.cuda.current_stream(x.device).cuda_stream)
+        _abi.check(lib.lt_gru_forward(vp(ig.data_ptr()), vp(h0c.data_ptr()), vp(w_hh_c.data_ptr()), vp(b_ih.data_ptr()), vp(b_hh.data_ptr()),
+                                      L, B, H, vp(out.data_ptr()), vp(ws.data_ptr()), stream), "lt_gru_forward")
+        ctx.save_for_backward(x, h0c, w_ih, w_hh_c, out, ws)
+        return out, out[-1]
+
+    @staticmethod
+    def backward(ctx, dout, dhn):
+        import ctypes
+
+        from .. import _abi
+
+        lib = _abi.load()
+        x, h0, w_ih, w_hh, out, ws = ctx.saved_tensors
+        L, B, _ = x.shape
+        H = w_hh.shape[1]
+        dout = dout.contiguous()
+        dig = x.new_empty(L, B, 3 * H)
+        dhg = x.new_empty(L, B, 3 * H)
+        scratch = x.new_empty(3, B, H)
+        dh0 = x.new_empty(B, H)
+        vp = ctypes.c_void_p
+        stream = vp(torch.cuda.current_stream(x.device).cuda_stream)
+        dhn_p = vp(dhn.contiguous().data_ptr()) if dhn is not None else vp(None)
+        _abi.check(lib.lt_gru_backward(vp(dout.data_ptr()), dhn_p, vp(out.data_ptr()), vp(ws.data_ptr()), vp(h0.data_ptr()), vp(w_hh.data_ptr()),
+                                       L, B, H, vp(dig.data_ptr()), vp(dhg.data_ptr()), vp(scratch.data_ptr()), vp(dh0.data_ptr()), stream),
+                   "lt_gru_backward")
+        return _finish_backward(ctx, x, h0, w_ih, out, dig, dhg, dh0)
 
 
 def gru_sequence(gru: torch.nn.GRU, x: torch.Tensor, h0: torch.Tensor | None = None):
     """`gru(x, h0)` for a single-layer, unidirectional, time-major `nn.GRU`: (output [L, B, H], h_n [1, B, H])."""
     assert gru.num_layers == 1 and not gru.bidirectional and not gru.batch_first and gru.bias
     h = h0[0] if h0 is not None else x.new_zeros(x.shape[1], gru.hidden_size)
-    out, hn = _GRUSequence.apply(x.contiguous(), h, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
+    fn = _GRUSequenceHip if (x.is_cuda and x.dtype == torch.float32 and gru.hidden_size % 64 == 0 and use_hip_kernels) else _GRUSequence
+    out, hn = fn.apply(x.contiguous(), h, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
     return out, hn.unsqueeze(0)
+
+
+use_hip_kernels = True  # False: the PyTorch-op time loop on the GPU as well (tools/gru_probe.py compares the three forms)

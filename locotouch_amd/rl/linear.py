@@ -37,6 +37,31 @@ class _SplitKLinear(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _SplitKMatmul(torch.autograd.Function):
+    """`x @ w` for x [M, K], w [K, N] with the weight gradient x^T dy issued as a split-K batched GEMM (long reduction over M)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dy @ w.t() if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            m = x.shape[0]
+            s = pick_splits(m)
+            dyc = dy if dy.is_contiguous() else dy.contiguous()
+            dw = (torch.bmm(x.view(s, m // s, -1).transpose(1, 2), dyc.view(s, m // s, -1)).sum(0) if s > 1 else x.t() @ dyc)
+        return dx, dw
+
+
+def split_k_matmul(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    return _SplitKMatmul.apply(x, w)
+
+
 def pick_splits(m: int) -> int:
     """Row blocks for the split-K weight gradient: the largest of a few small factors of m that leaves >= 64 rows per block."""
     for s in (8, 4, 5, 2, 3, 7):

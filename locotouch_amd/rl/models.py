@@ -106,6 +106,39 @@ class RNN(nn.Module):
         return self.memory.get_hidden_states()
 
 
+class Conv2dAsGemm(nn.Conv2d):
+    """`nn.Conv2d` for tiny images and huge batches: on CUDA the layer is applied as ONE dense GEMM.
+
+    The student's three convolutions work on 2 x 17 x 13 ... 24 x 5 x 3 maps but on N = L * B ~ 50 000 images per batch.  MIOpen
+    needs a solver search per new N (0.1-0.3 s, once a 151 s kernel compile, tools/shape_probe.py) and without the search
+    (MIOPEN_FIND_MODE=FAST) takes 42 ms for the stack forward + backward.  A convolution on a C x H x W image is a linear map
+    of C*H*W inputs to C'*H'*W' outputs; its matrix is the layer's response to the identity basis,
+    `conv2d(eye(C*H*W).view(-1, C, H, W), weight)` - a convolution on a FIXED batch of C*H*W (442 / 840 / 360) tiny images,
+    differentiable w.r.t. the weights.  The batch then passes through `x.flatten(1) @ matrix`: 14x the FLOPs of the
+    convolution but at GEMM efficiency, the same few milliseconds at every N, no search.  Same parameters and state_dict as
+    nn.Conv2d; equal to it to fp32 rounding (tests/test_rl_conv.py)."""
+
+    as_gemm = True
+
+    def forward(self, x):
+        if not (Conv2dAsGemm.as_gemm and x.is_cuda and x.dim() == 4 and x.shape[0] >= 1024):
+            return super().forward(x)
+        from .linear import split_k_matmul
+
+        n, c, h, w = x.shape
+        key = (c, h, w, x.device)
+        basis = getattr(self, "_basis", {}).get(key)
+        if basis is None:
+            basis = torch.eye(c * h * w, device=x.device, dtype=x.dtype).view(c * h * w, c, h, w)
+            self._basis = {key: basis}
+        resp = self._conv_forward(basis, self.weight, None)  # (C H W, C', H', W'): row i = the layer's response to input element i
+        ho, wo = resp.shape[2], resp.shape[3]
+        y = split_k_matmul(x.flatten(1), resp.flatten(1))
+        if self.bias is not None:
+            y = y + self.bias.repeat_interleave(ho * wo)
+        return y.view(n, self.out_channels, ho, wo)
+
+
 def conv2d_output_shape(h, w, kernel_size=1, stride=1, padding=0, dilation=1):
     pair = lambda v: v if isinstance(v, tuple) else (v, v)  # noqa: E731
     (kh, kw), (sh, sw), (ph, pw) = pair(kernel_size), pair(stride), pair(padding)
@@ -127,7 +160,7 @@ class CNN2d(nn.Module):
         conv_strides = [1] * n if use_maxpool else list(strides)
         pool_strides = list(strides) if use_maxpool else [1] * n
         ins = [in_channels] + list(channels)[:-1]
-        convs = [nn.Conv2d(in_channels=i, out_channels=o, kernel_size=k, stride=s, padding=p)
+        convs = [Conv2dAsGemm(in_channels=i, out_channels=o, kernel_size=k, stride=s, padding=p)
                  for i, o, k, s, p in zip(ins, channels, kernel_sizes, conv_strides, paddings)]  # all convs first: the RNG order
         seq: list[nn.Module] = []
         for conv, o, ps in zip(convs, channels, pool_strides):
@@ -167,7 +200,7 @@ class CNN2dHead(nn.Module):
             self._output_size = flat
 
     def forward(self, x):
-        return self.head(self.conv(x).view(x.shape[0], -1))
+        return self.head(self.conv(x).reshape(x.shape[0], -1))
 
     @property
     def output_size(self):

@@ -13,9 +13,6 @@ from __future__ import annotations
 import argparse
 import os
 
-import os as _os
-
-_os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # no exhaustive solver search per new conv shape (minutes on a cold cache)
 import torch
 
 

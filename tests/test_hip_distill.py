@@ -109,35 +109,3 @@ def test_export_policy_as_jit_matches_actor(tmp_path):
     except ImportError:
         with pytest.raises(ImportError, match="onnx"):
             export_policy_as_onnx(runner.alg.actor_critic, path=str(tmp_path / "exported"))
-
-
-@pytest.mark.parametrize("L,B", [(60, 9), (500, 101)])
-def test_graph_replayed_training_step_equals_eager(tmp_path, L, B):
-    """The hipGraph-captured training step (forward, backward, AdamW) leaves the student where eager steps leave it."""
-    import torch
-
-    from locotouch_amd.distill import Student, distillation_cfg
-
-    def make(graph):
-        cfg = distillation_cfg(STUDENT)
-        cfg.device, cfg.log_dir, cfg.graph_training = "cuda:0", str(tmp_path), graph
-        torch.manual_seed(3)
-        W = torch.randn(348, 12, device="cuda:0") * 0.05
-        return Student(cfg, 270, 442, 12, teacher_policy_inference=lambda o: o @ W, verbose=False).train()
-
-    g = torch.Generator(device="cuda:0").manual_seed(1)
-    masks = torch.arange(L, device="cuda:0").unsqueeze(1) < torch.randint(20, L + 1, (B,), device="cuda:0", generator=g).unsqueeze(0)
-    batches = [dict(proprioceptions=torch.randn(L, B, 270, device="cuda:0", generator=g) * masks.unsqueeze(-1),
-                    teacher_encoder_obses=torch.randn(L, B, 78, device="cuda:0", generator=g) * masks.unsqueeze(-1),
-                    tactile_signals=(torch.rand(L, B, 442, device="cuda:0", generator=g) < 0.1).float() * masks.unsqueeze(-1), masks=masks)
-               for _ in range(6)]
-    a, b = make(True), make(False)
-    la = [float(a.training_step(x)[0]) for x in batches]
-    lb = [float(b.training_step(x)[0]) for x in batches]
-    assert a.graph_training and len(a._graphs) == 1, "the step must really have been captured and replayed"
-    assert all(abs(x - y) <= 2e-4 * max(1.0, abs(y)) for x, y in zip(la, lb)), (la, lb)
-    assert lb[-1] < lb[0]
-    # parameters: AdamW moves an entry with a near-zero gradient by +-lr per step whatever its size, so rounding differences
-    # (split-K weight gradients inside the capture) show up as a few entries off by some lr = 5e-4; the bulk must agree
-    diff = torch.cat([(pa - pb).abs().flatten() for pa, pb in zip(a.parameters(), b.parameters())])
-    assert float((diff > 1e-3).float().mean()) < 0.01 and float(diff.max()) < 6 * 5e-4 + 1e-4, (float(diff.max()), float((diff > 1e-3).float().mean()))

@@ -20,6 +20,10 @@ for (L, B) in [(500, 48), (500, 128), (100, 256), (24, 822)]:
             out, _ = fn(x)
             out.sum().backward()
         return f
+    import locotouch_amd.rl.gru as G
     a = t(run(lambda v: gru(v)))
+    G.use_hip_kernels = False
     b = t(run(lambda v: gru_sequence(gru, v)))
-    print(f"L={L:4d} B={B:4d}: nn.GRU (MIOpen) {a:8.2f} ms | rl/gru.py {b:8.2f} ms | x{a / b:5.1f}   ({L * B / b * 1e3 / 1e6:.2f} M steps/s)")
+    G.use_hip_kernels = True
+    c = t(run(lambda v: gru_sequence(gru, v)))
+    print(f"L={L:4d} B={B:4d}: nn.GRU (MIOpen) {a:8.2f} ms | torch-op loop {b:8.2f} ms | lt_gru.hip {c:8.2f} ms | x{a / c:5.1f}   ({L * B / c * 1e3 / 1e6:.2f} M steps/s)", flush=True)

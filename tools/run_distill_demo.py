@@ -14,8 +14,6 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import numpy as np  # noqa: E402
-import os as _os
-_os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # no exhaustive solver search per new conv shape (minutes on a cold cache)
 import torch  # noqa: E402
 
 
