@@ -33,3 +33,18 @@ def test_gru_sequence_matches_nn_gru_cpu():
 @pytest.mark.gpu
 def test_gru_sequence_matches_nn_gru_on_distillation_shape():
     _check("cuda:0", 500, 48, 64, 512, 3e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,B,I,H", [(20, 37, 64, 512), (7, 1, 5, 64), (33, 101, 64, 128), (3, 200, 16, 192)])
+def test_hip_gru_kernels_on_ragged_shapes(L, B, I, H):
+    """Row counts that are not multiples of the 16-row tile, a single row, other hidden sizes (multiples of 64)."""
+    import locotouch_amd.rl.gru as G
+
+    assert G.use_hip_kernels
+    _check("cuda:0", L, B, I, H, 2e-4)
+
+
+@pytest.mark.gpu
+def test_hidden_sizes_the_kernels_do_not_cover_take_the_torch_loop():
+    _check("cuda:0", 6, 9, 8, 48, 2e-4)  # H = 48: not a multiple of 64 -> PyTorch-op time loop
