@@ -326,6 +326,15 @@ int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_pol
 /* Profiling variant of lt_env_step: HIP events bracket the step kernel on `stream`; the call WAITS for them (host
  * sync - never use it inside a captured region) and returns the step kernel's duration in milliseconds. */
 int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float* step_kernel_ms);
+/* PPO minibatch loss with its gradients in one launch (reference loco_rl/loco_rl/algorithms/ppo.py:251-311; csrc/lt_ppo.hip).
+ * mu, actions, old_mu, old_sigma: [M][A]; std: [A] (the policy's state-independent std); value, old_logp, adv, returns,
+ * old_values: [M].  Outputs: dmu [M][A] and dvalue [M] = d loss / d mu, d loss / d value for
+ * loss = mean(surrogate) + value_loss_coef * mean(value loss) - entropy_coef * entropy  (the entropy term depends on std only and
+ * is the caller's); acc [20]: [0] sum surrogate, [1] sum value loss, [2] sum KL, [4 + a] sum over rows of
+ * d surrogate-row / d sigma_a scaled by 1 / M.  1 <= A <= 16.  Device pointers, f32. */
+int lt_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_logp, const float* adv,
+                const float* returns, const float* old_values, const float* old_mu, const float* old_sigma, int64_t M, int A, float clip,
+                float value_loss_coef, int use_clipped_value_loss, float* dmu, float* dvalue, float* acc, void* stream);
 /* GRU recurrence of the student's tactile encoder over a padded batch of whole trajectories (reference
  * loco_rl/loco_rl/models/memory_module.py:10-14 -> nn.GRU, single layer; locotouch/distill/student.py:119-123 trains it on
  * (L, B, .) batches).  One launch per time step whose grid covers the chip (csrc/lt_gru.hip); the time loop runs here.

@@ -36,6 +36,7 @@ class PPO:
         #    statistics are read once per update.  Equal results (tests/test_hip_ppo_graph.py) but the capturable / tensor-lr
         #    Adam kernels cost more than the syncs they save: 60 ms per iteration against 53 ms.
         self.device_update = on_gpu and bool(unused.get("device_update", False))
+        self.fused_loss = on_gpu and bool(unused.get("fused_loss", True))  # csrc/lt_ppo.hip: the loss chain and its backward in one launch
         self._lr_t = None
         #  * `graph_update`: that minibatch step captured once and replayed 20x per iteration from a hipGraph: 46 ms per
         #    iteration, but on this stack (ROCm 7.0 PyTorch) back-to-back replays are not stream-ordered with each other and the
@@ -113,11 +114,19 @@ class PPO:
                                      normalize_advantage=not self.normalize_advantage_per_mini_batch, dist=self.dist)
 
     # ---- update ------------------------------------------------------------------------------------
+    def _fused_loss_ok(self, b) -> bool:
+        ac = self.actor_critic
+        return (self.fused_loss and b.obs.is_cuda and type(ac) is ActorCritic and getattr(ac, "noise_std_type", "scalar") == "scalar"
+                and b.actions.shape[-1] <= 16)
+
     def _adapt_learning_rate(self, mu, sigma, old_mu, old_sigma) -> None:
         with torch.inference_mode():
             kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5)
                            + (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
-            kl_mean = torch.mean(kl)
+            self._apply_kl(torch.mean(kl))
+
+    def _apply_kl(self, kl_mean) -> None:
+        with torch.inference_mode():
             if self.dist.world_size > 1:
                 kl_mean = self.dist.all_reduce_mean_(kl_mean.clone())
             kl_mean = float(kl_mean)  # host decision, as in the reference (ppo.py:273-281)
@@ -306,6 +315,28 @@ class PPO:
             if self.normalize_advantage_per_mini_batch:
                 with torch.no_grad():
                     adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+            if self._fused_loss_ok(b):
+                # GPU: log-prob, KL, surrogate, value loss, entropy and their gradients in one launch (csrc/lt_ppo.hip)
+                from .fused_loss import fused_ppo_loss
+
+                loss, surrogate_loss, value_loss, ent, kl_mean = fused_ppo_loss(
+                    ac.actor(b.obs), ac.std, ac.critic(b.critic_obs), b.actions, b.log_prob, adv, b.returns, b.values, b.mu, b.sigma,
+                    self.clip_param, self.value_loss_coef, self.entropy_coef, self.use_clipped_value_loss)
+                if self.desired_kl is not None and self.schedule == "adaptive":
+                    self._apply_kl(kl_mean)
+                if self._flat_grad is not None:
+                    self._flat_grad.zero_()
+                else:
+                    self.optimizer.zero_grad()
+                loss.backward()
+                if self._flat_grad is not None:
+                    self.dist.all_reduce_mean_(self._flat_grad)
+                nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
+                self.optimizer.step()
+                sum_value += value_loss.item()
+                sum_surr += surrogate_loss.item()
+                sum_ent += ent.item()
+                continue
             if recurrent:
                 ac.act(b.obs, masks=masks, hidden_states=hid_a)
                 log_prob = ac.get_actions_log_prob(b.actions)
