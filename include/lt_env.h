@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 5
+#define LT_ABI_VERSION 6
 
 /* error codes */
 #define LT_OK 0
@@ -331,10 +331,30 @@ int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float*
  * old_values: [M].  Outputs: dmu [M][A] and dvalue [M] = d loss / d mu, d loss / d value for
  * loss = mean(surrogate) + value_loss_coef * mean(value loss) - entropy_coef * entropy  (the entropy term depends on std only and
  * is the caller's); acc [20]: [0] sum surrogate, [1] sum value loss, [2] sum KL, [4 + a] sum over rows of
- * d surrogate-row / d sigma_a scaled by 1 / M.  1 <= A <= 16.  Device pointers, f32. */
+ * d surrogate-row / d sigma_a scaled by 1 / M.  1 <= A <= 16.  Device pointers, f32.
+ * idx (optional, int64 [M]): the batch tensors (actions ... old_sigma) are then the WHOLE rollout storage and minibatch row i is
+ * their row idx[i] (rollout_storage.py:189-215 gathers them; here the gather is the kernel's load). */
 int lt_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_logp, const float* adv,
-                const float* returns, const float* old_values, const float* old_mu, const float* old_sigma, int64_t M, int A, float clip,
-                float value_loss_coef, int use_clipped_value_loss, float* dmu, float* dvalue, float* acc, void* stream);
+                const float* returns, const float* old_values, const float* old_mu, const float* old_sigma, const int64_t* idx, int64_t M, int A,
+                float clip, float value_loss_coef, int use_clipped_value_loss, float* dmu, float* dvalue, float* acc, void* stream);
+/* ELU backward fused with the bias gradient of the layer that fed it (the `Linear -> ELU` blocks of the actor / critic MLPs,
+ * loco_rl/loco_rl/modules/actor_critic.py:45-66, in the backward pass of ppo.py:316): dz[M][N] = da * elu'(z) recovered from the
+ * activation OUTPUT a (1 where a > 0, a + alpha elsewhere), db[N] = column sums of dz.  dz may alias da.  N a multiple of 4,
+ * <= 1024; ws: lt_elu_backward_bias_ws_floats(M, N) floats of scratch. */
+int lt_elu_backward_bias(const float* da, const float* a, int64_t M, int N, float alpha, float* dz, float* db, float* ws, void* stream);
+int64_t lt_elu_backward_bias_ws_floats(int64_t M, int N);
+/* Weight and bias gradient of a narrow head layer (the action-mean and value heads of actor_critic.py:45-66 in the backward pass):
+ * dw[n][k] = sum_m dy[m][n] x[m][k], db[n] = sum_m dy[m][n] (db optional).  1 <= n <= 16, k a multiple of 4, <= 1024;
+ * ws: lt_head_wgrad_ws_floats(M, n, k) floats of scratch.  Deterministic (no float atomics). */
+int lt_head_wgrad(const float* dy, const float* x, int64_t M, int n, int k, float* dw, float* db, float* ws, void* stream);
+int64_t lt_head_wgrad_ws_floats(int64_t M, int n, int k);
+/* clip_grad_norm_(max_norm) + Adam.step() on FLAT f32 buffers of n elements in two launches (ppo.py:318-319; torch's arithmetic
+ * order, `step` = the 1-based count of this update).  grads are left scaled by the clip coefficient, as clip_grad_norm_ leaves
+ * them; max_norm <= 0 disables the clip; grad_norm (optional, device) receives the pre-clip norm.
+ * ws: lt_adam_clip_step_ws_floats(n) floats of scratch. */
+int lt_adam_clip_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float max_norm, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int64_t step, float* ws, float* grad_norm, void* stream);
+int64_t lt_adam_clip_step_ws_floats(int64_t n);
 /* GRU recurrence of the student's tactile encoder over a padded batch of whole trajectories (reference
  * loco_rl/loco_rl/models/memory_module.py:10-14 -> nn.GRU, single layer; locotouch/distill/student.py:119-123 trains it on
  * (L, B, .) batches).  One launch per time step whose grid covers the chip (csrc/lt_gru.hip); the time loop runs here.

@@ -432,12 +432,14 @@ class _PolicyExport(torch.nn.Module):
 
         if getattr(actor_critic, "is_recurrent", False):
             raise NotImplementedError("recurrent actor export is not implemented (no registered LocoTouch task trains one)")
-        self.actor = copy.deepcopy(actor_critic.actor).cpu()
-        for i, m in enumerate(self.actor):  # plain nn.Linear (rl/linear.py's training-time autograd function is not scriptable)
+        layers = []  # plain nn.Sequential of plain nn.Linear (rl/linear.py's training-time nodes are not scriptable)
+        for m in copy.deepcopy(actor_critic.actor).cpu():
             if isinstance(m, torch.nn.Linear) and type(m) is not torch.nn.Linear:
                 lin = torch.nn.Linear(m.in_features, m.out_features, bias=m.bias is not None)
                 lin.load_state_dict(m.state_dict())
-                self.actor[i] = lin
+                m = lin
+            layers.append(m)
+        self.actor = torch.nn.Sequential(*layers)
         self.normalizer = copy.deepcopy(normalizer).cpu() if normalizer is not None else torch.nn.Identity()
 
     def forward(self, x):

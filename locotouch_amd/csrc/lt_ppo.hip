@@ -8,6 +8,7 @@
 // are written directly.  `torch.max(a, b)` splits the gradient evenly on ties; inside the clip range both surrogate branches
 // (and both value branches) are equal AND have the same derivative, so the closed forms below are exactly autograd's.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "lt_env.h"
@@ -23,11 +24,12 @@ __global__ __launch_bounds__(256) void lt_ppo_loss_kernel(const float* __restric
                                                           const float* __restrict__ actions, const float* __restrict__ old_logp,
                                                           const float* __restrict__ adv, const float* __restrict__ returns,
                                                           const float* __restrict__ old_values, const float* __restrict__ old_mu,
-                                                          const float* __restrict__ old_sigma, long long M, int A, float clip, float vcoef,
-                                                          int clipped_value, float* __restrict__ dmu, float* __restrict__ dvalue,
-                                                          float* __restrict__ acc) {
+                                                          const float* __restrict__ old_sigma, const long long* __restrict__ idx,
+                                                          long long M, int A, float clip, float vcoef, int clipped_value,
+                                                          float* __restrict__ dmu, float* __restrict__ dvalue, float* __restrict__ acc) {
   const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
   const bool ok = row < M;
+  const long long src = (ok && idx) ? idx[row] : row;  // row of the rollout storage this minibatch row was drawn from
   float part[4 + MAX_A];
 #pragma unroll
   for (int i = 0; i < 4 + MAX_A; ++i) part[i] = 0.f;
@@ -38,16 +40,16 @@ __global__ __launch_bounds__(256) void lt_ppo_loss_kernel(const float* __restric
 #pragma unroll
     for (int a = 0; a < MAX_A; ++a) {
       if (a < A) {
-        const float sg = stdp[a], m = mu[row * A + a], x = actions[row * A + a];
-        const float om = old_mu[row * A + a], os = old_sigma[row * A + a];
+        const float sg = stdp[a], m = mu[row * A + a], x = actions[src * A + a];
+        const float om = old_mu[src * A + a], os = old_sigma[src * A + a];
         isg[a] = 1.f / sg;
         z[a] = (x - m) * isg[a];
         logp += -0.5f * z[a] * z[a] - __logf(sg) - kHalfLog2Pi;
         kl += __logf(sg / os + 1.0e-5f) + (os * os + (om - m) * (om - m)) / (2.f * sg * sg) - 0.5f;
       }
     }
-    const float advr = adv[row];
-    const float ratio = __expf(logp - old_logp[row]);
+    const float advr = adv[src];
+    const float ratio = __expf(logp - old_logp[src]);
     const float s1 = -advr * ratio;
     const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
     const float s2 = -advr * rc;
@@ -61,10 +63,10 @@ __global__ __launch_bounds__(256) void lt_ppo_loss_kernel(const float* __restric
         part[4 + a] = dlogp * (z[a] * z[a] - 1.f) * isg[a];  // d logp / d sigma_a = ((x - mu)^2 / sigma^3 - 1 / sigma)
       }
     }
-    const float v = value[row], R = returns[row];
+    const float v = value[row], R = returns[src];
     float vl, dv;
     if (clipped_value) {
-      const float ov = old_values[row];
+      const float ov = old_values[src];
       const float dcl = fminf(fmaxf(v - ov, -clip), clip);
       const float vc = ov + dcl;
       const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
@@ -97,11 +99,262 @@ __global__ __launch_bounds__(256) void lt_ppo_loss_kernel(const float* __restric
   }
 }
 
+// ---- ELU backward fused with the bias gradient ---------------------------------------------------------------------------------
+// dz = da * elu'(z) with elu'(z) recovered from the OUTPUT a = elu(z): 1 for a > 0, a + alpha otherwise (PyTorch's own
+// `elu_backward(..., is_result=true)`), and db[n] = sum over rows of dz[., n] in the same pass.  A thread owns 4 adjacent columns
+// (one 16-byte load per operand and row); the 256 / (N / 4) row lanes of a block meet in LDS; per-block column sums go to `ws`
+// and a second, tiny launch adds them in a fixed order (deterministic, no float atomics).
+constexpr int EB_ROWS = 48;  // rows per block: 512 blocks at 24 576 rows
+
+__global__ __launch_bounds__(256) void lt_elu_bwd_bias_kernel(const float* da, const float* __restrict__ a, long long M, int N, float alpha,
+                                                              float* dz, float* __restrict__ ws) {
+  const int n4 = N >> 2, lanes = 256 / n4;
+  const int c4 = threadIdx.x % n4, rl = threadIdx.x / n4;
+  const long long r0 = (long long)blockIdx.x * EB_ROWS;
+  float4 sum = {0.f, 0.f, 0.f, 0.f};
+  if (rl < lanes) {
+    for (int r = rl; r < EB_ROWS; r += lanes) {
+      const long long row = r0 + r;
+      if (row >= M) break;
+      const float4 g = ((const float4*)(da + row * N))[c4], y = ((const float4*)(a + row * N))[c4];
+      float4 o;
+      o.x = g.x * (y.x > 0.f ? 1.f : y.x + alpha);
+      o.y = g.y * (y.y > 0.f ? 1.f : y.y + alpha);
+      o.z = g.z * (y.z > 0.f ? 1.f : y.z + alpha);
+      o.w = g.w * (y.w > 0.f ? 1.f : y.w + alpha);
+      ((float4*)(dz + row * N))[c4] = o;
+      sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+    }
+  }
+  __shared__ float4 red[256];
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x < n4) {
+    float4 t = red[threadIdx.x];
+    for (int l = 1; l < lanes; ++l) {
+      const float4 u = red[l * n4 + threadIdx.x];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    ((float4*)(ws + (long long)blockIdx.x * N))[threadIdx.x] = t;
+  }
+}
+
+// out[e] = sum over b < nblk of ws[b * stride + e], e < count, added in block order by 16 row lanes of 16 adjacent elements each
+// (a lane's loads are independent, so a block's latency is ~nblk / 16 loads deep, not nblk); elements >= split go to out1.
+__global__ __launch_bounds__(256) void lt_partial_sum_kernel(const float* __restrict__ ws, int nblk, long long stride, int count, int split,
+                                                             float* __restrict__ out0, float* __restrict__ out1) {
+  const int e = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < count) {
+    int b = lane;
+    for (; b + 48 < nblk; b += 64) {
+      s0 += ws[(long long)b * stride + e];
+      s1 += ws[(long long)(b + 16) * stride + e];
+      s2 += ws[(long long)(b + 32) * stride + e];
+      s3 += ws[(long long)(b + 48) * stride + e];
+    }
+    for (; b < nblk; b += 16) s0 += ws[(long long)b * stride + e];
+  }
+  __shared__ float red[16][16];
+  red[lane][threadIdx.x & 15] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (lane == 0 && e < count) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += red[l][threadIdx.x];
+    if (e < split) out0[e] = t;
+    else if (out1) out1[e - split] = t;
+  }
+}
+
+// ---- weight + bias gradient of a narrow head layer -----------------------------------------------------------------------------------
+// dW[n][k] = sum_m dy[m][n] x[m][k], db[n] = sum_m dy[m][n] for n <= 16 outputs (the action-mean and value heads: 12 x 128 and
+// 1 x 128 over 24 576 rows).  As GEMMs these are all reduction and no tile: hipBLASLt takes 35-52 us for 75 MFLOP, plus a
+// column reduction for the bias.  Here a thread owns 4 adjacent k columns and all n outputs (one 16-byte load of x per row, dy
+// broadcast), row lanes meet by shuffle + LDS, a block writes ONE partial [n][k] and a second launch adds the partials in order.
+constexpr int HW_ROWS = 96, HW_MAX_N = 16;
+
+template <int NN>
+__global__ __launch_bounds__(256) void lt_head_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, long long M, int n, int k,
+                                                            float* __restrict__ ws) {
+  const int k4 = k >> 2, lanes = 256 / k4;
+  const int c4 = threadIdx.x % k4, rl = threadIdx.x / k4;
+  const long long r0 = (long long)blockIdx.x * HW_ROWS;
+  float4 acc[NN];
+  float accb[NN];
+#pragma unroll
+  for (int j = 0; j < NN; ++j) { acc[j] = {0.f, 0.f, 0.f, 0.f}; accb[j] = 0.f; }
+  if (rl < lanes) {
+    for (int r = rl; r < HW_ROWS; r += 4 * lanes) {  // 4 rows in flight: their loads are issued before the first FMA
+      float4 xv[4];
+      float d[4][NN];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long row = r0 + r + u * lanes;
+        const bool ok = (r + u * lanes) < HW_ROWS && row < M;
+        xv[u] = ok ? ((const float4*)(x + row * k))[c4] : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NN; ++j) d[u][j] = (ok && j < n) ? dy[row * n + j] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+          acc[j].x += d[u][j] * xv[u].x; acc[j].y += d[u][j] * xv[u].y; acc[j].z += d[u][j] * xv[u].z; acc[j].w += d[u][j] * xv[u].w;
+          accb[j] += d[u][j];
+        }
+    }
+  }
+  // partial of this block: ws[blk][n][k] then [n] bias sums; row lanes are added through LDS in lane order
+  extern __shared__ float4 red[];  // [lanes][NN][k4] + bias [lanes][NN] floats behind it
+  float* const redb = (float*)(red + (size_t)lanes * NN * k4);
+  if (rl < lanes) {
+#pragma unroll
+    for (int j = 0; j < NN; ++j) red[((size_t)rl * NN + j) * k4 + c4] = acc[j];
+    if (c4 == 0)
+#pragma unroll
+      for (int j = 0; j < NN; ++j) redb[rl * NN + j] = accb[j];
+  }
+  __syncthreads();
+  float* const out = ws + (size_t)blockIdx.x * ((size_t)n * k + HW_MAX_N);
+  for (int e = threadIdx.x; e < n * k4; e += 256) {
+    const int j = e / k4, c = e - j * k4;
+    float4 t = red[(size_t)j * k4 + c];
+    for (int l = 1; l < lanes; ++l) {
+      const float4 u = red[((size_t)l * NN + j) * k4 + c];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    ((float4*)(out + (size_t)j * k))[c] = t;
+  }
+  if (threadIdx.x < n) {
+    float t = redb[threadIdx.x];
+    for (int l = 1; l < lanes; ++l) t += redb[l * NN + threadIdx.x];
+    out[(size_t)n * k + threadIdx.x] = t;
+  }
+}
+
+// ---- gradient-norm clip + Adam on flat buffers ------------------------------------------------------------------------------------
+// torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step() (loco_rl/loco_rl/algorithms/ppo.py:318-319) are ~12 multi-tensor
+// launches over 17 small tensors; with parameters, gradients and both moments flat they are two: sum of squares per block, then
+// every block re-adds the block sums in order (deterministic), scales its gradients and applies the update.  Arithmetic in
+// torch's own order: clip coefficient min(1, max_norm / (norm + 1e-6)); exp_avg.lerp_(g, 1 - b1); exp_avg_sq = b2 * v + (1 - b2) g g;
+// denom = sqrt(v) / sqrt(1 - b2^t) + eps; p -= lr / (1 - b1^t) * m / denom.
+constexpr int AD_PER_BLOCK = 2048;  // elements per block (256 threads x 2 float4)
+
+__global__ __launch_bounds__(256) void lt_sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ ws) {
+  const long long base = (long long)blockIdx.x * AD_PER_BLOCK;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < AD_PER_BLOCK; k += 256) {
+    const long long i = base + k;
+    if (i < n) s += g[i] * g[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void lt_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                      long long n, const float* __restrict__ ws, int nblk, float max_norm, float b1,
+                                                      float b2, float eps, float wd, float step_size, float bc2_sqrt, float* __restrict__ norm_out) {
+  __shared__ float s_coef;
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += ws[b];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) {
+      const float norm = sqrtf(s);
+      const float c = max_norm / (norm + 1.0e-6f);
+      s_coef = max_norm > 0.f ? (c < 1.f ? c : 1.f) : 1.f;
+      if (blockIdx.x == 0 && norm_out) *norm_out = norm;
+    }
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  const long long base = (long long)blockIdx.x * AD_PER_BLOCK;
+  for (int k = threadIdx.x; k < AD_PER_BLOCK; k += 256) {
+    const long long i = base + k;
+    if (i >= n) break;
+    float gi = g[i] * coef;
+    g[i] = gi;  // clip_grad_norm_ leaves the scaled gradients in .grad
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = m[i] + (1.f - b1) * (gi - m[i]);
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+
 }  // namespace
 
+extern "C" int lt_elu_backward_bias(const float* da, const float* a, int64_t M, int N, float alpha, float* dz, float* db, float* ws, void* stream) {
+  if (!da || !a || !dz || !db || !ws || M < 1 || N < 4 || (N & 3) || N > 1024) {
+    lt_set_error("lt_elu_backward_bias: invalid argument (N a multiple of 4, 4 <= N <= 1024)");
+    return LT_EINVAL;
+  }
+  const int nblk = (int)((M + EB_ROWS - 1) / EB_ROWS);
+  hipLaunchKernelGGL(lt_elu_bwd_bias_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, da, a, (long long)M, N, alpha, dz, ws);
+  hipLaunchKernelGGL(lt_partial_sum_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, ws, nblk, (long long)N, N, N, db, (float*)nullptr);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
+  return LT_OK;
+}
+
+extern "C" int64_t lt_head_wgrad_ws_floats(int64_t M, int n, int k) { return ((M + HW_ROWS - 1) / HW_ROWS) * ((int64_t)n * k + HW_MAX_N); }
+
+extern "C" int lt_head_wgrad(const float* dy, const float* x, int64_t M, int n, int k, float* dw, float* db, float* ws, void* stream) {
+  if (!dy || !x || !dw || !ws || M < 1 || n < 1 || n > HW_MAX_N || k < 4 || (k & 3) || k > 1024) {
+    lt_set_error("lt_head_wgrad: invalid argument (1 <= n <= 16, k a multiple of 4, 4 <= k <= 1024)");
+    return LT_EINVAL;
+  }
+  const int nblk = (int)((M + HW_ROWS - 1) / HW_ROWS), k4 = k / 4, lanes = 256 / k4;
+  const int nn = n <= 1 ? 1 : (n <= 4 ? 4 : (n <= 8 ? 8 : (n <= 12 ? 12 : 16)));
+  const size_t lds = (size_t)lanes * nn * k4 * 16 + (size_t)lanes * nn * 4;
+  if (lds > 64 * 1024) {
+    lt_set_error("lt_head_wgrad: n * k too large for one block's LDS partials");
+    return LT_EINVAL;
+  }
+  const dim3 g((unsigned)nblk), b(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (nn) {
+    case 1: hipLaunchKernelGGL(lt_head_wgrad_kernel<1>, g, b, lds, st, dy, x, (long long)M, n, k, ws); break;
+    case 4: hipLaunchKernelGGL(lt_head_wgrad_kernel<4>, g, b, lds, st, dy, x, (long long)M, n, k, ws); break;
+    case 8: hipLaunchKernelGGL(lt_head_wgrad_kernel<8>, g, b, lds, st, dy, x, (long long)M, n, k, ws); break;
+    case 12: hipLaunchKernelGGL(lt_head_wgrad_kernel<12>, g, b, lds, st, dy, x, (long long)M, n, k, ws); break;
+    default: hipLaunchKernelGGL(lt_head_wgrad_kernel<16>, g, b, lds, st, dy, x, (long long)M, n, k, ws); break;
+  }
+  hipLaunchKernelGGL(lt_partial_sum_kernel, dim3((unsigned)((n * k + n + 15) / 16)), b, 0, st, ws, nblk, (long long)n * k + HW_MAX_N, n * k + n, n * k, dw, db);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
+  return LT_OK;
+}
+
+extern "C" int64_t lt_elu_backward_bias_ws_floats(int64_t M, int N) { return ((M + EB_ROWS - 1) / EB_ROWS) * (int64_t)N; }
+
+extern "C" int lt_adam_clip_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float max_norm, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int64_t step, float* ws, float* grad_norm, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !ws || n < 1 || step < 1) {
+    lt_set_error("lt_adam_clip_step: invalid argument");
+    return LT_EINVAL;
+  }
+  const int nblk = (int)((n + AD_PER_BLOCK - 1) / AD_PER_BLOCK);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(lt_sumsq_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, grads, (long long)n, ws);
+  hipLaunchKernelGGL(lt_adam_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (long long)n, ws, nblk,
+                     max_norm, beta1, beta2, eps, weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_norm);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
+  return LT_OK;
+}
+
+extern "C" int64_t lt_adam_clip_step_ws_floats(int64_t n) { return (n + AD_PER_BLOCK - 1) / AD_PER_BLOCK; }
+
 extern "C" int lt_ppo_loss(const float* mu, const float* stdp, const float* value, const float* actions, const float* old_logp, const float* adv,
-                           const float* returns, const float* old_values, const float* old_mu, const float* old_sigma, int64_t M, int A,
-                           float clip, float value_loss_coef, int use_clipped_value_loss, float* dmu, float* dvalue, float* acc, void* stream) {
+                           const float* returns, const float* old_values, const float* old_mu, const float* old_sigma, const int64_t* idx,
+                           int64_t M, int A, float clip, float value_loss_coef, int use_clipped_value_loss, float* dmu, float* dvalue, float* acc, void* stream) {
   if (!mu || !stdp || !value || !actions || !old_logp || !adv || !returns || !old_values || !old_mu || !old_sigma || !dmu || !dvalue || !acc ||
       M < 1 || A < 1 || A > MAX_A) {
     lt_set_error("lt_ppo_loss: invalid argument (1 <= num_actions <= 16)");
@@ -110,7 +363,7 @@ extern "C" int lt_ppo_loss(const float* mu, const float* stdp, const float* valu
   hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * (4 + MAX_A), (hipStream_t)stream);
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   hipLaunchKernelGGL(lt_ppo_loss_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu, stdp, value, actions, old_logp, adv,
-                     returns, old_values, old_mu, old_sigma, (long long)M, A, clip, value_loss_coef, use_clipped_value_loss, dmu, dvalue, acc);
+                     returns, old_values, old_mu, old_sigma, (const long long*)idx, (long long)M, A, clip, value_loss_coef, use_clipped_value_loss, dmu, dvalue, acc);
   e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;

@@ -16,7 +16,7 @@ from .. import _abi
 
 class _FusedPPOLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mu, std, value, actions, old_logp, adv, returns, old_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped):
+    def forward(ctx, mu, std, value, actions, old_logp, adv, returns, old_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped, idx):
         lib = _abi.load()
         m, a = mu.shape
         c = lambda t: t.detach().contiguous()  # noqa: E731
@@ -26,10 +26,16 @@ class _FusedPPOLoss(torch.autograd.Function):
         acc = torch.empty(20, device=mu.device, dtype=torch.float32)
         vp = ctypes.c_void_p
         args = [c(actions), c(old_logp).view(-1), c(adv).view(-1), c(returns).view(-1), c(old_values).view(-1), c(old_mu), c(old_sigma)]
-        _abi.check(lib.lt_ppo_loss(vp(mu_c.data_ptr()), vp(std_c.data_ptr()), vp(v_c.data_ptr()), *[vp(t.data_ptr()) for t in args], m, a,
+        rows = args[0].shape[0]
+        if (any(t.shape[0] != rows for t in args) or any(t.shape != (rows, a) for t in (args[0], args[5], args[6]))
+                or (idx is None and rows != m) or (idx is not None and (idx.dtype != torch.int64 or idx.numel() != m))):
+            raise ValueError("fused_ppo_loss: batch tensors do not match the minibatch / index")
+        idx_c = None if idx is None else c(idx)
+        _abi.check(lib.lt_ppo_loss(vp(mu_c.data_ptr()), vp(std_c.data_ptr()), vp(v_c.data_ptr()), *[vp(t.data_ptr()) for t in args],
+                                   vp(None if idx_c is None else idx_c.data_ptr()), m, a,
                                    float(clip), float(vcoef), int(bool(clipped)), vp(dmu.data_ptr()), vp(dvalue.data_ptr()), vp(acc.data_ptr()),
                                    vp(torch.cuda.current_stream(mu.device).cuda_stream)), "lt_ppo_loss")
-        surr, vl, kl = acc[0] / m, acc[1] / m, acc[2] / m
+        surr, vl, kl = (acc[:3] / m).unbind(0)
         ent = (0.5 + 0.5 * math.log(2.0 * math.pi) + torch.log(std_c)).sum()  # Normal entropy, summed over actions; same in every row
         loss = surr + vcoef * vl - ecoef * ent
         ctx.save_for_backward(dmu, dvalue.view_as(value), acc[4:4 + a] - ecoef / std_c)
@@ -38,10 +44,12 @@ class _FusedPPOLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *unused):
         dmu, dvalue, dstd = ctx.saved_tensors
-        return g * dmu, g * dstd, g * dvalue, None, None, None, None, None, None, None, None, None, None, None
+        return g * dmu, g * dstd, g * dvalue, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def fused_ppo_loss(mu, std, value, actions, old_logp, adv, returns, old_values, old_mu, old_sigma, clip_param, value_loss_coef,
-                   entropy_coef, use_clipped_value_loss):
+                   entropy_coef, use_clipped_value_loss, idx=None):
+    """`idx` (int64 [M], optional): the batch tensors `actions ... old_sigma` are then the WHOLE flattened rollout storage and
+    minibatch row i is their row idx[i] - the kernel gathers while it loads, seven gather launches less per step."""
     return _FusedPPOLoss.apply(mu, std, value, actions, old_logp, adv, returns, old_values, old_mu, old_sigma, clip_param, value_loss_coef,
-                               entropy_coef, use_clipped_value_loss)
+                               entropy_coef, use_clipped_value_loss, idx)

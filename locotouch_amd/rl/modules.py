@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 from torch.distributions import Normal
 
-from .linear import Linear
+from .linear import Linear, MLPSequential
 
 _ACTIVATIONS = {"elu": nn.ELU, "relu": nn.ReLU, "selu": nn.SELU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid,
                 "lrelu": nn.LeakyReLU, "identity": nn.Identity}
@@ -25,7 +25,7 @@ def build_mlp(in_dim: int, hidden: list[int], out_dim: int, activation: str) -> 
     for a, b in zip(sizes[:-1], sizes[1:]):
         layers += [Linear(a, b), act()]
     layers.append(Linear(sizes[-1], out_dim))
-    return nn.Sequential(*layers)
+    return MLPSequential(*layers)
 
 
 class ActorCritic(nn.Module):
@@ -64,6 +64,8 @@ class ActorCritic(nn.Module):
 
     @property
     def action_std(self) -> torch.Tensor:
+        if self.distribution is None:  # fused rollout + fused update build no Normal object: the state-independent std itself
+            return self.std if self.noise_std_type == "scalar" else torch.exp(self.log_std)
         return self.distribution.stddev
 
     @property

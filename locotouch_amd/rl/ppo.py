@@ -56,9 +56,19 @@ class PPO:
         self.normalize_advantage_per_mini_batch = normalize_advantage_per_mini_batch
         self._t = {}
         self._flat_grad: torch.Tensor | None = None
+        # clip_grad_norm_ + Adam.step() in two launches on flat buffers (rl/flat_adam.py); the tensors the module and the optimizer
+        # hold become views of those buffers, checkpoints keep the reference's layout
+        self._flat_adam = None
+        use_flat_adam = on_gpu and bool(unused.get("fused_adam", True)) and not (self.device_update or self.graph_update)
         if self.dist.world_size > 1:
-            self._make_flat_grad_bucket()
+            if not use_flat_adam:
+                self._make_flat_grad_bucket()
             self.broadcast_parameters()
+        if use_flat_adam:
+            from .flat_adam import FlatAdam
+
+            self._flat_adam = FlatAdam(self.optimizer)
+            self._flat_grad = self._flat_adam.flat_g  # also the all-reduce bucket of a multi-rank job
 
     # ---- data-parallel plumbing ------------------------------------------------------------------
     def _make_flat_grad_bucket(self) -> None:
@@ -116,8 +126,37 @@ class PPO:
     # ---- update ------------------------------------------------------------------------------------
     def _fused_loss_ok(self, b) -> bool:
         ac = self.actor_critic
-        return (self.fused_loss and b.obs.is_cuda and type(ac) is ActorCritic and getattr(ac, "noise_std_type", "scalar") == "scalar"
-                and b.actions.shape[-1] <= 16)
+        st = self.storage
+        return (self.fused_loss and st.observations.is_cuda and type(ac) is ActorCritic and getattr(ac, "noise_std_type", "scalar") == "scalar"
+                and st.actions.shape[-1] <= 16)
+
+    def _fused_update(self):
+        """The update of the plain ActorCritic on the GPU: per minibatch step two row gathers (obs, critic obs), the two MLPs,
+        ONE loss launch that reads the seven small per-row tensors of the rollout storage through the minibatch index
+        (csrc/lt_ppo.hip), backward, two launches of clip + Adam; one host read per step (the KL of the learning-rate rule,
+        ppo.py:273-281), the statistics once at the end.  Same arithmetic as the op chain below (tests/test_hip_ppo_graph.py)."""
+        from .fused_loss import fused_ppo_loss
+
+        ac, st = self.actor_critic, self.storage
+        f = lambda t: t.flatten(0, 1)  # noqa: E731
+        obs, cobs = f(st.observations), f(st.privileged_observations)
+        small = [f(t).contiguous() for t in (st.actions, st.actions_log_prob, st.advantages, st.returns, st.values, st.mu, st.sigma)]
+        stats = torch.zeros(3, device=obs.device)
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        for idx in st.mini_batch_indices(self.num_mini_batches, self.num_learning_epochs):
+            loss, surrogate_loss, value_loss, ent, kl_mean = fused_ppo_loss(
+                ac.actor(obs[idx]), ac.std, ac.critic(cobs[idx]), *small, self.clip_param, self.value_loss_coef, self.entropy_coef,
+                self.use_clipped_value_loss, idx=idx)
+            if adaptive:
+                self._apply_kl(kl_mean)
+            self._zero_grad()
+            loss.backward()
+            self._optim_step()
+            stats = stats + torch.stack((value_loss, surrogate_loss, ent.detach()))
+        n = self.num_learning_epochs * self.num_mini_batches
+        sv, ss, se = (stats / n).tolist()
+        st.clear()
+        return sv, ss, se, None, None
 
     def _adapt_learning_rate(self, mu, sigma, old_mu, old_sigma) -> None:
         with torch.inference_mode():
@@ -301,7 +340,10 @@ class PPO:
     def _eager_update(self):
         ac = self.actor_critic
         sum_value = sum_surr = sum_ent = 0.0
+        stats = None
         recurrent = getattr(ac, "is_recurrent", False)
+        if not recurrent and not self.normalize_advantage_per_mini_batch and self._fused_loss_ok(None):
+            return self._fused_update()
         batches = (self.storage.recurrent_mini_batches(self.num_mini_batches, self.num_learning_epochs) if recurrent
                    else self.storage.mini_batches(self.num_mini_batches, self.num_learning_epochs))
         for raw in batches:
@@ -324,18 +366,12 @@ class PPO:
                     self.clip_param, self.value_loss_coef, self.entropy_coef, self.use_clipped_value_loss)
                 if self.desired_kl is not None and self.schedule == "adaptive":
                     self._apply_kl(kl_mean)
-                if self._flat_grad is not None:
-                    self._flat_grad.zero_()
-                else:
-                    self.optimizer.zero_grad()
+                if stats is None:
+                    stats = torch.zeros(3, device=loss.device)
+                self._zero_grad()
                 loss.backward()
-                if self._flat_grad is not None:
-                    self.dist.all_reduce_mean_(self._flat_grad)
-                nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
-                self.optimizer.step()
-                sum_value += value_loss.item()
-                sum_surr += surrogate_loss.item()
-                sum_ent += ent.item()
+                self._optim_step()
+                stats = stats + torch.stack((value_loss, surrogate_loss, ent.detach()))  # read once, after the last step
                 continue
             if recurrent:
                 ac.act(b.obs, masks=masks, hidden_states=hid_a)
@@ -357,18 +393,35 @@ class PPO:
             else:
                 value_loss = (b.returns - value).pow(2).mean()
             loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
-            if self._flat_grad is not None:
-                self._flat_grad.zero_()
-            else:
-                self.optimizer.zero_grad()
+            self._zero_grad()
             loss.backward()
-            if self._flat_grad is not None:
-                self.dist.all_reduce_mean_(self._flat_grad)  # RCCL all-reduce of the policy gradients over xGMI
-            nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
-            self.optimizer.step()
+            self._optim_step()
             sum_value += value_loss.item()
             sum_surr += surrogate_loss.item()
             sum_ent += entropy.mean().item()
         n = self.num_learning_epochs * self.num_mini_batches
+        if stats is not None:
+            sv, ss, se = stats.tolist()
+            sum_value, sum_surr, sum_ent = sum_value + sv, sum_surr + ss, sum_ent + se
         self.storage.clear()
         return sum_value / n, sum_surr / n, sum_ent / n, None, None
+
+    def _zero_grad(self) -> None:
+        if self._flat_adam is not None:
+            self._flat_adam.zero_grad()
+        elif self._flat_grad is not None:
+            self._flat_grad.zero_()
+        else:
+            self.optimizer.zero_grad()
+
+    def _optim_step(self) -> None:
+        """All-reduce of the gradients (multi-rank), clip_grad_norm_, Adam (ppo.py:318-319)."""
+        if self._flat_adam is not None:
+            self._flat_adam.gather_grads()               # one multi-tensor copy into the flat bucket
+        if self.dist.world_size > 1:
+            self.dist.all_reduce_mean_(self._flat_grad)  # RCCL all-reduce of the policy gradients over xGMI
+        if self._flat_adam is not None:
+            self._flat_adam.step(self.max_grad_norm, gathered=True)  # clip + Adam in two launches (csrc/lt_ppo.hip)
+        else:
+            nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm)
+            self.optimizer.step()

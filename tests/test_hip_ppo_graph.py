@@ -48,6 +48,16 @@ def test_fused_loss_kernel_matches_the_torch_formulas(m, clipped):
     mu, std, value = leaves(torch.float32)
     loss, surr, vl, ent, kl = fused_ppo_loss(mu, std, value, actions, old_logp, adv, returns, old_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped)
     (2.0 * loss).backward()  # a non-unit upstream gradient
+    # index form: the batch tensors are a larger storage, the minibatch is rows idx of it
+    perm = torch.randperm(3 * m, device="cuda:0", generator=g)
+    idx, big = perm[:m], lambda t: torch.randn(3 * m, *t.shape[1:], device="cuda:0", generator=g).index_copy_(0, perm[:m], t)  # noqa: E731
+    mu_i, std_i, value_i = leaves(torch.float32)
+    big_sigma = (torch.rand(3 * m, A, device="cuda:0", generator=g) + 0.1).index_copy_(0, idx, old_sigma)
+    out_i = fused_ppo_loss(mu_i, std_i, value_i, big(actions), big(old_logp), big(adv), big(returns), big(old_values), big(old_mu),
+                           big_sigma, clip, vcoef, ecoef, clipped, idx=idx)
+    (2.0 * out_i[0]).backward()
+    torch.testing.assert_close(torch.stack(out_i), torch.stack((loss, surr, vl, ent, kl)), rtol=1e-5, atol=1e-6)
+    assert torch.equal(mu_i.grad, mu.grad) and torch.equal(value_i.grad, value.grad)
 
     mu_d, std_d, value_d = leaves(torch.float64)
     d = lambda t: t.double()  # noqa: E731
@@ -67,7 +77,7 @@ def test_fused_loss_kernel_matches_the_torch_formulas(m, clipped):
     loss_ref = surr_ref + vcoef * vl_ref - ecoef * ent_ref
     (2.0 * loss_ref).backward()
     for got, ref in ((loss, loss_ref), (surr, surr_ref), (vl, vl_ref), (ent, ent_ref), (kl, kl_ref)):
-        assert abs(float(got) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref))), (float(got), float(ref))
+        assert abs(float(got.detach()) - float(ref.detach())) <= 2e-5 * max(1.0, abs(float(ref))), (float(got), float(ref))
     torch.testing.assert_close(mu.grad.double(), mu_d.grad, rtol=2e-4, atol=2e-6 / m)
     torch.testing.assert_close(value.grad.double(), value_d.grad, rtol=2e-4, atol=2e-6 / m)
     torch.testing.assert_close(std.grad.double(), std_d.grad, rtol=5e-4, atol=2e-5)
@@ -79,16 +89,16 @@ def test_update_with_fused_loss_equals_update_with_torch_ops():
     from locotouch_amd.rl import PPO, ActorCritic
     from tests.rl_synth import N_ACT, N_OBS, POLICY_CFG, PPO_CFG
 
-    n, T = 512, 24
+    n, T = 1024, 24  # 6144-row minibatches: the fused Linear -> ELU nodes and split-K weight gradients are on the path
     cfg = dict(PPO_CFG, num_learning_epochs=2, num_mini_batches=4)
     algs = []
     for fused in (True, False):
         torch.manual_seed(0)
-        alg = PPO(ActorCritic(N_OBS, N_OBS, N_ACT, **POLICY_CFG), device="cuda:0", fused_loss=fused, **cfg)
+        alg = PPO(ActorCritic(N_OBS, N_OBS, N_ACT, **POLICY_CFG), device="cuda:0", fused_loss=fused, fused_adam=fused, **cfg)
         alg.init_storage(n, T, [N_OBS], [N_OBS], [N_ACT])
         algs.append(alg)
     a, b = algs
-    assert a.fused_loss and not b.fused_loss
+    assert a.fused_loss and a._flat_adam is not None and not b.fused_loss and b._flat_adam is None
     lrs = set()
     for it in range(4):
         outs = []
@@ -142,3 +152,77 @@ def test_device_side_update_equals_host_side_update():
     assert len({round(x, 9) for x, _ in lrs}) > 1, "the adaptive rule must have moved the learning rate"
     for pa, pb in zip(a.actor_critic.parameters(), b.actor_critic.parameters()):
         torch.testing.assert_close(pa, pb, rtol=5e-3, atol=5e-4)
+
+
+@pytest.mark.parametrize("m,n", [(24576, 512), (4100, 256), (5000, 128), (4096, 400), (4097, 4)])
+def test_linear_elu_node_matches_torch(m, n):
+    """`MLPSequential`'s fused Linear -> ELU node (csrc/lt_ppo.hip lt_elu_backward_bias) against nn.Linear + nn.ELU."""
+    import torch
+
+    from locotouch_amd.rl.linear import Linear, MLPSequential
+
+    torch.manual_seed(m + n)
+    k = 96
+    net = MLPSequential(Linear(k, n), torch.nn.ELU(), Linear(n, 8)).cuda()
+    ref = torch.nn.Sequential(torch.nn.Linear(k, n), torch.nn.ELU(), torch.nn.Linear(n, 8)).cuda()
+    ref.load_state_dict(net.state_dict())
+    x = torch.randn(m, k, device="cuda:0")
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    w = torch.randn(m, 8, device="cuda:0") / m
+    y1, y2 = net(x1), ref(x2)
+    assert y1.grad_fn is not None and "LinearELU" in type(y1.grad_fn.next_functions[0][0]).__name__, "the fused node must have been taken"
+    torch.testing.assert_close(y1, y2, rtol=1e-5, atol=1e-5)
+    (y1 * w).sum().backward()
+    (y2 * w).sum().backward()
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-4, atol=1e-8)
+    for (name, p1), p2 in zip(net.named_parameters(), ref.parameters()):
+        torch.testing.assert_close(p1.grad, p2.grad, rtol=2e-4, atol=2e-6, msg=lambda s_: f"{name}: {s_}")
+
+
+def test_flat_adam_matches_clip_grad_norm_plus_torch_adam():
+    """rl/flat_adam.py (csrc/lt_ppo.hip lt_adam_clip_step) against clip_grad_norm_ + torch.optim.Adam.step(), including the views
+    kept in the optimizer state, a state_dict round trip through a second optimizer, and steps where the clip does / does not bind."""
+    import copy
+
+    import torch
+
+    from locotouch_amd.rl import ActorCritic
+    from locotouch_amd.rl.flat_adam import FlatAdam
+    from tests.rl_synth import N_ACT, N_OBS, POLICY_CFG
+
+    torch.manual_seed(3)
+    a = ActorCritic(N_OBS, N_OBS, N_ACT, **POLICY_CFG).cuda()
+    b = copy.deepcopy(a)
+    oa, ob = torch.optim.Adam(a.parameters(), lr=1e-3), torch.optim.Adam(b.parameters(), lr=1e-3)
+    fa = FlatAdam(oa)
+    assert all(p.data_ptr() >= fa.flat_p.data_ptr() for p in a.parameters()) and fa.n % 64 == 0
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    for it in range(6):
+        scale = 10.0 if it % 2 else 1e-3  # norm above / below max_norm = 1
+        fa.zero_grad()
+        for i, (pa, pb) in enumerate(zip(a.parameters(), b.parameters())):
+            gr = scale * torch.randn(pb.shape, device="cuda:0", generator=g)
+            pb.grad = gr.clone()
+            if not (it == 4 and i == 2):  # one step leaves a parameter without a gradient: counts as zero
+                pa.grad = gr.clone()
+            else:
+                pb.grad.zero_()
+        if it == 3:  # learning-rate change + a checkpoint round trip of the optimizer state in between
+            for grp in (*oa.param_groups, *ob.param_groups):
+                grp["lr"] = 4e-4
+            sd = copy.deepcopy(oa.state_dict())
+            oa.load_state_dict(sd)  # re-binds the state tensors: must be re-adopted, not lost
+        norm_b = torch.nn.utils.clip_grad_norm_(b.parameters(), 1.0)
+        ob.step()
+        fa.step(1.0)
+        torch.testing.assert_close(fa.grad_norm[0], norm_b, rtol=1e-5, atol=0)
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            torch.testing.assert_close(pa, pb, rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(pa.grad, pb.grad, rtol=1e-5, atol=1e-9)
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        assert float(sa[k]["step"]) == float(sb[k]["step"]) == 6.0
+        torch.testing.assert_close(sa[k]["exp_avg"], sb[k]["exp_avg"], rtol=1e-5, atol=1e-9)
+        torch.testing.assert_close(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    assert (fa.flat_p.view(-1, 64)[:, :].abs().sum() > 0) and float(fa.flat_m.abs().sum()) > 0
