@@ -49,6 +49,13 @@ extern "C" {
 #define LT_TACTILE_ROWS 17          /* taxel grid: rows along x (front -> back), columns along y (left -> right);        */
 #define LT_TACTILE_COLS 13          /* reference utils/urdf_processor/go1/generate_locotouch_urdf.py:4-8,59-72          */
 #define LT_TACTILE_DIM 442          /* BinaryTactileSignals: two identical channels of the 17 x 13 contact map (mdp/observations.py:307-308) */
+#define LT_TACTILE_WIDE_DIM 884 /* 4 channels x 17 x 13: the 4-channel formats and the arena's per-group capacity */
+#define LT_TACTILE_BINARY 0     /* BinaryTactileSignals: (contact, contact) */
+#define LT_TACTILE_NORMALIZED 1 /* NormalizedTactileSignals: (contact, min-max normalised force) */
+#define LT_TACTILE_DISCRETE 2   /* DiscreteTactileSignals: (contact, discretised signal) */
+#define LT_TACTILE_CONTINUOUS 3 /* CotinuousTactileSignals [sic]: (contact, clamp(force / maximal_force)) */
+#define LT_TACTILE_PROCESSED 4  /* ProcessedTactileSignals: (contact, normalised force, min-max, discretised) after dropout / addition / noise */
+#define LT_TACTILE_ORIGINAL 5   /* TactileSignals: the same four channels of the raw sensor reading */
 #define LT_GATE_RING 32             /* passes kept in LT_F_GATE_RING (>= steps per rollout between two global gate evaluations) */
 
 /* reward terms, in manager order (reference config/base/locomotion_base_env_cfg.py:139-218 then
@@ -203,6 +210,15 @@ typedef struct lt_cfg {
   float tactile_threshold_noise;  /* +- half-width of the per-(env, taxel) threshold offset drawn once: 0.05 * 0.2 */
   float tactile_dropout_prob;     /* contact_dropout_prob 0.005 */
   float tactile_addition_prob;    /* contact_addition_prob 0.005 */
+  int32_t tactile_format;         /* LT_TACTILE_*: which TactileSignals class feeds the `tactile` group (observations.py:281-429);
+                                   * only LT_TACTILE_BINARY is evaluated by the reference (object_transport_student_env_cfg.py:45) */
+  float tactile_force_noise;      /* add_force_noise: contact forces x (1 + U(-p, p)), p = 0.1; 0 = off */
+  float tactile_maximal_force;    /* 3.0 N: normalised force = clamp(force / maximal_force, 0, 1) */
+  int32_t tactile_total_levels;   /* 5: discretisation levels of the min-max normalised signal */
+  float tactile_level_noise;      /* add_level_noise: + U(-w, w) levels before re-scaling, w = 1; 0 = off */
+  int32_t tactile_aux_groups;     /* bit 0: group `original_tactile` (TactileSignals, 4 channels), bit 1: `processed_tactile`
+                                   * (ProcessedTactileSignals, 4 channels) - the two extra groups of the student -Play- env
+                                   * (object_transport_student_env_cfg.py:166-171); each term draws its own thresholds and noise */
   /* multi-rank runs (one process per GPU) */
   int32_t cur_gate_external;      /* 1: the step kernel keeps the per-env curriculum trackers and publishes its population sums
                                    * into LT_F_GATE_RING, but leaves the success test / widening (mdp/curriculums.py:224-238,
@@ -257,11 +273,13 @@ enum lt_field {
   LT_F_GATE_RING,       /* float [LT_GATE_RING][8]: the population sums of the last curriculum passes, one row per pass:
                          * (envs with a non-zero command, envs reset this step, lin trackers not all reset, sum ep_len lin,
                          *  sum reward lin, ang trackers not all reset, sum ep_len ang, sum reward ang) */
-  LT_F_OBS_TACTILE,     /* float [N][442]: observation group `tactile` (tactile tasks; no history) */
+  LT_F_OBS_TACTILE,     /* float [N][442 or 884 by cfg.tactile_format]: observation group `tactile` (tactile tasks; no history) */
   LT_F_OBS_OBJECT_STATE,/* float [N][78] (row stride obs_dim): observation group `object_state` = the object-state block of the
                          * policy rows (same term, same parameters; the reference draws its noise separately) */
   LT_F_OBJ_SIZES,       /* float [N][2]: explicit per-env cylinder (radius, length), read by lt_env_reset_all when
                          * cfg.obj_size_explicit is set; lt_env_reset_all does not clear it */
+  LT_F_OBS_TACTILE_ORIGINAL,  /* float [N][884]: group `original_tactile` (cfg.tactile_aux_groups bit 0) */
+  LT_F_OBS_TACTILE_PROCESSED, /* float [N][884]: group `processed_tactile` (cfg.tactile_aux_groups bit 1) */
   LT_F_END
 };
 
@@ -301,6 +319,8 @@ int lt_cfg_num_presets(void);
 const char* lt_cfg_preset_id(int i);
 /* Observation width of a task (policy and critic groups are equally wide): 270 / 348. */
 int lt_cfg_obs_dim(const lt_cfg* cfg);
+/* Width of the `tactile` observation group: 442 (two-channel formats), 884 (LT_TACTILE_PROCESSED / _ORIGINAL), 0 without tactile. */
+int lt_cfg_tactile_dim(const lt_cfg* cfg);
 
 int lt_env_create(const lt_cfg* cfg, lt_env** out);
 int lt_env_destroy(lt_env* env);

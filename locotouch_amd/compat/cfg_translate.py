@@ -92,11 +92,13 @@ def task_kind(env_cfg) -> int:
     return C["LT_TASK_TRANSPORT_TEACHER"] if getattr(env_cfg.scene, "object", None) is not None else C["LT_TASK_LOCOMOTION"]
 
 
-# Observation groups of the student -Play- registration that exist for visualisation only: all tactile formats side by side
-# (object_transport_student_env_cfg.py:171-177), read by nothing but the ROS publisher block the reference keeps switched off
-# (distillation.py:141 `self.publish_tactile_ros_topic = False`, :190-199).  `translate(..., omit_groups=...)` leaves exactly
-# these out - by name, with a warning - and still raises on any other unknown group.
+# The student -Play- registration adds two 4-channel tactile groups next to `tactile` (object_transport_student_env_cfg.py:166-171;
+# read by the ROS publisher block of distillation.py:190-199, which the reference keeps switched off).  They are computed
+# (cfg.tactile_aux_groups); `translate(..., omit_groups=VISUALISATION_ONLY_GROUPS)` still lets a caller leave them out by name.
 VISUALISATION_ONLY_GROUPS = ("original_tactile", "processed_tactile")
+TACTILE_FORMATS = {"BinaryTactileSignals": "LT_TACTILE_BINARY", "NormalizedTactileSignals": "LT_TACTILE_NORMALIZED",
+                   "DiscreteTactileSignals": "LT_TACTILE_DISCRETE", "CotinuousTactileSignals": "LT_TACTILE_CONTINUOUS",
+                   "ProcessedTactileSignals": "LT_TACTILE_PROCESSED", "TactileSignals": "LT_TACTILE_ORIGINAL"}
 
 
 def translate(env_cfg, seed: int | None = None, omit_groups: tuple = ()) -> "_abi.LtCfg":
@@ -238,11 +240,11 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = ()) -> "_ab
     if omitted:
         import warnings
 
-        warnings.warn(f"observation groups {omitted} are visualisation-only in the reference and are not computed by this env")
+        warnings.warn(f"observation groups {omitted} left out on request (visualisation-only in the reference)")
         groups = {k: v for k, v in groups.items() if k not in omitted}
-    extra = set(groups) - {"policy", "critic", "tactile", "object_state"}
-    _need(not extra, f"observation groups {sorted(extra)} have no fused implementation "
-                     "(only the binary tactile map and the object-state group of the student tasks do)")
+    extra = set(groups) - {"policy", "critic", "tactile", "object_state", "original_tactile", "processed_tactile"}
+    _need(not extra, f"observation groups {sorted(extra)} have no fused implementation")
+    _need("tactile" in groups or not (set(groups) & {"original_tactile", "processed_tactile"}), "the 4-channel tactile groups come with the `tactile` group")
     _need(("tactile" in groups) == ("object_state" in groups), "the student tasks carry the tactile and object_state groups together")
     pol = groups["policy"]
     cfg.enable_corruption = 1 if pol.enable_corruption else 0
@@ -395,32 +397,49 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = ()) -> "_ab
 
 
 def _translate_student_groups(env_cfg, cfg, groups, pterms) -> None:
-    """`tactile` (BinaryTactileSignals on the 17 x 13 taxel sensor) and `object_state` groups of the student tasks
+    """`tactile` (any TactileSignals class on the 17 x 13 taxel sensor), the -Play- env's 4-channel groups and `object_state`
     (reference config/locotouch/object_transport_student_env_cfg.py:13-43,161-201)."""
     _need(cfg.task == C["LT_TASK_TRANSPORT_TEACHER"], "tactile observations need the transport scene")
-    tac = groups["tactile"]
-    tterms = {k: v for k, v in vars(tac).items() if hasattr(v, "func") and v is not None}
-    _need(list(tterms) == ["tactile_signals"], f"tactile group terms {list(tterms)} != ['tactile_signals']")
-    t = tterms["tactile_signals"]
-    _need(_name(t.func) == "BinaryTactileSignals", f"tactile term {_name(t.func)}: only the binary map is implemented "
-                                                   "(the reference evaluates no other format, object_transport_student_env_cfg.py:45)")
-    _need(tac.enable_corruption and tac.concatenate_terms and not t.history_length and t.noise is None and _close(t.scale, 1.0)
-          and t.clip is None and not t.modifiers, "tactile group: corruption on, concatenated, no history / manager noise / scale / clip")
-    p = t.params
-    _need(tuple(p["tactile_signal_shape"]) == (C["LT_TACTILE_ROWS"], C["LT_TACTILE_COLS"]), "taxel grid must be 17 x 13")
-    _need(not float(p.get("add_continuous_artifact", 0.0)) > 0.5, "continuous tactile artifacts are not implemented")
     sensor = getattr(env_cfg.scene, "tactile_contact_sensor", None)
     _need(sensor is not None and sensor.prim_path.endswith("/Robot/sensor_.*"), "scene.tactile_contact_sensor on the taxel bodies")
     cfg.tactile_enabled = 1
     cfg.tactile_update_period = float(sensor.update_period)
-    cfg.tactile_threshold = float(p["contact_threshold"])
-    if p["add_threshold_noise"]:
-        _need(_close(-float(p["threshold_n_min"]), float(p["threshold_n_max"])), "tactile threshold noise must be symmetric")
-        cfg.tactile_threshold_noise = float(p["threshold_n_max"])
-    else:
-        cfg.tactile_threshold_noise = 0.0
-    cfg.tactile_dropout_prob = float(p["contact_dropout_prob"])
-    cfg.tactile_addition_prob = float(p["contact_addition_prob"])
+
+    def term_params(gname, expect_func=None):
+        """(format, parameter tuple) of a tactile group's single term; every TactileSignals class is served (observations.py:248-429)."""
+        grp = groups[gname]
+        tterms = {k: v for k, v in vars(grp).items() if hasattr(v, "func") and v is not None}
+        _need(list(tterms) == ["tactile_signals"], f"{gname} group terms {list(tterms)} != ['tactile_signals']")
+        t = tterms["tactile_signals"]
+        _need(_name(t.func) in TACTILE_FORMATS, f"{gname} term {_name(t.func)} is not a TactileSignals class")
+        _need(expect_func is None or _name(t.func) == expect_func, f"{gname} group must be {expect_func}, got {_name(t.func)}")
+        _need(grp.enable_corruption and grp.concatenate_terms and not t.history_length and t.noise is None and _close(t.scale, 1.0)
+              and t.clip is None and not t.modifiers, f"{gname} group: corruption on, concatenated, no history / manager noise / scale / clip")
+        p = t.params
+        _need(tuple(p["tactile_signal_shape"]) == (C["LT_TACTILE_ROWS"], C["LT_TACTILE_COLS"]), "taxel grid must be 17 x 13")
+        _need(not float(p.get("add_continuous_artifact", 0.0)) > 0.5, "continuous tactile artifacts are not implemented (nor by the reference: the flag is read and never used)")
+
+        def half(flag, lo, hi, what):
+            if not p[flag]:
+                return 0.0
+            _need(_close(-float(p[lo]), float(p[hi])), f"tactile {what} noise must be symmetric")
+            return float(p[hi])
+
+        return C[TACTILE_FORMATS[_name(t.func)]], (float(p["contact_threshold"]), half("add_threshold_noise", "threshold_n_min", "threshold_n_max", "threshold"),
+                                                   float(p["contact_dropout_prob"]), float(p["contact_addition_prob"]),
+                                                   half("add_force_noise", "force_n_prop_min", "force_n_prop_max", "force"), float(p["maximal_force"]),
+                                                   int(p["total_levels"]), half("add_level_noise", "level_n_min", "level_n_max", "level"))
+
+    fmt, par = term_params("tactile")
+    cfg.tactile_format = fmt
+    (cfg.tactile_threshold, cfg.tactile_threshold_noise, cfg.tactile_dropout_prob, cfg.tactile_addition_prob, cfg.tactile_force_noise,
+     cfg.tactile_maximal_force, cfg.tactile_total_levels, cfg.tactile_level_noise) = par
+    cfg.tactile_aux_groups = 0
+    for bit, gname, func in ((1, "original_tactile", "TactileSignals"), (2, "processed_tactile", "ProcessedTactileSignals")):
+        if gname in groups:
+            _, par_aux = term_params(gname, func)
+            _need(all(_close(a_, b_) for a_, b_ in zip(par_aux, par)), f"{gname}: the tactile groups of an env share one parameter set (lt_cfg.tactile_*)")
+            cfg.tactile_aux_groups |= bit
     # object_state group: served as a window of the policy rows, so it must be the policy group's own object_state term
     og = groups["object_state"]
     oterms = {k: v for k, v in vars(og).items() if hasattr(v, "func") and v is not None}

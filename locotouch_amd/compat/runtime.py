@@ -118,7 +118,7 @@ def translate_env_cfg(task_id: str, cfg):
 
     if cfg is None:
         return _abi.preset_cfg(task_id), None
-    lt = cfg_translate.translate(cfg, omit_groups=cfg_translate.VISUALISATION_ONLY_GROUPS)
+    lt = cfg_translate.translate(cfg)
     sizes = None
     spawn = getattr(getattr(cfg.scene, "object", None), "spawn", None)
     if spawn is not None and type(spawn).__name__ == "MultiAssetSpawnerCfg":

@@ -226,6 +226,20 @@ void transport_teacher(lt_cfg* c) {
   set2(c->push_obj_vel[3], -kPi / 20, kPi / 20);
   set2(c->push_obj_vel[4], -kPi / 20, kPi / 20);
   set2(c->push_obj_vel[5], -kPi / 5, kPi / 5);
+  // tactile sensor of the student tasks, OFF here: term parameters of object_transport_student_env_cfg.py:16-37 (shared by every
+  // TactileSignals class), sensor cadence :195-201
+  c->tactile_enabled = 0;
+  c->tactile_update_period = 0.025f;
+  c->tactile_threshold = 0.05f;
+  c->tactile_threshold_noise = 0.05f * 0.2f;
+  c->tactile_dropout_prob = 0.005f;
+  c->tactile_addition_prob = 0.005f;
+  c->tactile_format = LT_TACTILE_BINARY;                             // :49-53 NoisyBinaryTactileCfg
+  c->tactile_force_noise = 0.1f;                                     // force_n_prop_min / max -+0.1
+  c->tactile_maximal_force = 3.0f;
+  c->tactile_total_levels = 5;
+  c->tactile_level_noise = 1.0f;                                     // level_n_min / max -+1
+  c->tactile_aux_groups = 0;
 }
 // Isaac-LocomotionVelCur-LocoTouch-v1: locomotion + the MultiSampling command term and the velocity curriculum
 // (config/base/locomotion_vel_cur_base_env_cfg.py:14-50; maxima = the locomotion ranges)
@@ -268,12 +282,13 @@ void student_binary_tac(lt_cfg* c) {
   c->cur_len_threshold = 0.98f * 10.0f;
   c->cur_reward_threshold[0] = (float)(std::exp(-0.08 / 0.25) * 1.0 * 10.0);
   c->cur_reward_threshold[1] = (float)(std::exp(-0.1 / 0.25) * 0.5 * 10.0);
-  c->tactile_enabled = 1;                                            // :195-201, term params :16-37
-  c->tactile_update_period = 0.025f;
-  c->tactile_threshold = 0.05f;
-  c->tactile_threshold_noise = 0.05f * 0.2f;
-  c->tactile_dropout_prob = 0.005f;
-  c->tactile_addition_prob = 0.005f;
+  c->tactile_enabled = 1;                                            // :195-201; the term parameters are transport_teacher()'s
+}
+
+// ... -Play-v1 (:164-171): 20 envs and the two 4-channel groups a ROS publisher of the reference visualises
+void student_binary_tac_play(lt_cfg* c) {
+  student_binary_tac(c);
+  c->tactile_aux_groups = 3;
 }
 
 struct Preset { const char* id; int task; void (*extra)(lt_cfg*); int num_envs; };
@@ -289,7 +304,7 @@ const Preset kPresets[] = {
     {"Isaac-RandCylinderTransportTeacher-LocoTouch-v1", LT_TASK_TRANSPORT_TEACHER, nullptr, 4096},
     {"Isaac-RandCylinderTransportTeacher-LocoTouch-Play-v1", LT_TASK_TRANSPORT_TEACHER, nullptr, 50},
     {"Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-v1", LT_TASK_TRANSPORT_TEACHER, student_binary_tac, 405},
-    {"Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-Play-v1", LT_TASK_TRANSPORT_TEACHER, student_binary_tac, 20},
+    {"Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-Play-v1", LT_TASK_TRANSPORT_TEACHER, student_binary_tac_play, 20},
 };
 }  // namespace
 
@@ -328,6 +343,12 @@ const char* lt_cfg_preset_id(int i) { return (i >= 0 && i < lt_cfg_num_presets()
 int lt_cfg_obs_dim(const lt_cfg* cfg) {
   if (!cfg) return LT_EINVAL;
   return (cfg->task == LT_TASK_LOCOMOTION ? 45 : 58) * cfg->obs_history;
+}
+
+int lt_cfg_tactile_dim(const lt_cfg* cfg) {
+  if (!cfg) return LT_EINVAL;
+  if (!cfg->tactile_enabled) return 0;
+  return (cfg->tactile_format == LT_TACTILE_PROCESSED || cfg->tactile_format == LT_TACTILE_ORIGINAL) ? LT_TACTILE_WIDE_DIM : LT_TACTILE_DIM;
 }
 
 }  // extern "C"

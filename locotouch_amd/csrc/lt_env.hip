@@ -91,8 +91,8 @@ enum {
   RS_NOISE_JPOS = 0x100, RS_NOISE_JVEL = 0x110, RS_NOISE_BASE = 0x120, RS_NOISE_OBJ = 0x130,
   RS_RESET_ROOT = 0x200, RS_RESET_JOINT = 0x210, RS_RESET_MAT = 0x220, RS_RESET_OBJ = 0x221, RS_RESET_EVENT = 0x223,
   RS_CMD_RESET = 0x230, RS_CMD_TIMER = 0x240, RS_PUSH_ROBOT = 0x250, RS_PUSH_OBJ = 0x260, RS_STARTUP = 0x300,
-  RS_TACTILE_THR = 0x400,  // + taxel / 4 (startup stream): the per-(env, taxel) threshold offsets, drawn once
-  RS_TACTILE = 0x500       // + taxel / 2 (step stream): (dropout, addition) uniforms of two taxels per call
+  RS_TACTILE_THR = 0x400,  // + 0x40 term + taxel / 4 (startup stream): the per-(env, taxel) threshold offsets, drawn once
+  RS_TACTILE = 0x500       // + 0x200 term + 2 taxel + {0, 1} (step stream): csrc/lt_tactile.hip
 };
 // kernel-template task index of the transport task WITH the tactile sensor (cfg.task stays LT_TASK_TRANSPORT_TEACHER, the
 // student registrations derive from the teacher's env cfg: object_transport_student_env_cfg.py:161-168)

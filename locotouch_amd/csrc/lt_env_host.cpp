@@ -20,6 +20,10 @@ bool cfg_valid(const lt_cfg* c) {
   if (c->obs_history != 6) return false;  // the kernels are specialised for the reference's history length
   if (!(c->sim_dt > 0.f) || c->max_episode_length <= 0) return false;
   if (c->tactile_enabled && (c->task != LT_TASK_TRANSPORT_TEACHER || !(c->tactile_update_period >= c->sim_dt))) return false;
+  if (c->tactile_enabled && (c->tactile_format < LT_TACTILE_BINARY || c->tactile_format > LT_TACTILE_ORIGINAL || (c->tactile_aux_groups & ~3) ||
+                             !(c->tactile_maximal_force > 0.f) || c->tactile_total_levels < 1 || c->tactile_force_noise < 0.f ||
+                             c->tactile_level_noise < 0.f))
+    return false;
   return true;
 }
 }  // namespace
@@ -78,7 +82,7 @@ int lt_env_get_view(lt_env* env, int field, lt_view* v) {
   const lt_layout& L = env->layout;
   char* base = (char*)env->arena;  // may be null: offsets are then relative to 0 (layout queries before bind)
   std::memset(v, 0, sizeof(*v));
-  if ((field == LT_F_PLATE_SAMPLES || field == LT_F_OBS_TACTILE) && !L.tactile) {
+  if ((field == LT_F_PLATE_SAMPLES || field == LT_F_OBS_TACTILE || field == LT_F_OBS_TACTILE_ORIGINAL || field == LT_F_OBS_TACTILE_PROCESSED) && !L.tactile) {
     lt_set_error("lt_env_get_view: the tactile fields exist only with cfg.tactile_enabled");
     return LT_EINVAL;
   }
@@ -111,7 +115,14 @@ int lt_env_get_view(lt_env* env, int field, lt_view* v) {
     case LT_F_COUNTERS: plain(L.off_counters, 1, 4, 0); break;
     case LT_F_OBJ_SIZES: plain(L.off_obj_sizes, 0, L.n, 2); break;
     case LT_F_GATE_RING: plain(L.off_gate_ring, 0, LT_GATE_RING, LT_PARTIAL_FLOATS); break;
-    case LT_F_OBS_TACTILE: plain(L.off_obs_tactile, 0, L.n, LT_TACTILE_DIM); break;
+    case LT_F_OBS_TACTILE: plain(L.off_obs_tactile, 0, L.n, lt_cfg_tactile_dim(&env->cfg)); break;
+    case LT_F_OBS_TACTILE_ORIGINAL:
+    case LT_F_OBS_TACTILE_PROCESSED: {
+      const int k = field == LT_F_OBS_TACTILE_ORIGINAL ? 1 : 2;
+      if (!(env->cfg.tactile_aux_groups & k)) { lt_set_error("lt_env_get_view: this tactile group is not enabled (cfg.tactile_aux_groups)"); return LT_EINVAL; }
+      plain(L.off_obs_tactile + (int64_t)k * L.npad * LT_TACTILE_WIDE_DIM * 4, 0, L.n, LT_TACTILE_WIDE_DIM);
+      break;
+    }
     case LT_F_OBS_OBJECT_STATE:  // the object-state term block (13 x 6) closes the policy rows of the transport tasks
       if (env->cfg.task != LT_TASK_TRANSPORT_TEACHER) { lt_set_error("lt_env_get_view: no object in this task"); return LT_EINVAL; }
       plain(L.off_obs_policy + (int64_t)(L.obs_dim - 13 * env->cfg.obs_history) * 4, 0, L.n, 13 * env->cfg.obs_history);

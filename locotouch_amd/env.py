@@ -96,6 +96,10 @@ class LocoTouchVecEnv:
         # (reference object_transport_student_env_cfg.py:165-166; the distillation reads them, distillation.py:57-59,159-162)
         self.tactile = bool(self.cfg.tactile_enabled)
         self.obs_tactile = self.view(C["LT_F_OBS_TACTILE"]) if self.tactile else None
+        # the student -Play- env's 4-channel groups [N][884] (object_transport_student_env_cfg.py:170-171; cfg.tactile_aux_groups)
+        aux = int(self.cfg.tactile_aux_groups) if self.tactile else 0
+        self.obs_tactile_original = self.view(C["LT_F_OBS_TACTILE_ORIGINAL"]) if aux & 1 else None
+        self.obs_tactile_processed = self.view(C["LT_F_OBS_TACTILE_PROCESSED"]) if aux & 2 else None
         self.obs_object_state = self.view(C["LT_F_OBS_OBJECT_STATE"]) if self.cfg.task == C["LT_TASK_TRANSPORT_TEACHER"] else None
         self.extras: dict = {}
         self._log_finished = None
@@ -151,6 +155,10 @@ class LocoTouchVecEnv:
         if self.tactile:
             groups["tactile"] = self.obs_tactile
             groups["object_state"] = self.obs_object_state
+            if self.obs_tactile_original is not None:
+                groups["original_tactile"] = self.obs_tactile_original
+            if self.obs_tactile_processed is not None:
+                groups["processed_tactile"] = self.obs_tactile_processed
         return {"observations": groups, "time_outs": self.time_out_buf.bool()}
 
     def tactile_update(self) -> None:

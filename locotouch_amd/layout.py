@@ -32,9 +32,11 @@ def _align(x: int) -> int:
 
 
 class Layout:
-    def __init__(self, num_envs: int, obs_dim: int, tactile: int = 0):
+    def __init__(self, num_envs: int, obs_dim: int, tactile: int = 0, tactile_dim: int | None = None):
+        """`tactile`: cfg.tactile_enabled; `tactile_dim`: width of the `tactile` group (442, or 884 for the 4-channel formats)."""
         self.n = num_envs
         self.tactile = int(bool(tactile))
+        self.tactile_dim = int(tactile_dim or C["LT_TACTILE_DIM"])
         self.npad = (num_envs + 15) // 16 * 16
         self.obs_dim = obs_dim
         off = 0
@@ -57,11 +59,16 @@ class Layout:
             ("LT_F_COUNTERS", 4 * 8, np.int64, (4,)),
             ("LT_F_GATE_RING", C["LT_GATE_RING"] * 8 * 4, np.float32, (C["LT_GATE_RING"], 8)),
             ("_PARTIALS", self.npad // 16 * 8 * 4, np.float32, (self.npad // 16, 8)),  # per-wave curriculum partials
-            ("LT_F_OBS_TACTILE", self.npad * C["LT_TACTILE_DIM"] * 4 * self.tactile, np.float32, (self.npad * self.tactile, C["LT_TACTILE_DIM"])),
+            # three blocks of [npad][884] capacity: tactile | original_tactile | processed_tactile (include/lt_layout.h)
+            ("LT_F_OBS_TACTILE", 3 * self.npad * C["LT_TACTILE_WIDE_DIM"] * 4 * self.tactile, np.float32, (self.npad * self.tactile, self.tactile_dim)),
             ("LT_F_OBJ_SIZES", self.npad * 2 * 4, np.float32, (self.npad, 2)),
             ("_DEV_ARGS", 4096, np.uint8, (4096,)),  # device copy of (lt_cfg, lt_layout), include/lt_layout.h
         ]:
             self.plain[name] = (off, dtype, shape)
+            if name == "LT_F_OBS_TACTILE":
+                blk, wide = self.npad * C["LT_TACTILE_WIDE_DIM"] * 4, (self.npad * self.tactile, C["LT_TACTILE_WIDE_DIM"])
+                self.plain["LT_F_OBS_TACTILE_ORIGINAL"] = (off + blk, dtype, wide)
+                self.plain["LT_F_OBS_TACTILE_PROCESSED"] = (off + 2 * blk, dtype, wide)
             off = _align(off + nbytes)
         self.total_bytes = off
 

@@ -1375,8 +1375,8 @@ enum {
   RS_NOISE_JPOS = 0x100, RS_NOISE_JVEL = 0x110, RS_NOISE_BASE = 0x120, RS_NOISE_OBJ = 0x130,
   RS_RESET_ROOT = 0x200, RS_RESET_JOINT = 0x210, RS_RESET_MAT = 0x220, RS_RESET_OBJ = 0x221, RS_RESET_EVENT = 0x223,
   RS_CMD_RESET = 0x230, RS_CMD_TIMER = 0x240, RS_PUSH_ROBOT = 0x250, RS_PUSH_OBJ = 0x260, RS_STARTUP = 0x300,
-  RS_TACTILE_THR = 0x400, /* + taxel / 4 (startup stream): per-(env, taxel) threshold offsets, drawn once */
-  RS_TACTILE = 0x500      /* + taxel / 2 (step stream): (dropout, addition) uniforms of two taxels per call */
+  RS_TACTILE_THR = 0x400, /* + 0x40 term + taxel / 4 (startup stream): per-(env, taxel) threshold offsets, drawn once */
+  RS_TACTILE = 0x500      /* + 0x200 term + 2 taxel + {0, 1} (step stream): see tactile_pass */
 };
 
 /* RNG stream key of env e: its global index over all ranks (cfg.env_index_offset = index of this shard's env 0) */
@@ -1800,24 +1800,101 @@ void lt_oracle_tactile_signals_u(const lt_cfg* cfg, const float* forces, const f
   }
 }
 
-static void tactile_pass(const lt_cfg* cfg, void* arena, const lt_layout* L) {
+/* Every TactileSignals class with explicit uniforms (reference mdp/observations.py:154-246): forces [221] -> the four channel maps
+ * (contact, normalised force, per-env min-max normalised, discretised), each [221].  `original` != 0: TactileSignals.__call__
+ * (:248-279, the raw reading: thresholds and level noise only); otherwise the processed pipeline of get_normal_forces (:164-197):
+ * dropout (force <- u * thr), addition (force <- thr (1 + 0.2 u)), force noise on contact taxels with the too-small repair, then
+ * get_normalized_forces (:199-203), compute_min_max_normalized_signals (:205-222), compute_discretized_signals (:224-235).
+ * Uniforms, each [221]: u_thr (construction), u_drop, u_dropf, u_add, u_addf, u_noise, u_small, u_level.  The reference draws the
+ * masked ones only for the selected taxels; here they are indexed by taxel (the golden generator scatters its tape accordingly). */
+void lt_oracle_tactile_channels_u(const lt_cfg* cfg, int original, const float* forces, const float* u_thr, const float* u_drop,
+                                  const float* u_dropf, const float* u_add, const float* u_addf, const float* u_noise,
+                                  const float* u_small, const float* u_level, float* contact_out, float* norm_out, float* minmax_out,
+                                  float* disc_out) {
   const int nt = LT_TAXEL_ROWS * LT_TAXEL_COLS;
+  float valid[LT_TAXEL_ROWS * LT_TAXEL_COLS];
+  float mn = 2.0f, mx = -1.0f;
+  for (int t = 0; t < nt; ++t) {
+    const float n_min = -cfg->tactile_threshold_noise, n_max = cfg->tactile_threshold_noise;
+    const float thr = cfg->tactile_threshold + (u_thr[t] * (n_max - n_min) + n_min);   /* :126 */
+    int contact = forces[t] > thr;                                                       /* :158 */
+    float f = forces[t];
+    if (!original) {
+      if (cfg->tactile_dropout_prob > 0 && contact && u_drop[t] < cfg->tactile_dropout_prob) { f = u_dropf[t] * thr; contact = 0; }
+      if (cfg->tactile_addition_prob > 0 && !contact && u_add[t] < cfg->tactile_addition_prob) { f = thr * (1.0f + 0.2f * u_addf[t]); contact = 1; }
+      if (cfg->tactile_force_noise > 0) {
+        const float p_min = -cfg->tactile_force_noise, p_max = cfg->tactile_force_noise;
+        if (contact) f *= 1.0f + (u_noise[t] * (p_max - p_min) + p_min);
+        f = f > 0 ? f : 0;
+        if (contact && f < thr) f = thr * (1.0f + 0.2f * u_small[t]);
+      }
+    }
+    float nrm = f / cfg->tactile_maximal_force;
+    nrm = nrm < 0 ? 0 : (nrm > 1 ? 1 : nrm);
+    contact_out[t] = contact ? 1.0f : 0.0f;
+    norm_out[t] = nrm;
+    valid[t] = contact ? nrm : 0.0f;
+    if (valid[t] < mn) mn = valid[t];
+    if (valid[t] > mx) mx = valid[t];
+  }
+  const float range = (mx - mn) > 0 ? (mx - mn) : 1.0f;
+  const float bin = 1.0f / (float)cfg->tactile_total_levels;
+  for (int t = 0; t < nt; ++t) {
+    float mm = (valid[t] - mn) / range;
+    mm = mm < 0 ? 0 : (mm > 1 ? 1 : mm);
+    minmax_out[t] = mm;
+    float d = rintf(mm / bin); /* torch.round: half to even */
+    if (cfg->tactile_level_noise > 0) d += u_level[t] * (cfg->tactile_level_noise - (-cfg->tactile_level_noise)) + (-cfg->tactile_level_noise);
+    d *= bin;
+    d = d < 0 ? 0 : (d > 1 ? 1 : d);
+    disc_out[t] = contact_out[t] != 0 ? d : 0.0f;
+  }
+}
+
+/* One term in its class's channel layout (:279, :308, :332, :357, :383, :425-429): out [442] or [884] */
+void lt_oracle_tactile_format_u(const lt_cfg* cfg, int format, const float* forces, const float* u8[8], float* out) {
+  const int nt = LT_TAXEL_ROWS * LT_TAXEL_COLS;
+  float ch[4][LT_TAXEL_ROWS * LT_TAXEL_COLS];
+  lt_oracle_tactile_channels_u(cfg, format == LT_TACTILE_ORIGINAL, forces, u8[0], u8[1], u8[2], u8[3], u8[4], u8[5], u8[6], u8[7], ch[0], ch[1],
+                               ch[2], ch[3]);
+  if (format == LT_TACTILE_PROCESSED || format == LT_TACTILE_ORIGINAL) {
+    for (int k = 0; k < 4; ++k) memcpy(out + k * nt, ch[k], sizeof(float) * nt);
+    return;
+  }
+  const int second = format == LT_TACTILE_BINARY ? 0 : (format == LT_TACTILE_NORMALIZED ? 2 : (format == LT_TACTILE_DISCRETE ? 3 : 1));
+  memcpy(out, ch[0], sizeof(float) * nt);
+  memcpy(out + nt, ch[second], sizeof(float) * nt);
+}
+
+static void tactile_pass(const lt_cfg* cfg, void* arena, const lt_layout* L) {
+  enum { NT = LT_TAXEL_ROWS * LT_TAXEL_COLS };
   const uint64_t step = (uint64_t)((int64_t*)((char*)arena + L->off_counters))[0];
+  float* const base = (float*)((char*)arena + L->off_obs_tactile);
+  const int64_t blk = L->npad * (int64_t)LT_TACTILE_WIDE_DIM;
+  const int dim = (cfg->tactile_format == LT_TACTILE_PROCESSED || cfg->tactile_format == LT_TACTILE_ORIGINAL) ? LT_TACTILE_WIDE_DIM : LT_TACTILE_DIM;
   for (int64_t e = 0; e < L->n; ++e) {
-    float x[4], y[4], f[4], forces[LT_TAXEL_ROWS * LT_TAXEL_COLS], ut[LT_TAXEL_ROWS * LT_TAXEL_COLS + 4],
-        ud[LT_TAXEL_ROWS * LT_TAXEL_COLS + 2], ua[LT_TAXEL_ROWS * LT_TAXEL_COLS + 2], u[4];
+    float x[4], y[4], f[4], forces[NT], ut[NT + 4], U[7][NT], u[4];
     for (int k = 0; k < 4; ++k) {
       x[k] = lt_quad(arena, L, LT_F_PLATE_SAMPLES, 0)[e * 4 + k];
       y[k] = lt_quad(arena, L, LT_F_PLATE_SAMPLES, 1)[e * 4 + k];
       f[k] = lt_quad(arena, L, LT_F_PLATE_SAMPLES, 2)[e * 4 + k];
     }
     lt_oracle_taxel_forces(x, y, f, forces);
-    for (int t = 0; t < nt; t += 4) { lt_rng4(cfg->seed, EKEY(cfg, e), ~(uint64_t)0, RS_TACTILE_THR + (uint32_t)(t >> 2), u); memcpy(ut + t, u, sizeof(u)); }
-    for (int t = 0; t < nt; t += 2) {
-      lt_rng4(cfg->seed, EKEY(cfg, e), step, RS_TACTILE + (uint32_t)(t >> 1), u);
-      ud[t] = u[0]; ua[t] = u[1]; ud[t + 1] = u[2]; ua[t + 1] = u[3];
+    for (int term = 0; term < 3; ++term) {
+      if (term > 0 && !(cfg->tactile_aux_groups & term)) continue;
+      /* stream ids: thresholds RS_TACTILE_THR + 0x40 term + taxel / 4 (startup key); per step RS_TACTILE + 0x200 term + 2 taxel
+       * -> (drop, add, drop force, add force), + 1 -> (force noise, too-small repair, level noise, -) */
+      for (int t = 0; t < NT; t += 4) { lt_rng4(cfg->seed, EKEY(cfg, e), ~(uint64_t)0, RS_TACTILE_THR + 0x40u * (uint32_t)term + (uint32_t)(t >> 2), u); memcpy(ut + t, u, sizeof(u)); }
+      for (int t = 0; t < NT; ++t) {
+        lt_rng4(cfg->seed, EKEY(cfg, e), step, RS_TACTILE + 0x200u * (uint32_t)term + 2u * (uint32_t)t, u);
+        U[0][t] = u[0]; U[2][t] = u[1]; U[1][t] = u[2]; U[3][t] = u[3];
+        lt_rng4(cfg->seed, EKEY(cfg, e), step, RS_TACTILE + 0x200u * (uint32_t)term + 2u * (uint32_t)t + 1u, u);
+        U[4][t] = u[0]; U[5][t] = u[1]; U[6][t] = u[2];
+      }
+      const float* u8[8] = {ut, U[0], U[1], U[2], U[3], U[4], U[5], U[6]};
+      if (term == 0) lt_oracle_tactile_format_u(cfg, cfg->tactile_format, forces, u8, base + e * dim);
+      else lt_oracle_tactile_format_u(cfg, term == 1 ? LT_TACTILE_ORIGINAL : LT_TACTILE_PROCESSED, forces, u8, base + term * blk + e * LT_TACTILE_WIDE_DIM);
     }
-    lt_oracle_tactile_signals_u(cfg, forces, ut, ud, ua, (float*)((char*)arena + L->off_obs_tactile) + e * LT_TACTILE_DIM);
   }
 }
 

@@ -70,6 +70,13 @@ void lt_oracle_command_resample_u(const lt_cfg* cfg, const float* P, const float
 void lt_oracle_taxel_forces(const float x[4], const float y[4], const float f[4], float* out);
 void lt_oracle_tactile_signals_u(const lt_cfg* cfg, const float* forces, const float* u_thr, const float* u_drop, const float* u_add,
                                  float* out);
+/* all TactileSignals classes (observations.py:154-429) with explicit per-taxel uniforms: the four channel maps, and one term in
+ * its class's layout (format = LT_TACTILE_*; u8 = {u_thr, u_drop, u_dropf, u_add, u_addf, u_noise, u_small, u_level}) */
+void lt_oracle_tactile_channels_u(const lt_cfg* cfg, int original, const float* forces, const float* u_thr, const float* u_drop,
+                                  const float* u_dropf, const float* u_add, const float* u_addf, const float* u_noise,
+                                  const float* u_small, const float* u_level, float* contact_out, float* norm_out, float* minmax_out,
+                                  float* disc_out);
+void lt_oracle_tactile_format_u(const lt_cfg* cfg, int format, const float* forces, const float* u8[8], float* out);
 void lt_oracle_material_u(const float range_static[2], const float range_dynamic[2], const float range_restitution[2],
                           const float u[3], float out[3]);
 void lt_oracle_reset_object_u(const lt_cfg* cfg, const float root_pos[3], const float root_quat[4], const float root_lin[3],

@@ -67,6 +67,8 @@ def load() -> ctypes.CDLL:
     lib.lt_oracle_material_u.argtypes = [P(f32), P(f32), P(f32), P(f32), P(f32)]
     lib.lt_oracle_taxel_forces.argtypes = [P(f32), P(f32), P(f32), P(f32)]
     lib.lt_oracle_tactile_signals_u.argtypes = [P(_abi.LtCfg)] + [P(f32)] * 5
+    lib.lt_oracle_tactile_channels_u.argtypes = [P(_abi.LtCfg), ctypes.c_int] + [P(f32)] * 13
+    lib.lt_oracle_tactile_format_u.argtypes = [P(_abi.LtCfg), ctypes.c_int, P(f32), P(P(f32)), P(f32)]
     lib.lt_oracle_reset_object_u.argtypes = [P(_abi.LtCfg)] + [P(f32)] * 4 + [f32] + [P(f32)] * 5
     lib.lt_oracle_curriculum_update.argtypes = [P(_abi.LtCfg), ctypes.c_void_p, P(f32)]
     lib.lt_oracle_gate_on_sums.argtypes = [P(_abi.LtCfg), P(f32), P(f32), f32, ctypes.c_int, ctypes.c_int, P(i32)]

@@ -28,7 +28,8 @@ class OracleVecEnv:
         self.num_envs, self.device = num_envs, torch.device("cpu")
         self.num_obs = int(oracle_lib.load().lt_oracle_obs_dim(self.o.cfg))
         self.num_privileged_obs = self.num_obs
-        self.layout = Layout(num_envs, self.num_obs, int(self.cfg.tactile_enabled))
+        wide = int(self.cfg.tactile_format) in (_abi.CONSTS["LT_TACTILE_PROCESSED"], _abi.CONSTS["LT_TACTILE_ORIGINAL"])
+        self.layout = Layout(num_envs, self.num_obs, int(self.cfg.tactile_enabled), 884 if wide else 442)
         self.max_episode_length = int(self.cfg.max_episode_length)
         self.step_dt = float(self.cfg.sim_dt) * int(self.cfg.decimation)
 
@@ -52,6 +53,10 @@ class OracleVecEnv:
         groups = {"policy": obs, "critic": torch.from_numpy(self._arr("LT_F_OBS_CRITIC"))}
         if self.cfg.tactile_enabled:  # student tasks: same groups as LocoTouchVecEnv (object_state = the policy rows' object block)
             groups["tactile"] = torch.from_numpy(self._arr("LT_F_OBS_TACTILE"))
+            if self.cfg.tactile_aux_groups & 1:
+                groups["original_tactile"] = torch.from_numpy(self._arr("LT_F_OBS_TACTILE_ORIGINAL"))
+            if self.cfg.tactile_aux_groups & 2:
+                groups["processed_tactile"] = torch.from_numpy(self._arr("LT_F_OBS_TACTILE_PROCESSED"))
             groups["object_state"] = obs[:, self.num_obs - 13 * int(self.cfg.obs_history):]
         return obs, {"observations": groups}
 

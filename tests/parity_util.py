@@ -52,7 +52,8 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
     deciding quantity sat within rounding of its threshold.  Callers bound the total over a run as well."""
     n = int(cfg.num_envs)
     obs_dim = (45 if cfg.task == C["LT_TASK_LOCOMOTION"] else 58) * int(cfg.obs_history)
-    L = Layout(n, obs_dim, int(cfg.tactile_enabled))
+    wide = int(cfg.tactile_format) in (C["LT_TACTILE_PROCESSED"], C["LT_TACTILE_ORIGINAL"])
+    L = Layout(n, obs_dim, int(cfg.tactile_enabled), C["LT_TACTILE_WIDE_DIM"] if wide else C["LT_TACTILE_DIM"])
     assert dev.shape == ref.shape == (L.total_bytes,), (dev.shape, ref.shape, L.total_bytes)
     report, failures, flip_envs, event_envs, soft_envs = [], [], set(), set(), {}
     for name in QUAD_FIELDS:
@@ -89,18 +90,31 @@ def compare_host_arenas(cfg, dev: np.ndarray, ref: np.ndarray, what: str = "", m
         if name in skip or name.startswith("_"):
             continue
         a, b = L.arr(dev, name), L.arr(ref, name)
-        if name == "LT_F_OBS_TACTILE":
-            if not L.tactile:
+        if name in ("LT_F_OBS_TACTILE", "LT_F_OBS_TACTILE_ORIGINAL", "LT_F_OBS_TACTILE_PROCESSED"):
+            bit = {"LT_F_OBS_TACTILE": 4, "LT_F_OBS_TACTILE_ORIGINAL": 1, "LT_F_OBS_TACTILE_PROCESSED": 2}[name]
+            if not L.tactile or not ((int(cfg.tactile_aux_groups) | 4) & bit):
                 continue
             a, b = a[:n], b[:n]
-            assert np.isin(a, (0.0, 1.0)).all(), "tactile rows must be binary"
-            per_env = (a != b).sum(axis=1) // 2  # two identical channels
+            nt = C["LT_TACTILE_ROWS"] * C["LT_TACTILE_COLS"]
+            assert np.isin(a[:, :nt], (0.0, 1.0)).all(), "the contact channel must be binary"
+            per_env = (a[:, :nt] != b[:, :nt]).sum(axis=1)  # flipped taxels of the contact channel
             bad = per_env > 0
             err = float(per_env.max()) if n else 0.0
             if (per_env > MAX_TAXEL_FLIPS_PER_ENV).any():
                 hard.append((name, err, np.nonzero(per_env > MAX_TAXEL_FLIPS_PER_ENV)[0][:5].tolist()))
             else:
                 flip_envs |= set(np.nonzero(bad)[0].tolist())
+            # the force channels (normalised / min-max / discretised) of envs whose contact map agrees: fp32 band (a flipped
+            # taxel moves the env's min-max range and with it every other taxel's value)
+            same = ~bad
+            dv = np.abs(a[same, nt:] - b[same, nt:])
+            if dv.size and not (dv <= 2e-4 + 2e-4 * np.abs(b[same, nt:])).all():
+                # a discretisation level is 1 / total_levels: a rounding-boundary flip of single taxels is a flip, more is a failure
+                lvl = (dv > 2e-4 + 2e-4 * np.abs(b[same, nt:])).sum(axis=1)
+                if (lvl > MAX_TAXEL_FLIPS_PER_ENV).any():
+                    hard.append((name + " (force channels)", float(dv.max()), np.nonzero(same)[0][lvl > MAX_TAXEL_FLIPS_PER_ENV][:5].tolist()))
+                else:
+                    flip_envs |= set(np.nonzero(same)[0][lvl > 0].tolist())
             report.append((name, err, int(bad.sum())))
             continue
         if name in ("LT_F_OBS_POLICY", "LT_F_OBS_CRITIC", "LT_F_REWARD"):

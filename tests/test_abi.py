@@ -38,17 +38,20 @@ def test_cfg_struct_mirror_and_defaults():
     assert lib.lt_cfg_default(7, ctypes.byref(loco)) == C["LT_EINVAL"]
 
 
-@pytest.mark.parametrize("task,n,tactile", [(0, 4096, 0), (1, 4096, 0), (1, 100, 0), (1, 17, 0), (1, 405, 1), (1, 20, 1)])
-def test_layout_mirror_matches_c(task, n, tactile):
+@pytest.mark.parametrize("task,n,tactile,fmt,aux", [(0, 4096, 0, 0, 0), (1, 4096, 0, 0, 0), (1, 100, 0, 0, 0), (1, 17, 0, 0, 0), (1, 405, 1, 0, 0),
+                                                    (1, 20, 1, 0, 3), (1, 33, 1, 4, 2), (1, 16, 1, 2, 1)])
+def test_layout_mirror_matches_c(task, n, tactile, fmt, aux):
     lib = _abi.load()
     cfg = _abi.default_cfg(task, num_envs=n)
     cfg.tactile_enabled = tactile
-    cfg.tactile_update_period = 0.025
+    cfg.tactile_format, cfg.tactile_aux_groups = fmt, aux
+    tdim = lib.lt_cfg_tactile_dim(ctypes.byref(cfg))
+    assert tdim == (0 if not tactile else 884 if fmt in (4, 5) else 442)
     h = ctypes.c_void_p()
     assert lib.lt_env_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
     nbytes = ctypes.c_size_t()
     assert lib.lt_env_state_bytes(ctypes.byref(cfg), ctypes.byref(nbytes)) == 0
-    L = Layout(n, lib.lt_cfg_obs_dim(ctypes.byref(cfg)), tactile)
+    L = Layout(n, lib.lt_cfg_obs_dim(ctypes.byref(cfg)), tactile, tdim or None)
     assert L.total_bytes == nbytes.value
     v = _abi.LtView()
     for name in QUAD_FIELDS:
@@ -61,11 +64,14 @@ def test_layout_mirror_matches_c(task, n, tactile):
     for name, (off, dtype, shape) in L.plain.items():
         if name.startswith("_"):
             continue  # internal regions (device args block) have no public view
-        if name == "LT_F_OBS_TACTILE" and not tactile:
+        bit = {"LT_F_OBS_TACTILE": 4, "LT_F_OBS_TACTILE_ORIGINAL": 1, "LT_F_OBS_TACTILE_PROCESSED": 2}.get(name)
+        if bit and (not tactile or not ((aux | 4) & bit)):  # the tactile groups exist only when enabled
             assert lib.lt_env_get_view(h, C[name], ctypes.byref(v)) == C["LT_EINVAL"]
             continue
         assert lib.lt_env_get_view(h, C[name], ctypes.byref(v)) == 0
         assert (v.ptr or 0) == off, name
+        if bit:
+            assert list(v.shape)[:2] == [n, shape[1]] and list(v.stride)[:2] == [shape[1], 1], name
     assert lib.lt_env_get_view(h, 63, ctypes.byref(v)) == C["LT_EINVAL"]
     rc = lib.lt_env_get_view(h, C["LT_F_OBS_OBJECT_STATE"], ctypes.byref(v))  # a strided window of the policy rows
     if task == 1:

@@ -18,10 +18,10 @@ IDS = ["Isaac-Locomotion-LocoTouch-v1", "Isaac-Locomotion-LocoTouch-Play-v1", "I
        "Isaac-LocomotionVelCur-LocoTouch-Play-v1", "Isaac-CylinderTransportTeacher-LocoTouch-v1",
        "Isaac-CylinderTransportTeacher-LocoTouch-Play-v1", "Isaac-RandCylinderTransportTeacher-LocoTouch-v1",
        "Isaac-RandCylinderTransportTeacher-LocoTouch-Play-v1",
-       "Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-v1"]
-# the student -Play- registration adds two visualisation-only observation groups (all tactile formats side by side,
-# object_transport_student_env_cfg.py:171-177; read only by the ROS publisher the reference keeps switched off): the strict
-# translation REFUSES them, gym.make's translation leaves exactly these two out with a warning
+       "Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-v1",
+       "Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-Play-v1"]
+# the student -Play- registration adds the two 4-channel tactile groups (object_transport_student_env_cfg.py:166-171):
+# cfg.tactile_aux_groups = 3 in its preset
 STUDENT_PLAY = "Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-Play-v1"
 
 
@@ -45,25 +45,30 @@ def test_presets_cover_the_reference_registry(rt):
     import gymnasium as gym
 
     ids = sorted(k for k in gym.registry.keys() if "LocoTouch" in k)
-    assert ids == sorted(IDS + [STUDENT_PLAY])
+    assert ids == sorted(IDS) and STUDENT_PLAY in IDS
     assert set(ids) == set(_abi.preset_ids())
 
 
-def test_student_play_groups_are_refused_or_omitted_by_name(rt):
+def test_student_play_groups_are_translated_and_can_be_left_out_by_name(rt):
     from locotouch_amd.compat import cfg_translate as T
 
     cfg = rt.load_cfg_from_registry(STUDENT_PLAY, "env_cfg_entry_point")
-    with pytest.raises(T.UnsupportedCfg, match="original_tactile"):
-        T.translate(cfg)
+    lt, sizes = rt.translate_env_cfg(STUDENT_PLAY, cfg)
+    preset = _abi.preset_cfg(STUDENT_PLAY)
+    assert lt.num_envs == preset.num_envs == 20 and lt.tactile_enabled == 1 and lt.tactile_aux_groups == preset.tactile_aux_groups == 3
+    assert lt.tactile_format == C["LT_TACTILE_BINARY"]
+    assert T.diff(lt, preset, skip=("seed", "num_envs", "reserved", "debug_terms", "obj_radius", "obj_length", "obj_size_explicit")) == []
     cfg.observations.my_group = cfg.observations.original_tactile
-    with pytest.raises(T.UnsupportedCfg, match="my_group"):  # only the two known names may be left out
+    with pytest.raises(T.UnsupportedCfg, match="my_group"):  # an unknown group is refused, whatever it holds
         rt.translate_env_cfg(STUDENT_PLAY, cfg)
     del cfg.observations.my_group
-    with pytest.warns(UserWarning, match="visualisation-only"):
-        lt, sizes = rt.translate_env_cfg(STUDENT_PLAY, cfg)
-    preset = _abi.preset_cfg(STUDENT_PLAY)
-    assert lt.num_envs == preset.num_envs == 20 and lt.tactile_enabled == 1
-    assert T.diff(lt, preset, skip=("seed", "num_envs", "reserved", "debug_terms", "obj_radius", "obj_length", "obj_size_explicit")) == []
+    with pytest.warns(UserWarning, match="left out on request"):
+        lt2 = T.translate(cfg, omit_groups=T.VISUALISATION_ONLY_GROUPS)
+    assert lt2.tactile_aux_groups == 0
+    # the groups of one env share one parameter set
+    cfg.observations.processed_tactile.tactile_signals.params["maximal_force"] = 5.0
+    with pytest.raises(T.UnsupportedCfg, match="share one parameter set"):
+        T.translate(cfg)
 
 
 @pytest.mark.parametrize("task", IDS)
@@ -132,7 +137,7 @@ def test_cfg_edits_reach_lt_cfg_or_raise(rt):
     cfg.commands.base_velocity.heading_command = True
     with pytest.raises(T.UnsupportedCfg, match="heading"):
         T.translate(cfg)
-    # student tasks: the binary map translates; another tactile format / artifact injection raises
+    # student tasks: every tactile format translates; artifact injection (unused by the reference) raises
     sid = "Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-v1"
     cfg = rt.load_cfg_from_registry(sid, "env_cfg_entry_point")
     cfg.observations.tactile.tactile_signals.params["contact_threshold"] = 0.08
@@ -140,8 +145,14 @@ def test_cfg_edits_reach_lt_cfg_or_raise(rt):
     lt = T.translate(cfg)
     assert lt.tactile_enabled == 1 and abs(lt.tactile_threshold - 0.08) < 1e-7 and lt.tactile_threshold_noise == 0.0
     cfg = rt.load_cfg_from_registry(sid, "env_cfg_entry_point")
-    cfg.observations.tactile.tactile_signals.func = mdp.NormalizedTactileSignals
-    with pytest.raises(T.UnsupportedCfg, match="binary map"):
+    for cls, fmt in ((mdp.NormalizedTactileSignals, "LT_TACTILE_NORMALIZED"), (mdp.DiscreteTactileSignals, "LT_TACTILE_DISCRETE"),
+                     (mdp.CotinuousTactileSignals, "LT_TACTILE_CONTINUOUS"), (mdp.ProcessedTactileSignals, "LT_TACTILE_PROCESSED"),
+                     (mdp.TactileSignals, "LT_TACTILE_ORIGINAL")):
+        cfg.observations.tactile.tactile_signals.func = cls  # every TactileSignals class is a format of the same kernel
+        lt = T.translate(cfg)
+        assert lt.tactile_format == C[fmt] and abs(lt.tactile_force_noise - 0.1) < 1e-7 and lt.tactile_total_levels == 5
+    cfg.observations.tactile.tactile_signals.params["add_continuous_artifact"] = 1.0
+    with pytest.raises(T.UnsupportedCfg, match="artifacts"):
         T.translate(cfg)
     cfg = rt.load_cfg_from_registry(sid, "env_cfg_entry_point")
     cfg.observations.object_state.object_state.params["n_max"] = [0.5] * 12

@@ -138,6 +138,48 @@ def test_step_parity_resynced(task, n, steps, phys, pre):
     assert tally.events <= 0.003 * n * steps, f"too many discontinuous-event divergences: {tally.events}"
 
 
+@pytest.mark.parametrize("fmt,aux", [("LT_TACTILE_PROCESSED", 3), ("LT_TACTILE_DISCRETE", 0), ("LT_TACTILE_NORMALIZED", 1),
+                                     ("LT_TACTILE_CONTINUOUS", 2), ("LT_TACTILE_ORIGINAL", 0)])
+def test_tactile_formats_and_play_groups_match_oracle(fmt, aux):
+    """O6 + the student -Play- env's groups: every TactileSignals class through lt_tactile_kernel against the oracle (itself pinned
+    to the reference's classes by replayed uniforms, tests/test_oracle_replay.py), resynced every step: contact channels exact up to
+    threshold flips, force channels in the fp32 band (parity_util)."""
+    import torch
+
+    from locotouch_amd import _abi
+
+    C = _abi.CONSTS
+    n, steps = 64, 45
+    env = make_env("student", n, tactile_format=C[fmt], tactile_aux_groups=aux)
+    ora = O.OracleEnv(env.cfg)
+    ora.reset_all()
+    wide = fmt in ("LT_TACTILE_PROCESSED", "LT_TACTILE_ORIGINAL")
+    g = torch.Generator().manual_seed(5)
+    tally = Tally(n)
+    seen = {k: 0.0 for k in ("contact", "second", "levels")}
+    for t in range(steps):
+        act = (0.0 if t < 10 else 0.5) * torch.randn(n, 12, generator=g)
+        env._arena_aligned.copy_(torch.from_numpy(ora.arena))
+        env.step(act.cuda())
+        ora.step(act.numpy())
+        torch.cuda.synchronize()
+        tally.add(compare_arenas(env, ora, what=f"{fmt} aux {aux} step {t}", max_flip_frac=0.05, max_event_frac=2.0 / n))
+        ex = env.get_observations()[1]["observations"]
+        want = {"policy", "critic", "tactile", "object_state"} | ({"original_tactile"} if aux & 1 else set()) | ({"processed_tactile"} if aux & 2 else set())
+        assert set(ex) == want and ex["tactile"].shape == (n, 884 if wide else 442)
+        for k in ("original_tactile", "processed_tactile"):
+            if k in ex:
+                assert ex[k].shape == (n, 884) and ex[k].is_contiguous()
+        tac = ex["tactile"]
+        seen["contact"] += float(tac[:, :221].sum())
+        seen["second"] += float(tac[:, 221:442].sum())
+        lv = tac[:, -221:][tac[:, :221] > 0]
+        seen["levels"] = max(seen["levels"], float(lv.max()) if lv.numel() else 0.0)
+    print(tally.line(f"{fmt} aux {aux}"))
+    assert seen["contact"] > n * steps and seen["second"] > 0 and 0 < seen["levels"] <= 1.0
+    assert tally.flips <= 0.02 * n * steps and tally.events <= 0.005 * n * steps
+
+
 def test_global_gate_kernel_matches_oracle():
     """Multi-rank curriculum gate (cfg.cur_gate_external): the step kernel publishes its population sums into LT_F_GATE_RING and
     leaves the widening to lt_env_curriculum_apply_global; HIP and oracle, fed the same (here: single-rank) sums, must keep

@@ -10,6 +10,7 @@ import ctypes
 import os
 
 import numpy as np
+import pytest
 
 from locotouch_amd import _abi
 from tests import oracle_lib as O
@@ -143,3 +144,55 @@ def test_binary_tactile_matches_reference_replay():
             added += int((~raw & (ua < padd)).sum())
             readded += int((raw & (ud < pdrop) & (ua < padd)).sum())
     assert dropped >= 5 and added >= 20  # the vectors exercise both corruption branches
+
+
+FORMATS = {"binary": "LT_TACTILE_BINARY", "normalized": "LT_TACTILE_NORMALIZED", "discrete": "LT_TACTILE_DISCRETE",
+           "continuous": "LT_TACTILE_CONTINUOUS", "processed": "LT_TACTILE_PROCESSED", "original": "LT_TACTILE_ORIGINAL"}
+
+
+def tactile_cfg_for(g, pi, num_envs=16, play=False):
+    """Student preset with parameter set `pi` of the golden (0: the registered cfg, 1: dropout / addition raised to 8 %, 2: the
+    Denoised variants - no threshold / force / level noise).  Set 0 must BE the preset."""
+    task = "Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-" + ("Play-v1" if play else "v1")
+    cfg = _abi.preset_cfg(task, num_envs=num_envs)
+    thr, tn, pdrop, padd, fn, fmax, levels, ln = g["tf_params"][pi]
+    if pi == 0:
+        got = [cfg.tactile_threshold, cfg.tactile_threshold_noise, cfg.tactile_dropout_prob, cfg.tactile_addition_prob, cfg.tactile_force_noise,
+               cfg.tactile_maximal_force, cfg.tactile_total_levels, cfg.tactile_level_noise]
+        np.testing.assert_allclose(got, g["tf_params"][0], rtol=1e-6)
+    cfg.tactile_threshold, cfg.tactile_threshold_noise, cfg.tactile_dropout_prob, cfg.tactile_addition_prob = thr, tn, pdrop, padd
+    cfg.tactile_force_noise, cfg.tactile_maximal_force, cfg.tactile_total_levels, cfg.tactile_level_noise = fn, fmax, int(levels), ln
+    return cfg
+
+
+@pytest.mark.parametrize("pi", [0, 1, 2])
+@pytest.mark.parametrize("cname", list(FORMATS))
+def test_every_tactile_signals_class_matches_reference_replay(pi, cname):
+    """O6: TactileSignals / Binary / Normalized / Discrete / Cotinuous / Processed (observations.py:248-429) on replayed uniforms:
+    contact maps exact, force channels to f32 rounding (a discretisation level is 0.2: a flipped level would fail)."""
+    g = np.load(GOLD)
+    lib = O.load()
+    cfg = tactile_cfg_for(g, pi)
+    fmt = C[FORMATS[cname]]
+    pre = f"tf_{pi}_{cname}_"
+    T, n, nt = g[pre + "forces"].shape
+    width = g[pre + "out"].shape[-1]
+    assert width == (4 * nt if cname in ("processed", "original") else 2 * nt)
+    PF = ctypes.POINTER(ctypes.c_float)
+    stats = dict(contact=0, dropped=0, added=0, levels=set())
+    for t in range(T):
+        for e in range(n):
+            f = np.ascontiguousarray(g[pre + "forces"][t, e], np.float32)
+            us = [np.ascontiguousarray(g[pre + "u_thr"][e], np.float32)] + [np.ascontiguousarray(g[pre + "u"][t, k, e], np.float32) for k in range(7)]
+            u8 = (PF * 8)(*[O.fptr(u) for u in us])
+            out = np.zeros(width, np.float32)
+            lib.lt_oracle_tactile_format_u(ctypes.byref(cfg), fmt, O.fptr(f), u8, O.fptr(out))
+            ref = g[pre + "out"][t, e]
+            assert np.array_equal(out[:nt], ref[:nt]), (t, e, np.nonzero(out[:nt] != ref[:nt]))
+            np.testing.assert_allclose(out[nt:], ref[nt:], rtol=2e-6, atol=2e-7, err_msg=f"{cname} set {pi} t {t} env {e}")
+            stats["contact"] += int(ref[:nt].sum())
+            if cname in ("discrete", "processed", "original"):
+                stats["levels"] |= set(np.round(ref[-nt:][ref[:nt] > 0] * 5).astype(int).tolist())
+    assert stats["contact"] > 50
+    if cname in ("discrete", "processed", "original"):
+        assert len(stats["levels"]) >= 4  # several discretisation levels occur

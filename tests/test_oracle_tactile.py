@@ -111,3 +111,33 @@ def test_student_env_tactile_rows_and_sensor_cadence():
     assert np.median(lit[15:30]) >= 3 and lit.max() < 120, (np.median(lit[15:30]), lit.max())
     # object_state group = the object block of the policy rows
     assert L.arr(ora.arena, "LT_F_OBS_POLICY").shape[1] == 348
+
+
+def test_play_env_serves_the_four_channel_groups():
+    """The -Play- registration's `original_tactile` / `processed_tactile` (object_transport_student_env_cfg.py:170-171) next to
+    `tactile`, each with its own thresholds / noise draws, and the channel relations of the TactileSignals classes."""
+    import torch
+
+    from tests.oracle_vec_env import OracleVecEnv
+
+    env = OracleVecEnv(STUDENT.replace("-v1", "-Play-v1"), seed=3)
+    n = env.num_envs
+    assert n == 20 and env.cfg.tactile_aux_groups == 3
+    env.reset()
+    acc = {"orig": 0.0, "proc": 0.0, "differ": 0}
+    for t in range(40):
+        env.step(torch.zeros(n, 12))
+        g = env.get_observations()[1]["observations"]
+        assert set(g) == {"policy", "critic", "tactile", "object_state", "original_tactile", "processed_tactile"}
+        tac, orig, proc = (g[k].numpy() for k in ("tactile", "original_tactile", "processed_tactile"))
+        assert tac.shape == (n, 442) and orig.shape == proc.shape == (n, 884)
+        for x in (orig, proc):
+            c, nrm, mm, disc = x[:, :221], x[:, 221:442], x[:, 442:663], x[:, 663:]
+            assert np.isin(c, (0.0, 1.0)).all() and (x >= 0).all() and (x <= 1).all()
+            assert (mm[c == 0] == 0).all() and (disc[c == 0] == 0).all()           # masked by the contact map (:206, :234)
+            has = c.sum(axis=1) > 0
+            assert (mm[has].max(axis=1) == 1.0).all()                               # min-max normalised per env (min is 0: some taxel is off)
+        acc["orig"] += orig[:, :221].sum()
+        acc["proc"] += proc[:, :221].sum()
+        acc["differ"] += int((orig[:, :221] != proc[:, :221]).sum() + (tac[:, :221] != proc[:, :221]).sum())
+    assert acc["orig"] > 100 and acc["proc"] > 100 and acc["differ"] > 0  # separate term instances: separate thresholds and noise

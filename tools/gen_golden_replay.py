@@ -12,6 +12,7 @@ Philox uniforms, which is what the HIP kernels are compared with.
   E6  ResetObjectStateUniform.__call__                                   locotouch/mdp/events.py:85-109
   O1  object_state_in_robot_frame, add_uniform_noise branch              locotouch/mdp/observations.py:71-83
   K10 BinaryTactileSignals (thresholds, dropout, addition)               locotouch/mdp/observations.py:121-126,154-184,281-308
+  O6  every TactileSignals class, all noise branches                      locotouch/mdp/observations.py:154-246,248-429
 
 Runs ONLY in the build container (imports /root/reference read-only on the throw-away isaaclab stand-in); writes data only:
 tests/golden/mdp_replay.npz.  Parameters come from the reference's RESOLVED task config
@@ -364,6 +365,121 @@ def gen_binary_tactile(out, n=40, T=4, seed=61):
                                   params["contact_dropout_prob"], params["contact_addition_prob"]], np.float64)
 
 
+def gen_tactile_formats(out, n=12, T=3, seed=83):
+    """O6 + the -Play- env's groups: every TactileSignals class (observations.py:248-429) with the student cfg's term params
+    (object_transport_student_env_cfg.py:13-43), uniforms replayed from a tape.  The masked draws of get_normal_forces
+    (`torch.rand_like(x[mask])`: dropout force, addition force, force noise, too-small repair) are scattered to per-taxel arrays in
+    the boolean-index (row-major) order, with the masks recomputed from the reference's own intermediate state and their sizes
+    checked against the tape log.  Dropout / addition probabilities are raised to 0.08 in a second parameter set so that every
+    branch is populated; forces are scaled into 0..3 N so the normalisation does not saturate."""
+    from isaaclab.managers import ObservationTermCfg, SceneEntityCfg
+
+    scfg = runtime.load_cfg_from_registry("Isaac-RandCylinderTransportStudent_SingleBinaryTac_CNNRNN_Mon-LocoTouch-Play-v1", "env_cfg_entry_point")
+    classes = {"binary": mdp.BinaryTactileSignals, "normalized": mdp.NormalizedTactileSignals, "discrete": mdp.DiscreteTactileSignals,
+               "continuous": mdp.CotinuousTactileSignals, "processed": mdp.ProcessedTactileSignals, "original": mdp.TactileSignals}
+    assert scfg.observations.original_tactile.tactile_signals.func is mdp.TactileSignals
+    assert scfg.observations.processed_tactile.tactile_signals.func is mdp.ProcessedTactileSignals
+    strip = lambda d: {k: v for k, v in d.items() if k not in ("asset_cfg", "sensor_cfg")}  # noqa: E731
+    base = strip(scfg.observations.processed_tactile.tactile_signals.params)
+    assert base == strip(scfg.observations.original_tactile.tactile_signals.params) == strip(scfg.observations.tactile.tactile_signals.params)
+    R, Cc = base["tactile_signal_shape"]
+    nt = R * Cc
+    names = ["trunk"] + [f"sensor_{r + 1:02d}_{c + 1:02d}" for r in range(R) for c in range(Cc)]
+    ac, sc = SceneEntityCfg("robot", body_names="sensor_.*"), SceneEntityCfg("tactile_contact_sensor", body_names="sensor_.*")
+    ac.body_ids = sc.body_ids = list(range(1, 1 + nt))
+    psets = [dict(base), dict(base, contact_dropout_prob=0.08, contact_addition_prob=0.08),
+             dict(base, add_threshold_noise=False, add_force_noise=False, add_level_noise=False)]  # the Denoised cfgs (:57-63)
+    out["tf_params"] = np.array([[p["contact_threshold"], p["threshold_n_max"] if p["add_threshold_noise"] else 0.0, p["contact_dropout_prob"],
+                                  p["contact_addition_prob"], p["force_n_prop_max"] if p["add_force_noise"] else 0.0, p["maximal_force"],
+                                  p["total_levels"], p["level_n_max"] if p["add_level_noise"] else 0.0] for p in psets], np.float64)
+    assert base["threshold_n_min"] == -base["threshold_n_max"] and base["force_n_prop_min"] == -base["force_n_prop_max"] and base["level_n_min"] == -base["level_n_max"]
+    g = torch.Generator().manual_seed(seed)
+    rec = {}
+    for pi, params in enumerate(psets):
+        params = dict(params, asset_cfg=ac, sensor_cfg=sc)
+        for ci, (cname, cls) in enumerate(classes.items()):
+            env = FakeEnv(n)
+            env.scene["robot"] = GG.FakeAsset(names)
+            env.scene.sensors["tactile_contact_sensor"] = GG.FakeAsset(names)
+            tape = Tape(seed + 100 * pi + 10 * ci)
+            with replay(tape):
+                term = cls(ObservationTermCfg(func=cls, params=params), env)
+            if params["add_threshold_noise"]:
+                assert tape.log == [("rand_like", n * nt, 0)]
+                u_thr = tape.u[:n * nt].reshape(n, nt).clone()
+            else:
+                assert tape.log == []
+                u_thr = torch.full((n, nt), 0.5)
+            rows = {k: [] for k in ("forces", "u", "out")}
+            for t in range(T):
+                quat = rand_quat(g, n, rp=0.3)
+                f_local = torch.zeros(n, R, Cc)
+                for e in range(n):
+                    if e == 0 and t == 0:
+                        continue  # an env with no contact at all: min == max == 0 (the range -> 1 branch, :215-217)
+                    r0, w = int(torch.randint(0, R - 2, (1,), generator=g)), int(torch.randint(1, 3, (1,), generator=g))
+                    c0, c1 = sorted(int(x) for x in torch.randint(0, Cc, (2,), generator=g))
+                    f_local[e, r0:r0 + w, c0:c1 + 1] = U(g, (w, c1 + 1 - c0), 0.0, 3.4)  # some above maximal_force = 3
+                near = torch.rand(n, R, Cc, generator=g) < 0.15
+                f_local = torch.where(near, U(g, (n, R, Cc), 0.035, 0.065), f_local)
+                if t == 1:
+                    f_local[1] = 0.5  # every taxel pressed equally: min == max > 0 without noise
+                f_body = torch.cat([U(g, (n, nt, 2), -0.2, 0.2), -f_local.reshape(n, nt, 1)], dim=2)
+                q = quat[:, None, :].expand(n, nt, 4)
+                env.scene["robot"].data.body_quat_w = torch.cat([quat[:, None, :], q], dim=1)
+                env.scene.sensors["tactile_contact_sensor"].data.net_forces_w = torch.cat(
+                    [torch.zeros(n, 1, 3), M.quat_apply(q.reshape(-1, 4), f_body.reshape(-1, 3)).reshape(n, nt, 3)], dim=1)
+                tape = Tape(seed + 1000 + 100 * pi + 10 * ci + t)
+                with replay(tape):
+                    obs = term(env, **params)
+                # --- scatter the tape to per-taxel uniform arrays, in the reference's draw order ---
+                forces = term.original_normal_forces.reshape(n, nt).clone()
+                thr = term.contact_threshold_envs_sensors.reshape(n, nt)
+                u7 = torch.full((7, n, nt), 0.5)  # drop, dropf, add, addf, noise, small, level
+                log = list(tape.log)
+                pos = 0
+
+                def take(count):
+                    nonlocal pos
+                    kind, c, p0 = log[pos]
+                    assert kind == "rand_like" and c == count, (cname, pos, log[pos], count)
+                    pos += 1
+                    return tape.u[p0:p0 + c]
+
+                if cname != "original":
+                    contact = forces > thr
+                    fcur = forces.clone()
+                    if params["contact_dropout_prob"] > 0:
+                        u7[0] = take(n * nt).reshape(n, nt)
+                        m = contact & (u7[0] < params["contact_dropout_prob"])
+                        u7[1][m] = take(int(m.sum()))
+                        fcur[m] = u7[1][m] * thr[m]
+                        contact = contact & ~m
+                    if params["contact_addition_prob"] > 0:
+                        u7[2] = take(n * nt).reshape(n, nt)
+                        m = ~contact & (u7[2] < params["contact_addition_prob"])
+                        u7[3][m] = take(int(m.sum()))
+                        fcur[m] = thr[m] * (1.0 + 0.2 * u7[3][m])
+                        contact = contact | m
+                    if params["add_force_noise"]:
+                        u7[4][contact] = take(int(contact.sum()))
+                        fcur[contact] *= 1.0 + (u7[4][contact] * (params["force_n_prop_max"] - params["force_n_prop_min"]) + params["force_n_prop_min"])
+                        fcur = torch.clamp(fcur, min=0.0)
+                        m = contact & (fcur < thr)
+                        u7[5][m] = take(int(m.sum()))
+                    assert torch.equal(contact.reshape(n, R, Cc), term.processed_contact_taxels), cname
+                if cname in ("discrete", "processed", "original") and params["add_level_noise"]:
+                    u7[6] = take(n * nt).reshape(n, nt)
+                assert pos == len(log), (cname, pos, log)
+                rows["forces"].append(forces), rows["u"].append(u7.clone()), rows["out"].append(obs.clone())
+            rec[(pi, cname)] = (u_thr, torch.stack(rows["forces"]), torch.stack(rows["u"]), torch.stack(rows["out"]))
+    for (pi, cname), (u_thr, forces, u7, o) in rec.items():
+        out[f"tf_{pi}_{cname}_u_thr"] = u_thr.numpy()
+        out[f"tf_{pi}_{cname}_forces"] = forces.numpy()
+        out[f"tf_{pi}_{cname}_u"] = u7.numpy()
+        out[f"tf_{pi}_{cname}_out"] = o.numpy()
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -374,6 +490,7 @@ if __name__ == "__main__":
     gen_reset_object(cfg, out)
     gen_object_state_noise(cfg, out)
     gen_binary_tactile(out)
+    gen_tactile_formats(out)
     np.savez_compressed(os.path.join(OUT, "mdp_replay.npz"), **out)
     print("mdp_replay.npz", {k: v.shape for k, v in out.items()})
     _ = GG
