@@ -216,6 +216,12 @@ typedef struct lt_cfg {
   float tactile_maximal_force;    /* 3.0 N: normalised force = clamp(force / maximal_force, 0, 1) */
   int32_t tactile_total_levels;   /* 5: discretisation levels of the min-max normalised signal */
   float tactile_level_noise;      /* add_level_noise: + U(-w, w) levels before re-scaling, w = 1; 0 = off */
+  int32_t foot_material_buckets;  /* randomize_rigid_body_material num_buckets [DEP]: the materials are a POOL of this many (static, dynamic,
+                                   * restitution) triples drawn once; every (env, shape) picks a pool entry.  4000 for the feet at startup
+                                   * (locomotion_base_env_cfg.py:233-244), 8000 for the object at every reset
+                                   * (object_transport_teacher_env_cfg.py:132-143).  Entry b of a pool is the Philox draw keyed by b (no
+                                   * stored table; the same pool on every rank).  0: a fresh draw per (env, shape) */
+  int32_t obj_material_buckets;
   int32_t tactile_aux_groups;     /* bit 0: group `original_tactile` (TactileSignals, 4 channels), bit 1: `processed_tactile`
                                    * (ProcessedTactileSignals, 4 channels) - the two extra groups of the student -Play- env
                                    * (object_transport_student_env_cfg.py:166-171); each term draws its own thresholds and noise */

@@ -315,10 +315,12 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = ()) -> "_ab
                   "foot material: feet, consistent, one friction range")
             _rng(cfg.foot_friction, p["static_friction_range"])
             _rng(cfg.foot_restitution, p["restitution_range"])
+            cfg.foot_material_buckets = int(p["num_buckets"])
         elif key == ("randomize_rigid_body_material", "object", "reset"):
             _need(p["make_consistent"] and tuple(p["dynamic_friction_range"]) == (1.0, 1.0), "object material: consistent, dynamic range (1, 1)")
             _rng(cfg.obj_friction, p["static_friction_range"])
             _rng(cfg.obj_restitution, p["restitution_range"])
+            cfg.obj_material_buckets = int(p["num_buckets"])
         elif key == ("randomize_friction_restitution", "robot", "reset"):
             _need(bodies == "trunk" and p["make_consistent"] and tuple(p["dynamic_friction_range"]) == (1.0, 1.0), "trunk material: consistent, dynamic range (1, 1)")
             _rng(cfg.trunk_friction, p["static_friction_range"])

@@ -126,6 +126,8 @@ void base_locomotion(lt_cfg* c) {
   set2(c->trunk_mass_add, -1.0f, 2.0f);
   set2(c->foot_friction, 0.4f, 2.0f);
   set2(c->foot_restitution, 0.0f, 0.5f);
+  c->foot_material_buckets = 4000;                                   // :242
+  c->obj_material_buckets = 0;
   // interval events: locomotion_base_env_cfg.py:279-292
   set2(c->push_robot_interval, 4.0f, 8.0f);
   set2(c->push_robot_vel[0], -1.0f, 1.0f);
@@ -202,6 +204,7 @@ void transport_teacher(lt_cfg* c) {
   set2(c->trunk_restitution, 0.0f, 0.2f);
   set2(c->obj_friction, 0.3f, 1.0f);
   set2(c->obj_restitution, 0.0f, 0.2f);
+  c->obj_material_buckets = 8000;                                    // object_transport_teacher_env_cfg.py:141
   set2(c->obj_mass_add, -0.5f, 1.5f);
   set2(c->reset_root_pos[2], 0.0f, 0.0f);
   for (int i = 0; i < 3; ++i) set2(c->reset_root_rpy[i], 0.0f, 0.0f);

@@ -91,6 +91,7 @@ enum {
   RS_NOISE_JPOS = 0x100, RS_NOISE_JVEL = 0x110, RS_NOISE_BASE = 0x120, RS_NOISE_OBJ = 0x130,
   RS_RESET_ROOT = 0x200, RS_RESET_JOINT = 0x210, RS_RESET_MAT = 0x220, RS_RESET_OBJ = 0x221, RS_RESET_EVENT = 0x223,
   RS_CMD_RESET = 0x230, RS_CMD_TIMER = 0x240, RS_PUSH_ROBOT = 0x250, RS_PUSH_OBJ = 0x260, RS_STARTUP = 0x300,
+  RS_BUCKET_FEET = 0x310, RS_BUCKET_OBJ = 0x311,  // material pools: key = bucket index (not an env), startup stream
   RS_TACTILE_THR = 0x400,  // + 0x40 term + taxel / 4 (startup stream): the per-(env, taxel) threshold offsets, drawn once
   RS_TACTILE = 0x500       // + 0x200 term + 2 taxel + {0, 1} (step stream): csrc/lt_tactile.hip
 };
@@ -844,7 +845,11 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       const float* sz = (const float*)(arena + L.off_obj_sizes) + env * 2;
       O.rad = sz[0]; O.len = sz[1];
     }
-    const U4 uf = rng4(c.seed, ekey, st, RS_STARTUP + 0x10 + leg);
+    U4 uf = rng4(c.seed, ekey, st, RS_STARTUP + 0x10 + leg);
+    if (c.foot_material_buckets > 0) {  // bucketed materials [DEP randomize_rigid_body_material]: pool entry b = the draw keyed by b
+      const int b = min((int)(uf.a * (float)c.foot_material_buckets), c.foot_material_buckets - 1);
+      uf = rng4(c.seed, (uint32_t)b, st, RS_BUCKET_FEET);
+    }
     const float ms = lerp2(c.foot_friction, uf.a), md = lerp2(c.foot_friction, uf.b);
     G.mu = md < ms ? md : ms;
     O.mass = 1.0f; O.mu = 1.0f; X.trunk_mu = 1.0f; X.trunk_rest = 0.f; X.obj_rest = 0.f;
@@ -1180,6 +1185,11 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       u = rng4(c.seed, e32, step, RS_RESET_MAT);                                                               // E3 (events.py:160-196), E2
       X.trunk_mu = lerp2(c.trunk_friction, u.a); X.trunk_mu = X.trunk_mu > 1.f ? 1.f : X.trunk_mu;
       X.trunk_rest = lerp2(c.trunk_restitution, u.b);
+      if (c.obj_material_buckets > 0) {  // E2: the object's material comes from a pool of obj_material_buckets entries
+        const int b = min((int)(u.c * (float)c.obj_material_buckets), c.obj_material_buckets - 1);
+        const U4 ub = rng4(c.seed, (uint32_t)b, ~0ull, RS_BUCKET_OBJ);
+        u.c = ub.a; u.d = ub.b;
+      }
       O.mu = lerp2(c.obj_friction, u.c); O.mu = O.mu > 1.f ? 1.f : O.mu;
       X.obj_rest = lerp2(c.obj_restitution, u.d);
       u = rng4(c.seed, e32, step, RS_RESET_OBJ);                                                               // E6 (events.py:85-109)

@@ -1375,6 +1375,7 @@ enum {
   RS_NOISE_JPOS = 0x100, RS_NOISE_JVEL = 0x110, RS_NOISE_BASE = 0x120, RS_NOISE_OBJ = 0x130,
   RS_RESET_ROOT = 0x200, RS_RESET_JOINT = 0x210, RS_RESET_MAT = 0x220, RS_RESET_OBJ = 0x221, RS_RESET_EVENT = 0x223,
   RS_CMD_RESET = 0x230, RS_CMD_TIMER = 0x240, RS_PUSH_ROBOT = 0x250, RS_PUSH_OBJ = 0x260, RS_STARTUP = 0x300,
+  RS_BUCKET_FEET = 0x310, RS_BUCKET_OBJ = 0x311, /* material pools: key = bucket index (not an env), startup stream */
   RS_TACTILE_THR = 0x400, /* + 0x40 term + taxel / 4 (startup stream): per-(env, taxel) threshold offsets, drawn once */
   RS_TACTILE = 0x500      /* + 0x200 term + 2 taxel + {0, 1} (step stream): see tactile_pass */
 };
@@ -1394,6 +1395,11 @@ static void startup_env(const lt_cfg* cfg, env_t* E, uint32_t env, const float* 
   if (cfg->obj_size_explicit && sizes) { E->obj_radius = sizes[0]; E->obj_length = sizes[1]; }
   for (int l = 0; l < 4; ++l) {
     lt_rng4(cfg->seed, env, st, RS_STARTUP + 0x10 + l, u);
+    if (cfg->foot_material_buckets > 0) { /* bucketed materials [DEP randomize_rigid_body_material]: pool entry b = the draw keyed by b */
+      int b = (int)(u[0] * (float)cfg->foot_material_buckets);
+      if (b > cfg->foot_material_buckets - 1) b = cfg->foot_material_buckets - 1;
+      lt_rng4(cfg->seed, (uint32_t)b, st, RS_BUCKET_FEET, u);
+    }
     real ms = lt_lerp(cfg->foot_friction, u[0]), md = lt_lerp(cfg->foot_friction, u[1]);
     E->foot_mu[l] = md < ms ? md : ms; /* make_consistent: dynamic = min(static, dynamic); the contact law uses it */
   }
@@ -1461,6 +1467,13 @@ static void reset_env(const lt_cfg* cfg, const float* P, env_t* E, uint32_t env,
   if (has_object) {
     /* E3 randomize_friction_restitution (events.py:160-196, make_consistent) and E2 object material */
     lt_rng4(cfg->seed, env, step, RS_RESET_MAT, u);
+    if (cfg->obj_material_buckets > 0) { /* E2: the object's (friction, restitution) come from a pool of obj_material_buckets entries */
+      float ub[4];
+      int b = (int)(u[2] * (float)cfg->obj_material_buckets);
+      if (b > cfg->obj_material_buckets - 1) b = cfg->obj_material_buckets - 1;
+      lt_rng4(cfg->seed, (uint32_t)b, ~(uint64_t)0, RS_BUCKET_OBJ, ub);
+      u[2] = ub[0]; u[3] = ub[1];
+    }
     {
       /* the dynamic-friction range of both cfgs is (1, 1): its draw does not matter (object_transport_teacher_env_cfg.py:121-143) */
       const float one[2] = {1.0f, 1.0f};
