@@ -36,9 +36,10 @@ def test_gru_sequence_matches_nn_gru_on_distillation_shape():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("L,B,I,H", [(20, 37, 64, 512), (7, 1, 5, 64), (33, 101, 64, 128), (3, 200, 16, 192)])
+@pytest.mark.parametrize("L,B,I,H", [(20, 37, 64, 512), (7, 1, 5, 64), (33, 101, 64, 128), (3, 200, 16, 192), (2, 16, 8, 512), (1, 3, 8, 256)])
 def test_hip_gru_kernels_on_ragged_shapes(L, B, I, H):
-    """Row counts that are not multiples of the 16-row tile, a single row, other hidden sizes (multiples of 64)."""
+    """Row counts that are not multiples of the 16-row tile, a single row, other hidden sizes (multiples of 64), and the one- and
+    two-step sequences where the backward recursion opens and closes at once (lt_gru_step_bwd_gates -> lt_gru_step_bwd_fused)."""
     import locotouch_amd.rl.gru as G
 
     assert G.use_hip_kernels
@@ -48,3 +49,4 @@ def test_hip_gru_kernels_on_ragged_shapes(L, B, I, H):
 @pytest.mark.gpu
 def test_hidden_sizes_the_kernels_do_not_cover_take_the_torch_loop():
     _check("cuda:0", 6, 9, 8, 48, 2e-4)  # H = 48: not a multiple of 64 -> PyTorch-op time loop
+
