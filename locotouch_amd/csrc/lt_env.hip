@@ -498,8 +498,7 @@ __device__ __forceinline__ void object_state_obs(const lt_cfg& c, const Base& B,
 }
 
 // command resampling (reference locotouch/mdp/commands.py:517-559 + UniformVelocityCommand [DEP])
-__device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P, uint32_t env, uint64_t step, uint32_t stream, Misc& X) {
-  const U4 u0 = rng4(c.seed, env, step, stream), u1 = rng4(c.seed, env, step, stream + 1);
+__device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P, const U4& u0, const U4& u1, Misc& X) {
   const float ub[3] = {u0.a, u0.c, u1.a}, uv[3] = {u0.b, u0.d, u1.b};
   float cmd[3];
 #pragma unroll
@@ -517,6 +516,9 @@ __device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P
   X.cmd_buf = X.cmd;
   X.cmd_standing = (u1.c <= P[16]) ? 1.f : 0.f;
   X.cmd_time_left = c.cmd_resample_time[0] + u1.d * (c.cmd_resample_time[1] - c.cmd_resample_time[0]);
+}
+__device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P, uint32_t env, uint64_t step, uint32_t stream, Misc& X) {
+  command_resample(c, P, rng4(c.seed, env, step, stream), rng4(c.seed, env, step, stream + 1), X);
 }
 
 // =====================================================================================================
@@ -657,6 +659,11 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   __shared__ float s_mb_in[HELPERS ? MB_IN : 1][64], s_mb_crba[HELPERS ? MB_CRBA : 1][64], s_mb_obj[HELPERS ? MB_OBJ : 1][64],
       s_mb_ofin[HELPERS ? MB_OFIN : 1][64];  // physics mailboxes (HelperParts)
   __shared__ float s_mb_rng[HELPERS ? 16 : 1][64];  // wave 3 -> wave 0: this step's observation-noise uniforms
+  // wave 3 -> wave 0: the step's EVENT draws (reset events, command resampling, pushes), computed beside the physics.  An env
+  // uses them on few steps, but some tile of the launch does on every step and the launch ends with its slowest tile: 13 Philox
+  // calls (~8 k cycles) sat on that tile's critical path.  Slot = one rng4 result of an owner lane: [slot][component][lane].
+  constexpr int BANK_SLOTS = 7;
+  __shared__ float s_bank[HELPERS ? BANK_SLOTS : 1][4][64];
   if (!HELPERS) {
     const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
     for (int i = lane; i < 352; i += 64) { s_tab[0][i] = tab.src[i]; s_tab[0][352 + i] = tab.frame[i]; }
@@ -678,6 +685,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       const float sgnh[4] = {1.f, sxh, syh, sxh * syh};
       Obj Oh;
       float trunk_mu = 0.f;
+      float bank_mat_c = 0.f;
       if (HAS_OBJ && wave == 2) {
         float t;
         t = hot.obj_pos; Oh.p = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
@@ -716,6 +724,30 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
 #pragma unroll
             for (int i = 0; i < MB_OFIN; ++i) s_mb_ofin[i][lane] = w[i];
           }
+        } else if (wave == 3 && MODE == MODE_STEP) {
+          // the step's event draws, at most two Philox calls per substep (~2 k of the substep's ~11 k cycles).  Same seeds, keys
+          // and streams as the inline form: bit-identical uniforms.  Slots 0-2 are per lane (stream + leg); slots 3-5 hold four
+          // per-env streams, one per lane of the quad; slot 6 is the object-material pool entry picked by RS_RESET_MAT's third draw.
+          auto put = [&](int slot, const U4& u) { s_bank[slot][0][lane] = u.a; s_bank[slot][1][lane] = u.b; s_bank[slot][2][lane] = u.c; s_bank[slot][3][lane] = u.d; };
+          const int last = nsub - 1;
+          if (it == 0) {
+            put(0, rng4(c.seed, ekey, step, RS_RESET_ROOT + leg));
+            put(1, rng4(c.seed, ekey, step, RS_RESET_JOINT + leg));
+          }
+          if (it == 1 || (it == last && last < 1)) {
+            put(2, rng4(c.seed, ekey, step, RS_RESET_JOINT + 4 + leg));
+            const U4 ua = rng4(c.seed, ekey, step, leg == 0 ? RS_RESET_MAT : (leg == 1 ? RS_RESET_OBJ : (leg == 2 ? RS_RESET_OBJ + 1 : RS_RESET_EVENT)));
+            put(3, ua);
+            bank_mat_c = qbcast<0>(ua.c);
+          }
+          if (it == 2 || (it == last && last < 2)) {
+            put(4, rng4(c.seed, ekey, step, leg == 0 ? RS_CMD_RESET : (leg == 1 ? RS_CMD_RESET + 1 : (leg == 2 ? RS_CMD_TIMER : RS_CMD_TIMER + 1))));
+            put(5, rng4(c.seed, ekey, step, leg == 0 ? RS_PUSH_ROBOT : (leg == 1 ? RS_PUSH_ROBOT + 1 : (leg == 2 ? RS_PUSH_OBJ : RS_PUSH_OBJ + 1))));
+          }
+          if ((it == 3 || (it == last && last < 3)) && HAS_OBJ && c.obj_material_buckets > 0) {
+            const int b = min((int)(bank_mat_c * (float)c.obj_material_buckets), c.obj_material_buckets - 1);
+            put(6, rng4(c.seed, (uint32_t)b, ~0ull, RS_BUCKET_OBJ));
+          }
         }
         wg_barrier_lds();  // B
       }
@@ -740,7 +772,11 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       in.valid = env < L.n;
       in.reset = s_cur[lane * 5 + 0] != 0.f; in.ep_len = s_cur[lane * 5 + 1];
       in.sum_lin = s_cur[lane * 5 + 2]; in.sum_ang = s_cur[lane * 5 + 3]; in.cmd_nonzero = s_cur[lane * 5 + 4] != 0.f;
-      if (curriculum_publish(L, arena, gid, leg, in)) curriculum_decide(c, L, arena, 1);  // + common_step_counter += 1
+      curriculum_publish(L, arena, gid, leg, in);  // the decision is lt_gate_decide_kernel's, behind this launch
+#ifdef LT_STAMPS
+      LT_STAMP(1);
+      if (lane == 0) ((float*)(arena + L.quad_off[LT_F_REWARD_TERMS]) + 3 * L.npad * 4 + (long long)blockIdx.x * 64)[3] = (float)(long long)(stamps_[1] - stamps_[0]);
+#endif
       return;
     }
     // ---- waves 1, 2: history rows of group g.  Row(t) is built from row(t-1): every term block shifts left by one frame
@@ -784,14 +820,34 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     }
     wg_barrier_lds();  // C (wave 3's noise uniforms -> wave 0)
     __syncthreads();  // B1: newest frame + reset flags are in LDS
-    for (int r = 0; r < 16; ++r) {
-      const bool fill = s_fill[r] != 0;  // first push after a reset fills all 6 slots
+    // after B1: the newest-frame columns of every row (1/6 of the columns: each lane owns about one of its NCH), and whole rows
+    // for envs that were just reset.  The per-lane column routing is loop-invariant, so the row loop is one LDS read + one store
+    // per owned newest column; reset rows (rare) take the full pass.
+    unsigned fills = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fills |= (s_fill[r] != 0 ? 1u : 0u) << r;  // first push after a reset fills all 6 slots
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int col = i * 64 + lane;
+      if (col < OBS && src[i] < 0) {
+        const int fe = (-src[i] - 1) & 63;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rows[r * OBS + col] = s_frame[g][r][fe];
+      }
+    }
+    while (fills) {
+      const int r = __builtin_ctz(fills);
+      fills &= fills - 1;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const int col = i * 64 + lane;
-        if (col < OBS && (fill || src[i] < 0)) rows[r * OBS + col] = s_frame[g][r][(fill ? frm[i] : (-src[i] - 1)) & 63];
+        if (col < OBS && src[i] >= 0) rows[r * OBS + col] = s_frame[g][r][frm[i] & 63];
       }
     }
+#ifdef LT_STAMPS
+    LT_STAMP(1);
+    if (lane == 0) ((float*)(arena + L.quad_off[LT_F_REWARD_TERMS]) + 3 * L.npad * 4 + (long long)blockIdx.x * 64)[wave] = (float)(long long)(stamps_[1] - stamps_[0]);
+#endif
     return;
   }
 
@@ -958,7 +1014,6 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   // =================================================================================================
   int bits = 0;
   bool terminated = false, time_out = false, reset = false;
-  bool last_arriver = false;
   CurIn cur_in;
   cur_in.valid = env < L.n; cur_in.reset = false; cur_in.ep_len = cur_in.sum_lin = cur_in.sum_ang = 0.f; cur_in.cmd_nonzero = false;
   float sums[LT_REWARD_SLOTS / 4];  // this lane's episode sums: terms leg, leg+4, ...  (quad array q holds terms 4q..4q+3)
@@ -1149,20 +1204,27 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       *F(LT_F_LAST_EPISODE_INFO, 0) = sel4(leg, fin + 1.f, (float)X.ep_len, (float)bits, 0.f);
     }
   }
+  // the step's event draws: from wave 3's bank (helper form: computed beside the physics) or inline Philox - the same uniforms
+  auto draw = [&](uint32_t stream, int slot, int owner) -> U4 {
+    if (HELPERS && MODE == MODE_STEP) {
+      const int src = (lane & ~3) | owner;
+      return U4{s_bank[slot][0][src], s_bank[slot][1][src], s_bank[slot][2][src], s_bank[slot][3][src]};
+    }
+    return rng4(c.seed, ekey, step, stream);
+  };
   if ((MODE == MODE_STEP && reset) || MODE == MODE_RESET_ALL) {
-    const uint32_t e32 = ekey;
     // E4 reset_root_state_uniform [DEP] (params locomotion_base_env_cfg.py:249-267 / object_transport_teacher...:144-160)
-    U4 u = rng4(c.seed, e32, step, RS_RESET_ROOT);
+    U4 u = draw(RS_RESET_ROOT, 0, 0);
     B.p = v3(lerp2(c.reset_root_pos[0], u.a), lerp2(c.reset_root_pos[1], u.b), LT_ROOT_INIT_HEIGHT + lerp2(c.reset_root_pos[2], u.c));
-    u = rng4(c.seed, e32, step, RS_RESET_ROOT + 1);
+    u = draw(RS_RESET_ROOT + 1, 0, 1);
     B.q = q_from_euler(lerp2(c.reset_root_rpy[0], u.a), lerp2(c.reset_root_rpy[1], u.b), lerp2(c.reset_root_rpy[2], u.c));
-    u = rng4(c.seed, e32, step, RS_RESET_ROOT + 2);
-    U4 w4 = rng4(c.seed, e32, step, RS_RESET_ROOT + 3);
+    u = draw(RS_RESET_ROOT + 2, 0, 2);
+    U4 w4 = draw(RS_RESET_ROOT + 3, 0, 3);
     B.u = v3(lerp2(c.reset_root_vel[0], u.a), lerp2(c.reset_root_vel[1], u.b), lerp2(c.reset_root_vel[2], u.c));
     B.w = v3(lerp2(c.reset_root_vel[3], w4.a), lerp2(c.reset_root_vel[4], w4.b), lerp2(c.reset_root_vel[5], w4.c));
     // E5 reset_joints_by_offset [DEP] :269-276
-    u = rng4(c.seed, e32, step, RS_RESET_JOINT + leg);
-    w4 = rng4(c.seed, e32, step, RS_RESET_JOINT + 4 + leg);
+    u = draw(RS_RESET_JOINT + leg, 1, leg);
+    w4 = draw(RS_RESET_JOINT + 4 + leg, 2, leg);
     const float up[3] = {u.a, u.b, u.c}, uv[3] = {w4.a, w4.b, w4.c};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -1182,18 +1244,18 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     X.trunk_fh[0] = X.trunk_fh[1] = X.trunk_fh[2] = 0.f;
     X.gait_cmd = v3(0, 0, 0); X.gait_step = 0.f;
     if (HAS_OBJ) {
-      u = rng4(c.seed, e32, step, RS_RESET_MAT);                                                               // E3 (events.py:160-196), E2
+      u = draw(RS_RESET_MAT, 3, 0);                                                                            // E3 (events.py:160-196), E2
       X.trunk_mu = lerp2(c.trunk_friction, u.a); X.trunk_mu = X.trunk_mu > 1.f ? 1.f : X.trunk_mu;
       X.trunk_rest = lerp2(c.trunk_restitution, u.b);
       if (c.obj_material_buckets > 0) {  // E2: the object's material comes from a pool of obj_material_buckets entries
         const int b = min((int)(u.c * (float)c.obj_material_buckets), c.obj_material_buckets - 1);
-        const U4 ub = rng4(c.seed, (uint32_t)b, ~0ull, RS_BUCKET_OBJ);
+        const U4 ub = (HELPERS && MODE == MODE_STEP) ? draw(0, 6, 0) : rng4(c.seed, (uint32_t)b, ~0ull, RS_BUCKET_OBJ);
         u.c = ub.a; u.d = ub.b;
       }
       O.mu = lerp2(c.obj_friction, u.c); O.mu = O.mu > 1.f ? 1.f : O.mu;
       X.obj_rest = lerp2(c.obj_restitution, u.d);
-      u = rng4(c.seed, e32, step, RS_RESET_OBJ);                                                               // E6 (events.py:85-109)
-      w4 = rng4(c.seed, e32, step, RS_RESET_OBJ + 1);
+      u = draw(RS_RESET_OBJ, 3, 1);                                                                            // E6 (events.py:85-109)
+      w4 = draw(RS_RESET_OBJ + 1, 3, 2);
       {
         // class variant: offset in world axes (events.py:98-99); function variant: rotated by the robot quat (:43-44)
         const V3 d = v3(lerp2(c.obj_reset_pos[0], u.a), lerp2(c.obj_reset_pos[1], u.b), lerp2(c.obj_reset_pos[2], u.c) + O.len / 2.f);
@@ -1206,8 +1268,8 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     }
 #pragma unroll
     for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) sums[q] = 0.f;
-    command_resample(c, P, e32, step, RS_CMD_RESET, X);
-    u = rng4(c.seed, e32, step, RS_RESET_EVENT);
+    command_resample(c, P, draw(RS_CMD_RESET, 4, 0), draw(RS_CMD_RESET + 1, 4, 1), X);
+    u = draw(RS_RESET_EVENT, 3, 3);
     X.push_robot_left = lerp2(c.push_robot_interval, u.a);
     X.push_obj_left = lerp2(c.push_obj_interval, u.b);
     X.ep_len = 0;
@@ -1218,7 +1280,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   if (MODE == MODE_STEP) {
     // 7. CommandTerm.compute [DEP] + MultiSampling._update_command (commands.py:561-576)
     X.cmd_time_left -= step_dt;
-    if (X.cmd_time_left <= 0.f) command_resample(c, P, ekey, step, RS_CMD_TIMER, X);
+    if (X.cmd_time_left <= 0.f) command_resample(c, P, draw(RS_CMD_TIMER, 4, 2), draw(RS_CMD_TIMER + 1, 4, 3), X);
     if (c.cmd_multi_sampling) {
       const long long zs = (long long)(int)P[15];
       if (X.ep_len < zs) X.cmd = 0.0f * X.cmd_buf;
@@ -1228,7 +1290,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     // 8. interval events: push_by_setting_velocity [DEP] (cfg locomotion_base_env_cfg.py:279-292, teacher :189-209)
     X.push_robot_left -= step_dt;
     if (X.push_robot_left < 1e-6f) {
-      const U4 u = rng4(c.seed, ekey, step, RS_PUSH_ROBOT), w4 = rng4(c.seed, ekey, step, RS_PUSH_ROBOT + 1);
+      const U4 u = draw(RS_PUSH_ROBOT, 5, 0), w4 = draw(RS_PUSH_ROBOT + 1, 5, 1);
       X.push_robot_left = lerp2(c.push_robot_interval, u.d);
       B.u += v3(lerp2(c.push_robot_vel[0], u.a), lerp2(c.push_robot_vel[1], u.b), lerp2(c.push_robot_vel[2], u.c));
       B.w += v3(lerp2(c.push_robot_vel[3], w4.a), lerp2(c.push_robot_vel[4], w4.b), lerp2(c.push_robot_vel[5], w4.c));
@@ -1236,21 +1298,20 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     if (HAS_OBJ) {
       X.push_obj_left -= step_dt;
       if (X.push_obj_left < 1e-6f) {
-        const U4 u = rng4(c.seed, ekey, step, RS_PUSH_OBJ), w4 = rng4(c.seed, ekey, step, RS_PUSH_OBJ + 1);
+        const U4 u = draw(RS_PUSH_OBJ, 5, 2), w4 = draw(RS_PUSH_OBJ + 1, 5, 3);
         X.push_obj_left = lerp2(c.push_obj_interval, u.d);
         O.u += v3(lerp2(c.push_obj_vel[0], u.a), lerp2(c.push_obj_vel[1], u.b), lerp2(c.push_obj_vel[2], u.c));
         O.w += v3(lerp2(c.push_obj_vel[3], w4.a), lerp2(c.push_obj_vel[4], w4.b), lerp2(c.push_obj_vel[5], w4.c));
       }
     }
-    // curriculum / population gate (lt_post.h).  Single-wave form: publish this wave's partials here - after the last read
-    // of the command block, with few memory operations outstanding; the wave that arrives last decides at the very end of
-    // the kernel.  With helper waves the record goes to wave 3 through LDS.
+    // curriculum / population gate (lt_post.h).  Single-wave form: publish this tile's partials here; with helper waves the
+    // record goes to wave 3 through LDS.  The global decision is lt_gate_decide_kernel's.
     cur_in.cmd_nonzero = X.cmd.x != 0.f || X.cmd.y != 0.f || X.cmd.z != 0.f;
     if (HELPERS) {
       s_cur[lane * 5 + 0] = cur_in.reset ? 1.f : 0.f; s_cur[lane * 5 + 1] = cur_in.ep_len;
       s_cur[lane * 5 + 2] = cur_in.sum_lin; s_cur[lane * 5 + 3] = cur_in.sum_ang; s_cur[lane * 5 + 4] = cur_in.cmd_nonzero ? 1.f : 0.f;
     } else {
-      last_arriver = curriculum_publish(L, arena, gid, leg, cur_in);
+      curriculum_publish(L, arena, gid, leg, cur_in);
     }
   }
 
@@ -1428,12 +1489,12 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
 #pragma unroll
     for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) *F(LT_F_EPISODE_SUMS, q) = sums[q];
   }
-  if (MODE == MODE_STEP && !HELPERS && last_arriver) curriculum_decide(c, L, arena, 1);  // + common_step_counter += 1
 #ifdef LT_STAMPS
   LT_STAMP(7);
   if (lane == 0)
     for (int q = 0; q < 7; ++q) *F(LT_F_LAST_EPISODE_SUMS, q) = (float)(long long)(stamps_[q + 1] - stamps_[q]);
   if (lane == 0) { *F(LT_F_REWARD_TERMS, 0) = (float)(long long)bar_wait_[0]; *F(LT_F_REWARD_TERMS, 1) = (float)(long long)bar_wait_[1]; }
+  if (lane == 0) ((float*)(arena + L.quad_off[LT_F_REWARD_TERMS]) + 3 * L.npad * 4 + (long long)blockIdx.x * 64)[0] = (float)(long long)(stamps_[7] - stamps_[0]);
 #endif
 }
 
@@ -1442,7 +1503,6 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
 // kernel's tail without a physics step.  Same grid and lane mapping as the step kernel.
 // =====================================================================================================
 __global__ __launch_bounds__(64) void lt_curriculum_kernel(const KArgs a, const float* __restrict__ records) {
-  const lt_cfg& c = a.d->cfg;
   const lt_layout& L = a.d->layout;
   const int leg = threadIdx.x & 3;
   const long long gid = (long long)blockIdx.x * 64 + threadIdx.x, env = gid >> 2;
@@ -1453,7 +1513,11 @@ __global__ __launch_bounds__(64) void lt_curriculum_kernel(const KArgs a, const 
   in.ep_len = r[1]; in.sum_lin = r[2]; in.sum_ang = r[3];
   const float cm = ((const float*)(a.arena + L.quad_off[LT_F_CMD]))[gid];
   in.cmd_nonzero = qor((leg < 3 && cm != 0.f) ? 1 : 0) != 0;
-  if (curriculum_publish(L, a.arena, gid, leg, in)) curriculum_decide(c, L, a.arena, 0);
+  curriculum_publish(L, a.arena, gid, leg, in);
+}
+// the global half of the pass (lt_post.h): one wave behind the step kernel / the curriculum hook
+__global__ __launch_bounds__(64) void lt_gate_decide_kernel(const KArgs a, int bump_counter) {
+  curriculum_decide(a.d->cfg, a.d->layout, a.arena, bump_counter);
 }
 // multi-rank curriculum gate on cross-rank sums (lt_post.h curriculum_apply_global); one wave
 __global__ __launch_bounds__(64) void lt_gate_apply_kernel(const KArgs a, const float* __restrict__ ring_sums, int nsteps, float inv_n_total) {
@@ -1518,7 +1582,7 @@ struct RecordArgs { const float* values; float gamma; float* rewards; unsigned c
 
 template <int MODE>
 int launch_step(const lt_env* env, const float* actions, hipStream_t s, const float* const* prev = nullptr, float* const* next = nullptr,
-                const RecordArgs* rec = nullptr) {
+                const RecordArgs* rec = nullptr, bool with_gate = true) {
   KArgs k = make_args(env, actions);
   if (rec) { k.rec_values = rec->values; k.rec_gamma = rec->gamma; k.rec_rewards = rec->rewards; k.rec_dones = rec->dones; }
   for (int g = 0; g < 2; ++g) {
@@ -1547,6 +1611,9 @@ int launch_step(const lt_env* env, const float* actions, hipStream_t s, const fl
     if (helpers) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE, MODE == MODE_STEP>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE, false>), grid, dim3(64), 0, s, k);
   }
+  // the population pass of the step (curriculum decision, population gate, step counter): one wave behind the step kernel,
+  // unless the caller places it itself (lt_env_defer_gate: beside the next policy launch in the rollout graph)
+  if (MODE == MODE_STEP && with_gate && !env->defer_gate) hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(64), 0, s, k, 1);
   return (int)hipGetLastError();
 }
 
@@ -1591,9 +1658,10 @@ int lt_launch_step_profiled(lt_env* env, const float* actions, void* stream, flo
     env->ev_start = a; env->ev_stop = b;
   }
   if ((e = hipEventRecord((hipEvent_t)env->ev_start, s)) != hipSuccess) return (int)e;
-  int rc = launch_step<MODE_STEP>(env, actions, s);
+  int rc = launch_step<MODE_STEP>(env, actions, s, nullptr, nullptr, nullptr, false);  // the events bracket lt_step_kernel alone
   if (rc != 0) return rc;
   if ((e = hipEventRecord((hipEvent_t)env->ev_stop, s)) != hipSuccess) return (int)e;
+  if (!env->defer_gate && (rc = lt_launch_gate_decide(env, 1, s)) != 0) return rc;
   if ((e = hipEventSynchronize((hipEvent_t)env->ev_stop)) != hipSuccess) return (int)e;
   return (int)hipEventElapsedTime(ms, (hipEvent_t)env->ev_start, (hipEvent_t)env->ev_stop);
 }
@@ -1616,6 +1684,13 @@ int lt_launch_eval_terms(const lt_env* env, void* stream) {
 int lt_launch_curriculum(const lt_env* env, const float* records, void* stream) {
   const KArgs k = make_args(env, nullptr);
   hipLaunchKernelGGL(lt_curriculum_kernel, dim3((unsigned)(env->layout.npad / 16)), dim3(64), 0, (hipStream_t)stream, k, records);
+  hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, 0);
+  return (int)hipGetLastError();
+}
+
+int lt_launch_gate_decide(const lt_env* env, int bump_counter, void* stream) {
+  const KArgs k = make_args(env, nullptr);
+  hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, bump_counter);
   return (int)hipGetLastError();
 }
 

@@ -14,6 +14,7 @@ struct lt_env {
   size_t arena_bytes = 0;
   void* ev_start = nullptr;  // hipEvent_t pair for lt_env_step_profiled (created lazily)
   void* ev_stop = nullptr;
+  int defer_gate = 0;        // lt_env_defer_gate: the caller launches the population pass (lt_env_gate_update) itself
 };
 
 // implemented in lt_env.hip -------------------------------------------------------------------------
@@ -27,6 +28,7 @@ int lt_launch_step_profiled(lt_env* env, const float* actions, void* stream, flo
 int lt_launch_eval_terms(const lt_env* env, void* stream);
 void lt_release_events(lt_env* env);
 int lt_launch_curriculum(const lt_env* env, const float* records, void* stream);
+int lt_launch_gate_decide(const lt_env* env, int bump_counter, void* stream);  // the one-wave global half of the curriculum pass
 int lt_launch_set_command_ranges(const lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream);
 int lt_launch_curriculum_apply_global(const lt_env* env, const float* ring_sums, int nsteps, long long n_total, void* stream);
 int lt_launch_tactile(const lt_env* env, void* stream);  // lt_tactile.hip

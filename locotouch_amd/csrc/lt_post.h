@@ -1,19 +1,22 @@
-// Curriculum / population-gate pass of one env step, run at the TAIL of the step kernel (lt_env.hip) - no launch of its own.
+// Curriculum / population-gate pass of one env step: per-wave partial sums at the tail of the step kernel (lt_env.hip), the global
+// decision in a one-wave kernel behind it (lt_gate_decide_kernel).
 //
 // Reference: ModifyVelCommandsRangeBasedonReward (locotouch/mdp/curriculums.py:184-275) + MultiSampling.set_ranges
 // (locotouch/mdp/commands.py:471-505), the population gate of rewards.py:190 and `common_step_counter += 1`.
 //
-// The pass needs sums over ALL envs and then a global decision.  Protocol (MI355X_MICROARCH.md, "Valid forms" row 1):
-//   1. every wave (16 envs) first applies the tracker operations the PREVIOUS pass decided (LT_F_CMD_PARAMS[27..30]) to its
-//      own envs' trackers, then forms its partial sums with this step's records merged in hypothetically (registers only),
-//   2. publishes them - 8 floats, one write-through (sc1) dword store per lane - drains its stores and takes a ticket
-//      (agent-scope atomic add on one counter),
-//   3. the wave whose ticket is the last one reduces the slots in a fixed order (sc1 loads: deterministic, run-to-run
-//      identical), replays the reference's decision sequence (lin gate -> maybe widen -> ang gate -> maybe widen), writes
-//      the command block + the tracker operations for the next pass, bumps the step counter and re-arms the ticket.
-// No wave ever touches another wave's envs, so the per-env trackers need no cross-XCD visibility at all; they simply lag
-// the reference's by one pass (the oracle keeps the same representation; the decisions are the reference's own).
-// Every read of the command block by any wave of the launch precedes that wave's ticket, hence the last arriver's writes.
+// The pass needs sums over ALL envs and then a global decision:
+//   1. every wave (16 envs) of the step kernel first applies the tracker operations the PREVIOUS pass decided
+//      (LT_F_CMD_PARAMS[27..30]) to its own envs' trackers, then forms its partial sums with this step's records merged in
+//      hypothetically (registers only) and stores them - 8 floats - into its slot (curriculum_publish);
+//   2. lt_gate_decide_kernel (one wave, next on the stream - or, in the rollout graph, on a side branch beside the next policy
+//      launch: nothing but the next STEP kernel reads what it writes) reduces the slots in a fixed order (deterministic, run-to-run
+//      identical), replays the reference's decision sequence (lin gate -> maybe widen -> ang gate -> maybe widen), writes the
+//      command block + the tracker operations for the next pass and bumps the step counter (curriculum_decide).
+// Until round 2 step 2 ran inside the step kernel, in the wave that took the last of an agent-scope ticket: the write-through
+// stores, the drain, the ticket round trip and the last arriver's dependent loads put 18 k cycles (7.6 us) behind the physics of
+// the last tile (tools/stamp_probe.py) for 1.5 us of boundary saved.  No wave ever touches another wave's envs, so the per-env
+// trackers need no cross-workgroup visibility at all; they simply lag the reference's by one pass (the oracle keeps the same
+// representation; the decisions are the reference's own).
 #pragma once
 
 namespace lt {
@@ -44,10 +47,9 @@ struct CurIn {
   bool cmd_nonzero;  // the env's command after this step's command update
 };
 
-// Steps 1-3.  One block of the launch = one wave64 with lane = env * 4 + leg (the step kernel's mapping); every wave of the
-// grid calls this exactly once, after its last read of the command block.  Returns true in the wave that arrived last:
-// that wave (only) then calls curriculum_decide - at the very end of the kernel, where nothing else is live in registers.
-__device__ __forceinline__ bool curriculum_publish(const lt_layout& L, char* const arena, long long gid, int leg, const CurIn& in) {
+// Step 1.  One block of the launch = one wave64 with lane = env * 4 + leg (the step kernel's mapping); every 16-env tile of the
+// grid calls this exactly once per pass.
+__device__ __forceinline__ void curriculum_publish(const lt_layout& L, char* const arena, long long gid, int leg, const CurIn& in) {
   float* const P = (float*)(arena + L.off_cmd_params);
   const long long q4 = L.npad * 4;
   float* const rec_p = (float*)(arena + L.quad_off[LT_F_CURRICULUM]) + gid;
@@ -82,22 +84,15 @@ __device__ __forceinline__ bool curriculum_publish(const lt_layout& L, char* con
   flags = wave_or(flags);
   const float w_llin = wave_sum(mine ? l_lin : 0.f), w_slin = wave_sum(mine ? s_lin : 0.f);
   const float w_lang = wave_sum(mine ? l_ang : 0.f), w_sang = wave_sum(mine ? s_ang : 0.f);
-  // ---- 3. publish (write-through stores), drain, take a ticket ----
+  // ---- 3. publish: this tile's slot (plain stores; the decision kernel starts behind a kernel boundary) ----
   const int lane = threadIdx.x & 63;
-  const unsigned nwaves = (unsigned)(L.npad / 16);
   float* const slots = (float*)(arena + L.off_partials);
-  unsigned* const ticket_p = (unsigned*)(arena + L.off_counters) + 4;  // counters[2], low word
   {
     const float bit[4] = {(float)(flags & 1), (float)((flags >> 1) & 1), (float)((flags >> 2) & 1), (float)((flags >> 3) & 1)};
     const float v = lane == 0 ? bit[0] : lane == 1 ? bit[1] : lane == 2 ? bit[2] : lane == 3 ? w_llin : lane == 4 ? w_slin
                     : lane == 5 ? bit[3] : lane == 6 ? w_lang : w_sang;
-    if (lane < LT_PARTIAL_FLOATS) __hip_atomic_store(slots + (long long)blockIdx.x * LT_PARTIAL_FLOATS + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < LT_PARTIAL_FLOATS) slots[(long long)blockIdx.x * LT_PARTIAL_FLOATS + lane] = v;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  unsigned ticket = 0;
-  if (lane == 0) ticket = __hip_atomic_fetch_add(ticket_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
-  return ticket == nwaves - 1;
 }
 
 // The reference's decision sequence on one pass's population sums `r` (lin gate -> maybe widen -> ang gate -> maybe widen);
@@ -173,25 +168,27 @@ __device__ __forceinline__ void curriculum_apply_global(const lt_cfg& c, const l
   }
 }
 
-// Step 4, last arriver only: fixed-order reduction of the slots, then the reference's decision sequence.
+// Step 2 (one wave): fixed-order reduction of the slots, then the reference's decision sequence.
 __device__ __forceinline__ void curriculum_decide(const lt_cfg& c, const lt_layout& L, char* const arena, int bump_counter) {
   float* const P = (float*)(arena + L.off_cmd_params);
   const int lane = threadIdx.x & 63;
   const unsigned nwaves = (unsigned)(L.npad / 16);
-  float* const slots = (float*)(arena + L.off_partials);
-  unsigned* const ticket_p = (unsigned*)(arena + L.off_counters) + 4;  // counters[2], low word
+  const float* const slots = (const float*)(arena + L.off_partials);
+  long long* const cnt = (long long*)(arena + L.off_counters);
+  // everything this wave reads is requested up front: one memory round trip, not four dependent ones
+  float Pl[31];
+#pragma unroll
+  for (int i = 0; i < 31; ++i) Pl[i] = P[i];
+  const long long cnt0 = cnt[0], cnt3 = cnt[3];
   float r[LT_PARTIAL_FLOATS];
 #pragma unroll
   for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] = 0.f;
   for (unsigned w = (unsigned)lane; w < nwaves; w += 64) {
 #pragma unroll
-    for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] += __hip_atomic_load(slots + (long long)w * LT_PARTIAL_FLOATS + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] += slots[(long long)w * LT_PARTIAL_FLOATS + i];
   }
 #pragma unroll
   for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] = wave_sum(r[i]);
-  float Pl[31];
-#pragma unroll
-  for (int i = 0; i < 31; ++i) Pl[i] = P[i];
   const bool ext = c.cur_gate_external != 0;  // multi-rank: the success test runs on cross-rank sums (curriculum_apply_global)
   GateOut g = gate_decision(c, Pl, r, 1.f / (float)L.n, !ext, !ext);
   if (g.run) { Pl[24] = g.lin_open ? 1.f : 0.f; Pl[25] = g.ang_open ? 1.f : 0.f; }
@@ -199,17 +196,13 @@ __device__ __forceinline__ void curriculum_decide(const lt_cfg& c, const lt_layo
   Pl[27] = g.lin_open ? 1.f : 0.f; Pl[28] = g.ang_open ? 1.f : 0.f;  // tracker operations for the next pass
   Pl[29] = g.lin_pass ? 1.f : 0.f; Pl[30] = g.ang_pass ? 1.f : 0.f;
   if (lane == 0) {  // this pass's population sums, for a cross-rank gate
-    long long* const cnt = (long long*)(arena + L.off_counters);
-    float* const ring = (float*)(arena + L.off_gate_ring) + (cnt[3] % LT_GATE_RING) * LT_PARTIAL_FLOATS;
+    float* const ring = (float*)(arena + L.off_gate_ring) + (cnt3 % LT_GATE_RING) * LT_PARTIAL_FLOATS;
 #pragma unroll
     for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) ring[i] = r[i];
-    cnt[3] += 1;
-  }
-  if (lane == 0) {
+    cnt[3] = cnt3 + 1;
 #pragma unroll
     for (int i = 0; i < 31; ++i) P[i] = Pl[i];
-    if (bump_counter) ((long long*)(arena + L.off_counters))[0] += 1;
-    __hip_atomic_store(ticket_p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+    if (bump_counter) cnt[0] = cnt0 + 1;
   }
 }
 

@@ -17,3 +17,9 @@ for i, nm in enumerate(names):
 bw = env.field("LT_F_REWARD_TERMS")[::16, :2, 0].cpu()
 print(f"wave 0 waiting in physics barriers: A {bw[:, 0].mean():.0f} ticks, B {bw[:, 1].mean():.0f} ticks (4 substeps)")
 print("total ticks", float(tot), "(s_memtime ticks at 100 MHz => us:", float(tot) / 100.0, ")")
+
+if n <= 4096:  # helper form: when does each wave of a tile finish, relative to its own entry?  (LT_F_REWARD_TERMS quad array 3 carries the stamps)
+    rt = env.field("LT_F_REWARD_TERMS").cpu()  # [n][7][4]
+    ends = rt[::16, 3, :]  # (wave 0 end, wave 1 end, wave 2 end, wave 3 end)
+    print(f"cycles since the wave's entry: wave 0 ends at {ends[:, 0].mean():8.0f} (max {ends[:, 0].max():8.0f}); waves 1 / 2 (history rows) at "
+          f"{ends[:, 1].mean():8.0f} / {ends[:, 2].mean():8.0f} (max {ends[:, 1:3].max():8.0f}); wave 3 (noise RNG, curriculum partials) at {ends[:, 3].mean():8.0f} (max {ends[:, 3].max():8.0f})")
