@@ -194,6 +194,14 @@ class LocoTouchVecEnv:
                                                  vp(next_policy or None), vp(next_critic or None), vp(values_ptr), float(gamma),
                                                  vp(st_rewards_ptr), vp(st_dones_ptr), self._stream()), "lt_env_step_rollout")
 
+    def defer_gate(self, on: bool) -> None:
+        """lt_env_defer_gate: the step entry points stop launching the population pass (curriculum decision, population gate,
+        step counter); the caller runs `gate_update()` after every step, on any stream ordered after the step's."""
+        _abi.check(self._lib.lt_env_defer_gate(self._handle, 1 if on else 0), "lt_env_defer_gate")
+
+    def gate_update(self) -> None:
+        _abi.check(self._lib.lt_env_gate_update(self._handle, self._stream()), "lt_env_gate_update")
+
     @property
     def handle(self) -> ctypes.c_void_p:
         return self._handle

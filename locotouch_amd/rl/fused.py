@@ -4,10 +4,11 @@
 
 Packed path (network shapes lt_mlp.hip covers - every LocoTouch agent config): launches on ONE stream,
     [lt_rollout_policy_value: actor + critic MLPs, sampling, log-prob, storage writes of actions/mu/sigma/values/log-prob]
- -> [lt_env_step_rollout: env step, observation rows written into storage slot t+1, bootstrapped reward + dones into slot t,
-     curriculum / population gate / step counter at the kernel's tail]
+ -> [lt_env_step_rollout: env step, observation rows written into storage slot t+1, bootstrapped reward + dones into slot t;
+     behind it the one-wave population pass: curriculum decision / population gate / step counter]
 with no host sync, so a whole 24-step rollout captures into one hipGraph.  The chain is kept linear on purpose: forked
-streams turn graph edges into cross-queue dependencies that cost more (~10 us each on this stack) than the overlap returns.
+streams turn graph edges into cross-queue dependencies that cost more than the overlap returns (measured again with the
+population pass on a side branch beside the next policy launch, lt_env_defer_gate: 99.8 us per step against 86.3 us linear).
 
 Torch path (shapes outside lt_mlp's limits): torch GEMMs -> lt_rollout_act -> lt_env_step_rows -> lt_rollout_record, with the
 critic on a side stream.
@@ -74,7 +75,7 @@ class FusedRollout:
     @property
     def launches_per_step(self) -> int:
         """Kernel launches of one rollout step (the reference-shaped eager loop needs ~30)."""
-        return 2 if self.actor_mlp is not None else 11
+        return 3 if self.actor_mlp is not None else 12  # policy + value, env step, population pass (one wave)
 
     def policy_value_launch(self, t: int) -> None:
         """The MLP launch of step t alone (bench.py times it for the MFMA roofline entry)."""
@@ -88,8 +89,8 @@ class FusedRollout:
             "lt_rollout_policy_value")
 
     def _step_packed(self, t: int, last: bool) -> None:
-        """Two launches on ONE stream (a linear graph: cross-queue edges of a forked graph cost ~10 us each on this stack):
-        [actor + critic MLPs + sampling] -> [env step + storage record + curriculum tail]."""
+        """Launches on ONE stream (a linear graph: cross-queue edges of a forked graph cost more than they return on this stack):
+        [actor + critic MLPs + sampling] -> [env step + storage record] -> [population pass, one wave]."""
         env, alg, st, p = self.env, self.alg, self.alg.storage, self._p
         ac = alg.actor_critic
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

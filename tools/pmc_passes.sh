@@ -1,7 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r02f
+OUT=$R/gpurun_out/r02pmc
 mkdir -p $OUT
 for N in 4096 32768; do
   for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
@@ -13,7 +13,7 @@ import csv, sys, glob
 n, tag = sys.argv[1:3]
 src = glob.glob('/tmp/pmc/*counter_collection.csv')[0]
 import os
-out = os.path.join(os.environ['GRAFT_REPO_ROOT'], 'gpurun_out', 'r02f', f'cc_{n}_{tag}.csv')
+out = os.path.join(os.environ['GRAFT_REPO_ROOT'], 'gpurun_out', 'r02pmc', f'cc_{n}_{tag}.csv')
 rows = [r for r in csv.DictReader(open(src)) if 'lt_step_kernel' in r['Kernel_Name'] or 'lt_mlp_kernel' in r['Kernel_Name']]
 w = csv.DictWriter(open(out, 'w'), fieldnames=['Kernel_Name', 'Counter_Name', 'Counter_Value'])
 w.writeheader()
