@@ -274,7 +274,7 @@ enum lt_field {
   LT_F_TIME_OUT,        /* uint8 [N] */
   LT_F_TERM_BITS,       /* int32 [N] which termination terms fired this step */
   LT_F_CMD_PARAMS,      /* float [LT_CMD_PARAMS_LEN], device-resident command/curriculum block */
-  LT_F_COUNTERS,        /* int64 [4]: (common_step_counter, _, _ (ABI <= 6: arrival ticket of the in-kernel reduction),
+  LT_F_COUNTERS,        /* int64 [4]: (common_step_counter, _, scratch: step id whose chained population pass is final (lt_env_defer_gate mode 2),
                          *             number of curriculum passes so far = next LT_F_GATE_RING slot, mod LT_GATE_RING) */
   LT_F_GATE_RING,       /* float [LT_GATE_RING][8]: the population sums of the last curriculum passes, one row per pass:
                          * (envs with a non-zero command, envs reset this step, lin trackers not all reset, sum ep_len lin,
@@ -350,11 +350,16 @@ int lt_env_step_rows(lt_env* env, const float* actions, const float* prev_policy
 int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_policy, const float* prev_critic, float* next_policy,
                         float* next_critic, const float* values, float gamma, float* st_rewards, uint8_t* st_dones, void* stream);
 /* The population pass of a step - curriculum decision, population gate of rewards.py:190, common_step_counter += 1
- * (curriculums.py:184-275; csrc/lt_post.h) - is a one-wave kernel that every step entry point launches behind the step kernel.
- * lt_env_defer_gate(env, 1) leaves that launch to the caller: lt_env_gate_update(env, stream) must then run once after every step
- * and before the next one, on any stream ordered after the step's - nothing but the next STEP reads what it writes, so a rollout
- * graph runs it on a side branch beside the next policy launch.  Results are identical either way. */
-int lt_env_defer_gate(lt_env* env, int on);
+ * (curriculums.py:184-275; csrc/lt_post.h) - needs sums over all envs; it is one wave of work.  lt_env_defer_gate(env, mode):
+ *   0 (default) every step entry point launches it behind the step kernel: after a step the command block and the counters are final;
+ *   1 the caller launches it: lt_env_gate_update(env, stream) once after every step and before the next one, on any stream ordered
+ *     after the step's (nothing but the next STEP reads what it writes);
+ *   2 chained: the pass of step t runs INSIDE the launch of step t + 1 (one workgroup's idle wave, beside the physics - a step reads
+ *     the command block only after its physics), so a chain of steps is one launch per step.  A chain ends with lt_env_gate_update,
+ *     before anything else reads the command block or the counters (between the steps of a chain both lag by the outstanding
+ *     passes).  Grids beyond one workgroup per CU behave as mode 0.
+ * Results are identical in all modes.  Mode 0 can only be selected while no pass is outstanding. */
+int lt_env_defer_gate(lt_env* env, int mode);
 int lt_env_gate_update(lt_env* env, void* stream);
 /* Profiling variant of lt_env_step: HIP events bracket the step kernel on `stream`; the call WAITS for them (host
  * sync - never use it inside a captured region) and returns the step kernel's duration in milliseconds. */

@@ -46,6 +46,11 @@ struct KArgs {
   float rec_gamma;
   float* rec_rewards;
   unsigned char* rec_dones;
+  // chained steps (lt_env_defer_gate mode 2; helper form): `step_offset` steps precede this one whose common_step_counter bump is
+  // still outstanding (step id = counters[0] + step_offset); `decide_first`: the population pass of the previous step has not run
+  // yet - workgroup 0's RNG wave runs it beside this step's first physics substep (lt_post.h, chained form)
+  int step_offset;
+  int decide_first;
 };
 static_assert(sizeof(lt_dev_args) <= LT_DEV_ARGS_BYTES, "lt_dev_args outgrew its arena slot");
 
@@ -671,8 +676,10 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   __syncthreads();  // B0: the (cfg, layout) block is in LDS
   const lt_cfg& c = s_d.cfg;
   const lt_layout& L = s_d.layout;
-  const float* P = (const float*)(arena + L.off_cmd_params);
-  const uint64_t step = MODE == MODE_RESET_ALL ? 0ull : (uint64_t)((const long long*)(arena + L.off_counters))[0];
+  // the command block: global memory, or - helper form - the copy wave 3 leaves in LDS beside the last physics substep
+  __shared__ float s_P[HELPERS ? 32 : 1];
+  const float* P = (HELPERS && MODE == MODE_STEP) ? (const float*)s_P : (const float*)(arena + L.off_cmd_params);
+  const uint64_t step = MODE == MODE_RESET_ALL ? 0ull : (uint64_t)(((const long long*)(arena + L.off_counters))[0] + (MODE == MODE_STEP ? a.step_offset : 0));
   const float step_dt = c.sim_dt * (float)c.decimation;
   const uint32_t ekey = (uint32_t)env + (uint32_t)c.env_index_offset;  // RNG stream key of this env (global index over all ranks)
 
@@ -730,6 +737,20 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
           // per-env streams, one per lane of the quad; slot 6 is the object-material pool entry picked by RS_RESET_MAT's third draw.
           auto put = [&](int slot, const U4& u) { s_bank[slot][0][lane] = u.a; s_bank[slot][1][lane] = u.b; s_bank[slot][2][lane] = u.c; s_bank[slot][3][lane] = u.d; };
           const int last = nsub - 1;
+          // chained steps: the previous step's population pass, once per launch, here - ~6 k cycles inside an 11 k-cycle substep
+          if (it == 0 && a.decide_first && blockIdx.x == 0) curriculum_decide(c, L, arena, 0, (long long)step);
+          if (it == last) {
+            // the command block of THIS step -> LDS.  Chained: wait until the launch's decision is final (it has been for ~35 us)
+            // and read it with sc1 loads; nobody in this launch read the block earlier, so no cache of this XCD holds an older line.
+            const float* const Pg = (const float*)(arena + L.off_cmd_params);
+            if (a.decide_first) {
+              const long long* const flag = (const long long*)(arena + L.off_counters) + 2;
+              while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (long long)step) __builtin_amdgcn_s_sleep(2);
+              if (lane < 31) s_P[lane] = __hip_atomic_load(Pg + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (lane < 31) {
+              s_P[lane] = Pg[lane];
+            }
+          }
           if (it == 0) {
             put(0, rng4(c.seed, ekey, step, RS_RESET_ROOT + leg));
             put(1, rng4(c.seed, ekey, step, RS_RESET_JOINT + leg));
@@ -772,7 +793,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       in.valid = env < L.n;
       in.reset = s_cur[lane * 5 + 0] != 0.f; in.ep_len = s_cur[lane * 5 + 1];
       in.sum_lin = s_cur[lane * 5 + 2]; in.sum_ang = s_cur[lane * 5 + 3]; in.cmd_nonzero = s_cur[lane * 5 + 4] != 0.f;
-      curriculum_publish(L, arena, gid, leg, in);  // the decision is lt_gate_decide_kernel's, behind this launch
+      curriculum_publish(L, arena, P, gid, leg, in);  // the decision is lt_gate_decide_kernel's (or the next launch's, chained)
 #ifdef LT_STAMPS
       LT_STAMP(1);
       if (lane == 0) ((float*)(arena + L.quad_off[LT_F_REWARD_TERMS]) + 3 * L.npad * 4 + (long long)blockIdx.x * 64)[3] = (float)(long long)(stamps_[1] - stamps_[0]);
@@ -1311,7 +1332,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       s_cur[lane * 5 + 0] = cur_in.reset ? 1.f : 0.f; s_cur[lane * 5 + 1] = cur_in.ep_len;
       s_cur[lane * 5 + 2] = cur_in.sum_lin; s_cur[lane * 5 + 3] = cur_in.sum_ang; s_cur[lane * 5 + 4] = cur_in.cmd_nonzero ? 1.f : 0.f;
     } else {
-      curriculum_publish(L, arena, gid, leg, cur_in);
+      curriculum_publish(L, arena, P, gid, leg, cur_in);
     }
   }
 
@@ -1513,7 +1534,7 @@ __global__ __launch_bounds__(64) void lt_curriculum_kernel(const KArgs a, const 
   in.ep_len = r[1]; in.sum_lin = r[2]; in.sum_ang = r[3];
   const float cm = ((const float*)(a.arena + L.quad_off[LT_F_CMD]))[gid];
   in.cmd_nonzero = qor((leg < 3 && cm != 0.f) ? 1 : 0) != 0;
-  curriculum_publish(L, a.arena, gid, leg, in);
+  curriculum_publish(L, a.arena, (const float*)(a.arena + L.off_cmd_params), gid, leg, in);
 }
 // the global half of the pass (lt_post.h): one wave behind the step kernel / the curriculum hook
 __global__ __launch_bounds__(64) void lt_gate_decide_kernel(const KArgs a, int bump_counter) {
@@ -1575,6 +1596,7 @@ KArgs make_args(const lt_env* env, const float* actions) {
   k.obs_prev[0] = rp; k.obs_prev[1] = rc;
   k.obs_next[0] = rp; k.obs_next[1] = rc;
   k.rec_values = nullptr; k.rec_gamma = 0.f; k.rec_rewards = nullptr; k.rec_dones = nullptr;
+  k.step_offset = 0; k.decide_first = 0;
   return k;
 }
 
@@ -1601,6 +1623,17 @@ int launch_step(const lt_env* env, const float* actions, hipStream_t s, const fl
     return (unsigned)cus;
   }();
   const bool helpers = MODE == MODE_STEP && grid.x <= helpers_max;
+  // population pass of the step (lt_post.h): its own one-wave launch behind the step kernel (mode 0), the caller's (mode 1), or
+  // chained into the next step launch (mode 2; helper form only - larger grids fall back to mode 0 behaviour)
+  const int gate_mode = (MODE == MODE_STEP && with_gate) ? ((env->defer_gate == 2 && !helpers) ? 0 : env->defer_gate) : -1;
+  if (MODE == MODE_STEP) {
+    k.step_offset = env->pending_steps;
+    k.decide_first = (helpers && env->gate_pending) ? 1 : 0;
+    if (env->gate_pending && !k.decide_first) {  // an outstanding pass this launch cannot absorb: run it now
+      hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(64), 0, s, k, env->pending_steps);
+      env->pending_steps = 0; env->gate_pending = 0; k.step_offset = 0;
+    }
+  }
   if (env->cfg.task == LT_TASK_LOCOMOTION) {
     if (helpers) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, MODE == MODE_STEP>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, false>), grid, dim3(64), 0, s, k);
@@ -1613,7 +1646,15 @@ int launch_step(const lt_env* env, const float* actions, hipStream_t s, const fl
   }
   // the population pass of the step (curriculum decision, population gate, step counter): one wave behind the step kernel,
   // unless the caller places it itself (lt_env_defer_gate: beside the next policy launch in the rollout graph)
-  if (MODE == MODE_STEP && with_gate && !env->defer_gate) hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(64), 0, s, k, 1);
+  if (MODE == MODE_STEP) {
+    const int outstanding = env->pending_steps + 1;  // this step's bump joins the ones before it
+    if (gate_mode == 0) {
+      hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(64), 0, s, k, outstanding);
+      env->pending_steps = 0; env->gate_pending = 0;
+    } else {  // modes 1, 2 (and the profiled launch, whose caller launches the pass behind its stop event)
+      env->pending_steps = outstanding; env->gate_pending = 1;
+    }
+  }
   return (int)hipGetLastError();
 }
 
@@ -1661,7 +1702,7 @@ int lt_launch_step_profiled(lt_env* env, const float* actions, void* stream, flo
   int rc = launch_step<MODE_STEP>(env, actions, s, nullptr, nullptr, nullptr, false);  // the events bracket lt_step_kernel alone
   if (rc != 0) return rc;
   if ((e = hipEventRecord((hipEvent_t)env->ev_stop, s)) != hipSuccess) return (int)e;
-  if (!env->defer_gate && (rc = lt_launch_gate_decide(env, 1, s)) != 0) return rc;
+  if (!env->defer_gate && (rc = lt_launch_gate_decide(env, -1, s)) != 0) return rc;
   if ((e = hipEventSynchronize((hipEvent_t)env->ev_stop)) != hipSuccess) return (int)e;
   return (int)hipEventElapsedTime(ms, (hipEvent_t)env->ev_start, (hipEvent_t)env->ev_stop);
 }
@@ -1688,9 +1729,12 @@ int lt_launch_curriculum(const lt_env* env, const float* records, void* stream) 
   return (int)hipGetLastError();
 }
 
+// the outstanding population pass (if any) with every outstanding step-counter bump; `bump_counter` < 0: those, else exactly that many
 int lt_launch_gate_decide(const lt_env* env, int bump_counter, void* stream) {
   const KArgs k = make_args(env, nullptr);
-  hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, bump_counter);
+  const int bump = bump_counter < 0 ? env->pending_steps : bump_counter;
+  hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, bump);
+  env->pending_steps = 0; env->gate_pending = 0;
   return (int)hipGetLastError();
 }
 

@@ -199,16 +199,18 @@ int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_pol
   return finish(lt_launch_step_rows(env, actions, prev, next, values, gamma, st_rewards, st_dones, stream), "lt_env_step_rollout");
 }
 
-int lt_env_defer_gate(lt_env* env, int on) {
-  if (!env) return LT_EINVAL;
-  env->defer_gate = on ? 1 : 0;
+int lt_env_defer_gate(lt_env* env, int mode) {
+  if (!env || mode < 0 || mode > 2) return LT_EINVAL;
+  if (env->gate_pending && mode == 0) { lt_set_error("lt_env_defer_gate: a population pass is outstanding - call lt_env_gate_update first"); return LT_EINVAL; }
+  env->defer_gate = mode;
   return LT_OK;
 }
 
 int lt_env_gate_update(lt_env* env, void* stream) {
   if (!env) return LT_EINVAL;
   if (!env->arena) { lt_set_error("lt_env_gate_update: arena not bound"); return LT_EFAULT; }
-  return finish(lt_launch_gate_decide(env, 1, stream), "lt_env_gate_update");
+  if (!env->gate_pending) return LT_OK;
+  return finish(lt_launch_gate_decide(env, -1, stream), "lt_env_gate_update");
 }
 
 int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float* step_kernel_ms) {

@@ -14,7 +14,9 @@ struct lt_env {
   size_t arena_bytes = 0;
   void* ev_start = nullptr;  // hipEvent_t pair for lt_env_step_profiled (created lazily)
   void* ev_stop = nullptr;
-  int defer_gate = 0;        // lt_env_defer_gate: the caller launches the population pass (lt_env_gate_update) itself
+  int defer_gate = 0;        // lt_env_defer_gate mode: 0 pass behind every step, 1 the caller's lt_env_gate_update, 2 chained (next step launch)
+  mutable int pending_steps = 0;  // steps launched whose common_step_counter bump is outstanding (modes 1, 2)
+  mutable int gate_pending = 0;   // a population pass is outstanding
 };
 
 // implemented in lt_env.hip -------------------------------------------------------------------------

@@ -49,8 +49,8 @@ struct CurIn {
 
 // Step 1.  One block of the launch = one wave64 with lane = env * 4 + leg (the step kernel's mapping); every 16-env tile of the
 // grid calls this exactly once per pass.
-__device__ __forceinline__ void curriculum_publish(const lt_layout& L, char* const arena, long long gid, int leg, const CurIn& in) {
-  float* const P = (float*)(arena + L.off_cmd_params);
+// `P`: the command block as this tile may read it (global memory, or the workgroup's LDS copy in the step kernel's helper form).
+__device__ __forceinline__ void curriculum_publish(const lt_layout& L, char* const arena, const float* const P, long long gid, int leg, const CurIn& in) {
   const long long q4 = L.npad * 4;
   float* const rec_p = (float*)(arena + L.quad_off[LT_F_CURRICULUM]) + gid;
   float* const t1_p = rec_p + q4;
@@ -169,7 +169,12 @@ __device__ __forceinline__ void curriculum_apply_global(const lt_cfg& c, const l
 }
 
 // Step 2 (one wave): fixed-order reduction of the slots, then the reference's decision sequence.
-__device__ __forceinline__ void curriculum_decide(const lt_cfg& c, const lt_layout& L, char* const arena, int bump_counter) {
+// `bump_counter`: added to common_step_counter (the steps whose pass this call completes).
+// `chain_flag` != 0 - the chained form: the pass of step t runs inside the launch of step t + 1 (lt_step_kernel, workgroup 0's RNG
+// wave, beside the first physics substep; nothing of a step reads the command block before its physics is over).  The command block
+// is then stored write-through and drained, and counters[2] = chain_flag (the launch's step id) tells the other workgroups of that
+// launch that it is final (MI355X_MICROARCH.md, "Valid forms": sc1 payload -> vmcnt(0) -> flag; consumers poll and load with sc1).
+__device__ __forceinline__ void curriculum_decide(const lt_cfg& c, const lt_layout& L, char* const arena, int bump_counter, long long chain_flag = 0) {
   float* const P = (float*)(arena + L.off_cmd_params);
   const int lane = threadIdx.x & 63;
   const unsigned nwaves = (unsigned)(L.npad / 16);
@@ -200,9 +205,16 @@ __device__ __forceinline__ void curriculum_decide(const lt_cfg& c, const lt_layo
 #pragma unroll
     for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) ring[i] = r[i];
     cnt[3] = cnt3 + 1;
+    if (chain_flag) {
 #pragma unroll
-    for (int i = 0; i < 31; ++i) P[i] = Pl[i];
-    if (bump_counter) cnt[0] = cnt0 + 1;
+      for (int i = 0; i < 31; ++i) __hip_atomic_store(P + i, Pl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(cnt + 2, chain_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 31; ++i) P[i] = Pl[i];
+    }
+    if (bump_counter) cnt[0] = cnt0 + bump_counter;
   }
 }
 

@@ -194,12 +194,14 @@ class LocoTouchVecEnv:
                                                  vp(next_policy or None), vp(next_critic or None), vp(values_ptr), float(gamma),
                                                  vp(st_rewards_ptr), vp(st_dones_ptr), self._stream()), "lt_env_step_rollout")
 
-    def defer_gate(self, on: bool) -> None:
-        """lt_env_defer_gate: the step entry points stop launching the population pass (curriculum decision, population gate,
-        step counter); the caller runs `gate_update()` after every step, on any stream ordered after the step's."""
-        _abi.check(self._lib.lt_env_defer_gate(self._handle, 1 if on else 0), "lt_env_defer_gate")
+    def defer_gate(self, mode: int) -> None:
+        """lt_env_defer_gate (include/lt_env.h): where the population pass of a step (curriculum decision, population gate, step
+        counter) runs - 0 behind every step (default), 1 the caller's `gate_update()`, 2 chained into the next step launch (a
+        chain ends with `gate_update()`; until then the command block and the counters lag)."""
+        _abi.check(self._lib.lt_env_defer_gate(self._handle, int(mode)), "lt_env_defer_gate")
 
     def gate_update(self) -> None:
+        """The outstanding population pass, if any (lt_env_gate_update)."""
         _abi.check(self._lib.lt_env_gate_update(self._handle, self._stream()), "lt_env_gate_update")
 
     @property

@@ -5,7 +5,8 @@
 Packed path (network shapes lt_mlp.hip covers - every LocoTouch agent config): launches on ONE stream,
     [lt_rollout_policy_value: actor + critic MLPs, sampling, log-prob, storage writes of actions/mu/sigma/values/log-prob]
  -> [lt_env_step_rollout: env step, observation rows written into storage slot t+1, bootstrapped reward + dones into slot t;
-     behind it the one-wave population pass: curriculum decision / population gate / step counter]
+     the one-wave population pass of the PREVIOUS step (curriculum decision / population gate) rides in this launch, on an idle
+     wave beside the physics (lt_env_defer_gate mode 2); one explicit pass closes the rollout]
 with no host sync, so a whole 24-step rollout captures into one hipGraph.  The chain is kept linear on purpose: forked
 streams turn graph edges into cross-queue dependencies that cost more than the overlap returns (measured again with the
 population pass on a side branch beside the next policy launch, lt_env_defer_gate: 99.8 us per step against 86.3 us linear).
@@ -75,7 +76,7 @@ class FusedRollout:
     @property
     def launches_per_step(self) -> int:
         """Kernel launches of one rollout step (the reference-shaped eager loop needs ~30)."""
-        return 3 if self.actor_mlp is not None else 12  # policy + value, env step, population pass (one wave)
+        return 2 if self.actor_mlp is not None else 11  # policy + value, env step (the population pass rides in the next step's launch)
 
     def policy_value_launch(self, t: int) -> None:
         """The MLP launch of step t alone (bench.py times it for the MFMA roofline entry)."""
@@ -89,8 +90,8 @@ class FusedRollout:
             "lt_rollout_policy_value")
 
     def _step_packed(self, t: int, last: bool) -> None:
-        """Launches on ONE stream (a linear graph: cross-queue edges of a forked graph cost more than they return on this stack):
-        [actor + critic MLPs + sampling] -> [env step + storage record] -> [population pass, one wave]."""
+        """Two launches on ONE stream (a linear graph: cross-queue edges of a forked graph cost more than they return on this stack):
+        [actor + critic MLPs + sampling] -> [env step + storage record (+ the previous step's population pass on an idle wave)]."""
         env, alg, st, p = self.env, self.alg, self.alg.storage, self._p
         ac = alg.actor_critic
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -147,5 +148,15 @@ class FusedRollout:
             if self.rows_in_storage:
                 st.observations[0].copy_(env.obs_policy)
                 st.privileged_observations[0].copy_(env.obs_critic)
-            for t in range(num_steps):
-                self.step(t, last=t == num_steps - 1)
+            # chained steps (lt_env_defer_gate mode 2): the one-wave population pass of step t runs inside the launch of step t + 1,
+            # beside its physics, so a rollout step is two launches; the pass of the last step closes the chain
+            chain = not env.tactile  # (the tactile kernel keys its draws by the step counter, which lags inside a chain)
+            if chain:
+                env.defer_gate(2)
+            try:
+                for t in range(num_steps):
+                    self.step(t, last=t == num_steps - 1)
+            finally:
+                if chain:
+                    env.gate_update()
+                    env.defer_gate(0)

@@ -223,6 +223,50 @@ def test_global_gate_kernel_matches_oracle():
     assert int(L.arr(ora.arena, "LT_F_COUNTERS")[3]) == 30 * rollout
 
 
+def test_chained_population_pass_equals_the_pass_behind_every_step():
+    """lt_env_defer_gate mode 2: the population pass of step t (curriculum decision, population gate, step counter) runs inside the
+    launch of step t + 1, on workgroup 0's RNG wave beside the physics; the other workgroups read the command block it leaves
+    through the flag / sc1 protocol.  Chains of irregular length against the default mode on a twin env: identical arenas, bit for
+    bit (counters[2], the chain's scratch flag, aside), with a curriculum that really widens the command ranges on the way."""
+    import torch
+    from locotouch_amd.env import LocoTouchVecEnv
+
+    n = 4096  # 256 tiles: every CU has one, so the cross-workgroup hand-off of the command block is exercised across all XCDs
+    cfg = _abi.preset_cfg(TASKS["teacher"], num_envs=n, seed=23)
+    cfg.max_episode_length, cfg.cur_len_threshold = 10, 2.0  # frequent time-outs: the gate opens and the ranges widen within the run
+    cfg.cur_reward_threshold[0] = cfg.cur_reward_threshold[1] = -1.0e3
+    a = LocoTouchVecEnv(TASKS["teacher"], device="cuda:0", cfg=cfg)
+    b = LocoTouchVecEnv(TASKS["teacher"], device="cuda:0", cfg=cfg)
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    P0 = a.cmd_params.clone()
+    t = 0
+    for chain in (1, 2, 5, 24, 3, 24, 7):
+        a.defer_gate(2)
+        for _ in range(chain):
+            act = 0.4 * torch.randn(n, 12, device="cuda:0", generator=g)
+            a.step_rows_raw(act.data_ptr(), 0, 0, 0, 0)
+            b.step(act)
+            t += 1
+        a.gate_update()
+        a.defer_gate(0)
+        torch.cuda.synchronize()
+        ha, hb = a._arena_aligned.clone(), b._arena_aligned.clone()
+        L = Layout(n, a.num_obs)
+        off = L.plain["LT_F_COUNTERS"][0] + 16
+        ha[off:off + 8] = 0
+        hb[off:off + 8] = 0
+        assert torch.equal(ha, hb), f"after {t} steps (chain of {chain})"
+        assert int(a.counters[0]) == t + 1
+    assert not torch.equal(a.cmd_params[:6], P0[:6]), "the command ranges must have widened"
+    # a pass left outstanding is absorbed by the next launch whatever the mode; mode 0 cannot be selected over it
+    a.defer_gate(1)
+    a.step_rows_raw(act.data_ptr(), 0, 0, 0, 0)
+    with pytest.raises(RuntimeError):
+        a.defer_gate(0)
+    a.gate_update()
+    a.defer_gate(0)
+
+
 def test_free_running_statistics_teacher():
     """Without re-syncing, chaotic contact dynamics decorrelate trajectories; episode statistics must still agree."""
     import torch
@@ -464,7 +508,8 @@ def test_fused_rollout_kernels_match_torch():
         nxt_c = st.privileged_observations[t + 1] if t < 2 else env.obs_critic
         assert torch.equal(o, nxt_p) and torch.equal(twin.obs_critic, nxt_c), f"step {t}"
         assert torch.equal(d.to(torch.uint8), st.dones[t].squeeze(1))
-    assert torch.equal(twin.counters, env.counters) and torch.equal(twin.cmd_params, env.cmd_params)
+    # (counters[2] is scratch: the chained rollout leaves its last step id there, include/lt_env.h)
+    assert torch.equal(twin.counters[[0, 3]], env.counters[[0, 3]]) and torch.equal(twin.cmd_params, env.cmd_params)
     assert torch.equal(st.observations[0], obs0) and torch.equal(st.privileged_observations[0], cobs0)
     torch.testing.assert_close(st.mu[0], mu_ref, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(st.values[0], v_ref, rtol=1e-5, atol=1e-5)
