@@ -110,3 +110,51 @@ def test_product_path_has_no_oracle_dependency():
         assert not re.search(r'#include\s+"[^"]*oracle', text), path
         assert not re.search(r"oracle_lib|liblt_oracle|from\s+oracle|import\s+oracle|lt_oracle_\w+\s*\(", text), path
     _ = np
+
+
+def test_update_and_recurrence_entry_points_validate_their_arguments_before_touching_the_gpu():
+    """Error behaviour of the PPO-update / GRU entry points (include/lt_env.h): a bad argument is LT_EINVAL with a message, decided
+    on the host - no launch, so this runs without a GPU."""
+    lib = _abi.load()
+    vp = ctypes.c_void_p
+    one = vp(16)  # any non-null address: argument checks come before the first dereference / launch
+    null = vp(None)
+    bad = C["LT_EINVAL"]
+    # lt_ppo_loss: null operand, zero rows, more than 16 actions
+    args = [one] * 10 + [null]
+    assert lib.lt_ppo_loss(*([null] + args[1:]), 128, 12, 0.2, 1.0, 1, one, one, one, null) == bad
+    assert lib.lt_ppo_loss(*args, 0, 12, 0.2, 1.0, 1, one, one, one, null) == bad
+    assert lib.lt_ppo_loss(*args, 128, 17, 0.2, 1.0, 1, one, one, one, null) == bad
+    assert b"lt_ppo_loss" in lib.lt_last_error()
+    # lt_elu_backward_bias: N not a multiple of 4 / beyond 1024
+    assert lib.lt_elu_backward_bias(one, one, 64, 130, 1.0, one, one, one, null) == bad
+    assert lib.lt_elu_backward_bias(one, one, 64, 2048, 1.0, one, one, one, null) == bad
+    assert lib.lt_elu_backward_bias_ws_floats(96, 512) == 2 * 512 and lib.lt_elu_backward_bias_ws_floats(97, 512) == 3 * 512
+    # lt_head_wgrad: more than 16 outputs, k not a multiple of 4, partials beyond one block's LDS
+    assert lib.lt_head_wgrad(one, one, 64, 17, 128, one, one, one, null) == bad
+    assert lib.lt_head_wgrad(one, one, 64, 12, 130, one, one, one, null) == bad
+    assert lib.lt_head_wgrad(one, one, 64, 16, 1024, one, one, one, null) == bad and b"LDS" in lib.lt_last_error()
+    assert lib.lt_head_wgrad_ws_floats(96, 12, 128) == 12 * 128 + 16
+    # lt_adam_clip_step: empty buffer, step 0
+    assert lib.lt_adam_clip_step(one, one, one, one, 0, 1.0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, one, null, null) == bad
+    assert lib.lt_adam_clip_step(one, one, one, one, 10, 1.0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, one, null, null) == bad
+    assert lib.lt_adam_clip_step_ws_floats(2048) == 1 and lib.lt_adam_clip_step_ws_floats(2049) == 2
+    # GRU: hidden size must be a multiple of 64
+    assert lib.lt_gru_forward(one, one, one, one, one, 4, 8, 96, one, one, null) == bad
+    assert lib.lt_gru_backward(one, null, one, one, one, one, 4, 8, 96, one, one, one, one, null) == bad
+    assert b"multiple of 64" in lib.lt_last_error()
+
+
+def test_population_pass_placement_api():
+    """lt_env_defer_gate / lt_env_gate_update (include/lt_env.h): modes 0..2, nothing to do while no pass is outstanding, no launch
+    without a bound arena."""
+    lib = _abi.load()
+    cfg = _abi.default_cfg(1, num_envs=64)
+    h = ctypes.c_void_p()
+    assert lib.lt_env_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    for mode in (0, 1, 2, 0):
+        assert lib.lt_env_defer_gate(h, mode) == 0
+    assert lib.lt_env_defer_gate(h, 3) == C["LT_EINVAL"] and lib.lt_env_defer_gate(h, -1) == C["LT_EINVAL"]
+    assert lib.lt_env_defer_gate(None, 0) == C["LT_EINVAL"]
+    assert lib.lt_env_gate_update(h, None) == C["LT_EFAULT"] and b"not bound" in lib.lt_last_error()
+    assert lib.lt_env_destroy(h) == 0
