@@ -1078,16 +1078,19 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     const float cn = norm(cmd);
     const float lin_err = sqrtf((cmd.x - vb.x) * (cmd.x - vb.x) + (cmd.y - vb.y) * (cmd.y - vb.y));
     const float ang_err = fabsf(cmd.z - wb.z);
-    if (w[LT_R_ALIVE] != 0.f) terms[LT_R_ALIVE] = alive_in ? 0.f : 1.f;
-    if (w[LT_R_TRACK_LIN_VEL_XY] != 0.f) terms[LT_R_TRACK_LIN_VEL_XY] = expf(-(lin_err / c.track_sigma));       // :15-20
-    if (w[LT_R_TRACK_ANG_VEL_Z] != 0.f) terms[LT_R_TRACK_ANG_VEL_Z] = expf(-(ang_err / c.track_sigma));         // :22-27
+    // Every term is evaluated and then kept or zeroed by its weight (a select, not a branch: a disabled term stays exactly 0, as
+    // the guarded form and the oracle have it).  25 guarded terms were 25 scheduling regions; as straight-line code their
+    // independent dependency chains interleave - a lone wave issues a DEPENDENT VALU operation only every 7 cycles.
+    auto on = [&](int i, float v) { return w[i] != 0.f ? v : 0.f; };
+    terms[LT_R_ALIVE] = on(LT_R_ALIVE, alive_in ? 0.f : 1.f);
+    terms[LT_R_TRACK_LIN_VEL_XY] = on(LT_R_TRACK_LIN_VEL_XY, expf(-(lin_err / c.track_sigma)));                 // :15-20
+    terms[LT_R_TRACK_ANG_VEL_Z] = on(LT_R_TRACK_ANG_VEL_Z, expf(-(ang_err / c.track_sigma)));                   // :22-27
     const float foot_pv = sqrtf(G.foot_v.x * G.foot_v.x + G.foot_v.y * G.foot_v.y);
-    if (w[LT_R_FOOT_SLIP] != 0.f) {                                                                           // :31-42
+    {                                                                                                         // :31-42
       const float mx = fmaxf(G.fh[0][3], fmaxf(G.fh[1][3], G.fh[2][3]));
-      terms[LT_R_FOOT_SLIP] = qsum(mx > c.foot_slip_threshold ? foot_pv : 0.f);
+      terms[LT_R_FOOT_SLIP] = on(LT_R_FOOT_SLIP, qsum(mx > c.foot_slip_threshold ? foot_pv : 0.f));
     }
-    if (w[LT_R_FOOT_DRAGGING] != 0.f)                                                                         // :44-56
-      terms[LT_R_FOOT_DRAGGING] = qsum((G.foot_p.z <= c.foot_drag_height && foot_pv > c.foot_drag_vel) ? 1.f : 0.f);
+    terms[LT_R_FOOT_DRAGGING] = on(LT_R_FOOT_DRAGGING, qsum((G.foot_p.z <= c.foot_drag_height && foot_pv > c.foot_drag_vel) ? 1.f : 0.f));  // :44-56
     // gait: gather the four feet in class column order [FR, RL, FL, RR] = legs [0, 3, 1, 2]
     Gait GT;
     {
@@ -1118,10 +1121,10 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       G.g_flags = leg == 0 ? fl0 : (leg == 1 ? fl2 : (leg == 2 ? fl3 : fl1));
       X.gait_cmd = GT.last_cmd; X.gait_step = GT.step_from_change;
     }
-    if (w[LT_R_TRACK_BASE_HEIGHT] != 0.f) { const float d = B.p.z - c.base_height_target; terms[LT_R_TRACK_BASE_HEIGHT] = d * d; }  // :398-402
-    if (w[LT_R_BASE_Z_VELOCITY] != 0.f) terms[LT_R_BASE_Z_VELOCITY] = vb.z * vb.z;                              // :404-408
-    if (w[LT_R_BASE_ROLL_PITCH_ANGLE] != 0.f) terms[LT_R_BASE_ROLL_PITCH_ANGLE] = gb.x * gb.x + gb.y * gb.y;     // :416-420
-    if (w[LT_R_BASE_ROLL_PITCH_VELOCITY] != 0.f) terms[LT_R_BASE_ROLL_PITCH_VELOCITY] = fabsf(wb.x) + fabsf(wb.y); // :410-414
+    { const float d = B.p.z - c.base_height_target; terms[LT_R_TRACK_BASE_HEIGHT] = on(LT_R_TRACK_BASE_HEIGHT, d * d); }  // :398-402
+    terms[LT_R_BASE_Z_VELOCITY] = on(LT_R_BASE_Z_VELOCITY, vb.z * vb.z);                                        // :404-408
+    terms[LT_R_BASE_ROLL_PITCH_ANGLE] = on(LT_R_BASE_ROLL_PITCH_ANGLE, gb.x * gb.x + gb.y * gb.y);              // :416-420
+    terms[LT_R_BASE_ROLL_PITCH_VELOCITY] = on(LT_R_BASE_ROLL_PITCH_VELOCITY, fabsf(wb.x) + fabsf(wb.y));        // :410-414
     {
       float s_lim = 0.f, s_pos = 0.f, s_acc = 0.f, s_vel = 0.f, s_tau = 0.f, s_act = 0.f;
 #pragma unroll
@@ -1137,47 +1140,46 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
         s_act += da * da;
       }
       s_lim = qsum(s_lim); s_pos = qsum(s_pos); s_acc = qsum(s_acc); s_vel = qsum(s_vel); s_tau = qsum(s_tau); s_act = qsum(s_act);
-      if (w[LT_R_JOINT_POSITION_LIMIT] != 0.f) terms[LT_R_JOINT_POSITION_LIMIT] = s_lim;
-      if (w[LT_R_JOINT_POSITION] != 0.f) {                                                                    // :429-440
+      terms[LT_R_JOINT_POSITION_LIMIT] = on(LT_R_JOINT_POSITION_LIMIT, s_lim);
+      {                                                                                                       // :429-440
         const float bv = sqrtf(vb.x * vb.x + vb.y * vb.y), r = sqrtf(s_pos);
-        terms[LT_R_JOINT_POSITION] = (cn > 0.f || bv > c.joint_pos_vel_threshold) ? r : c.joint_pos_stand_scale * r;
+        terms[LT_R_JOINT_POSITION] = on(LT_R_JOINT_POSITION, (cn > 0.f || bv > c.joint_pos_vel_threshold) ? r : c.joint_pos_stand_scale * r);
       }
-      if (w[LT_R_JOINT_ACCELERATION] != 0.f) terms[LT_R_JOINT_ACCELERATION] = sqrtf(s_acc);                     // :446-448
-      if (w[LT_R_JOINT_VELOCITY] != 0.f) terms[LT_R_JOINT_VELOCITY] = sqrtf(s_vel);                             // :442-444
-      if (w[LT_R_JOINT_TORQUE] != 0.f) terms[LT_R_JOINT_TORQUE] = sqrtf(s_tau);                                 // :450-452
-      if (w[LT_R_ACTION_RATE] != 0.f) terms[LT_R_ACTION_RATE] = s_act;                                          // :454-456
+      terms[LT_R_JOINT_ACCELERATION] = on(LT_R_JOINT_ACCELERATION, sqrtf(s_acc));                               // :446-448
+      terms[LT_R_JOINT_VELOCITY] = on(LT_R_JOINT_VELOCITY, sqrtf(s_vel));                                       // :442-444
+      terms[LT_R_JOINT_TORQUE] = on(LT_R_JOINT_TORQUE, sqrtf(s_tau));                                           // :450-452
+      terms[LT_R_ACTION_RATE] = on(LT_R_ACTION_RATE, s_act);                                                    // :454-456
     }
-    if (w[LT_R_THIGH_CALF_COLLISION] != 0.f) {                                                                // :459-466
+    {                                                                                                         // :459-466
       const float m1 = fmaxf(G.fh[0][1], fmaxf(G.fh[1][1], G.fh[2][1])), m2 = fmaxf(G.fh[0][2], fmaxf(G.fh[1][2], G.fh[2][2]));
-      terms[LT_R_THIGH_CALF_COLLISION] = qsum((m1 > c.thigh_calf_threshold ? 1.f : 0.f) + (m2 > c.thigh_calf_threshold ? 1.f : 0.f));
+      terms[LT_R_THIGH_CALF_COLLISION] = on(LT_R_THIGH_CALF_COLLISION, qsum((m1 > c.thigh_calf_threshold ? 1.f : 0.f) + (m2 > c.thigh_calf_threshold ? 1.f : 0.f)));
     }
     if (HAS_OBJ) {
       const V3 dpos = O.p - B.p;
       const V3 pr = qapply_inv(B.q, dpos), lr = qapply_inv(B.q, O.u - B.u), ar = qapply_inv(B.q, O.w - B.w);
-      if (w[LT_R_OBJECT_XY_POSITION] != 0.f)                                                                  // :469-481
-        terms[LT_R_OBJECT_XY_POSITION] = sqrtf(dpos.x * dpos.x + dpos.y * dpos.y) * (cn > 0.f ? 1.f : 0.f);
-      if (w[LT_R_OBJECT_XY_VELOCITY] != 0.f) terms[LT_R_OBJECT_XY_VELOCITY] = lr.x * lr.x + lr.y * lr.y;        // :483-491
-      if (w[LT_R_OBJECT_Z_CONTACT] != 0.f) terms[LT_R_OBJECT_Z_CONTACT] = (O.last_con > 0.f && O.cur_air > 0.f) ? 1.f : 0.f;  // :596-604
-      if (w[LT_R_OBJECT_Z_VELOCITY] != 0.f) terms[LT_R_OBJECT_Z_VELOCITY] = lr.z * lr.z;                        // :493-501
-      if (w[LT_R_OBJECT_ROLL_PITCH_ANGLE] != 0.f) {                                                           // :524-533
+      terms[LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_XY_POSITION, sqrtf(dpos.x * dpos.x + dpos.y * dpos.y) * (cn > 0.f ? 1.f : 0.f));  // :469-481
+      terms[LT_R_OBJECT_XY_VELOCITY] = on(LT_R_OBJECT_XY_VELOCITY, lr.x * lr.x + lr.y * lr.y);                  // :483-491
+      terms[LT_R_OBJECT_Z_CONTACT] = on(LT_R_OBJECT_Z_CONTACT, (O.last_con > 0.f && O.cur_air > 0.f) ? 1.f : 0.f);  // :596-604
+      terms[LT_R_OBJECT_Z_VELOCITY] = on(LT_R_OBJECT_Z_VELOCITY, lr.z * lr.z);                                  // :493-501
+      {                                                                                                       // :524-533
         const V3 gz = v3(0.f, 0.f, -1.f);
         const V3 gr = qapply_inv(B.q, qapply(O.q, qapply_inv(O.q, gz)));
-        terms[LT_R_OBJECT_ROLL_PITCH_ANGLE] = gr.y * gr.y;
+        terms[LT_R_OBJECT_ROLL_PITCH_ANGLE] = on(LT_R_OBJECT_ROLL_PITCH_ANGLE, gr.y * gr.y);
       }
-      if (w[LT_R_OBJECT_ROLL_PITCH_VELOCITY] != 0.f) terms[LT_R_OBJECT_ROLL_PITCH_VELOCITY] = ar.x * ar.x;      // :535-543
-      if (w[LT_R_OBJECT_YAW_ALIGNMENT] != 0.f) {                                                              // :545-567
+      terms[LT_R_OBJECT_ROLL_PITCH_VELOCITY] = on(LT_R_OBJECT_ROLL_PITCH_VELOCITY, ar.x * ar.x);                // :535-543
+      {                                                                                                       // :545-567
         const Q4 qr = q_from_euler(0.f, 0.f, q_yaw_2pi(B.q)), qo = q_from_euler(0.f, 0.f, q_yaw_2pi(O.q));
         float yd = q_yaw_2pi(qmul(qconj(qr), qo));
         const float pi = 3.14159265358979323846f;
-        if (yd > pi) yd -= 2.f * pi;
-        if (yd > 0.5f * pi) yd -= pi;
-        if (yd <= -0.5f * pi) yd += pi;
-        terms[LT_R_OBJECT_YAW_ALIGNMENT] = yd * yd * (cn > 0.f ? 1.f : 0.f);
+        yd = yd > pi ? yd - 2.f * pi : yd;
+        yd = yd > 0.5f * pi ? yd - pi : yd;
+        yd = yd <= -0.5f * pi ? yd + pi : yd;
+        terms[LT_R_OBJECT_YAW_ALIGNMENT] = on(LT_R_OBJECT_YAW_ALIGNMENT, yd * yd * (cn > 0.f ? 1.f : 0.f));
       }
-      if (w[LT_R_OBJECT_DANGEROUS_STATE] != 0.f) {                                                            // :569-594
+      {                                                                                                       // :569-594
         const bool danger = (fabsf(pr.x) > c.danger_x_max) || (fabsf(pr.y) > c.danger_y_max) || (pr.z < c.danger_z_min) ||
                             (sqrtf(lr.x * lr.x + lr.y * lr.y) > c.danger_vel_xy_max);
-        terms[LT_R_OBJECT_DANGEROUS_STATE] = danger ? 1.f : 0.f;
+        terms[LT_R_OBJECT_DANGEROUS_STATE] = on(LT_R_OBJECT_DANGEROUS_STATE, danger ? 1.f : 0.f);
       }
     }
     float rew = 0.f;
