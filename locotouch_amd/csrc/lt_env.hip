@@ -474,6 +474,77 @@ __device__ __forceinline__ float gait_reward(const lt_cfg& c, Gait& G, V3 cmd, f
   return nonzero ? stepping : stance;                                                                       // :153-154
 }
 
+// The gait term of one step for the quad's four feet (reference rewards.py:60-392, AdaptiveSymmetricGaitReward[withObject]).
+// `io`: the class state of this lane (per-foot last air / contact time, valid last air time, flags) and of the env (last command,
+// steps since it changed), updated in place; unchanged and 0 when the term's weight is 0.
+struct GaitIO { float last_air, last_con, valid; int flags; V3 cmd; float step; };
+template <bool HAS_OBJ>
+__device__ __forceinline__ float gait_term(const lt_cfg& c, int leg, float cur_air, float cur_con, float sensor_last_air, GaitIO& io, const V3& bp,
+                                           const Q4& bq, const V3& op, const V3& cmd, float lin_err, float ang_err, bool any_nonzero_cmd,
+                                           float step_dt) {
+  if (c.reward_weight[LT_R_GAIT] == 0.f) return 0.f;
+  // gather the four feet in class column order [FR, RL, FL, RR] = legs [0, 3, 1, 2]
+  Gait GT;
+  GT.cur_air[0] = qbcast<0>(cur_air); GT.cur_air[1] = qbcast<3>(cur_air); GT.cur_air[2] = qbcast<1>(cur_air); GT.cur_air[3] = qbcast<2>(cur_air);
+  GT.cur_con[0] = qbcast<0>(cur_con); GT.cur_con[1] = qbcast<3>(cur_con); GT.cur_con[2] = qbcast<1>(cur_con); GT.cur_con[3] = qbcast<2>(cur_con);
+  GT.sensor_last_air[0] = qbcast<0>(sensor_last_air); GT.sensor_last_air[1] = qbcast<3>(sensor_last_air); GT.sensor_last_air[2] = qbcast<1>(sensor_last_air); GT.sensor_last_air[3] = qbcast<2>(sensor_last_air);
+  GT.last_air[0] = qbcast<0>(io.last_air); GT.last_air[1] = qbcast<3>(io.last_air); GT.last_air[2] = qbcast<1>(io.last_air); GT.last_air[3] = qbcast<2>(io.last_air);
+  GT.last_con[0] = qbcast<0>(io.last_con); GT.last_con[1] = qbcast<3>(io.last_con); GT.last_con[2] = qbcast<1>(io.last_con); GT.last_con[3] = qbcast<2>(io.last_con);
+  GT.valid[0] = qbcast<0>(io.valid); GT.valid[1] = qbcast<3>(io.valid); GT.valid[2] = qbcast<1>(io.valid); GT.valid[3] = qbcast<2>(io.valid);
+  const int f0 = qbcasti<0>(io.flags), f1 = qbcasti<3>(io.flags), f2 = qbcasti<1>(io.flags), f3 = qbcasti<2>(io.flags);
+  GT.swing0[0] = f0 & 1; GT.swing0[1] = f1 & 1; GT.swing0[2] = f2 & 1; GT.swing0[3] = f3 & 1;
+  GT.prevc[0] = (f0 >> 1) & 1; GT.prevc[1] = (f1 >> 1) & 1; GT.prevc[2] = (f2 >> 1) & 1; GT.prevc[3] = (f3 >> 1) & 1;
+  GT.last_cmd = io.cmd; GT.step_from_change = io.step;
+  float ox = 0.f, oy = 0.f;
+  if (HAS_OBJ && c.gait_with_object) {                                                                      // :372-385
+    const Q4 qy = q_from_euler(0.f, 0.f, q_yaw_2pi(bq));
+    const V3 o = qapply_inv(qy, op - bp);
+    ox = o.x; oy = o.y;
+  }
+  const float term = gait_reward(c, GT, cmd, lin_err, ang_err, ox, oy, any_nonzero_cmd, step_dt);
+  // scatter the class state back: lane (leg) owns column {0:0, 1:2, 2:3, 3:1}
+  io.last_air = sel4(leg, GT.last_air[0], GT.last_air[2], GT.last_air[3], GT.last_air[1]);
+  io.last_con = sel4(leg, GT.last_con[0], GT.last_con[2], GT.last_con[3], GT.last_con[1]);
+  io.valid = sel4(leg, GT.valid[0], GT.valid[2], GT.valid[3], GT.valid[1]);
+  const int fl0 = GT.swing0[0] | (GT.prevc[0] << 1), fl1 = GT.swing0[1] | (GT.prevc[1] << 1), fl2 = GT.swing0[2] | (GT.prevc[2] << 1), fl3 = GT.swing0[3] | (GT.prevc[3] << 1);
+  io.flags = leg == 0 ? fl0 : (leg == 1 ? fl2 : (leg == 2 ? fl3 : fl1));
+  io.cmd = GT.last_cmd; io.step = GT.step_from_change;
+  return term;
+}
+
+// The eight object reward terms (reference rewards.py:469-604), in enum order from LT_R_OBJECT_XY_POSITION; a term whose weight
+// is 0 stays exactly 0.  `cn`: norm of the env's command.
+__device__ __forceinline__ void object_terms(const lt_cfg& c, const Base& B, const Obj& O, float cn, float (&t)[8]) {
+  const float* w = c.reward_weight;
+  auto on = [&](int i, float v) { return w[i] != 0.f ? v : 0.f; };
+  const V3 dpos = O.p - B.p;
+  const V3 pr = qapply_inv(B.q, dpos), lr = qapply_inv(B.q, O.u - B.u), ar = qapply_inv(B.q, O.w - B.w);
+  t[LT_R_OBJECT_XY_POSITION - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_XY_POSITION, sqrtf(dpos.x * dpos.x + dpos.y * dpos.y) * (cn > 0.f ? 1.f : 0.f));  // :469-481
+  t[LT_R_OBJECT_XY_VELOCITY - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_XY_VELOCITY, lr.x * lr.x + lr.y * lr.y);                  // :483-491
+  t[LT_R_OBJECT_Z_CONTACT - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_Z_CONTACT, (O.last_con > 0.f && O.cur_air > 0.f) ? 1.f : 0.f);  // :596-604
+  t[LT_R_OBJECT_Z_VELOCITY - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_Z_VELOCITY, lr.z * lr.z);                                  // :493-501
+  {                                                                                                         // :524-533
+    const V3 gz = v3(0.f, 0.f, -1.f);
+    const V3 gr = qapply_inv(B.q, qapply(O.q, qapply_inv(O.q, gz)));
+    t[LT_R_OBJECT_ROLL_PITCH_ANGLE - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_ROLL_PITCH_ANGLE, gr.y * gr.y);
+  }
+  t[LT_R_OBJECT_ROLL_PITCH_VELOCITY - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_ROLL_PITCH_VELOCITY, ar.x * ar.x);                // :535-543
+  {                                                                                                         // :545-567
+    const Q4 qr = q_from_euler(0.f, 0.f, q_yaw_2pi(B.q)), qo = q_from_euler(0.f, 0.f, q_yaw_2pi(O.q));
+    float yd = q_yaw_2pi(qmul(qconj(qr), qo));
+    const float pi = 3.14159265358979323846f;
+    yd = yd > pi ? yd - 2.f * pi : yd;
+    yd = yd > 0.5f * pi ? yd - pi : yd;
+    yd = yd <= -0.5f * pi ? yd + pi : yd;
+    t[LT_R_OBJECT_YAW_ALIGNMENT - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_YAW_ALIGNMENT, yd * yd * (cn > 0.f ? 1.f : 0.f));
+  }
+  {                                                                                                         // :569-594
+    const bool danger = (fabsf(pr.x) > c.danger_x_max) || (fabsf(pr.y) > c.danger_y_max) || (pr.z < c.danger_z_min) ||
+                        (sqrtf(lr.x * lr.x + lr.y * lr.y) > c.danger_vel_xy_max);
+    t[LT_R_OBJECT_DANGEROUS_STATE - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_DANGEROUS_STATE, danger ? 1.f : 0.f);
+  }
+}
+
 // object_state_in_robot_frame (reference locotouch/mdp/observations.py:38-91); u16 = 16 uniforms or nullptr-like flag
 __device__ __forceinline__ void object_state_obs(const lt_cfg& c, const Base& B, const Obj& O, bool noisy, const float* u16, float* out) {
   float s[13];
@@ -667,6 +738,11 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   // wave 3 -> wave 0: the step's EVENT draws (reset events, command resampling, pushes), computed beside the physics.  An env
   // uses them on few steps, but some tile of the launch does on every step and the launch ends with its slowest tile: 13 Philox
   // calls (~8 k cycles) sat on that tile's critical path.  Slot = one rng4 result of an owner lane: [slot][component][lane].
+  // wave 0 <-> waves 1 / 2 after the physics: the robot's final base state, the tracking errors and this leg's sensor timers go out
+  // (s_mb_fin), the gait term with its updated class state (wave 1) and the eight object terms (wave 2, the object's owner) come
+  // back (s_mb_rew) - evaluated beside wave 0's terminations and remaining 15 terms, between two extra barriers (D, E)
+  constexpr int MB_FIN = 24, MB_REW = 17;
+  __shared__ float s_mb_fin[HELPERS ? MB_FIN : 1][64], s_mb_rew[HELPERS ? MB_REW : 1][64];
   constexpr int BANK_SLOTS = 7;
   __shared__ float s_bank[HELPERS ? BANK_SLOTS : 1][4][64];
   if (!HELPERS) {
@@ -693,6 +769,13 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       Obj Oh;
       float trunk_mu = 0.f;
       float bank_mat_c = 0.f;
+      GaitIO gio = {0.f, 0.f, 0.f, 0, v3(0, 0, 0), 0.f};
+      if (wave == 1 && MODE == MODE_STEP) {  // the gait class state of this lane / env: wave 1 evaluates the gait term (below)
+        gio.last_air = *F(LT_F_GAIT_LAST_AIR, 0); gio.last_con = *F(LT_F_GAIT_LAST_CONTACT, 0); gio.valid = *F(LT_F_GAIT_VALID_LAST_AIR, 0);
+        gio.flags = *(const int*)F(LT_F_GAIT_FLAGS, 0);
+        const float t = *F(LT_F_GAIT_CMD, 0);
+        gio.cmd = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); gio.step = qbcast<3>(t);
+      }
       if (HAS_OBJ && wave == 2) {
         float t;
         t = hot.obj_pos; Oh.p = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t));
@@ -702,6 +785,22 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
         t = hot.obj_params; Oh.rad = qbcast<0>(t); Oh.len = qbcast<1>(t); Oh.mass = qbcast<2>(t); Oh.mu = qbcast<3>(t);
         Oh.cur_air = Oh.cur_con = Oh.last_air = Oh.last_con = 0.f;
         trunk_mu = qbcast<1>(hot.env_params);
+      }
+      if (wave == 1 || wave == 2) {
+        // history rows, step 0 (waves 1 / 2): the group's 16 old rows = one contiguous chunk of 16*OBS floats, fetched by LDS-DMA -
+        // each wave-instruction moves 64 lanes x 16 B = 1 KiB, lane-linear in LDS, no VGPRs - NOW, so that it lands beside the
+        // physics (the physics barriers wait for LDS traffic only; B0, a full barrier, is behind us).
+        const int g = wave - 1;
+        constexpr int CHUNK16 = 16 * OBS / 4;  // float4 count per group (OBS*16 is a multiple of 4 for both tasks)
+        const float* gsrc = a.obs_prev[g] + (long long)blockIdx.x * 16 * OBS;
+        for (int i = 0; i < (CHUNK16 + 63) / 64; ++i) {
+          const int v = i * 64 + lane;
+          if (v < CHUNK16)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + v * 4),
+                                             (__attribute__((address_space(3))) void*)(s_old + g * 16 * OBS + i * 256), 16, 0, 0);
+        }
+        const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
+        for (int i = lane; i < 352; i += 64) { s_tab[g][i] = tab.src[i]; s_tab[g][352 + i] = tab.frame[i]; }
       }
       for (int it = 0; it < nsub; ++it) {
         wg_barrier_lds();  // A
@@ -772,20 +871,45 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
         }
         wg_barrier_lds();  // B
       }
+      if (MODE == MODE_STEP) {
+        // ---- D .. E: the gait term (wave 1) and the object terms (wave 2) beside wave 0's own terms ----
+        wg_barrier_lds();  // D: wave 0's hand-over (s_mb_fin) is in LDS
+        if (wave == 1) {
+          const V3 bp = v3(s_mb_fin[0][lane], s_mb_fin[1][lane], s_mb_fin[2][lane]);
+          Q4 bq; bq.w = s_mb_fin[3][lane]; bq.x = s_mb_fin[4][lane]; bq.y = s_mb_fin[5][lane]; bq.z = s_mb_fin[6][lane];
+          const V3 op = HAS_OBJ ? v3(s_mb_ofin[0][lane], s_mb_ofin[1][lane], s_mb_ofin[2][lane]) : v3(0, 0, 0);
+          const V3 cmdh = v3(s_mb_fin[21][lane], s_mb_fin[22][lane], s_mb_fin[23][lane]);
+          const float term = gait_term<HAS_OBJ>(c, leg, s_mb_fin[16][lane], s_mb_fin[17][lane], s_mb_fin[18][lane], gio, bp, bq, op, cmdh,
+                                                s_mb_fin[13][lane], s_mb_fin[14][lane], s_P[26] != 0.f, step_dt);
+          const float v[9] = {term, gio.last_air, gio.last_con, gio.valid, __int_as_float(gio.flags), gio.cmd.x, gio.cmd.y, gio.cmd.z, gio.step};
+#pragma unroll
+          for (int i = 0; i < 9; ++i) s_mb_rew[i][lane] = v[i];
+        } else if (HAS_OBJ && wave == 2) {
+          Base Bf;
+          Bf.p = v3(s_mb_fin[0][lane], s_mb_fin[1][lane], s_mb_fin[2][lane]);
+          Bf.q.w = s_mb_fin[3][lane]; Bf.q.x = s_mb_fin[4][lane]; Bf.q.y = s_mb_fin[5][lane]; Bf.q.z = s_mb_fin[6][lane];
+          Bf.u = v3(s_mb_fin[7][lane], s_mb_fin[8][lane], s_mb_fin[9][lane]);
+          Bf.w = v3(s_mb_fin[10][lane], s_mb_fin[11][lane], s_mb_fin[12][lane]);
+          Oh.last_con = s_mb_fin[19][lane]; Oh.cur_air = s_mb_fin[20][lane];  // (the object's contact timers are kept by wave 0)
+          float ot[8];
+          object_terms(c, Bf, Oh, s_mb_fin[15][lane], ot);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) s_mb_rew[9 + i][lane] = ot[i];
+        } else if (wave == 3) {
+          // the observation-noise uniforms of this step (Philox is ~1 k cycles per call).  Per lane: joint-pos and joint-vel noise of
+          // its leg, object-noise block `leg`, base-noise block (legs 2, 3 -> RS_NOISE_BASE, + 1).  Same streams and keys as the
+          // inline form: bit-identical draws.
+          const U4 uj = rng4(c.seed, ekey, step, RS_NOISE_JPOS + leg), uv = rng4(c.seed, ekey, step, RS_NOISE_JVEL + leg);
+          const U4 uo = rng4(c.seed, ekey, step, RS_NOISE_OBJ + leg);
+          const U4 ub = rng4(c.seed, ekey, step, RS_NOISE_BASE + (leg == 3 ? 1 : 0));
+          const float v[16] = {uj.a, uj.b, uj.c, uj.d, uv.a, uv.b, uv.c, uv.d, uo.a, uo.b, uo.c, uo.d, ub.a, ub.b, ub.c, ub.d};
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s_mb_rng[i][lane] = v[i];
+        }
+        wg_barrier_lds();  // E: the terms are in LDS
+      }
     }
     if (wave == 3) {
-      // ---- wave 3, beside wave 0's terminations / rewards: the observation-noise uniforms of this step (Philox is ~1 k
-      //      cycles per call - quarter-rate integer multiplies - and wave 0 would run its 8 calls serially through divergent
-      //      branches).  Per lane: joint-pos and joint-vel noise of its leg, object-noise block `leg`, base-noise block
-      //      (legs 2, 3 -> RS_NOISE_BASE, + 1).  Same streams and keys as the inline form: bit-identical draws. ----
-      {
-        const U4 uj = rng4(c.seed, ekey, step, RS_NOISE_JPOS + leg), uv = rng4(c.seed, ekey, step, RS_NOISE_JVEL + leg);
-        const U4 uo = rng4(c.seed, ekey, step, RS_NOISE_OBJ + leg);
-        const U4 ub = rng4(c.seed, ekey, step, RS_NOISE_BASE + (leg == 3 ? 1 : 0));
-        const float v[16] = {uj.a, uj.b, uj.c, uj.d, uv.a, uv.b, uv.c, uv.d, uo.a, uo.b, uo.c, uo.d, ub.a, ub.b, ub.c, ub.d};
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s_mb_rng[i][lane] = v[i];
-      }
       wg_barrier_lds();  // C: the uniforms are in LDS
       // ---- curriculum / population gate / step counter (lt_post.h) on the record wave 0 leaves in LDS ----
       __syncthreads();  // B1
@@ -806,20 +930,6 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     //      has landed (vmcnt(0)) before this wave stores anything, and only this wave touches the group's rows. ----
     const int g = wave - 1;
     constexpr int NCH = (OBS + 63) / 64;
-    {
-      // the group's 16 old rows = one contiguous chunk of 16*OBS floats; each wave-instruction moves 64 lanes x 16 B = 1 KiB,
-      // lane-linear in LDS.  (Issued after B0: a workgroup barrier drains vmcnt, so an earlier issue would hold wave 0 up.)
-      constexpr int CHUNK16 = 16 * OBS / 4;  // float4 count per group (OBS*16 is a multiple of 4 for both tasks)
-      const float* gsrc = a.obs_prev[g] + (long long)blockIdx.x * 16 * OBS;
-      for (int i = 0; i < (CHUNK16 + 63) / 64; ++i) {
-        const int v = i * 64 + lane;
-        if (v < CHUNK16)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + v * 4),
-                                           (__attribute__((address_space(3))) void*)(s_old + g * 16 * OBS + i * 256), 16, 0, 0);
-      }
-      const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
-      for (int i = lane; i < 352; i += 64) { s_tab[g][i] = tab.src[i]; s_tab[g][352 + i] = tab.frame[i]; }
-    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     int src[NCH], frm[NCH];
 #pragma unroll
@@ -1008,11 +1118,13 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     t = *F(LT_F_CMD, 0); X.cmd = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.cmd_time_left = qbcast<3>(t);
     t = *F(LT_F_CMD_BUF, 0); X.cmd_buf = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.cmd_standing = qbcast<3>(t);
     t = *F(LT_F_EVENT_TIMERS, 0); X.push_robot_left = qbcast<0>(t); X.push_obj_left = qbcast<1>(t);
-    t = *F(LT_F_GAIT_CMD, 0); X.gait_cmd = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.gait_step = qbcast<3>(t);
     X.ep_len = ((const long long*)(arena + L.off_ep_len))[env];
-    G.g_last_air = *F(LT_F_GAIT_LAST_AIR, 0); G.g_last_con = *F(LT_F_GAIT_LAST_CONTACT, 0);
-    G.g_valid = *F(LT_F_GAIT_VALID_LAST_AIR, 0);
-    G.g_flags = *(const int*)F(LT_F_GAIT_FLAGS, 0);
+    if (!(HELPERS && MODE == MODE_STEP)) {  // (helper form: wave 1 holds the gait class state and hands it back with the gait term)
+      t = *F(LT_F_GAIT_CMD, 0); X.gait_cmd = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.gait_step = qbcast<3>(t);
+      G.g_last_air = *F(LT_F_GAIT_LAST_AIR, 0); G.g_last_con = *F(LT_F_GAIT_LAST_CONTACT, 0);
+      G.g_valid = *F(LT_F_GAIT_VALID_LAST_AIR, 0);
+      G.g_flags = *(const int*)F(LT_F_GAIT_FLAGS, 0);
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       if (MODE == MODE_STEP) {
@@ -1033,6 +1145,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   // =================================================================================================
   // stages 4-5: terminations and rewards
   // =================================================================================================
+  constexpr bool OFFLOAD = HELPERS && MODE == MODE_STEP;  // gait / object terms evaluated by helper waves 1 / 2 (between barriers D, E)
   int bits = 0;
   bool terminated = false, time_out = false, reset = false;
   CurIn cur_in;
@@ -1044,6 +1157,17 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
     const V3 vb = tmul(R0, B.u), wb = tmul(R0, B.w);
     const V3 gb = -row(R0, 2);  // R0^T (0,0,-1)
+    const V3 cmd = X.cmd;
+    const float cn = norm(cmd);
+    const float lin_err = sqrtf((cmd.x - vb.x) * (cmd.x - vb.x) + (cmd.y - vb.y) * (cmd.y - vb.y));
+    const float ang_err = fabsf(cmd.z - wb.z);
+    if (OFFLOAD) {  // hand-over to waves 1 (gait) and 2 (object terms); they work while this wave runs its terminations and other terms
+      const float v[MB_FIN] = {B.p.x, B.p.y, B.p.z, B.q.w, B.q.x, B.q.y, B.q.z, B.u.x, B.u.y, B.u.z, B.w.x, B.w.y, B.w.z, lin_err, ang_err, cn,
+                               G.cur_air, G.cur_con, G.last_air, O.last_con, O.cur_air, cmd.x, cmd.y, cmd.z};
+#pragma unroll
+      for (int i = 0; i < MB_FIN; ++i) s_mb_fin[i][lane] = v[i];
+      wg_barrier_lds();  // D
+    }
     // ---- 4. terminations (stock terms [DEP], cfg locomotion_base_env_cfg.py:296-313; mdp/terminations.py:10-23)
     {
       const V3 gq = qapply_inv(B.q, v3(0.f, 0.f, -1.f));
@@ -1074,10 +1198,6 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
 #pragma unroll
     for (int i = 0; i < LT_REWARD_SLOTS; ++i) terms[i] = 0.f;
     const float* w = c.reward_weight;
-    const V3 cmd = X.cmd;
-    const float cn = norm(cmd);
-    const float lin_err = sqrtf((cmd.x - vb.x) * (cmd.x - vb.x) + (cmd.y - vb.y) * (cmd.y - vb.y));
-    const float ang_err = fabsf(cmd.z - wb.z);
     // Every term is evaluated and then kept or zeroed by its weight (a select, not a branch: a disabled term stays exactly 0, as
     // the guarded form and the oracle have it).  25 guarded terms were 25 scheduling regions; as straight-line code their
     // independent dependency chains interleave - a lone wave issues a DEPENDENT VALU operation only every 7 cycles.
@@ -1091,35 +1211,13 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       terms[LT_R_FOOT_SLIP] = on(LT_R_FOOT_SLIP, qsum(mx > c.foot_slip_threshold ? foot_pv : 0.f));
     }
     terms[LT_R_FOOT_DRAGGING] = on(LT_R_FOOT_DRAGGING, qsum((G.foot_p.z <= c.foot_drag_height && foot_pv > c.foot_drag_vel) ? 1.f : 0.f));  // :44-56
-    // gait: gather the four feet in class column order [FR, RL, FL, RR] = legs [0, 3, 1, 2]
-    Gait GT;
-    {
-      GT.cur_air[0] = qbcast<0>(G.cur_air); GT.cur_air[1] = qbcast<3>(G.cur_air); GT.cur_air[2] = qbcast<1>(G.cur_air); GT.cur_air[3] = qbcast<2>(G.cur_air);
-      GT.cur_con[0] = qbcast<0>(G.cur_con); GT.cur_con[1] = qbcast<3>(G.cur_con); GT.cur_con[2] = qbcast<1>(G.cur_con); GT.cur_con[3] = qbcast<2>(G.cur_con);
-      GT.sensor_last_air[0] = qbcast<0>(G.last_air); GT.sensor_last_air[1] = qbcast<3>(G.last_air); GT.sensor_last_air[2] = qbcast<1>(G.last_air); GT.sensor_last_air[3] = qbcast<2>(G.last_air);
-      GT.last_air[0] = qbcast<0>(G.g_last_air); GT.last_air[1] = qbcast<3>(G.g_last_air); GT.last_air[2] = qbcast<1>(G.g_last_air); GT.last_air[3] = qbcast<2>(G.g_last_air);
-      GT.last_con[0] = qbcast<0>(G.g_last_con); GT.last_con[1] = qbcast<3>(G.g_last_con); GT.last_con[2] = qbcast<1>(G.g_last_con); GT.last_con[3] = qbcast<2>(G.g_last_con);
-      GT.valid[0] = qbcast<0>(G.g_valid); GT.valid[1] = qbcast<3>(G.g_valid); GT.valid[2] = qbcast<1>(G.g_valid); GT.valid[3] = qbcast<2>(G.g_valid);
-      const int f0 = qbcasti<0>(G.g_flags), f1 = qbcasti<3>(G.g_flags), f2 = qbcasti<1>(G.g_flags), f3 = qbcasti<2>(G.g_flags);
-      GT.swing0[0] = f0 & 1; GT.swing0[1] = f1 & 1; GT.swing0[2] = f2 & 1; GT.swing0[3] = f3 & 1;
-      GT.prevc[0] = (f0 >> 1) & 1; GT.prevc[1] = (f1 >> 1) & 1; GT.prevc[2] = (f2 >> 1) & 1; GT.prevc[3] = (f3 >> 1) & 1;
-      GT.last_cmd = X.gait_cmd; GT.step_from_change = X.gait_step;
-    }
-    if (w[LT_R_GAIT] != 0.f) {
-      float ox = 0.f, oy = 0.f;
-      if (HAS_OBJ && c.gait_with_object) {                                                                    // :372-385
-        const Q4 qy = q_from_euler(0.f, 0.f, q_yaw_2pi(B.q));
-        const V3 o = qapply_inv(qy, O.p - B.p);
-        ox = o.x; oy = o.y;
-      }
-      terms[LT_R_GAIT] = gait_reward(c, GT, cmd, lin_err, ang_err, ox, oy, P[26] != 0.f, step_dt);
-      // scatter the class state back: lane (leg) owns column {0:0, 1:2, 2:3, 3:1}
-      G.g_last_air = sel4(leg, GT.last_air[0], GT.last_air[2], GT.last_air[3], GT.last_air[1]);
-      G.g_last_con = sel4(leg, GT.last_con[0], GT.last_con[2], GT.last_con[3], GT.last_con[1]);
-      G.g_valid = sel4(leg, GT.valid[0], GT.valid[2], GT.valid[3], GT.valid[1]);
-      const int fl0 = GT.swing0[0] | (GT.prevc[0] << 1), fl1 = GT.swing0[1] | (GT.prevc[1] << 1), fl2 = GT.swing0[2] | (GT.prevc[2] << 1), fl3 = GT.swing0[3] | (GT.prevc[3] << 1);
-      G.g_flags = leg == 0 ? fl0 : (leg == 1 ? fl2 : (leg == 2 ? fl3 : fl1));
-      X.gait_cmd = GT.last_cmd; X.gait_step = GT.step_from_change;
+    // gait (rewards.py:60-392): the quad's four feet, the class state (G.g_*, X.gait_*) updated in place.  Helper form: wave 1 has
+    // evaluated it beside the terms above (s_mb_rew), from the state wave 0 handed over after the physics.
+    if (!OFFLOAD) {
+      GaitIO gio{G.g_last_air, G.g_last_con, G.g_valid, G.g_flags, X.gait_cmd, X.gait_step};
+      terms[LT_R_GAIT] = gait_term<HAS_OBJ>(c, leg, G.cur_air, G.cur_con, G.last_air, gio, B.p, B.q, O.p, cmd, lin_err, ang_err, P[26] != 0.f, step_dt);
+      G.g_last_air = gio.last_air; G.g_last_con = gio.last_con; G.g_valid = gio.valid; G.g_flags = gio.flags;
+      X.gait_cmd = gio.cmd; X.gait_step = gio.step;
     }
     { const float d = B.p.z - c.base_height_target; terms[LT_R_TRACK_BASE_HEIGHT] = on(LT_R_TRACK_BASE_HEIGHT, d * d); }  // :398-402
     terms[LT_R_BASE_Z_VELOCITY] = on(LT_R_BASE_Z_VELOCITY, vb.z * vb.z);                                        // :404-408
@@ -1154,32 +1252,20 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       const float m1 = fmaxf(G.fh[0][1], fmaxf(G.fh[1][1], G.fh[2][1])), m2 = fmaxf(G.fh[0][2], fmaxf(G.fh[1][2], G.fh[2][2]));
       terms[LT_R_THIGH_CALF_COLLISION] = on(LT_R_THIGH_CALF_COLLISION, qsum((m1 > c.thigh_calf_threshold ? 1.f : 0.f) + (m2 > c.thigh_calf_threshold ? 1.f : 0.f)));
     }
-    if (HAS_OBJ) {
-      const V3 dpos = O.p - B.p;
-      const V3 pr = qapply_inv(B.q, dpos), lr = qapply_inv(B.q, O.u - B.u), ar = qapply_inv(B.q, O.w - B.w);
-      terms[LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_XY_POSITION, sqrtf(dpos.x * dpos.x + dpos.y * dpos.y) * (cn > 0.f ? 1.f : 0.f));  // :469-481
-      terms[LT_R_OBJECT_XY_VELOCITY] = on(LT_R_OBJECT_XY_VELOCITY, lr.x * lr.x + lr.y * lr.y);                  // :483-491
-      terms[LT_R_OBJECT_Z_CONTACT] = on(LT_R_OBJECT_Z_CONTACT, (O.last_con > 0.f && O.cur_air > 0.f) ? 1.f : 0.f);  // :596-604
-      terms[LT_R_OBJECT_Z_VELOCITY] = on(LT_R_OBJECT_Z_VELOCITY, lr.z * lr.z);                                  // :493-501
-      {                                                                                                       // :524-533
-        const V3 gz = v3(0.f, 0.f, -1.f);
-        const V3 gr = qapply_inv(B.q, qapply(O.q, qapply_inv(O.q, gz)));
-        terms[LT_R_OBJECT_ROLL_PITCH_ANGLE] = on(LT_R_OBJECT_ROLL_PITCH_ANGLE, gr.y * gr.y);
-      }
-      terms[LT_R_OBJECT_ROLL_PITCH_VELOCITY] = on(LT_R_OBJECT_ROLL_PITCH_VELOCITY, ar.x * ar.x);                // :535-543
-      {                                                                                                       // :545-567
-        const Q4 qr = q_from_euler(0.f, 0.f, q_yaw_2pi(B.q)), qo = q_from_euler(0.f, 0.f, q_yaw_2pi(O.q));
-        float yd = q_yaw_2pi(qmul(qconj(qr), qo));
-        const float pi = 3.14159265358979323846f;
-        yd = yd > pi ? yd - 2.f * pi : yd;
-        yd = yd > 0.5f * pi ? yd - pi : yd;
-        yd = yd <= -0.5f * pi ? yd + pi : yd;
-        terms[LT_R_OBJECT_YAW_ALIGNMENT] = on(LT_R_OBJECT_YAW_ALIGNMENT, yd * yd * (cn > 0.f ? 1.f : 0.f));
-      }
-      {                                                                                                       // :569-594
-        const bool danger = (fabsf(pr.x) > c.danger_x_max) || (fabsf(pr.y) > c.danger_y_max) || (pr.z < c.danger_z_min) ||
-                            (sqrtf(lr.x * lr.x + lr.y * lr.y) > c.danger_vel_xy_max);
-        terms[LT_R_OBJECT_DANGEROUS_STATE] = on(LT_R_OBJECT_DANGEROUS_STATE, danger ? 1.f : 0.f);
+    if (HAS_OBJ && !OFFLOAD) {  // helper form: wave 2 (the object's owner) has evaluated them beside the terms above (s_mb_rew)
+      float ot[8];
+      object_terms(c, B, O, cn, ot);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) terms[LT_R_OBJECT_XY_POSITION + i] = ot[i];
+    }
+    if (OFFLOAD) {
+      wg_barrier_lds();  // E: wave 1's gait term + class state and wave 2's object terms are in LDS
+      terms[LT_R_GAIT] = s_mb_rew[0][lane];
+      G.g_last_air = s_mb_rew[1][lane]; G.g_last_con = s_mb_rew[2][lane]; G.g_valid = s_mb_rew[3][lane]; G.g_flags = __float_as_int(s_mb_rew[4][lane]);
+      X.gait_cmd = v3(s_mb_rew[5][lane], s_mb_rew[6][lane], s_mb_rew[7][lane]); X.gait_step = s_mb_rew[8][lane];
+      if (HAS_OBJ) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) terms[LT_R_OBJECT_XY_POSITION + i] = s_mb_rew[9 + i][lane];
       }
     }
     float rew = 0.f;
