@@ -157,9 +157,4 @@ def test_population_pass_placement_api():
     assert lib.lt_env_defer_gate(h, 3) == C["LT_EINVAL"] and lib.lt_env_defer_gate(h, -1) == C["LT_EINVAL"]
     assert lib.lt_env_defer_gate(None, 0) == C["LT_EINVAL"]
     assert lib.lt_env_gate_update(h, None) == C["LT_EFAULT"] and b"not bound" in lib.lt_last_error()
-    # lt_env_set_l2_warm: a hint - aligned buffers or NULL, non-negative sizes
-    vp = ctypes.c_void_p
-    assert lib.lt_env_set_l2_warm(h, vp(4096), 1 << 20, vp(8192), 1 << 20) == 0 and lib.lt_env_set_l2_warm(h, vp(None), 0, vp(None), 0) == 0
-    assert lib.lt_env_set_l2_warm(h, vp(4100), 1 << 20, vp(None), 0) == C["LT_EINVAL"]
-    assert lib.lt_env_set_l2_warm(h, vp(4096), -1, vp(None), 0) == C["LT_EINVAL"]
     assert lib.lt_env_destroy(h) == 0
