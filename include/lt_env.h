@@ -360,11 +360,6 @@ int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_pol
  *     passes).  Grids beyond one workgroup per CU behave as mode 0.
  * Results are identical in all modes.  Mode 0 can only be selected while no pass is outstanding. */
 int lt_env_defer_gate(lt_env* env, int mode);
-/* Hint: two read-only device buffers (16-byte aligned; NULL = none) that the launch FOLLOWING every step on the stream streams from
- * L2 - in a rollout the packed weights of the policy and value networks (lt_mlp_pack).  Waves of the step kernel that idle near its
- * end touch them, so that launch finds them L2-resident (grids of at most one workgroup per CU; otherwise ignored).  Results are
- * unaffected; the buffers must stay valid until the hint is cleared (NULL, 0). */
-int lt_env_set_l2_warm(lt_env* env, const void* buf0, int64_t bytes0, const void* buf1, int64_t bytes1);
 int lt_env_gate_update(lt_env* env, void* stream);
 /* Profiling variant of lt_env_step: HIP events bracket the step kernel on `stream`; the call WAITS for them (host
  * sync - never use it inside a captured region) and returns the step kernel's duration in milliseconds. */

@@ -51,11 +51,6 @@ struct KArgs {
   // yet - workgroup 0's RNG wave runs it beside this step's first physics substep (lt_post.h, chained form)
   int step_offset;
   int decide_first;
-  // lt_env_set_l2_warm (helper form): two read-only buffers the NEXT launch on the stream will stream from L2 - the policy / value
-  // weight streams.  The history waves touch them (LDS-DMA into their spent staging area) while they wait for wave 0's newest frame,
-  // so the next launch finds them in the L2 of the XCDs that will read them instead of refetching them behind this step's traffic.
-  const float* warm[2];
-  int warm_kib[2];
 };
 static_assert(sizeof(lt_dev_args) <= LT_DEV_ARGS_BYTES, "lt_dev_args outgrew its arena slot");
 
@@ -955,22 +950,6 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       }
     }
     wg_barrier_lds();  // C (wave 3's noise uniforms -> wave 0)
-    if (MODE == MODE_STEP) {
-      // L2 warm-up for the next launch (lt_env_set_l2_warm): this wave's 1/64 of the buffer its XCD's workgroups will stream
-      // (workgroups are dealt round-robin over the 8 XCDs; lt_mlp.hip runs one network on XCDs 0-3, the other on 4-7).  The
-      // staging area of the old rows is spent; B1 below drains the loads.
-      const int net = (blockIdx.x & 7) < 4 ? 0 : 1;
-      const float* const wsrc = a.warm[net];
-      if (wsrc) {
-        const int total = a.warm_kib[net], per = (total + 63) / 64, first = (((int)blockIdx.x >> 3) * 2 + g) % 64 * per;
-        for (int i = 0; i < per && i < 16 * OBS / 256; ++i) {
-          const int kib = first + i;
-          if (kib < total)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (long long)kib * 256 + lane * 4),
-                                             (__attribute__((address_space(3))) void*)(s_old + g * 16 * OBS + i * 256), 16, 0, 0);
-        }
-      }
-    }
     __syncthreads();  // B1: newest frame + reset flags are in LDS
     // after B1: the newest-frame columns of every row (1/6 of the columns: each lane owns about one of its NCH), and whole rows
     // for envs that were just reset.  The per-lane column routing is loop-invariant, so the row loop is one LDS read + one store
@@ -1706,7 +1685,6 @@ KArgs make_args(const lt_env* env, const float* actions) {
   k.obs_next[0] = rp; k.obs_next[1] = rc;
   k.rec_values = nullptr; k.rec_gamma = 0.f; k.rec_rewards = nullptr; k.rec_dones = nullptr;
   k.step_offset = 0; k.decide_first = 0;
-  k.warm[0] = env->warm[0]; k.warm[1] = env->warm[1]; k.warm_kib[0] = env->warm_kib[0]; k.warm_kib[1] = env->warm_kib[1];
   return k;
 }
 

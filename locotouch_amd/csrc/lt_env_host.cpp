@@ -199,13 +199,6 @@ int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_pol
   return finish(lt_launch_step_rows(env, actions, prev, next, values, gamma, st_rewards, st_dones, stream), "lt_env_step_rollout");
 }
 
-int lt_env_set_l2_warm(lt_env* env, const void* buf0, int64_t bytes0, const void* buf1, int64_t bytes1) {
-  if (!env || bytes0 < 0 || bytes1 < 0 || (((uintptr_t)buf0 | (uintptr_t)buf1) & 15)) return LT_EINVAL;
-  env->warm[0] = (const float*)buf0; env->warm_kib[0] = buf0 ? (int)(bytes0 / 1024) : 0;  // whole KiB: never past the end
-  env->warm[1] = (const float*)buf1; env->warm_kib[1] = buf1 ? (int)(bytes1 / 1024) : 0;
-  return LT_OK;
-}
-
 int lt_env_defer_gate(lt_env* env, int mode) {
   if (!env || mode < 0 || mode > 2) return LT_EINVAL;
   if (env->gate_pending && mode == 0) { lt_set_error("lt_env_defer_gate: a population pass is outstanding - call lt_env_gate_update first"); return LT_EINVAL; }

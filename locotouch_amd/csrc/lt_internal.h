@@ -17,8 +17,6 @@ struct lt_env {
   int defer_gate = 0;        // lt_env_defer_gate mode: 0 pass behind every step, 1 the caller's lt_env_gate_update, 2 chained (next step launch)
   mutable int pending_steps = 0;  // steps launched whose common_step_counter bump is outstanding (modes 1, 2)
   mutable int gate_pending = 0;   // a population pass is outstanding
-  const float* warm[2] = {nullptr, nullptr};  // lt_env_set_l2_warm
-  int warm_kib[2] = {0, 0};
 };
 
 // implemented in lt_env.hip -------------------------------------------------------------------------

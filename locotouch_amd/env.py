@@ -200,14 +200,6 @@ class LocoTouchVecEnv:
         chain ends with `gate_update()`; until then the command block and the counters lag)."""
         _abi.check(self._lib.lt_env_defer_gate(self._handle, int(mode)), "lt_env_defer_gate")
 
-    def set_l2_warm(self, buf0: torch.Tensor | None, buf1: torch.Tensor | None) -> None:
-        """lt_env_set_l2_warm: buffers (e.g. the packed policy / value weights) the launch after every step will stream from L2."""
-        vp = ctypes.c_void_p
-        self._warm = (buf0, buf1)  # keep them alive
-        a = (vp(buf0.data_ptr()), buf0.numel() * buf0.element_size()) if buf0 is not None else (vp(None), 0)
-        b = (vp(buf1.data_ptr()), buf1.numel() * buf1.element_size()) if buf1 is not None else (vp(None), 0)
-        _abi.check(self._lib.lt_env_set_l2_warm(self._handle, a[0], a[1], b[0], b[1]), "lt_env_set_l2_warm")
-
     def gate_update(self) -> None:
         """The outstanding population pass, if any (lt_env_gate_update)."""
         _abi.check(self._lib.lt_env_gate_update(self._handle, self._stream()), "lt_env_gate_update")

@@ -53,8 +53,6 @@ class FusedRollout:
 
             if describe(ac.actor) is not None and describe(ac.critic) is not None and env.num_actions == 12:
                 self.actor_mlp, self.critic_mlp = PackedMLP(ac.actor), PackedMLP(ac.critic)
-                # the step kernel's idle waves touch the two weight streams, so the policy launch behind it finds them in L2
-                env.set_l2_warm(self.actor_mlp.packed, self.critic_mlp.packed)
 
     @staticmethod
     def _p(t: torch.Tensor) -> ctypes.c_void_p:
