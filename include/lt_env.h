@@ -457,6 +457,11 @@ int lt_mlp_packed_floats(const lt_mlp_desc* desc, size_t* floats);
 int lt_mlp_pack(const lt_mlp_desc* desc, const float* const* weights, const float* const* biases, float* packed, void* stream);
 /* y[m][dims[L]] = MLP(x[m][dims[0]]). */
 int lt_mlp_forward(const lt_mlp_desc* desc, const float* packed, const float* x, int64_t m, float* y, void* stream);
+/* Training forward of the actor and the critic in one launch (the forward half of loco_rl/loco_rl/algorithms/ppo.py:251-262 on a
+ * minibatch): y0 / y1 [m][out] and the activations behind every hidden layer, acts0[l] / acts1[l] [m][dims[l + 1]] (l < L - 1), which
+ * the backward pass needs.  Same kernel and arithmetic as lt_mlp_forward. */
+int lt_mlp_forward_pair(const lt_mlp_desc* d0, const float* packed0, const float* x0, const lt_mlp_desc* d1, const float* packed1, const float* x1,
+                        int64_t m, float* y0, float* y1, float* const* acts0, float* const* acts1, void* stream);
 /* Actor forward + the sampling / log-prob / storage-slot writes of lt_rollout_act in one launch (the policy head must have 12 outputs).
  * Philox key step = *step_counter + step_offset. */
 int lt_rollout_policy(const lt_mlp_desc* actor, const float* packed, const float* obs, int64_t n, uint64_t seed, const int64_t* step_counter,

@@ -137,6 +137,7 @@ def load() -> ctypes.CDLL:
     lib.lt_mlp_packed_floats.argtypes = [dp, ctypes.POINTER(ctypes.c_size_t)]
     lib.lt_mlp_pack.argtypes = [dp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]
     lib.lt_mlp_forward.argtypes = [dp, vp, vp, ctypes.c_int64, vp, vp]
+    lib.lt_mlp_forward_pair.argtypes = [dp, vp, vp, dp, vp, vp, ctypes.c_int64, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
     lib.lt_rollout_policy.argtypes = [dp, vp, vp, ctypes.c_int64, ctypes.c_uint64, vp, ctypes.c_int64] + [vp] * 7
     lib.lt_rollout_policy_value.argtypes = [dp, vp, vp, dp, vp, vp, vp, ctypes.c_int64, ctypes.c_uint64, vp, ctypes.c_int64] + [vp] * 7
     lib.lt_env_step_rollout.argtypes = [ctypes.c_void_p] + [vp] * 6 + [ctypes.c_float, vp, vp, vp]
@@ -150,7 +151,7 @@ def load() -> ctypes.CDLL:
     return lib
 
 
-EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_preset", "lt_cfg_num_presets", "lt_cfg_preset_id", "lt_cfg_obs_dim", "lt_cfg_tactile_dim", "lt_env_create", "lt_env_tactile_update", "lt_env_defer_gate", "lt_env_gate_update", "lt_env_curriculum_apply_global", "lt_gru_forward", "lt_gru_backward", "lt_ppo_loss", "lt_elu_backward_bias", "lt_elu_backward_bias_ws_floats", "lt_adam_clip_step", "lt_adam_clip_step_ws_floats", "lt_head_wgrad", "lt_head_wgrad_ws_floats",
+EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_preset", "lt_cfg_num_presets", "lt_cfg_preset_id", "lt_cfg_obs_dim", "lt_cfg_tactile_dim", "lt_env_create", "lt_env_tactile_update", "lt_env_defer_gate", "lt_env_gate_update", "lt_mlp_forward_pair", "lt_env_curriculum_apply_global", "lt_gru_forward", "lt_gru_backward", "lt_ppo_loss", "lt_elu_backward_bias", "lt_elu_backward_bias_ws_floats", "lt_adam_clip_step", "lt_adam_clip_step_ws_floats", "lt_head_wgrad", "lt_head_wgrad_ws_floats",
            "lt_env_destroy", "lt_env_state_bytes", "lt_env_bind", "lt_env_reset_all", "lt_env_step", "lt_env_step_profiled", "lt_env_eval_terms",
            "lt_env_curriculum_update", "lt_env_step_rows", "lt_env_step_rollout", "lt_env_get_view", "lt_env_set_command_ranges", "lt_rollout_act", "lt_rollout_record", "lt_mlp_packed_floats", "lt_mlp_pack", "lt_mlp_forward", "lt_rollout_policy", "lt_rollout_policy_value",
            "lt_env_kernel_name"]

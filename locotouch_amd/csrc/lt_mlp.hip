@@ -91,6 +91,7 @@ struct MlpArgs {
   const float* x;
   long long m;
   float* y;
+  float* act_out[LT_MLP_MAX_LAYERS];  // optional: the activations behind hidden layer l, [m][dims[l + 1]] (training forward)
   // MODE_POLICY
   unsigned long long seed;
   const long long* step_counter;
@@ -397,6 +398,17 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
     else mlp_layer<1, RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);
     boff += pad16(a.dims[l + 1]);
     MLP_STAMP(2 + l);
+    // training forward (lt_mlp_forward_pair): the layer's activations, still in LDS, also go to memory for the backward pass -
+    // a cooperative, coalesced copy between the layers, where no accumulator is live (write_back itself is at the register limit)
+    if (!last && a.act_out[l]) {
+      const int N = a.dims[l + 1], n4 = N >> 2;
+      float* const dst = a.act_out[l];
+      for (int idx = tid; idx < ROWS * n4; idx += 64 * NW) {
+        const int rr = idx / n4, c4 = idx - rr * n4;
+        const long long e = row0 + rr;
+        if (e < a.m) *(f32x4*)(dst + e * N + 4 * c4) = *(const f32x4*)(s_act + rr * S + 4 * c4);
+      }
+    }
   }
 }
 
@@ -588,6 +600,33 @@ int lt_mlp_forward(const lt_mlp_desc* desc, const float* packed, const float* x,
   d.net[0].mode = MODE_FORWARD;
   d.net[0].packed = packed; d.net[0].x = x; d.net[0].m = m; d.net[0].y = y;
   return launch(d, 1, (hipStream_t)stream);
+}
+
+// Training forward of two networks in one launch (PPO update: actor on the observations, critic on the critic observations):
+// outputs y0 [m][dims0[L0]], y1 [m][dims1[L1]] and, for the backward pass, the activations behind every hidden layer
+// (acts0[l], acts1[l]: [m][dims[l + 1]], l < L - 1; hidden widths must be multiples of 4).
+int lt_mlp_forward_pair(const lt_mlp_desc* d0, const float* packed0, const float* x0, const lt_mlp_desc* d1, const float* packed1, const float* x1,
+                        int64_t m, float* y0, float* y1, float* const* acts0, float* const* acts1, void* stream) {
+  if (!desc_ok(d0) || !desc_ok(d1) || !packed0 || !packed1 || !x0 || !x1 || !y0 || !y1 || !acts0 || !acts1 || m <= 0) {
+    lt_set_error("lt_mlp_forward_pair: invalid argument");
+    return LT_EINVAL;
+  }
+  DualArgs d = {};
+  const lt_mlp_desc* ds[2] = {d0, d1};
+  const float* pk[2] = {packed0, packed1};
+  const float* xs[2] = {x0, x1};
+  float* ys[2] = {y0, y1};
+  float* const* as[2] = {acts0, acts1};
+  for (int k = 0; k < 2; ++k) {
+    fill_args(ds[k], d.net[k]);
+    d.net[k].mode = MODE_FORWARD;
+    d.net[k].packed = pk[k]; d.net[k].x = xs[k]; d.net[k].m = m; d.net[k].y = ys[k];
+    for (int l = 0; l + 1 < ds[k]->num_layers; ++l) {
+      if (!as[k][l] || (ds[k]->dims[l + 1] & 3)) { lt_set_error("lt_mlp_forward_pair: hidden widths must be multiples of 4 and every activation buffer given"); return LT_EINVAL; }
+      d.net[k].act_out[l] = as[k][l];
+    }
+  }
+  return launch(d, 2, (hipStream_t)stream);
 }
 
 int lt_rollout_policy(const lt_mlp_desc* actor, const float* packed, const float* obs, int64_t n, uint64_t seed, const int64_t* step_counter,

@@ -94,3 +94,94 @@ class PackedMLP:
         return out
 
     __call__ = forward
+
+
+class _PairForward(torch.autograd.Function):
+    """Actor and critic forward of a PPO minibatch in ONE launch of the MFMA MLP kernel (csrc/lt_mlp.hip `lt_mlp_forward_pair`),
+    with the hidden activations written out for the backward pass; backward is the layer chain by hand: ELU' + bias sums
+    (`lt_elu_backward_bias`), narrow-head gradients (`lt_head_wgrad`), split-K weight gradients and the input-gradient GEMMs
+    (rl/linear.py).  Inputs: x0, x1, then the (weight, bias) pairs of both stacks, so that autograd routes the gradients."""
+
+    @staticmethod
+    def forward(ctx, pair, x0, x1, *params):
+        lib = _abi.load()
+        vp = ctypes.c_void_p
+        m = x0.shape[0]
+        nets = (pair.a, pair.b)
+        ys, acts = [], []
+        for net in nets:
+            dims = [net.desc.dims[i] for i in range(net.desc.num_layers + 1)]
+            ys.append(torch.empty(m, dims[-1], device=x0.device, dtype=torch.float32))
+            acts.append([torch.empty(m, d, device=x0.device, dtype=torch.float32) for d in dims[1:-1]])
+        arr = [(vp * max(1, len(a)))(*[t.data_ptr() for t in a]) for a in acts]
+        _abi.check(lib.lt_mlp_forward_pair(ctypes.byref(nets[0].desc), vp(nets[0].packed.data_ptr()), vp(x0.data_ptr()),
+                                           ctypes.byref(nets[1].desc), vp(nets[1].packed.data_ptr()), vp(x1.data_ptr()), m,
+                                           vp(ys[0].data_ptr()), vp(ys[1].data_ptr()), arr[0], arr[1], PackedMLP._stream()), "lt_mlp_forward_pair")
+        ctx.nl = (len(nets[0].linears), len(nets[1].linears))
+        ctx.save_for_backward(x0, x1, *acts[0], *acts[1], *[p for p in params[0::2]])
+        ctx.alpha = 1.0
+        ctx.elu = nets[0].desc.activation == _abi.CONSTS["LT_ACT_ELU"]
+        return ys[0], ys[1]
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        from .linear import _head_wgrad, _head_wgrad_ok, _wgrad, pick_splits
+
+        lib = _abi.load()
+        vp = ctypes.c_void_p
+        saved = list(ctx.saved_tensors)
+        x = saved[:2]
+        n0, n1 = ctx.nl
+        acts = [saved[2:2 + n0 - 1], saved[2 + n0 - 1:2 + n0 - 1 + n1 - 1]]
+        ws = saved[2 + n0 - 1 + n1 - 1:]
+        weights = [ws[:n0], ws[n0:]]
+        grads = []
+        for k, dy in enumerate((dy0, dy1)):
+            L = len(weights[k])
+            g = dy if dy.is_contiguous() else dy.contiguous()
+            layer_grads = [None] * (2 * L)
+            for l in range(L - 1, -1, -1):
+                inp = acts[k][l - 1] if l > 0 else x[k]
+                w = weights[k][l]
+                m, n = g.shape
+                if l < L - 1:  # g is the gradient w.r.t. the activation output: through ELU', with the bias sums in the same pass
+                    a = acts[k][l]
+                    dz = torch.empty_like(a)
+                    db = torch.empty(n, device=a.device, dtype=torch.float32)
+                    scratch = torch.empty(int(lib.lt_elu_backward_bias_ws_floats(m, n)), device=a.device, dtype=torch.float32)
+                    _abi.check(lib.lt_elu_backward_bias(vp(g.data_ptr()), vp(a.data_ptr()), m, n, 1.0, vp(dz.data_ptr()), vp(db.data_ptr()), vp(scratch.data_ptr()),
+                                                        PackedMLP._stream()), "lt_elu_backward_bias")
+                    dw = _wgrad(dz, inp, pick_splits(m, n, inp.shape[1]))
+                else:  # the head: no activation
+                    dz = g
+                    if _head_wgrad_ok(dz, inp):
+                        dw, db = _head_wgrad(dz, inp)
+                    else:
+                        dw, db = _wgrad(dz, inp, pick_splits(m, n, inp.shape[1])), dz.sum(0)
+                layer_grads[2 * l], layer_grads[2 * l + 1] = dw, db
+                if l > 0:
+                    g = dz @ w
+            grads += layer_grads
+        return (None, None, None, *grads)
+
+
+class PackedPair:
+    """The actor and critic stacks of an ActorCritic as one training forward (see `_PairForward`).  `__call__(obs, critic_obs)`
+    re-packs the live parameters (they change at every optimizer step), runs the launch and returns (mean, value) with autograd
+    edges to every Linear's weight and bias."""
+
+    def __init__(self, actor: nn.Sequential, critic: nn.Sequential):
+        self.a, self.b = PackedMLP(actor), PackedMLP(critic)
+        for net in (self.a, self.b):
+            dims = [net.desc.dims[i] for i in range(net.desc.num_layers + 1)]
+            if any(d % 4 for d in dims[1:-1]) or net.desc.activation != _abi.CONSTS["LT_ACT_ELU"]:
+                raise ValueError("PackedPair: ELU stacks with hidden widths that are multiples of 4")
+
+    def __call__(self, x0: torch.Tensor, x1: torch.Tensor):
+        self.a.pack()
+        self.b.pack()
+        params = []
+        for net in (self.a, self.b):
+            for lin in net.linears:
+                params += [lin.weight, lin.bias]
+        return _PairForward.apply(self, x0.contiguous(), x1.contiguous(), *params)

@@ -37,6 +37,8 @@ class PPO:
         #    Adam kernels cost more than the syncs they save: 60 ms per iteration against 53 ms.
         self.device_update = on_gpu and bool(unused.get("device_update", False))
         self.fused_loss = on_gpu and bool(unused.get("fused_loss", True))  # csrc/lt_ppo.hip: the loss chain and its backward in one launch
+        self.packed_forward = on_gpu and bool(unused.get("packed_forward", True))  # csrc/lt_mlp.hip: both networks' training forward in one launch
+        self._pair = None
         self._lr_t = None
         #  * `graph_update`: that minibatch step captured once and replayed 20x per iteration from a hipGraph: 46 ms per
         #    iteration, but on this stack (ROCm 7.0 PyTorch) back-to-back replays are not stream-ordered with each other and the
@@ -130,6 +132,22 @@ class PPO:
         return (self.fused_loss and st.observations.is_cuda and type(ac) is ActorCritic and getattr(ac, "noise_std_type", "scalar") == "scalar"
                 and st.actions.shape[-1] <= 16)
 
+    def _packed_pair(self):
+        """PackedPair of the policy's two stacks (None: shapes the MLP kernel does not cover, or `packed_forward=False`)."""
+        if not self.packed_forward:
+            return None
+        if self._pair is None:
+            from .mlp import PackedPair, describe
+
+            ac = self.actor_critic
+            self._pair = False
+            if describe(ac.actor) is not None and describe(ac.critic) is not None:
+                try:
+                    self._pair = PackedPair(ac.actor, ac.critic)
+                except ValueError:
+                    self._pair = False
+        return self._pair or None
+
     def _fused_update(self):
         """The update of the plain ActorCritic on the GPU: per minibatch step two row gathers (obs, critic obs), the two MLPs,
         ONE loss launch that reads the seven small per-row tensors of the rollout storage through the minibatch index
@@ -143,9 +161,12 @@ class PPO:
         small = [f(t).contiguous() for t in (st.actions, st.actions_log_prob, st.advantages, st.returns, st.values, st.mu, st.sigma)]
         stats = torch.zeros(3, device=obs.device)
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        pair = self._packed_pair()
         for idx in st.mini_batch_indices(self.num_mini_batches, self.num_learning_epochs):
+            # both networks' forward in one launch of the MFMA MLP kernel where their shape allows (rl/mlp.py PackedPair)
+            mu, value = pair(obs[idx], cobs[idx]) if pair is not None else (ac.actor(obs[idx]), ac.critic(cobs[idx]))
             loss, surrogate_loss, value_loss, ent, kl_mean = fused_ppo_loss(
-                ac.actor(obs[idx]), ac.std, ac.critic(cobs[idx]), *small, self.clip_param, self.value_loss_coef, self.entropy_coef,
+                mu, ac.std, value, *small, self.clip_param, self.value_loss_coef, self.entropy_coef,
                 self.use_clipped_value_loss, idx=idx)
             if adaptive:
                 self._apply_kl(kl_mean)

@@ -226,3 +226,31 @@ def test_flat_adam_matches_clip_grad_norm_plus_torch_adam():
         torch.testing.assert_close(sa[k]["exp_avg"], sb[k]["exp_avg"], rtol=1e-5, atol=1e-9)
         torch.testing.assert_close(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
     assert (fa.flat_p.view(-1, 64)[:, :].abs().sum() > 0) and float(fa.flat_m.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("m", [24576, 4100, 33])
+def test_packed_pair_training_forward_and_backward_match_the_torch_modules(m):
+    """rl/mlp.py PackedPair (csrc/lt_mlp.hip lt_mlp_forward_pair + the hand-written backward chain): outputs and every parameter
+    gradient of actor and critic against the nn.Sequential stacks themselves.  f32-equivalent arithmetic (split-fp16 MFMA with error
+    compensation): tolerances are those of an f32 GEMM."""
+    import torch
+
+    from locotouch_amd.rl import ActorCritic
+    from locotouch_amd.rl.mlp import PackedPair
+    from tests.rl_synth import N_ACT, N_OBS, POLICY_CFG
+
+    torch.manual_seed(m)
+    ac = ActorCritic(N_OBS, N_OBS, N_ACT, **POLICY_CFG).cuda()
+    pair = PackedPair(ac.actor, ac.critic)
+    x0, x1 = torch.randn(m, N_OBS, device="cuda:0"), torch.randn(m, N_OBS, device="cuda:0")
+    g0, g1 = torch.randn(m, N_ACT, device="cuda:0") / m, torch.randn(m, 1, device="cuda:0") / m
+    res = []
+    for fn in (lambda: (ac.actor(x0), ac.critic(x1)), lambda: pair(x0, x1)):
+        ac.zero_grad()
+        mu, v = fn()
+        ((mu * g0).sum() + (v * g1).sum()).backward()
+        res.append([mu.detach(), v.detach()] + [p.grad.clone() for n_, p in ac.named_parameters() if n_ != "std"])
+    names = ["mu", "value"] + [n_ for n_, _ in ac.named_parameters() if n_ != "std"]
+    for name, a, b in zip(names, *res):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 2e-4 * max(scale, 1e-6) + 1e-7, (name, float((a - b).abs().max()), scale)

@@ -32,7 +32,8 @@ def run(**flags):
     return min(times[2:]) * 1e3, sum(times[2:]) / len(times[2:]) * 1e3, out[:3], alg.learning_rate
 
 
-for name, flags in (("all torch ops", dict(fused_loss=False, fused_adam=False)), ("fused loss", dict(fused_adam=False)), ("fused loss + flat Adam (default)", {})):
+for name, flags in (("all torch ops", dict(fused_loss=False, fused_adam=False, packed_forward=False)), ("fused loss", dict(fused_adam=False, packed_forward=False)),
+                    ("fused loss + flat Adam", dict(packed_forward=False)), ("+ packed forward (default)", {})):
     if name == "all torch ops":
         from locotouch_amd.rl import linear
         keep = linear.linear_elu_ok
