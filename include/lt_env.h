@@ -375,6 +375,11 @@ int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float*
 int lt_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_logp, const float* adv,
                 const float* returns, const float* old_values, const float* old_mu, const float* old_sigma, const int64_t* idx, int64_t M, int A,
                 float clip, float value_loss_coef, int use_clipped_value_loss, float* dmu, float* dvalue, float* acc, void* stream);
+/* GAE(lambda) of a rollout in one launch (RolloutStorage.compute_returns, loco_rl/loco_rl/storage/rollout_storage.py:170-186, before the
+ * advantage normalisation): rewards, values, returns, advantages [T][N] f32, dones [T][N] uint8, last_values [N] = V(obs after the last
+ * step).  returns = A + V, advantages = returns - V, as the reference forms them. */
+int lt_gae(const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float gamma, float lam, int T, int64_t N,
+           float* returns, float* advantages, void* stream);
 /* ELU backward fused with the bias gradient of the layer that fed it (the `Linear -> ELU` blocks of the actor / critic MLPs,
  * loco_rl/loco_rl/modules/actor_critic.py:45-66, in the backward pass of ppo.py:316): dz[M][N] = da * elu'(z) recovered from the
  * activation OUTPUT a (1 where a > 0, a + alpha elsewhere), db[N] = column sums of dz.  dz may alias da.  N a multiple of 4,

@@ -233,6 +233,29 @@ __global__ __launch_bounds__(256) void lt_head_wgrad_kernel(const float* __restr
   }
 }
 
+// ---- GAE(lambda) over a rollout ----------------------------------------------------------------------------------------------------
+// RolloutStorage.compute_returns (loco_rl/loco_rl/storage/rollout_storage.py:170-186) walks the T steps backwards with seven small
+// tensor ops per step - ~170 launches per iteration.  One thread per env does the same recursion in registers; the T x N arrays are
+// read / written one coalesced row per step.  delta = r + (1 - done) gamma V' - V;  A = delta + (1 - done) gamma lambda A';
+// returns = A + V;  advantages = returns - V (as the reference forms them, not A itself).
+__global__ __launch_bounds__(256) void lt_gae_kernel(const float* __restrict__ rewards, const unsigned char* __restrict__ dones,
+                                                     const float* __restrict__ values, const float* __restrict__ last_values, float gamma,
+                                                     float lam, int T, long long N, float* __restrict__ returns, float* __restrict__ advantages) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= N) return;
+  float next_v = last_values[e], gae = 0.f;
+  for (int t = T - 1; t >= 0; --t) {
+    const long long o = (long long)t * N + e;
+    const float v = values[o], alive = 1.f - (float)dones[o];
+    const float delta = rewards[o] + alive * gamma * next_v - v;
+    gae = delta + alive * gamma * lam * gae;
+    const float ret = gae + v;
+    returns[o] = ret;
+    advantages[o] = ret - v;
+    next_v = v;
+  }
+}
+
 // ---- gradient-norm clip + Adam on flat buffers ------------------------------------------------------------------------------------
 // torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step() (loco_rl/loco_rl/algorithms/ppo.py:318-319) are ~12 multi-tensor
 // launches over 17 small tensors; with parameters, gradients and both moments flat they are two: sum of squares per block, then
@@ -327,6 +350,19 @@ extern "C" int lt_head_wgrad(const float* dy, const float* x, int64_t M, int n, 
     default: hipLaunchKernelGGL(lt_head_wgrad_kernel<16>, g, b, lds, st, dy, x, (long long)M, n, k, ws); break;
   }
   hipLaunchKernelGGL(lt_partial_sum_kernel, dim3((unsigned)((n * k + n + 15) / 16)), b, 0, st, ws, nblk, (long long)n * k + HW_MAX_N, n * k + n, n * k, dw, db);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
+  return LT_OK;
+}
+
+extern "C" int lt_gae(const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float gamma, float lam, int T,
+                      int64_t N, float* returns, float* advantages, void* stream) {
+  if (!rewards || !dones || !values || !last_values || !returns || !advantages || T < 1 || N < 1) {
+    lt_set_error("lt_gae: invalid argument");
+    return LT_EINVAL;
+  }
+  hipLaunchKernelGGL(lt_gae_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, dones, values, last_values, gamma,
+                     lam, T, (long long)N, returns, advantages);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;

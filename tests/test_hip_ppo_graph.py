@@ -254,3 +254,27 @@ def test_packed_pair_training_forward_and_backward_match_the_torch_modules(m):
     for name, a, b in zip(names, *res):
         scale = float(a.abs().max())
         assert float((a - b).abs().max()) <= 2e-4 * max(scale, 1e-6) + 1e-7, (name, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("n,T", [(4096, 24), (405, 7), (1, 3)])
+def test_gae_kernel_matches_the_tensor_op_recursion(n, T):
+    """csrc/lt_ppo.hip lt_gae against RolloutStorage.compute_returns' per-step tensor ops (the CPU path, pinned to the reference's
+    golden in tests/test_rl_parity.py), incl. the advantage normalisation that follows."""
+    import torch
+
+    from locotouch_amd.rl.storage import RolloutStorage
+
+    g = torch.Generator().manual_seed(n + T)
+    cpu, gpu = RolloutStorage(n, T, 4, 4, 2, device="cpu"), RolloutStorage(n, T, 4, 4, 2, device="cuda:0")
+    for name in ("rewards", "values"):
+        v = torch.randn(T, n, 1, generator=g)
+        getattr(cpu, name).copy_(v), getattr(gpu, name).copy_(v)
+    d = (torch.rand(T, n, 1, generator=g) < 0.1).to(torch.uint8)
+    cpu.dones.copy_(d), gpu.dones.copy_(d)
+    last = torch.randn(n, 1, generator=g)
+    for norm in (False, True):
+        cpu.compute_returns(last, 0.99, 0.95, normalize_advantage=norm)
+        gpu.compute_returns(last.cuda(), 0.99, 0.95, normalize_advantage=norm)
+        torch.testing.assert_close(gpu.returns.cpu(), cpu.returns, rtol=1e-5, atol=1e-5)
+        if n * T > 1 or not norm:
+            torch.testing.assert_close(gpu.advantages.cpu(), cpu.advantages, rtol=1e-4, atol=1e-5)
