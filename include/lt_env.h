@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 7
+#define LT_ABI_VERSION 8
 
 /* error codes */
 #define LT_OK 0
@@ -370,11 +370,15 @@ int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float*
  * loss = mean(surrogate) + value_loss_coef * mean(value loss) - entropy_coef * entropy  (the entropy term depends on std only and
  * is the caller's); acc [20]: [0] sum surrogate, [1] sum value loss, [2] sum KL, [4 + a] sum over rows of
  * d surrogate-row / d sigma_a scaled by 1 / M.  1 <= A <= 16.  Device pointers, f32.
+ * out (optional, 24 floats): the finished scalars - [0] loss = mean surrogate + value_loss_coef * mean value loss - entropy_coef * entropy,
+ * [1] mean surrogate, [2] mean value loss, [3] entropy (sum_a 0.5 + 0.5 log 2 pi + log sigma_a), [4] mean KL, [8 + a] d loss / d sigma_a
+ * (incl. the entropy term) - written by a one-wave launch behind the main kernel.
  * idx (optional, int64 [M]): the batch tensors (actions ... old_sigma) are then the WHOLE rollout storage and minibatch row i is
  * their row idx[i] (rollout_storage.py:189-215 gathers them; here the gather is the kernel's load). */
 int lt_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_logp, const float* adv,
                 const float* returns, const float* old_values, const float* old_mu, const float* old_sigma, const int64_t* idx, int64_t M, int A,
-                float clip, float value_loss_coef, int use_clipped_value_loss, float* dmu, float* dvalue, float* acc, void* stream);
+                float clip, float value_loss_coef, float entropy_coef, int use_clipped_value_loss, float* dmu, float* dvalue, float* acc, float* out,
+                void* stream);
 /* GAE(lambda) of a rollout in one launch (RolloutStorage.compute_returns, loco_rl/loco_rl/storage/rollout_storage.py:170-186, before the
  * advantage normalisation): rewards, values, returns, advantages [T][N] f32, dones [T][N] uint8, last_values [N] = V(obs after the last
  * step).  returns = A + V, advantages = returns - V, as the reference forms them. */

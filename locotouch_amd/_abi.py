@@ -114,7 +114,7 @@ def load() -> ctypes.CDLL:
     _vp = ctypes.c_void_p
     lib.lt_gru_forward.argtypes = [_vp] * 5 + [ctypes.c_int] * 3 + [_vp] * 3
     lib.lt_gru_backward.argtypes = [_vp] * 6 + [ctypes.c_int] * 3 + [_vp] * 5
-    lib.lt_ppo_loss.argtypes = [_vp] * 11 + [ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int] + [_vp] * 4
+    lib.lt_ppo_loss.argtypes = [_vp] * 11 + [ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int] + [_vp] * 5
     lib.lt_elu_backward_bias.argtypes = [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp, _vp]
     lib.lt_elu_backward_bias_ws_floats.argtypes = [ctypes.c_int64, ctypes.c_int]
     lib.lt_elu_backward_bias_ws_floats.restype = ctypes.c_int64

@@ -99,6 +99,26 @@ __global__ __launch_bounds__(256) void lt_ppo_loss_kernel(const float* __restric
   }
 }
 
+// The scalars of the minibatch loss from the sums of lt_ppo_loss_kernel (one wave, behind it on the stream): out[0] loss, [1] mean
+// surrogate, [2] mean value loss, [3] entropy, [4] mean KL, [8 + a] d loss / d sigma_a.  In PyTorch ops this was a dozen launches on
+// 12-float tensors.  entropy = sum_a (0.5 + 0.5 log 2 pi + log sigma_a) (the same in every row: the std is state-independent).
+__global__ __launch_bounds__(64) void lt_ppo_finalize_kernel(const float* __restrict__ acc, const float* __restrict__ stdp, int A, float inv_m,
+                                                             float vcoef, float ecoef, float* __restrict__ out) {
+  const int a = threadIdx.x;
+  float e = 0.f;
+  if (a < A) {
+    const float sg = stdp[a];
+    e = 0.5f + kHalfLog2Pi + logf(sg);
+    out[8 + a] = acc[4 + a] - ecoef / sg;
+  }
+  for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+  if (a == 0) {
+    const float surr = acc[0] * inv_m, vl = acc[1] * inv_m;
+    out[0] = surr + vcoef * vl - ecoef * e;
+    out[1] = surr; out[2] = vl; out[3] = e; out[4] = acc[2] * inv_m;
+  }
+}
+
 // ---- ELU backward fused with the bias gradient ---------------------------------------------------------------------------------
 // dz = da * elu'(z) with elu'(z) recovered from the OUTPUT a = elu(z): 1 for a > 0, a + alpha otherwise (PyTorch's own
 // `elu_backward(..., is_result=true)`), and db[n] = sum over rows of dz[., n] in the same pass.  A thread owns 4 adjacent columns
@@ -390,7 +410,8 @@ extern "C" int64_t lt_adam_clip_step_ws_floats(int64_t n) { return (n + AD_PER_B
 
 extern "C" int lt_ppo_loss(const float* mu, const float* stdp, const float* value, const float* actions, const float* old_logp, const float* adv,
                            const float* returns, const float* old_values, const float* old_mu, const float* old_sigma, const int64_t* idx,
-                           int64_t M, int A, float clip, float value_loss_coef, int use_clipped_value_loss, float* dmu, float* dvalue, float* acc, void* stream) {
+                           int64_t M, int A, float clip, float value_loss_coef, float entropy_coef, int use_clipped_value_loss, float* dmu, float* dvalue,
+                           float* acc, float* out, void* stream) {
   if (!mu || !stdp || !value || !actions || !old_logp || !adv || !returns || !old_values || !old_mu || !old_sigma || !dmu || !dvalue || !acc ||
       M < 1 || A < 1 || A > MAX_A) {
     lt_set_error("lt_ppo_loss: invalid argument (1 <= num_actions <= 16)");
@@ -400,6 +421,7 @@ extern "C" int lt_ppo_loss(const float* mu, const float* stdp, const float* valu
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   hipLaunchKernelGGL(lt_ppo_loss_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu, stdp, value, actions, old_logp, adv,
                      returns, old_values, old_mu, old_sigma, (const long long*)idx, (long long)M, A, clip, value_loss_coef, use_clipped_value_loss, dmu, dvalue, acc);
+  if (out) hipLaunchKernelGGL(lt_ppo_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, stdp, A, 1.f / (float)M, value_loss_coef, entropy_coef, out);
   e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;

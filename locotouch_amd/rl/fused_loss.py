@@ -31,15 +31,14 @@ class _FusedPPOLoss(torch.autograd.Function):
                 or (idx is None and rows != m) or (idx is not None and (idx.dtype != torch.int64 or idx.numel() != m))):
             raise ValueError("fused_ppo_loss: batch tensors do not match the minibatch / index")
         idx_c = None if idx is None else c(idx)
+        out = torch.empty(24, device=mu.device, dtype=torch.float32)
         _abi.check(lib.lt_ppo_loss(vp(mu_c.data_ptr()), vp(std_c.data_ptr()), vp(v_c.data_ptr()), *[vp(t.data_ptr()) for t in args],
                                    vp(None if idx_c is None else idx_c.data_ptr()), m, a,
-                                   float(clip), float(vcoef), int(bool(clipped)), vp(dmu.data_ptr()), vp(dvalue.data_ptr()), vp(acc.data_ptr()),
-                                   vp(torch.cuda.current_stream(mu.device).cuda_stream)), "lt_ppo_loss")
-        surr, vl, kl = (acc[:3] / m).unbind(0)
-        ent = (0.5 + 0.5 * math.log(2.0 * math.pi) + torch.log(std_c)).sum()  # Normal entropy, summed over actions; same in every row
-        loss = surr + vcoef * vl - ecoef * ent
-        ctx.save_for_backward(dmu, dvalue.view_as(value), acc[4:4 + a] - ecoef / std_c)
-        return loss, surr, vl, ent, kl
+                                   float(clip), float(vcoef), float(ecoef), int(bool(clipped)), vp(dmu.data_ptr()), vp(dvalue.data_ptr()), vp(acc.data_ptr()),
+                                   vp(out.data_ptr()), vp(torch.cuda.current_stream(mu.device).cuda_stream)), "lt_ppo_loss")
+        # out: the finished scalars, written by a one-wave launch behind the main kernel (a dozen 12-float tensor ops otherwise)
+        ctx.save_for_backward(dmu, dvalue.view_as(value), out[8:8 + a])
+        return out[0], out[1], out[2], out[3], out[4]
 
     @staticmethod
     def backward(ctx, g, *unused):

@@ -122,9 +122,9 @@ def test_update_and_recurrence_entry_points_validate_their_arguments_before_touc
     bad = C["LT_EINVAL"]
     # lt_ppo_loss: null operand, zero rows, more than 16 actions
     args = [one] * 10 + [null]
-    assert lib.lt_ppo_loss(*([null] + args[1:]), 128, 12, 0.2, 1.0, 1, one, one, one, null) == bad
-    assert lib.lt_ppo_loss(*args, 0, 12, 0.2, 1.0, 1, one, one, one, null) == bad
-    assert lib.lt_ppo_loss(*args, 128, 17, 0.2, 1.0, 1, one, one, one, null) == bad
+    assert lib.lt_ppo_loss(*([null] + args[1:]), 128, 12, 0.2, 1.0, 0.01, 1, one, one, one, one, null) == bad
+    assert lib.lt_ppo_loss(*args, 0, 12, 0.2, 1.0, 0.01, 1, one, one, one, one, null) == bad
+    assert lib.lt_ppo_loss(*args, 128, 17, 0.2, 1.0, 0.01, 1, one, one, one, one, null) == bad
     assert b"lt_ppo_loss" in lib.lt_last_error()
     # lt_elu_backward_bias: N not a multiple of 4 / beyond 1024
     assert lib.lt_elu_backward_bias(one, one, 64, 130, 1.0, one, one, one, null) == bad
