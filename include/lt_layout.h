@@ -76,7 +76,7 @@ static inline void lt_layout_init(lt_layout* L, int64_t num_envs, int32_t obs_di
   L->off_cmd_params = off;  off = lt_align256(off + LT_CMD_PARAMS_LEN * 4);
   L->off_counters = off;    off = lt_align256(off + 4 * 8);
   L->off_gate_ring = off;   off = lt_align256(off + LT_GATE_RING * LT_PARTIAL_FLOATS * 4);
-  L->off_partials = off;    off = lt_align256(off + (L->npad / 16) * LT_PARTIAL_FLOATS * 4);
+  L->off_partials = off;    off = lt_align256(off + 2 * (L->npad / 16) * LT_PARTIAL_FLOATS * 4); /* two slot sets, by step parity */
   L->off_obs_tactile = off; off = lt_align256(off + (tactile ? 3 * L->npad * (int64_t)LT_TACTILE_WIDE_DIM * 4 : 0)); /* tactile | original | processed */
   L->off_obj_sizes = off;   off = lt_align256(off + L->npad * 2 * 4); /* this and what follows survive lt_env_reset_all */
   L->off_dev_args = off;    off = lt_align256(off + LT_DEV_ARGS_BYTES);

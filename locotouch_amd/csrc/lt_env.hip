@@ -837,7 +837,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
           auto put = [&](int slot, const U4& u) { s_bank[slot][0][lane] = u.a; s_bank[slot][1][lane] = u.b; s_bank[slot][2][lane] = u.c; s_bank[slot][3][lane] = u.d; };
           const int last = nsub - 1;
           // chained steps: the previous step's population pass, once per launch, here - ~6 k cycles inside an 11 k-cycle substep
-          if (it == 0 && a.decide_first && blockIdx.x == 0) curriculum_decide(c, L, arena, 0, (long long)step);
+          if (it == 0 && a.decide_first && blockIdx.x == 0) curriculum_decide(c, L, arena, 0, (long long)step, (int)((step - 1) & 1));
           if (it == last) {
             // the command block of THIS step -> LDS.  Chained: wait until the launch's decision is final (it has been for ~35 us)
             // and read it with sc1 loads; nobody in this launch read the block earlier, so no cache of this XCD holds an older line.
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       in.valid = env < L.n;
       in.reset = s_cur[lane * 5 + 0] != 0.f; in.ep_len = s_cur[lane * 5 + 1];
       in.sum_lin = s_cur[lane * 5 + 2]; in.sum_ang = s_cur[lane * 5 + 3]; in.cmd_nonzero = s_cur[lane * 5 + 4] != 0.f;
-      curriculum_publish(L, arena, P, gid, leg, in);  // the decision is lt_gate_decide_kernel's (or the next launch's, chained)
+      curriculum_publish(L, arena, P, gid, leg, in, (int)(step & 1));  // the decision is lt_gate_decide_kernel's (or the next launch's, chained)
 #ifdef LT_STAMPS
       LT_STAMP(1);
       if (lane == 0) ((float*)(arena + L.quad_off[LT_F_REWARD_TERMS]) + 3 * L.npad * 4 + (long long)blockIdx.x * 64)[3] = (float)(long long)(stamps_[1] - stamps_[0]);
@@ -1420,7 +1420,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       s_cur[lane * 5 + 0] = cur_in.reset ? 1.f : 0.f; s_cur[lane * 5 + 1] = cur_in.ep_len;
       s_cur[lane * 5 + 2] = cur_in.sum_lin; s_cur[lane * 5 + 3] = cur_in.sum_ang; s_cur[lane * 5 + 4] = cur_in.cmd_nonzero ? 1.f : 0.f;
     } else {
-      curriculum_publish(L, arena, P, gid, leg, cur_in);
+      curriculum_publish(L, arena, P, gid, leg, cur_in, (int)(step & 1));
     }
   }
 
@@ -1622,11 +1622,11 @@ __global__ __launch_bounds__(64) void lt_curriculum_kernel(const KArgs a, const 
   in.ep_len = r[1]; in.sum_lin = r[2]; in.sum_ang = r[3];
   const float cm = ((const float*)(a.arena + L.quad_off[LT_F_CMD]))[gid];
   in.cmd_nonzero = qor((leg < 3 && cm != 0.f) ? 1 : 0) != 0;
-  curriculum_publish(L, a.arena, (const float*)(a.arena + L.off_cmd_params), gid, leg, in);
+  curriculum_publish(L, a.arena, (const float*)(a.arena + L.off_cmd_params), gid, leg, in, 0);
 }
 // the global half of the pass (lt_post.h): one wave behind the step kernel / the curriculum hook
 __global__ __launch_bounds__(64) void lt_gate_decide_kernel(const KArgs a, int bump_counter) {
-  curriculum_decide(a.d->cfg, a.d->layout, a.arena, bump_counter);
+  curriculum_decide(a.d->cfg, a.d->layout, a.arena, bump_counter, 0, bump_counter > 0 ? -1 : 0);  // (the records hook publishes into set 0)
 }
 // multi-rank curriculum gate on cross-rank sums (lt_post.h curriculum_apply_global); one wave
 __global__ __launch_bounds__(64) void lt_gate_apply_kernel(const KArgs a, const float* __restrict__ ring_sums, int nsteps, float inv_n_total) {

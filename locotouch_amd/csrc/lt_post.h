@@ -50,7 +50,9 @@ struct CurIn {
 // Step 1.  One block of the launch = one wave64 with lane = env * 4 + leg (the step kernel's mapping); every 16-env tile of the
 // grid calls this exactly once per pass.
 // `P`: the command block as this tile may read it (global memory, or the workgroup's LDS copy in the step kernel's helper form).
-__device__ __forceinline__ void curriculum_publish(const lt_layout& L, char* const arena, const float* const P, long long gid, int leg, const CurIn& in) {
+// `set`: which of the two slot sets (the step's parity: the pass of step t may still be reading set t & 1 inside the launch of step
+// t + 1 - chained mode - while that launch's tiles publish into the other one).
+__device__ __forceinline__ void curriculum_publish(const lt_layout& L, char* const arena, const float* const P, long long gid, int leg, const CurIn& in, int set) {
   const long long q4 = L.npad * 4;
   float* const rec_p = (float*)(arena + L.quad_off[LT_F_CURRICULUM]) + gid;
   float* const t1_p = rec_p + q4;
@@ -86,7 +88,7 @@ __device__ __forceinline__ void curriculum_publish(const lt_layout& L, char* con
   const float w_lang = wave_sum(mine ? l_ang : 0.f), w_sang = wave_sum(mine ? s_ang : 0.f);
   // ---- 3. publish: this tile's slot (plain stores; the decision kernel starts behind a kernel boundary) ----
   const int lane = threadIdx.x & 63;
-  float* const slots = (float*)(arena + L.off_partials);
+  float* const slots = (float*)(arena + L.off_partials) + (long long)set * (L.npad / 16) * LT_PARTIAL_FLOATS;
   {
     const float bit[4] = {(float)(flags & 1), (float)((flags >> 1) & 1), (float)((flags >> 2) & 1), (float)((flags >> 3) & 1)};
     const float v = lane == 0 ? bit[0] : lane == 1 ? bit[1] : lane == 2 ? bit[2] : lane == 3 ? w_llin : lane == 4 ? w_slin
@@ -174,12 +176,14 @@ __device__ __forceinline__ void curriculum_apply_global(const lt_cfg& c, const l
 // wave, beside the first physics substep; nothing of a step reads the command block before its physics is over).  The command block
 // is then stored write-through and drained, and counters[2] = chain_flag (the launch's step id) tells the other workgroups of that
 // launch that it is final (MI355X_MICROARCH.md, "Valid forms": sc1 payload -> vmcnt(0) -> flag; consumers poll and load with sc1).
-__device__ __forceinline__ void curriculum_decide(const lt_cfg& c, const lt_layout& L, char* const arena, int bump_counter, long long chain_flag = 0) {
+// `set` < 0: the slot set of the last step launched, (common_step_counter + bump_counter - 1) & 1.
+__device__ __forceinline__ void curriculum_decide(const lt_cfg& c, const lt_layout& L, char* const arena, int bump_counter, long long chain_flag = 0, int set = -1) {
   float* const P = (float*)(arena + L.off_cmd_params);
   const int lane = threadIdx.x & 63;
   const unsigned nwaves = (unsigned)(L.npad / 16);
-  const float* const slots = (const float*)(arena + L.off_partials);
   long long* const cnt = (long long*)(arena + L.off_counters);
+  if (set < 0) set = (int)((cnt[0] + (bump_counter > 0 ? bump_counter - 1 : 0)) & 1);
+  const float* const slots = (const float*)(arena + L.off_partials) + (long long)set * (L.npad / 16) * LT_PARTIAL_FLOATS;
   // everything this wave reads is requested up front: one memory round trip, not four dependent ones
   float Pl[31];
 #pragma unroll

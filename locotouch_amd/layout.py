@@ -58,7 +58,7 @@ class Layout:
             ("LT_F_CMD_PARAMS", C["LT_CMD_PARAMS_LEN"] * 4, np.float32, (C["LT_CMD_PARAMS_LEN"],)),
             ("LT_F_COUNTERS", 4 * 8, np.int64, (4,)),
             ("LT_F_GATE_RING", C["LT_GATE_RING"] * 8 * 4, np.float32, (C["LT_GATE_RING"], 8)),
-            ("_PARTIALS", self.npad // 16 * 8 * 4, np.float32, (self.npad // 16, 8)),  # per-wave curriculum partials
+            ("_PARTIALS", 2 * (self.npad // 16) * 8 * 4, np.float32, (2 * (self.npad // 16), 8)),  # per-tile curriculum partials, two sets (step parity)
             # three blocks of [npad][884] capacity: tactile | original_tactile | processed_tactile (include/lt_layout.h)
             ("LT_F_OBS_TACTILE", 3 * self.npad * C["LT_TACTILE_WIDE_DIM"] * 4 * self.tactile, np.float32, (self.npad * self.tactile, self.tactile_dim)),
             ("LT_F_OBJ_SIZES", self.npad * 2 * 4, np.float32, (self.npad, 2)),
