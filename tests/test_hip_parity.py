@@ -267,6 +267,32 @@ def test_chained_population_pass_equals_the_pass_behind_every_step():
     a.defer_gate(0)
 
 
+@pytest.mark.parametrize("task,n", [("locomotion", 48), ("teacher", 8208)])
+def test_chained_mode_on_other_grids(task, n):
+    """Chained mode on a locomotion env (no object: the helper waves' object roles are idle) and on a grid beyond one tile per CU,
+    where the single-wave form cannot absorb a pass and the launcher issues it itself: identical arenas to the default mode."""
+    import torch
+
+    a, b = make_env(task, n, seed=5), make_env(task, n, seed=5)
+    g = torch.Generator(device="cuda:0").manual_seed(2)
+    L = Layout(n, a.num_obs)
+    off = L.plain["LT_F_COUNTERS"][0] + 16
+    for chain in (3, 1, 6):
+        a.defer_gate(2)
+        for _ in range(chain):
+            act = 0.4 * torch.randn(n, 12, device="cuda:0", generator=g)
+            a.step_rows_raw(act.data_ptr(), 0, 0, 0, 0)
+            b.step(act)
+        a.gate_update()
+        a.defer_gate(0)
+        torch.cuda.synchronize()
+        ha, hb = a._arena_aligned.clone(), b._arena_aligned.clone()
+        ha[off:off + 8] = 0
+        hb[off:off + 8] = 0
+        assert torch.equal(ha, hb), f"{task} n={n} after a chain of {chain}"
+    assert int(a.counters[0]) == 11
+
+
 def test_free_running_statistics_teacher():
     """Without re-syncing, chaotic contact dynamics decorrelate trajectories; episode statistics must still agree."""
     import torch
