@@ -420,7 +420,10 @@ struct PackArgs {
   long long bias_float_off; // first float of this layer's (pad16(N)) bias slice
   float* packed;
 };
-__global__ void lt_mlp_pack_kernel(const PackArgs p) {
+// all layers of a network in one launch: blockIdx.y = layer
+struct PackAll { PackArgs layer[LT_MLP_MAX_LAYERS]; };
+__global__ void lt_mlp_pack_kernel(const PackAll all) {
+  const PackArgs& p = all.layer[blockIdx.y];
   const int T = tiles_per_wave(pad16(p.N) / 16), G = pad32(p.K) / 32, C = 2 * T;
   const int chunks = layer_chunks(p.K, p.N), nact = active_waves(p.N);
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (wave, chunk, lane)
@@ -577,19 +580,22 @@ int lt_mlp_packed_floats(const lt_mlp_desc* desc, size_t* floats) {
 int lt_mlp_pack(const lt_mlp_desc* desc, const float* const* weights, const float* const* biases, float* packed, void* stream) {
   if (!desc_ok(desc) || !weights || !biases || !packed) { lt_set_error("lt_mlp_pack: invalid argument"); return LT_EINVAL; }
   const Geometry g = geometry(desc);
-  long long bias_off = 0;
+  long long bias_off = 0, most = 0;
+  PackAll all = {};
   for (int l = 0; l < desc->num_layers; ++l) {
     if (!weights[l] || !biases[l]) { lt_set_error("lt_mlp_pack: null layer pointer"); return LT_EINVAL; }
-    PackArgs p;
+    PackArgs& p = all.layer[l];
     p.w = weights[l]; p.b = biases[l]; p.K = desc->dims[l]; p.N = desc->dims[l + 1]; p.packed = packed;
     for (int w = 0; w < NW; ++w) p.chunk_off[w] = g.layer_off[l][w];
     p.bias_float_off = g.bias_chunk * 256 + bias_off;
     bias_off += pad16(p.N);
-    const long long total = (long long)active_waves(p.N) * layer_chunks(p.K, p.N) * 64;
-    hipLaunchKernelGGL(lt_mlp_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
+    long long total = (long long)active_waves(p.N) * layer_chunks(p.K, p.N) * 64;
+    total = total < pad16(p.N) ? pad16(p.N) : total;  // (the bias slice is written by the first pad16(N) threads)
+    most = total > most ? total : most;
   }
+  hipLaunchKernelGGL(lt_mlp_pack_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)desc->num_layers), dim3(256), 0, (hipStream_t)stream, all);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;
 }
 
