@@ -728,9 +728,21 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     hot.obj_params = *F(LT_F_OBJ_PARAMS, 0); hot.env_params = *F(LT_F_ENV_PARAMS, 0);
   }
   __shared__ float s_frame[2][16][64];
+  // the 16 old rows of history group g (one contiguous chunk of 16*OBS floats) -> LDS by LDS-DMA: each wave-instruction moves
+  // 64 lanes x 16 B = 1 KiB, lane-linear in LDS, no VGPRs
+  auto dma_old_rows = [&](int g, float* dst) {
+    constexpr int CHUNK16 = 16 * OBS / 4;  // float4 count per group (OBS*16 is a multiple of 4 for both tasks)
+    const float* gsrc = a.obs_prev[g] + (long long)blockIdx.x * 16 * OBS;
+    for (int i = 0; i < (CHUNK16 + 63) / 64; ++i) {
+      const int v = i * 64 + lane;
+      if (v < CHUNK16)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + v * 4),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+    }
+  };
   __shared__ int s_fill[16];
   __shared__ short s_tab[HELPERS ? 2 : 1][704];  // observation history tables (src[352] | frame[352]), one copy per history wave
-  __shared__ __attribute__((aligned(16))) float s_old[HELPERS ? 2 * 16 * OBS : 4];
+  __shared__ __attribute__((aligned(16))) float s_old[HELPERS ? 2 * 16 * OBS : 16 * OBS];  // old history rows (one-wave form: one group at a time)
   __shared__ float s_cur[HELPERS ? 64 * 5 : 1];  // wave 0 -> wave 3: this step's curriculum record per lane
   __shared__ float s_mb_in[HELPERS ? MB_IN : 1][64], s_mb_crba[HELPERS ? MB_CRBA : 1][64], s_mb_obj[HELPERS ? MB_OBJ : 1][64],
       s_mb_ofin[HELPERS ? MB_OFIN : 1][64];  // physics mailboxes (HelperParts)
@@ -748,8 +760,10 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   if (!HELPERS) {
     const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
     for (int i = lane; i < 352; i += 64) { s_tab[0][i] = tab.src[i]; s_tab[0][352 + i] = tab.frame[i]; }
+    dma_old_rows(0, s_old);  // the policy group's old history rows, behind the state loads (the critic group's follow at the end)
   }
-  __syncthreads();  // B0: the (cfg, layout) block is in LDS
+  if (HELPERS) __syncthreads();  // B0: the (cfg, layout) block is in LDS
+  else wg_barrier_lds();       //     (one-wave form: no vmcnt drain - the row DMA stays in flight beside the physics)
   const lt_cfg& c = s_d.cfg;
   const lt_layout& L = s_d.layout;
   // the command block: global memory, or - helper form - the copy wave 3 leaves in LDS beside the last physics substep
@@ -930,7 +944,9 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     //      has landed (vmcnt(0)) before this wave stores anything, and only this wave touches the group's rows. ----
     const int g = wave - 1;
     constexpr int NCH = (OBS + 63) / 64;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // (the builtin, not an asm: the waitcnt pass then knows the row DMA has landed; behind an opaque wait it re-waits vmcnt(0) - for
+    //  every store of the loops below - before each LDS read of the staged rows.  0x0070 = vmcnt 0, lgkmcnt 0, expcnt untouched)
+    __builtin_amdgcn_s_waitcnt(0x0070);
     int src[NCH], frm[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -1504,51 +1520,45 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   LT_STAMP(5);
   if (!HELPERS)
   {
-    // History rows.  The 16 env rows of this wave are one contiguous chunk of 16*OBS floats per group.  Row(t) is built in
-    // place from row(t-1): every term block shifts left by one frame and takes the newest frame from LDS.  Work is
-    // batched so that many loads are in flight per wait (a lone wave per SIMD has nothing else to hide latency with):
-    // a batch loads BATCH float4-columns per lane for BOTH groups, then stores them.  In-place safety: a column only
-    // reads higher addresses of its own row, all loads of a batch precede its stores, later batches only read above.
-    constexpr int VEC = (OBS % 4 == 0) ? 4 : 2;     // 348 = 87 float4 ; 270 = 135 float2
-    constexpr int ROWV = OBS / VEC;
-    constexpr int TOTAL = 16 * ROWV;
-    constexpr int BATCH = 6;
-    float* const rows_p = a.obs_next[0] + (long long)blockIdx.x * 16 * OBS;
-    float* const rows_c = a.obs_next[1] + (long long)blockIdx.x * 16 * OBS;
-    const float* const old_p = a.obs_prev[0] + (long long)blockIdx.x * 16 * OBS;
-    const float* const old_c = a.obs_prev[1] + (long long)blockIdx.x * 16 * OBS;
-    for (int base = 0; base < TOTAL; base += 64 * BATCH) {
-      float vp[BATCH][VEC], vc[BATCH][VEC];
+    // History rows (one-wave form).  The 16 env rows of this wave are one contiguous chunk of 16*OBS floats per group.  Row(t) is
+    // built from row(t-1): every term block shifts left by one frame and takes the newest frame from LDS.  The old rows come in by
+    // LDS-DMA (22 operations per group: the policy group's at kernel start - they land beside the physics - the critic group's
+    // after the policy rows are done, into the same 22-KB area); lane l owns columns l, l + 64, ... of every row (conflict-free LDS
+    // reads, table lookups once per lane), a row costs NCH coalesced stores.  In-place safety: the DMA of a group has landed
+    // (vmcnt(0)) before any of its rows is stored.
+    constexpr int NCH = (OBS + 63) / 64;
+    int src[NCH], frm[NCH];
 #pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        const int idx = base + j * 64 + lane;
-        if (idx < TOTAL) {
-          const int r = idx / ROWV, cv = idx - r * ROWV;
-          const bool fill = s_fill[r] != 0;
+    for (int i = 0; i < NCH; ++i) {
+      const int col = i * 64 + lane;
+      const int cc = col < OBS ? col : OBS - 1;
+      src[i] = s_tab[0][cc];         // >= 0: old column (one slot newer); < 0: newest frame element -src-1
+      frm[i] = s_tab[0][352 + cc];   // newest-frame element of this column's term (rows that were just reset)
+    }
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            const int col = cv * VEC + e;
-            const int sidx = s_tab[0][col];         // >= 0: old column (one slot newer); < 0: newest frame element -sidx-1
-            const int fidx = s_tab[0][352 + col];   // newest-frame element of this column's term
-            const bool from_frame = fill || sidx < 0;
-            const int fi = fill ? fidx : (-sidx - 1);
-            vp[j][e] = from_frame ? s_frame[0][r][fi & 63] : old_p[r * OBS + sidx];
-            vc[j][e] = from_frame ? s_frame[1][r][fi & 63] : old_c[r * OBS + sidx];
-          }
-        }
+    for (int g = 0; g < 2; ++g) {
+      if (g == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the policy rows are done
+        dma_old_rows(1, s_old);
       }
+      // vmcnt(0) as the BUILTIN (0x0F70 = vmcnt 0, expcnt / lgkmcnt untouched): the waitcnt pass then knows the DMA has landed; behind
+      // an opaque asm wait it re-waits vmcnt(0) - i.e. for every store of the loop below - before each LDS read of the staged rows
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      float* const rows = a.obs_next[g] + (long long)blockIdx.x * 16 * OBS;
+#pragma unroll 4
+      for (int r = 0; r < 16; ++r) {
+        const bool fill = s_fill[r] != 0;  // first push after a reset fills all 6 slots
+        float fv[NCH], ov[NCH];
 #pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        const int idx = base + j * 64 + lane;
-        if (idx < TOTAL) {
-          const int r = idx / ROWV, cv = idx - r * ROWV;
-          if (VEC == 4) {
-            *(float4*)(rows_p + r * OBS + cv * 4) = make_float4(vp[j][0], vp[j][1], vp[j][2], vp[j][VEC - 1]);
-            *(float4*)(rows_c + r * OBS + cv * 4) = make_float4(vc[j][0], vc[j][1], vc[j][2], vc[j][VEC - 1]);
-          } else {
-            *(float2*)(rows_p + r * OBS + cv * 2) = make_float2(vp[j][0], vp[j][1]);
-            *(float2*)(rows_c + r * OBS + cv * 2) = make_float2(vc[j][0], vc[j][1]);
-          }
+        for (int i = 0; i < NCH; ++i) {
+          const int fi = (fill ? frm[i] : (-src[i] - 1)) & 63;
+          const int si = src[i] >= 0 ? src[i] : 0;
+          fv[i] = s_frame[g][r][fi]; ov[i] = s_old[r * OBS + si];
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int col = i * 64 + lane;
+          if (col < OBS) rows[r * OBS + col] = (fill || src[i] < 0) ? fv[i] : ov[i];
         }
       }
     }
