@@ -805,6 +805,10 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
         // each wave-instruction moves 64 lanes x 16 B = 1 KiB, lane-linear in LDS, no VGPRs - NOW, so that it lands beside the
         // physics (the physics barriers wait for LDS traffic only; B0, a full barrier, is behind us).
         const int g = wave - 1;
+        // (the routing tables first: their loads are waited for before the LDS copy, and vmcnt retires in order - behind the DMA
+        //  that wait would hold this wave until all 22 KB have landed, i.e. into the first substep)
+        const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
+        for (int i = lane; i < 352; i += 64) { s_tab[g][i] = tab.src[i]; s_tab[g][352 + i] = tab.frame[i]; }
         constexpr int CHUNK16 = 16 * OBS / 4;  // float4 count per group (OBS*16 is a multiple of 4 for both tasks)
         const float* gsrc = a.obs_prev[g] + (long long)blockIdx.x * 16 * OBS;
         for (int i = 0; i < (CHUNK16 + 63) / 64; ++i) {
@@ -813,8 +817,6 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + v * 4),
                                              (__attribute__((address_space(3))) void*)(s_old + g * 16 * OBS + i * 256), 16, 0, 0);
         }
-        const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
-        for (int i = lane; i < 352; i += 64) { s_tab[g][i] = tab.src[i]; s_tab[g][352 + i] = tab.frame[i]; }
       }
       for (int it = 0; it < nsub; ++it) {
         wg_barrier_lds();  // A
