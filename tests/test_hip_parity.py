@@ -411,7 +411,7 @@ def test_reward_terms_against_reference_golden():
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("task,n", [("teacher", 4096), ("locomotion", 4096), ("teacher", 32768), ("locomotion", 32768)])
 def test_full_size_properties(task, n):
-    """n = 4096: BASELINE.json's headline size (LDS-DMA history path); n = 32768: config 5's size (register history path)."""
+    """n = 4096: BASELINE.json's headline size (LDS-DMA history path); n = 32768: config 5's size (one-wave form: history rows staged one group at a time)."""
     import torch
 
     env = make_env(task, n, seed=42)
@@ -567,8 +567,8 @@ def test_fused_rollout_kernels_match_torch():
 
 
 def test_rollout_rows_large_grid_register_history_path():
-    """> 8192 envs: the register-path history variant writing rows into rollout-storage slots (distinct prev/next pointers)
-    must equal, bit for bit, the same variant shifting the arena rows in place (which test_step_parity_resynced pins to
+    """> 8192 envs: the one-wave form's history pass (old rows staged in LDS one group at a time) writing rows into
+    rollout-storage slots (distinct prev/next pointers) must equal, bit for bit, the same pass shifting the arena rows in place (which test_step_parity_resynced pins to
     the oracle at this size)."""
     import torch
     from locotouch_amd.rl import PPO, ActorCritic, FusedRollout
