@@ -47,7 +47,10 @@ class Dist:
 
     def barrier(self) -> None:
         if self.world_size > 1:
-            td.barrier()
+            if self.backend == "nccl":
+                td.barrier(device_ids=[self.local_rank])  # (no device guess from the rank: this process's GPU is LOCAL_RANK)
+            else:
+                td.barrier()
 
     def _collective(self, t: torch.Tensor, fn) -> torch.Tensor:
         if self.backend == "gloo" and t.is_cuda:  # gloo rehearsal on a GPU box: stage through the host
