@@ -615,8 +615,8 @@ __device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P
 //             physics runs, the newest frame (and whole rows of envs that reset) after the barrier;
 //   wave 3    the curriculum / population-gate publish (lt_post.h) - its write-through stores and the ticket round trip
 //             stall this wave, not the step.
-// Large grids run the single-wave form (HELPERS = false): there every SIMD already has work, the history pass uses a
-// register path (57 KB of LDS per tile would cap occupancy) and the tail runs inline.
+// Large grids run the single-wave form (HELPERS = false): there every SIMD already has work, the history pass stages ONE
+// group's old rows in LDS at a time (22 KB: four tiles per CU still fit) and the tail runs inline.
 #ifndef LT_STEP_MIN_WAVES_LARGE
 #define LT_STEP_MIN_WAVES_LARGE 1
 #endif
