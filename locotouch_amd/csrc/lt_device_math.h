@@ -41,6 +41,11 @@ __device__ __forceinline__ float sel4(int leg, float a, float b, float c, float 
   return leg == 0 ? a : (leg == 1 ? b : (leg == 2 ? c : d));
 }
 
+// v_sqrt_f32 / v_rsq_f32 as they are (1 ulp).  `sqrtf` expands to ~16 VALU operations (denormal pre-scaling + a correctly-rounded
+// fix-up) - 12 of them sat in every physics substep; nothing on this path is near the denormal range or needs the last bit.
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float frsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+
 // ---- vectors / matrices --------------------------------------------------------------------------------
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -52,7 +57,7 @@ __device__ __forceinline__ V3& operator+=(V3& a, V3 b) { a.x += b.x; a.y += b.y;
 __device__ __forceinline__ V3& operator-=(V3& a, V3 b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
 __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-__device__ __forceinline__ float norm(V3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ float norm(V3 a) { return fsqrt(dot(a, a)); }
 __device__ __forceinline__ V3 qsum(V3 a) { return v3(qsum(a.x), qsum(a.y), qsum(a.z)); }
 
 struct S3 { float xx, xy, xz, yy, yz, zz; };  // symmetric 3x3
@@ -192,7 +197,7 @@ __device__ __forceinline__ float q_yaw_2pi(Q4 q) {  // euler_xyz_from_quat(...)[
   return m < 0.f ? m + two_pi : m;
 }
 __device__ __forceinline__ Q4 q_normalize(Q4 q) {
-  float inv = 1.f / sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  float inv = frsqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
   q.w *= inv; q.x *= inv; q.y *= inv; q.z *= inv;
   return q;
 }

@@ -202,7 +202,7 @@ __device__ __forceinline__ Law contact_law(float d, V3 vrel, float kn, float cn,
   const float Bn = kn * h + cn * ramp;
   const float f0n = kn * d - Bn * vrel.z;
   if (!(f0n > 0.f)) return c;
-  const float vt = sqrtf(vrel.x * vrel.x + vrel.y * vrel.y);
+  const float vt = fsqrt(vrel.x * vrel.x + vrel.y * vrel.y);
   float cte = mu * f0n / (vt > 1e-6f ? vt : 1e-6f);
   cte = cte > ct ? ct : cte;
   c.active = true;
@@ -237,8 +237,11 @@ struct RC { Law law; V3 f0w; };
 __device__ __forceinline__ RC ground_contact(const lt_cfg& c, float h, V3 r, float rho, float mu, const M3& Rw, V3 pw, V3 om, V3 vl,
                                              I6& IA, S6& pA) {
   RC out;
+  out.law.active = false; out.law.fx = out.law.fy = out.law.fn = out.law.cte = out.law.Bn = 0.f;
+  out.f0w = v3(0, 0, 0);
   const V3 zb = row(Rw, 2);
   const V3 rc = r - rho * zb;
+  if (!(pw.z + dot(zb, rc) < 0.f)) return out;  // above the ground: nothing else to compute
   const V3 Pc = pw + mul(Rw, rc);
   const V3 vw = mul(Rw, vl + cross(om, rc));
   out.law = contact_law(-Pc.z, vw, c.ground_kn, c.ground_cn, c.ground_ct, mu, c.contact_ramp, h);
@@ -279,7 +282,7 @@ __device__ __forceinline__ void spd6_solve(const I6& M, V3 ba, V3 bl, V3& xa, V3
       float sacc = A[i][j];
 #pragma unroll
       for (int k = 0; k < j; ++k) sacc -= Lm[i][k] * Lm[j][k];
-      if (i == j) { Lm[i][i] = sqrtf(sacc); inv[i] = 1.f / Lm[i][i]; }
+      if (i == j) inv[i] = frsqrt(sacc);  // (the diagonal itself is never used)
       else Lm[i][j] = sacc * inv[j];
     }
   }
@@ -519,7 +522,7 @@ __device__ __forceinline__ void object_terms(const lt_cfg& c, const Base& B, con
   auto on = [&](int i, float v) { return w[i] != 0.f ? v : 0.f; };
   const V3 dpos = O.p - B.p;
   const V3 pr = qapply_inv(B.q, dpos), lr = qapply_inv(B.q, O.u - B.u), ar = qapply_inv(B.q, O.w - B.w);
-  t[LT_R_OBJECT_XY_POSITION - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_XY_POSITION, sqrtf(dpos.x * dpos.x + dpos.y * dpos.y) * (cn > 0.f ? 1.f : 0.f));  // :469-481
+  t[LT_R_OBJECT_XY_POSITION - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_XY_POSITION, fsqrt(dpos.x * dpos.x + dpos.y * dpos.y) * (cn > 0.f ? 1.f : 0.f));  // :469-481
   t[LT_R_OBJECT_XY_VELOCITY - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_XY_VELOCITY, lr.x * lr.x + lr.y * lr.y);                  // :483-491
   t[LT_R_OBJECT_Z_CONTACT - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_Z_CONTACT, (O.last_con > 0.f && O.cur_air > 0.f) ? 1.f : 0.f);  // :596-604
   t[LT_R_OBJECT_Z_VELOCITY - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_Z_VELOCITY, lr.z * lr.z);                                  // :493-501
@@ -540,7 +543,7 @@ __device__ __forceinline__ void object_terms(const lt_cfg& c, const Base& B, con
   }
   {                                                                                                         // :569-594
     const bool danger = (fabsf(pr.x) > c.danger_x_max) || (fabsf(pr.y) > c.danger_y_max) || (pr.z < c.danger_z_min) ||
-                        (sqrtf(lr.x * lr.x + lr.y * lr.y) > c.danger_vel_xy_max);
+                        (fsqrt(lr.x * lr.x + lr.y * lr.y) > c.danger_vel_xy_max);
     t[LT_R_OBJECT_DANGEROUS_STATE - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_DANGEROUS_STATE, danger ? 1.f : 0.f);
   }
 }
@@ -1177,7 +1180,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     const V3 gb = -row(R0, 2);  // R0^T (0,0,-1)
     const V3 cmd = X.cmd;
     const float cn = norm(cmd);
-    const float lin_err = sqrtf((cmd.x - vb.x) * (cmd.x - vb.x) + (cmd.y - vb.y) * (cmd.y - vb.y));
+    const float lin_err = fsqrt((cmd.x - vb.x) * (cmd.x - vb.x) + (cmd.y - vb.y) * (cmd.y - vb.y));
     const float ang_err = fabsf(cmd.z - wb.z);
     if (OFFLOAD) {  // hand-over to waves 1 (gait) and 2 (object terms); they work while this wave runs its terminations and other terms
       const float v[MB_FIN] = {B.p.x, B.p.y, B.p.z, B.q.w, B.q.x, B.q.y, B.q.z, B.u.x, B.u.y, B.u.z, B.w.x, B.w.y, B.w.z, lin_err, ang_err, cn,
@@ -1223,7 +1226,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     terms[LT_R_ALIVE] = on(LT_R_ALIVE, alive_in ? 0.f : 1.f);
     terms[LT_R_TRACK_LIN_VEL_XY] = on(LT_R_TRACK_LIN_VEL_XY, expf(-(lin_err / c.track_sigma)));                 // :15-20
     terms[LT_R_TRACK_ANG_VEL_Z] = on(LT_R_TRACK_ANG_VEL_Z, expf(-(ang_err / c.track_sigma)));                   // :22-27
-    const float foot_pv = sqrtf(G.foot_v.x * G.foot_v.x + G.foot_v.y * G.foot_v.y);
+    const float foot_pv = fsqrt(G.foot_v.x * G.foot_v.x + G.foot_v.y * G.foot_v.y);
     {                                                                                                         // :31-42
       const float mx = fmaxf(G.fh[0][3], fmaxf(G.fh[1][3], G.fh[2][3]));
       terms[LT_R_FOOT_SLIP] = on(LT_R_FOOT_SLIP, qsum(mx > c.foot_slip_threshold ? foot_pv : 0.f));
@@ -1258,12 +1261,12 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       s_lim = qsum(s_lim); s_pos = qsum(s_pos); s_acc = qsum(s_acc); s_vel = qsum(s_vel); s_tau = qsum(s_tau); s_act = qsum(s_act);
       terms[LT_R_JOINT_POSITION_LIMIT] = on(LT_R_JOINT_POSITION_LIMIT, s_lim);
       {                                                                                                       // :429-440
-        const float bv = sqrtf(vb.x * vb.x + vb.y * vb.y), r = sqrtf(s_pos);
+        const float bv = fsqrt(vb.x * vb.x + vb.y * vb.y), r = fsqrt(s_pos);
         terms[LT_R_JOINT_POSITION] = on(LT_R_JOINT_POSITION, (cn > 0.f || bv > c.joint_pos_vel_threshold) ? r : c.joint_pos_stand_scale * r);
       }
-      terms[LT_R_JOINT_ACCELERATION] = on(LT_R_JOINT_ACCELERATION, sqrtf(s_acc));                               // :446-448
-      terms[LT_R_JOINT_VELOCITY] = on(LT_R_JOINT_VELOCITY, sqrtf(s_vel));                                       // :442-444
-      terms[LT_R_JOINT_TORQUE] = on(LT_R_JOINT_TORQUE, sqrtf(s_tau));                                           // :450-452
+      terms[LT_R_JOINT_ACCELERATION] = on(LT_R_JOINT_ACCELERATION, fsqrt(s_acc));                               // :446-448
+      terms[LT_R_JOINT_VELOCITY] = on(LT_R_JOINT_VELOCITY, fsqrt(s_vel));                                       // :442-444
+      terms[LT_R_JOINT_TORQUE] = on(LT_R_JOINT_TORQUE, fsqrt(s_tau));                                           // :450-452
       terms[LT_R_ACTION_RATE] = on(LT_R_ACTION_RATE, s_act);                                                    // :454-456
     }
     {                                                                                                         // :459-466

@@ -437,13 +437,13 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
   }
 
   // ---- eliminate this leg's joints: H = L L^T (3x3), Y = L^-1 H_lb, z = L^-1 rhs ----
-  float l00, l10, l11, l20, l21, l22, i0, i1, i2;
+  float l10, l20, l21, i0, i1, i2;  // (only the inverse diagonal is ever used: one v_rsq_f32 each)
   {
-    l00 = sqrtf(S.h00); i0 = 1.f / l00;
+    i0 = frsqrt(S.h00);
     l10 = S.h01 * i0; l20 = S.h02 * i0;
-    l11 = sqrtf(S.h11 - l10 * l10); i1 = 1.f / l11;
+    i1 = frsqrt(S.h11 - l10 * l10);
     l21 = (S.h12 - l20 * l10) * i1;
-    l22 = sqrtf(S.h22 - l20 * l20 - l21 * l21); i2 = 1.f / l22;
+    i2 = frsqrt(S.h22 - l20 * l20 - l21 * l21);
   }
   V3 yn[3], yl[3];
   float z[3];
