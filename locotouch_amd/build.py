@@ -54,9 +54,13 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags: list[str]
     #   is ever produced on the path (divisions are guarded), and +-0 never changes a result we keep.
     # -freciprocal-math -fno-math-errno: x/y -> x*rcp(y) and bare v_sqrt (the IEEE division / sqrt expansions were 15 %
     #   of the physics phase); the ~1 ulp differences sit far inside the stated parity tolerances.
+    # -mllvm -disable-vector-combine: VectorCombine widens `insertelement(poison, load float)` of the packed-pair code into
+    #   `load <2 x float>` from the struct the scalar still lived in; the struct (the base position) then stayed a private
+    #   array, was promoted to LDS, and the LDS slot index needs the workgroup size - a scalar load from the AQL dispatch
+    #   packet in host memory: 18 k cycles (7.5 us) in front of every launch's first physics substep.
     common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize", "-ffinite-math-only",
-              "-fno-signed-zeros", "-freciprocal-math", "-fno-math-errno", "-Wall", "-Wno-unused-function",
-              "-I", os.path.join(REPO, "include")] + (extra_flags or [])
+              "-fno-signed-zeros", "-freciprocal-math", "-fno-math-errno", "-mllvm", "-disable-vector-combine", "-Wall",
+              "-Wno-unused-function", "-I", os.path.join(REPO, "include")] + (extra_flags or [])
     objs = []
     for s in sources():
         o = os.path.join(obj_dir, os.path.basename(s) + ".o")

@@ -5,21 +5,15 @@
 // (2 VALU ops, no LDS); per-env vectors are loaded one component per lane and broadcast inside the quad.
 #pragma once
 
-#include <hip/hip_runtime.h>
-
 #include <cstdint>
+
+#ifndef LT_PRIMS_H
+#define LT_PRIMS_H "lt_device_prims.h"
+#endif
+#include LT_PRIMS_H
 
 namespace lt {
 
-// ---- quad DPP primitives ---------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
-}
-template <int CTRL>
-__device__ __forceinline__ int dppi(int x) {
-  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
-}
 // value held by lane I of the caller's quad
 template <int I>
 __device__ __forceinline__ float qbcast(float x) { return dpp<I * 0x55>(x); }
@@ -40,11 +34,6 @@ __device__ __forceinline__ int qor(int x) {
 __device__ __forceinline__ float sel4(int leg, float a, float b, float c, float d) {
   return leg == 0 ? a : (leg == 1 ? b : (leg == 2 ? c : d));
 }
-
-// v_sqrt_f32 / v_rsq_f32 as they are (1 ulp).  `sqrtf` expands to ~16 VALU operations (denormal pre-scaling + a correctly-rounded
-// fix-up) - 12 of them sat in every physics substep; nothing on this path is near the denormal range or needs the last bit.
-__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ float frsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 
 // ---- vectors / matrices --------------------------------------------------------------------------------
 struct V3 { float x, y, z; };
@@ -118,6 +107,56 @@ __device__ __forceinline__ M3 quat_to_mat(float w, float x, float y, float z) { 
   return R;
 }
 
+// ---- packed pairs: two 3-vectors side by side ---------------------------------------------------------------
+// gfx950 issues v_pk_{fma,mul,add}_f32 - two f32 operations on a 64-bit register pair - at the rate of one scalar VALU
+// operation, and each source picks its halves freely (op_sel / neg_lo / neg_hi: broadcasts, swaps and sign flips cost
+// nothing).  The physics is issue-bound on one wave per SIMD, so wherever two 3-vectors go through the same arithmetic
+// (angular | linear parts of a spatial vector, velocity | acceleration of a link, two joints' Jacobian columns) they are held
+// as a P3 from the start: the pairs live in adjacent registers by construction (the SLP vectoriser's automatic packing lost
+// to its own register moves).
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct P3 { f2 x, y, z; };
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f2 sp2(float a) { f2 r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ f2 lolo(f2 a) { return __builtin_shufflevector(a, a, 0, 0); }
+__device__ __forceinline__ f2 hihi(f2 a) { return __builtin_shufflevector(a, a, 1, 1); }
+__device__ __forceinline__ f2 swp(f2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ P3 pair(V3 a, V3 b) { P3 r; r.x = mk2(a.x, b.x); r.y = mk2(a.y, b.y); r.z = mk2(a.z, b.z); return r; }
+__device__ __forceinline__ P3 both(V3 a) { return pair(a, a); }
+__device__ __forceinline__ V3 lo(const P3& a) { return v3(a.x.x, a.y.x, a.z.x); }
+__device__ __forceinline__ V3 hi(const P3& a) { return v3(a.x.y, a.y.y, a.z.y); }
+__device__ __forceinline__ P3 p3(f2 x, f2 y, f2 z) { P3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ P3 operator+(const P3& a, const P3& b) { return p3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ P3 operator-(const P3& a, const P3& b) { return p3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ P3 operator-(const P3& a) { return p3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ P3 operator*(f2 s, const P3& a) { return p3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ P3 operator*(float s, const P3& a) { return sp2(s) * a; }
+__device__ __forceinline__ P3& operator+=(P3& a, const P3& b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+__device__ __forceinline__ P3& operator-=(P3& a, const P3& b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
+__device__ __forceinline__ P3 cross(const P3& a, const P3& b) { return p3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ P3 cross(V3 a, const P3& b) {  // (a x b.lo | a x b.hi)
+  return p3(sp2(a.y) * b.z - sp2(a.z) * b.y, sp2(a.z) * b.x - sp2(a.x) * b.z, sp2(a.x) * b.y - sp2(a.y) * b.x);
+}
+__device__ __forceinline__ P3 cross(const P3& a, V3 b) {  // (a.lo x b | a.hi x b)
+  return p3(a.y * sp2(b.z) - a.z * sp2(b.y), a.z * sp2(b.x) - a.x * sp2(b.z), a.x * sp2(b.y) - a.y * sp2(b.x));
+}
+__device__ __forceinline__ f2 dot(const P3& a, const P3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f2 dot(V3 a, const P3& b) { return sp2(a.x) * b.x + sp2(a.y) * b.y + sp2(a.z) * b.z; }
+__device__ __forceinline__ P3 mul(const M3& a, const P3& v) {  // (a v.lo | a v.hi)
+  return p3(sp2(a.m[0]) * v.x + sp2(a.m[1]) * v.y + sp2(a.m[2]) * v.z, sp2(a.m[3]) * v.x + sp2(a.m[4]) * v.y + sp2(a.m[5]) * v.z,
+            sp2(a.m[6]) * v.x + sp2(a.m[7]) * v.y + sp2(a.m[8]) * v.z);
+}
+__device__ __forceinline__ P3 tmul(const M3& a, const P3& v) {  // (a^T v.lo | a^T v.hi)
+  return p3(sp2(a.m[0]) * v.x + sp2(a.m[3]) * v.y + sp2(a.m[6]) * v.z, sp2(a.m[1]) * v.x + sp2(a.m[4]) * v.y + sp2(a.m[7]) * v.z,
+            sp2(a.m[2]) * v.x + sp2(a.m[5]) * v.y + sp2(a.m[8]) * v.z);
+}
+__device__ __forceinline__ f2 qsum(f2 a) { return mk2(qsum(a.x), qsum(a.y)); }
+__device__ __forceinline__ P3 qsum(const P3& a) { return p3(qsum(a.x), qsum(a.y), qsum(a.z)); }
+__device__ __forceinline__ P3 mul(const S3& s, const P3& v) {
+  return p3(sp2(s.xx) * v.x + sp2(s.xy) * v.y + sp2(s.xz) * v.z, sp2(s.xy) * v.x + sp2(s.yy) * v.y + sp2(s.yz) * v.z,
+            sp2(s.xz) * v.x + sp2(s.yz) * v.y + sp2(s.zz) * v.z);
+}
+
 // ---- principal-axis joint rotations: R = rot(AX, q) maps child coords -> parent coords ------------
 template <int AX>
 __device__ __forceinline__ V3 rot_fwd(float c, float s, V3 v) {  // R v
@@ -128,6 +167,18 @@ template <int AX>
 __device__ __forceinline__ V3 rot_inv(float c, float s, V3 v) {  // R^T v
   if (AX == 0) return v3(v.x, c * v.y + s * v.z, -s * v.y + c * v.z);
   return v3(c * v.x - s * v.z, v.y, s * v.x + c * v.z);
+}
+template <int AX>
+__device__ __forceinline__ P3 rot_fwd(float c, float s, const P3& v) {  // (R v.lo | R v.hi)
+  const f2 cc = sp2(c), ss = sp2(s);
+  if (AX == 0) return p3(v.x, cc * v.y - ss * v.z, ss * v.y + cc * v.z);
+  return p3(cc * v.x + ss * v.z, v.y, cc * v.z - ss * v.x);
+}
+template <int AX>
+__device__ __forceinline__ P3 rot_inv(float c, float s, const P3& v) {  // (R^T v.lo | R^T v.hi)
+  const f2 cc = sp2(c), ss = sp2(s);
+  if (AX == 0) return p3(v.x, cc * v.y + ss * v.z, cc * v.z - ss * v.y);
+  return p3(cc * v.x - ss * v.z, v.y, ss * v.x + cc * v.z);
 }
 // R M R^T
 template <int AX>

@@ -73,24 +73,6 @@ constexpr CumQ make_cumq() {
 }
 __device__ constexpr CumQ k_cumq = make_cumq();
 
-// ---- robot model (generated from the reference URDF by tools/compile_robot_model.py), mirror form: every per-leg
-// constant is (FL-leg literal) x sign[pattern], sign = {1, sx, sy, sx*sy} of the lane's leg -> no table loads, nothing
-// held in registers across the physics loop.
-__device__ constexpr float k_m_mass[3] = LT_MIRROR_LINK_MASS_INIT;
-__device__ constexpr float k_m_mc[3][3] = LT_MIRROR_LINK_MC_INIT;
-__device__ constexpr int k_m_mc_pat[3][3] = LT_MIRROR_LINK_MC_PAT;
-__device__ constexpr float k_m_io[3][6] = LT_MIRROR_LINK_IO_INIT;
-__device__ constexpr int k_m_io_pat[3][6] = LT_MIRROR_LINK_IO_PAT;
-__device__ constexpr float k_m_off[3][3] = LT_MIRROR_JOINT_OFFSET_INIT;
-__device__ constexpr int k_m_off_pat[3][3] = LT_MIRROR_JOINT_OFFSET_PAT;
-__device__ constexpr float k_m_dq[3] = LT_MIRROR_JOINT_DEFAULT_INIT;
-__device__ constexpr int k_m_dq_pat[3] = LT_MIRROR_JOINT_DEFAULT_PAT;
-__device__ constexpr float k_joint_lo[3] = LT_JOINT_LOWER_INIT;
-__device__ constexpr float k_joint_hi[3] = LT_JOINT_UPPER_INIT;
-__device__ constexpr float k_trunk_com[3] = LT_TRUNK_COM_INIT;
-__device__ constexpr float k_trunk_icom[6] = LT_TRUNK_ICOM_INIT;
-__device__ constexpr float k_trunk_half[3] = LT_TRUNK_BOX_HALF_INIT;
-
 // RNG stream ids - shared spec with oracle/lt_oracle.c
 enum {
   RS_NOISE_JPOS = 0x100, RS_NOISE_JVEL = 0x110, RS_NOISE_BASE = 0x120, RS_NOISE_OBJ = 0x130,
@@ -127,202 +109,6 @@ constexpr ObsTable make_obs_table(int nterms) {
 __constant__ ObsTable k_obs_tab_loco = make_obs_table(6);
 __constant__ ObsTable k_obs_tab_teacher = make_obs_table(7);
 
-// ---- spatial algebra types ---------------------------------------------------------------------------
-struct I6 { M3 A, B, C; };  // [A B; B^T C], angular first
-struct S6 { V3 a, l; };
-struct LinkC { float m; V3 mc; S3 Io; V3 r; };  // mass, m*com, rotational inertia about the link origin, joint offset
-// constants of link K of the lane's leg: literal x sign (zero components stay literal zeros and fold away)
-template <int K>
-__device__ __forceinline__ LinkC make_link(const float (&sgn)[4]) {
-  LinkC L;
-  L.m = k_m_mass[K];
-  L.mc = v3(k_m_mc[K][0] * sgn[k_m_mc_pat[K][0]], k_m_mc[K][1] * sgn[k_m_mc_pat[K][1]], k_m_mc[K][2] * sgn[k_m_mc_pat[K][2]]);
-  L.Io.xx = k_m_io[K][0] * sgn[k_m_io_pat[K][0]]; L.Io.xy = k_m_io[K][1] * sgn[k_m_io_pat[K][1]]; L.Io.xz = k_m_io[K][2] * sgn[k_m_io_pat[K][2]];
-  L.Io.yy = k_m_io[K][3] * sgn[k_m_io_pat[K][3]]; L.Io.yz = k_m_io[K][4] * sgn[k_m_io_pat[K][4]]; L.Io.zz = k_m_io[K][5] * sgn[k_m_io_pat[K][5]];
-  L.r = v3(k_m_off[K][0] * sgn[k_m_off_pat[K][0]], k_m_off[K][1] * sgn[k_m_off_pat[K][1]], k_m_off[K][2] * sgn[k_m_off_pat[K][2]]);
-  return L;
-}
-
-__device__ __forceinline__ M3 skew_of(V3 v) {
-  M3 o = m3_zero();
-  o.m[1] = -v.z; o.m[2] = v.y; o.m[3] = v.z; o.m[5] = -v.x; o.m[6] = -v.y; o.m[7] = v.x;
-  return o;
-}
-__device__ __forceinline__ M3 inertia_about_origin(float m, V3 c, const float ic[6], float scale) {
-  // Ic*scale - m c~ c~ = Ic*scale + m (|c|^2 1 - c c^T)
-  M3 o;
-  const float cc = dot(c, c);
-  o.m[0] = ic[0] * scale + m * (cc - c.x * c.x); o.m[1] = ic[1] * scale - m * c.x * c.y; o.m[2] = ic[2] * scale - m * c.x * c.z;
-  o.m[3] = o.m[1]; o.m[4] = ic[3] * scale + m * (cc - c.y * c.y); o.m[5] = ic[4] * scale - m * c.y * c.z;
-  o.m[6] = o.m[2]; o.m[7] = o.m[5]; o.m[8] = ic[5] * scale + m * (cc - c.z * c.z);
-  return o;
-}
-
-// ---- per-env (replicated in the quad) and per-leg (one lane) register state ---------------------------
-struct Base {
-  V3 p; Q4 q; V3 u, w;  // root pose, world linear / angular velocity
-};
-struct Obj {
-  V3 p; Q4 q; V3 u, w;
-  float cur_air, cur_con, last_air, last_con;
-  float rad, len, mass, mu;
-};
-struct Leg {
-  float q[3], qd[3], qdd[3], tau[3], raw[3], prev[3], prev2[3];
-  float fh[3][4];  // |F| history [slot][hip,thigh,calf,foot]
-  float cur_air, cur_con, last_air, last_con;
-  float mu;
-  V3 foot_p, foot_v;
-  float g_last_air, g_last_con, g_valid;
-  int g_flags;
-};
-struct Misc {
-  float trunk_mass_add, trunk_mu, trunk_rest, obj_rest;
-  float trunk_fh[3];
-  V3 cmd; float cmd_time_left; V3 cmd_buf; float cmd_standing;
-  float push_robot_left, push_obj_left;
-  V3 gait_cmd; float gait_step;
-  long long ep_len;
-};
-struct Report {  // contact forces of the last physics substep (world frame)
-  V3 body[4];    // hip, thigh, calf, foot of this lane's leg
-  V3 trunk_part; // this lane's share of the trunk force (corners + plate reactions)
-  V3 obj_part;   // this lane's share of the object force
-  V3 plate;      // tactile tasks: this lane's plate sample - contact point (x, y) in the trunk frame, normal force on the plate
-};
-
-// ---- contact law (DESIGN.md "contact model"; executable spec: oracle/lt_oracle.c contact_eval) ----------
-struct Law { bool active; float fx, fy, fn, cte, Bn; };
-__device__ __forceinline__ Law contact_law(float d, V3 vrel, float kn, float cn, float ct, float mu, float ramp_depth, float h) {
-  Law c;
-  c.active = false; c.fx = c.fy = c.fn = c.cte = c.Bn = 0.f;
-  if (!(d > 0.f)) return c;
-  float ramp = d / ramp_depth;
-  ramp = ramp > 1.f ? 1.f : ramp;
-  const float Bn = kn * h + cn * ramp;
-  const float f0n = kn * d - Bn * vrel.z;
-  if (!(f0n > 0.f)) return c;
-  const float vt = fsqrt(vrel.x * vrel.x + vrel.y * vrel.y);
-  float cte = mu * f0n / (vt > 1e-6f ? vt : 1e-6f);
-  cte = cte > ct ? ct : cte;
-  c.active = true;
-  c.fx = -cte * vrel.x; c.fy = -cte * vrel.y; c.fn = f0n; c.cte = cte; c.Bn = Bn;
-  return c;
-}
-// add h J^T B J (J = [-r~ 1]) with B = cte 1 + (Bn - cte) n n^T to a 6x6, n in the coords of the 6x6
-__device__ __forceinline__ void add_contact_inertia(I6& IA, V3 r, V3 n, float cte, float Bn, float h) {
-  M3 hB = m3_diag(h * cte);
-  hB += outer(h * (Bn - cte) * n, n);
-  const M3 T = skew_mul(r, hB);
-  IA.B += T;
-  IA.A -= mul_skew(T, r);
-  IA.C += hB;
-}
-
-// ---- kinematics of one joint: parent (w,v,Rw,pw) -> child, plus the velocity-product term c = v x S qd -----
-template <int AX>
-__device__ __forceinline__ void joint_fk(V3 wp, V3 vp, const M3& Rwp, V3 pwp, V3 r, float c, float s, float qd,
-                                         V3& om, V3& vl, M3& Rw, V3& pw, V3& ca, V3& cl) {
-  const V3 t = vp + cross(wp, r);
-  const V3 vj = axis_scaled<AX>(qd);
-  om = rot_inv<AX>(c, s, wp) + vj;
-  vl = rot_inv<AX>(c, s, t);
-  ca = cross(om, vj);
-  cl = cross(vl, vj);
-  Rw = mul_rot<AX>(Rwp, c, s);
-  pw = pwp + mul(Rwp, r);
-}
-struct RC { Law law; V3 f0w; };
-// ground contact of a sphere (centre r in the link frame, radius rho); accumulates into (IA, pA)
-__device__ __forceinline__ RC ground_contact(const lt_cfg& c, float h, V3 r, float rho, float mu, const M3& Rw, V3 pw, V3 om, V3 vl,
-                                             I6& IA, S6& pA) {
-  RC out;
-  out.law.active = false; out.law.fx = out.law.fy = out.law.fn = out.law.cte = out.law.Bn = 0.f;
-  out.f0w = v3(0, 0, 0);
-  const V3 zb = row(Rw, 2);
-  const V3 rc = r - rho * zb;
-  if (!(pw.z + dot(zb, rc) < 0.f)) return out;  // above the ground: nothing else to compute
-  const V3 Pc = pw + mul(Rw, rc);
-  const V3 vw = mul(Rw, vl + cross(om, rc));
-  out.law = contact_law(-Pc.z, vw, c.ground_kn, c.ground_cn, c.ground_ct, mu, c.contact_ramp, h);
-  out.f0w = v3(out.law.fx, out.law.fy, out.law.fn);
-  if (out.law.active) {
-    add_contact_inertia(IA, rc, zb, out.law.cte, out.law.Bn, h);
-    const V3 f0b = tmul(Rw, out.f0w);
-    pA.a -= cross(rc, f0b);
-    pA.l -= f0b;
-  }
-  return out;
-}
-// final (post-solve) force of a ground contact on a link with spatial acceleration (aa, al)
-__device__ __forceinline__ V3 ground_force(const RC& rc_, float h, V3 r, float rho, const M3& Rw, V3 aa, V3 al) {
-  if (!rc_.law.active) return v3(0.f, 0.f, 0.f);
-  const V3 rc = r - rho * row(Rw, 2);
-  const V3 aw = mul(Rw, al + cross(aa, rc));
-  return v3(rc_.f0w.x - h * rc_.law.cte * aw.x, rc_.f0w.y - h * rc_.law.cte * aw.y, rc_.f0w.z - h * rc_.law.Bn * aw.z);
-}
-
-// 6x6 SPD solve (Cholesky), fully unrolled into registers.  M = [A B; B^T C] (upper blocks), rhs (a, l)
-__device__ __forceinline__ void spd6_solve(const I6& M, V3 ba, V3 bl, V3& xa, V3& xl) {
-  float A[6][6];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      A[i][j] = M.A.m[i * 3 + j];
-      A[i][3 + j] = M.B.m[i * 3 + j];
-      A[3 + i][j] = M.B.m[j * 3 + i];
-      A[3 + i][3 + j] = M.C.m[i * 3 + j];
-    }
-  float Lm[6][6], inv[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-#pragma unroll
-    for (int j = 0; j <= i; ++j) {
-      float sacc = A[i][j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) sacc -= Lm[i][k] * Lm[j][k];
-      if (i == j) inv[i] = frsqrt(sacc);  // (the diagonal itself is never used)
-      else Lm[i][j] = sacc * inv[j];
-    }
-  }
-  float b[6] = {ba.x, ba.y, ba.z, bl.x, bl.y, bl.z}, y[6], x[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    float sacc = b[i];
-#pragma unroll
-    for (int k = 0; k < i; ++k) sacc -= Lm[i][k] * y[k];
-    y[i] = sacc * inv[i];
-  }
-#pragma unroll
-  for (int i = 5; i >= 0; --i) {
-    float sacc = y[i];
-#pragma unroll
-    for (int k = i + 1; k < 6; ++k) sacc -= Lm[k][i] * x[k];
-    x[i] = sacc * inv[i];
-  }
-  xa = v3(x[0], x[1], x[2]);
-  xl = v3(x[3], x[4], x[5]);
-}
-__device__ __forceinline__ M3 qsum_sym(const M3& a) {  // quad-sum of a symmetric 3x3 (6 butterflies)
-  M3 o;
-  o.m[0] = qsum(a.m[0]); o.m[1] = qsum(a.m[1]); o.m[2] = qsum(a.m[2]); o.m[4] = qsum(a.m[4]); o.m[5] = qsum(a.m[5]); o.m[8] = qsum(a.m[8]);
-  o.m[3] = o.m[1]; o.m[6] = o.m[2]; o.m[7] = o.m[5];
-  return o;
-}
-__device__ __forceinline__ M3 qsum_full(const M3& a) {
-  M3 o;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) o.m[i] = qsum(a.m[i]);
-  return o;
-}
-
-// sphere table of this lane: 0 foot (calf), 1 calf mid (calf), 2 knee (thigh), 3 hip (hip), 4/5 trunk corners
-__device__ __forceinline__ V3 trunk_corner(int leg, bool hi) {
-  const float sx = leg < 2 ? 1.f : -1.f, sy = (leg & 1) ? 1.f : -1.f;
-  return hi ? v3(sx * k_trunk_half[0], sy * LT_BACK_HALF_Y, LT_BACK_TOP_Z) : v3(sx * k_trunk_half[0], sy * k_trunk_half[1], -k_trunk_half[2]);
-}
-
 #include "lt_physics_crba.h"
 
 // foot centre position / velocity (world) of this lane's leg for the current state
@@ -332,11 +118,11 @@ __device__ __forceinline__ void foot_kinematics(const float (&sgn)[4], const Bas
   V3 om[3], vl[3], pw[3], ca, cl;
   M3 Rw[3];
   float s, c;
-  sincosf(G.q[0], &s, &c);
+  s = fsin(G.q[0]); c = fcos(G.q[0]);
   joint_fk<0>(tmul(R0, B.w), tmul(R0, B.u), R0, B.p, LC[0].r, c, s, G.qd[0], om[0], vl[0], Rw[0], pw[0], ca, cl);
-  sincosf(G.q[1], &s, &c);
+  s = fsin(G.q[1]); c = fcos(G.q[1]);
   joint_fk<1>(om[0], vl[0], Rw[0], pw[0], LC[1].r, c, s, G.qd[1], om[1], vl[1], Rw[1], pw[1], ca, cl);
-  sincosf(G.q[2], &s, &c);
+  s = fsin(G.q[2]); c = fcos(G.q[2]);
   joint_fk<1>(om[1], vl[1], Rw[1], pw[1], LC[2].r, c, s, G.qd[2], om[2], vl[2], Rw[2], pw[2], ca, cl);
   const V3 rf = v3(0.f, 0.f, -0.213f);
   G.foot_p = pw[2] + mul(Rw[2], rf);
@@ -765,8 +551,15 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     for (int i = lane; i < 352; i += 64) { s_tab[0][i] = tab.src[i]; s_tab[0][352 + i] = tab.frame[i]; }
     dma_old_rows(0, s_old);  // the policy group's old history rows, behind the state loads (the critic group's follow at the end)
   }
+#ifdef LT_STAMPS
+  unsigned long long pro_a_, pro_b_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_a_) :: "memory");
+#endif
   if (HELPERS) __syncthreads();  // B0: the (cfg, layout) block is in LDS
   else wg_barrier_lds();       //     (one-wave form: no vmcnt drain - the row DMA stays in flight beside the physics)
+#ifdef LT_STAMPS
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_b_) :: "memory");
+#endif
   const lt_cfg& c = s_d.cfg;
   const lt_layout& L = s_d.layout;
   // the command block: global memory, or - helper form - the copy wave 3 leaves in LDS beside the last physics substep
@@ -776,7 +569,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   const float step_dt = c.sim_dt * (float)c.decimation;
   const uint32_t ekey = (uint32_t)env + (uint32_t)c.env_index_offset;  // RNG stream key of this env (global index over all ranks)
 
-  if (HELPERS && wave != 0) {
+  if (HELPERS && __builtin_expect(wave != 0, 0)) {  // (unlikely: keeps wave 0's path the fall-through behind B0 - see DESIGN.md "far jump")
     // ---- physics helpers: as many (A, B) barrier pairs as wave 0 runs substeps ----
     {
       const int nsub = c.decimation * c.phys_substeps;
@@ -821,6 +614,14 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
                                              (__attribute__((address_space(3))) void*)(s_old + g * 16 * OBS + i * 256), 16, 0, 0);
         }
       }
+      // wave 3: the observation-noise uniforms of this step (Philox is ~1 k cycles per call).  Per lane: joint-pos and joint-vel noise of
+      // its leg, object-noise block `leg`, base-noise block (legs 2, 3 -> RS_NOISE_BASE, + 1).  Same streams and keys as the
+      // inline form: bit-identical draws.  Block i -> rows 4 i .. 4 i + 3 of s_mb_rng.
+      auto noise_draw = [&](int i) {
+        const uint32_t stream = i == 0 ? RS_NOISE_JPOS + leg : (i == 1 ? RS_NOISE_JVEL + leg : (i == 2 ? RS_NOISE_OBJ + leg : RS_NOISE_BASE + (leg == 3 ? 1 : 0)));
+        const U4 u = rng4(c.seed, ekey, step, stream);
+        s_mb_rng[4 * i + 0][lane] = u.a; s_mb_rng[4 * i + 1][lane] = u.b; s_mb_rng[4 * i + 2][lane] = u.c; s_mb_rng[4 * i + 3][lane] = u.d;
+      };
       for (int it = 0; it < nsub; ++it) {
         wg_barrier_lds();  // A
         if (wave == 1) {
@@ -887,6 +688,9 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
             const int b = min((int)(bank_mat_c * (float)c.obj_material_buckets), c.obj_material_buckets - 1);
             put(6, rng4(c.seed, (uint32_t)b, ~0ull, RS_BUCKET_OBJ));
           }
+          // one of the step's four observation-noise draws per substep (the rest, if there are fewer substeps, behind the loop):
+          // drawn between D and E they ended ~3 k cycles after wave 0 reached barrier C
+          if (it < 4) noise_draw(it);
         }
         wg_barrier_lds();  // B
       }
@@ -915,15 +719,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
 #pragma unroll
           for (int i = 0; i < 8; ++i) s_mb_rew[9 + i][lane] = ot[i];
         } else if (wave == 3) {
-          // the observation-noise uniforms of this step (Philox is ~1 k cycles per call).  Per lane: joint-pos and joint-vel noise of
-          // its leg, object-noise block `leg`, base-noise block (legs 2, 3 -> RS_NOISE_BASE, + 1).  Same streams and keys as the
-          // inline form: bit-identical draws.
-          const U4 uj = rng4(c.seed, ekey, step, RS_NOISE_JPOS + leg), uv = rng4(c.seed, ekey, step, RS_NOISE_JVEL + leg);
-          const U4 uo = rng4(c.seed, ekey, step, RS_NOISE_OBJ + leg);
-          const U4 ub = rng4(c.seed, ekey, step, RS_NOISE_BASE + (leg == 3 ? 1 : 0));
-          const float v[16] = {uj.a, uj.b, uj.c, uj.d, uv.a, uv.b, uv.c, uv.d, uo.a, uo.b, uo.c, uo.d, ub.a, ub.b, ub.c, ub.d};
-#pragma unroll
-          for (int i = 0; i < 16; ++i) s_mb_rng[i][lane] = v[i];
+          for (int i = nsub; i < 4; ++i) noise_draw(i);  // (fewer than four substeps: the draws the loop above did not reach)
         }
         wg_barrier_lds();  // E: the terms are in LDS
       }
@@ -1003,6 +799,10 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     return;
   }
 
+#ifdef LT_STAMPS
+  unsigned long long pro_c_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_c_) :: "memory");
+#endif
   // ---- sign pattern of this lane's leg (mirror form of the model constants) ----
   const float sx = leg < 2 ? 1.f : -1.f, sy = (leg & 1) ? 1.f : -1.f;
   const float sgn[4] = {1.f, sx, sy, sx * sy};
@@ -1618,6 +1418,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   if (lane == 0)
     for (int q = 0; q < 7; ++q) *F(LT_F_LAST_EPISODE_SUMS, q) = (float)(long long)(stamps_[q + 1] - stamps_[q]);
   if (lane == 0) { *F(LT_F_REWARD_TERMS, 0) = (float)(long long)bar_wait_[0]; *F(LT_F_REWARD_TERMS, 1) = (float)(long long)bar_wait_[1]; }
+  if (lane == 0) { *F(LT_F_REWARD_TERMS, 4) = (float)(long long)(pro_a_ - stamps_[0]); *F(LT_F_REWARD_TERMS, 5) = (float)(long long)(pro_b_ - pro_a_); *F(LT_F_REWARD_TERMS, 6) = (float)(long long)(pro_c_ - pro_b_); }
   if (lane == 0) ((float*)(arena + L.quad_off[LT_F_REWARD_TERMS]) + 3 * L.npad * 4 + (long long)blockIdx.x * 64)[0] = (float)(long long)(stamps_[7] - stamps_[0]);
 #endif
 }

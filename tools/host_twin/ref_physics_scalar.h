@@ -1,3 +1,5 @@
+// FROZEN COPY (round 3) of the scalar-formulation physics (csrc/lt_physics_crba.h before the packed-pair rewrite): the reference the
+// host twin compares the product physics against.  Test tool only; not built into the product.
 // Forward dynamics of one env (floating base + 4 x 3-link legs + carried cylinder) for lt_env.hip.
 //
 // Formulation (kernel side; the oracle uses a generic ABA - the two must agree to fp32 tolerance):
@@ -540,227 +542,6 @@ __device__ __forceinline__ ObjOut object_part(const lt_cfg& c, float h, int leg,
 }
 
 // =====================================================================================================
-// Packed-pair formulation of the leg dynamics (lt_device_math.h "packed pairs").  What is paired:
-//   * (omega | velocity-product angular acceleration) and (v | velocity-product linear acceleration) of every link: the
-//     kinematics recursion, I v and I a of the bias wrench, the velocity and the velocity-product acceleration of a contact
-//     point all run once for both halves.  Gravity rides in the linear half as the fictitious base acceleration +g z, so no
-//     link has a gravity term of its own (the contact points subtract it again: one operation);
-//   * (moment | force) of every spatial force: the backward pass, the joints' coupling rows to the base, the Schur update
-//     of the base block - whose A and C blocks take the same outer products on the two halves, and whose B block takes
-//     B_ik and B_ki from one product with the halves of one operand swapped;
-//   * the Jacobian columns of the thigh and calf joints (their axes are the same world vector).
-// =====================================================================================================
-// base block [A B; B^T C] of the quad's 6x6 with the halves that take the same arithmetic side by side:
-//   ac[k] = (A_k | C_k), k = xx xy xz yy yz zz;   bo[] = (B01 | B10), (B02 | B20), (B12 | B21);   bd[i] = B_ii
-struct I6p { f2 ac[6]; f2 bo[3]; float bd[3]; };
-__device__ __forceinline__ I6p i6p_zero() {
-  I6p o;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) o.ac[k] = sp2(0.f);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { o.bo[k] = sp2(0.f); o.bd[k] = 0.f; }
-  return o;
-}
-// M += s u u^T for the 6-vector u = (u.lo ; u.hi)   [su = s u]
-__device__ __forceinline__ void i6p_rank1(I6p& M, const P3& su, const P3& u) {
-  M.ac[0] += su.x * u.x; M.ac[1] += su.x * u.y; M.ac[2] += su.x * u.z; M.ac[3] += su.y * u.y; M.ac[4] += su.y * u.z; M.ac[5] += su.z * u.z;
-  M.bo[0] += su.x * swp(u.y); M.bo[1] += su.x * swp(u.z); M.bo[2] += su.y * swp(u.z);
-  M.bd[0] += su.x.x * u.x.y; M.bd[1] += su.y.x * u.y.y; M.bd[2] += su.z.x * u.z.y;
-}
-// M += rigid inertia (Io about the origin, first moment mc, mass m): A += Io, B += mc~, C += m 1
-__device__ __forceinline__ void i6p_add_rigid(I6p& M, const S3& Io, V3 mc, float m) {
-  M.ac[0] += mk2(Io.xx, m); M.ac[1].x += Io.xy; M.ac[2].x += Io.xz; M.ac[3] += mk2(Io.yy, m); M.ac[4].x += Io.yz; M.ac[5] += mk2(Io.zz, m);
-  M.bo[0] += mk2(-mc.z, mc.z); M.bo[1] += mk2(mc.y, -mc.y); M.bo[2] += mk2(-mc.x, mc.x);
-}
-// M += h J^T B J, J = [-r~ 1], B = cte 1 + (Bn - cte) n n^T, n in the coords of the 6x6:
-//   A += a (|r|^2 1 - r r^T) + d m m^T,  B += a r~ + d m n^T,  C += a 1 + d n n^T   with a = h cte, d = h (Bn - cte), m = r x n
-__device__ __forceinline__ void i6p_add_contact(I6p& M, V3 r, V3 n, float a, float hbn) {  // a = h cte, hbn = h Bn
-  const float d = hbn - a;
-  const P3 u = pair(cross(r, n), n);
-  i6p_rank1(M, d * u, u);
-  const V3 ar = a * r;
-  const float rr = a * dot(r, r);
-  M.ac[0] += mk2(rr - ar.x * r.x, a); M.ac[3] += mk2(rr - ar.y * r.y, a); M.ac[5] += mk2(rr - ar.z * r.z, a);
-  M.ac[1].x -= ar.x * r.y; M.ac[2].x -= ar.x * r.z; M.ac[4].x -= ar.y * r.z;
-  M.bo[0] += mk2(-ar.z, ar.z); M.bo[1] += mk2(ar.y, -ar.y); M.bo[2] += mk2(-ar.x, ar.x);
-}
-__device__ __forceinline__ I6p qsum6(const I6p& a) {
-  I6p o;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) o.ac[k] = qsum(a.ac[k]);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { o.bo[k] = qsum(a.bo[k]); o.bd[k] = qsum(a.bd[k]); }
-  return o;
-}
-// 6x6 SPD solve on the packed block layout
-__device__ __forceinline__ void spd6_solve(const I6p& M, const P3& b, V3& xa, V3& xl) {
-  I6 F;
-  F.A.m[0] = M.ac[0].x; F.A.m[1] = M.ac[1].x; F.A.m[2] = M.ac[2].x; F.A.m[4] = M.ac[3].x; F.A.m[5] = M.ac[4].x; F.A.m[8] = M.ac[5].x;
-  F.A.m[3] = F.A.m[1]; F.A.m[6] = F.A.m[2]; F.A.m[7] = F.A.m[5];
-  F.C.m[0] = M.ac[0].y; F.C.m[1] = M.ac[1].y; F.C.m[2] = M.ac[2].y; F.C.m[4] = M.ac[3].y; F.C.m[5] = M.ac[4].y; F.C.m[8] = M.ac[5].y;
-  F.C.m[3] = F.C.m[1]; F.C.m[6] = F.C.m[2]; F.C.m[7] = F.C.m[5];
-  F.B.m[0] = M.bd[0]; F.B.m[4] = M.bd[1]; F.B.m[8] = M.bd[2];
-  F.B.m[1] = M.bo[0].x; F.B.m[3] = M.bo[0].y; F.B.m[2] = M.bo[1].x; F.B.m[6] = M.bo[1].y; F.B.m[5] = M.bo[2].x; F.B.m[7] = M.bo[2].y;
-  spd6_solve(F, lo(b), hi(b), xa, xl);
-}
-
-// child link's (omega | aa) and (v | al) from the parent's: rotate both halves, add the joint rate to omega and the
-// velocity products c = v x (S qd) to the acceleration halves
-template <int AX>
-__device__ __forceinline__ void joint_fk2(const P3& Wp, const P3& Vp, V3 r, float c, float s, float qd, P3& W, P3& V) {
-  W = rot_inv<AX>(c, s, Wp);
-  V = rot_inv<AX>(c, s, Vp + cross(Wp, r));
-  if (AX == 0) {
-    W.x.x += qd;
-    W.y.y += W.z.x * qd; W.z.y -= W.y.x * qd;
-    V.y.y += V.z.x * qd; V.z.y -= V.y.x * qd;
-  } else {
-    W.y.x += qd;
-    W.x.y -= W.z.x * qd; W.z.y += W.x.x * qd;
-    V.x.y -= V.z.x * qd; V.z.y += V.x.x * qd;
-  }
-}
-// M R for R = rot(AX, q): the two columns that mix come out of one packed product per row
-template <int AX>
-__device__ __forceinline__ M3 mul_rot2(const M3& a, float c, float s) {
-  M3 o = a;
-  const f2 cs = mk2(c, s);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    if (AX == 0) {  // (o1 | o2) = a1 (c | -s) + a2 (s | c)
-      const f2 r = sp2(a.m[3 * i + 1]) * mk2(c, -s) + sp2(a.m[3 * i + 2]) * swp(cs);
-      o.m[3 * i + 1] = r.x; o.m[3 * i + 2] = r.y;
-    } else {        // (o0 | o2) = a0 (c | s) + a2 (-s | c)
-      const f2 r = sp2(a.m[3 * i]) * cs + sp2(a.m[3 * i + 2]) * mk2(-s, c);
-      o.m[3 * i] = r.x; o.m[3 * i + 2] = r.y;
-    }
-  }
-  return o;
-}
-// wrench (n | f) a rigid body needs for velocity (W.lo, V.lo) and acceleration (W.hi, V.hi): I a + v x* I v
-__device__ __forceinline__ P3 rigid_bias2(const Rigid& R, const P3& W, const P3& V) {
-  const P3 N = mul(R.Io, W) + cross(R.mc, V);  // (n_v | n_a)
-  const P3 F = cross(W, R.mc) + R.m * V;       // (f_v | f_a)
-  const V3 om = lo(W), vl = lo(V), nv = lo(N), fv = lo(F);
-  return pair(hi(N) + cross(om, nv) + cross(vl, fv), hi(F) + cross(om, fv));
-}
-// spatial force (n | f) re-expressed in the parent frame (child origin at r, child -> parent rotation R)
-template <int AX>
-__device__ __forceinline__ P3 force_to_parent2(const P3& x, float c, float s, V3 r) {
-  P3 o = rot_fwd<AX>(c, s, x);
-  const V3 t = cross(r, hi(o));
-  o.x.x += t.x; o.y.x += t.y; o.z.x += t.z;
-  return o;
-}
-
-struct LegSys2 {       // this lane's 3 joints: H (sym 3x3), coupling rows to the base (moment | force), right-hand side
-  float h00, h01, h02, h11, h12, h22;
-  P3 b[3];
-  float rhs[3];
-};
-// what the post-solve force of a contact needs: the law's damping, and the explicit force with the velocity-product
-// acceleration of the point already folded in
-struct RC2 { bool active; float hct, hbn; V3 F0; };
-__device__ __forceinline__ RC2 rc2_none() { RC2 o; o.active = false; o.hct = o.hbn = 0.f; o.F0 = v3(0, 0, 0); return o; }
-
-// the contact law of one ground-contact sphere (centre r in the link frame, radius rho) of a link with packed motion (W, V):
-// contact point, its velocity and velocity-product acceleration (world), the law.  BRANCHY: early exits (the spheres that rarely
-// touch); otherwise straight-line code whose result is all zeros when the sphere is off the ground (the foot: nearly always on it
-// in some lane of the wave, and as straight-line code its contributions INITIALISE the accumulators - no zero fill, no merge copies).
-template <bool BRANCHY>
-__device__ __forceinline__ RC2 contact_eval(const lt_cfg& c, float h, V3 rc, float mu, const M3& Rw, V3 pwk, const P3& W, const P3& V, V3& Pc) {
-  RC2 out = rc2_none();
-  Pc = pwk + mul(Rw, rc);
-  const float d = -Pc.z;
-  if (BRANCHY && !(d > 0.f)) return out;
-  const P3 PV = mul(Rw, V + cross(W, rc));  // (velocity | velocity-product acceleration + g z) of the point, world
-  // contact_law, inlined for the two forms
-  float ramp = d / c.contact_ramp;
-  ramp = ramp > 1.f ? 1.f : ramp;
-  const float Bn = c.ground_kn * h + c.ground_cn * ramp;
-  const float f0n = c.ground_kn * d - Bn * PV.z.x;
-  const bool active = (d > 0.f) && (f0n > 0.f);
-  if (BRANCHY && !active) return out;
-  const float vt = fsqrt(PV.x.x * PV.x.x + PV.y.x * PV.y.x);
-  float cte = mu * f0n / (vt > 1e-6f ? vt : 1e-6f);
-  cte = cte > c.ground_ct ? c.ground_ct : cte;
-  const float hct = active ? h * cte : 0.f, hbn = active ? h * Bn : 0.f;
-  cte = active ? cte : 0.f;
-  out.active = active; out.hct = hct; out.hbn = hbn;
-  // explicit part with the velocity-product acceleration of the point folded in (the fictitious +g z taken out again)
-  out.F0 = v3(-cte * PV.x.x - hct * PV.x.y, -cte * PV.y.x - hct * PV.y.y, (active ? f0n : 0.f) - hbn * (PV.z.y - c.gravity));
-  return out;
-}
-// implicit + explicit contributions of an evaluated contact on link K (0 hip, 1 thigh, 2 calf) to the link force, the joint
-// system and the base block.  INIT: the accumulators are written, not added to (first contact of the substep).
-template <int K, bool INIT>
-__device__ __forceinline__ void leg_contact_add(float h, const RC2& k, V3 rc, V3 Pc, const M3& Rw, const M3& R0, V3 p0, V3 ax0, V3 ax12,
-                                                const V3 (&pw)[3], P3& Fk, LegSys2& S, I6p& Mbb) {
-  const float hct = k.hct, hbn = k.hbn;
-  const V3 f0b = tmul(Rw, k.F0);
-  Fk -= pair(cross(rc, f0b), f0b);
-  // implicit part through the Jacobian columns (world frame; the ground contact frame is world-aligned => B diagonal)
-  const V3 rho_b = tmul(R0, Pc - p0);
-  const V3 w0 = cross(ax0, Pc - pw[0]);
-  const V3 g0 = v3(hct * w0.x, hct * w0.y, hbn * w0.z);
-  {
-    const V3 gb = tmul(R0, g0);
-    const P3 t = pair(cross(rho_b, gb), gb);
-    if (INIT) { S.b[0] = t; S.h00 = dot(w0, g0); } else { S.b[0] += t; S.h00 += dot(w0, g0); }
-  }
-  if (K >= 1) {  // thigh and calf joints: one axis, two lever arms
-    const P3 W12 = cross(ax12, pair(Pc - pw[1], Pc - pw[2]));
-    const P3 G12 = p3(sp2(hct) * W12.x, sp2(hct) * W12.y, sp2(hbn) * W12.z);
-    const P3 GB = tmul(R0, G12);
-    const V3 gb1 = lo(GB);
-    const P3 t1 = pair(cross(rho_b, gb1), gb1);
-    const f2 h0x = dot(w0, G12), hxx = dot(W12, G12);
-    if (INIT) { S.b[1] = t1; S.h01 = h0x.x; S.h11 = hxx.x; } else { S.b[1] += t1; S.h01 += h0x.x; S.h11 += hxx.x; }
-    if (K >= 2) {
-      const V3 gb2 = hi(GB);
-      const P3 t2 = pair(cross(rho_b, gb2), gb2);
-      const float h12 = W12.x.x * G12.x.y + W12.y.x * G12.y.y + W12.z.x * G12.z.y;
-      if (INIT) { S.b[2] = t2; S.h02 = h0x.y; S.h22 = hxx.y; S.h12 = h12; } else { S.b[2] += t2; S.h02 += h0x.y; S.h22 += hxx.y; S.h12 += h12; }
-    }
-  }
-  if (INIT) Mbb = i6p_zero();
-  i6p_add_contact(Mbb, rho_b, row(R0, 2), hct, hbn);
-}
-// ground contact of a trunk corner (centre r in the base frame); (wb, vb) base velocity in base coords
-__device__ __forceinline__ RC2 trunk_eval(const lt_cfg& c, float h, V3 r, float mu, const M3& R0, V3 p0, V3 wb, V3 vb) {
-  RC2 out = rc2_none();
-  const V3 zb = row(R0, 2);
-  if (!(p0.z + dot(zb, r) < 0.f)) return out;
-  const V3 Pc = p0 + mul(R0, r);
-  const V3 vw = mul(R0, vb + cross(wb, r));
-  const Law law = contact_law(-Pc.z, vw, c.ground_kn, c.ground_cn, c.ground_ct, mu, c.contact_ramp, h);
-  out.F0 = v3(law.fx, law.fy, law.fn);
-  if (!law.active) return out;
-  out.active = true; out.hct = h * law.cte; out.hbn = h * law.Bn;
-  return out;
-}
-__device__ __forceinline__ void trunk_add(float h, const RC2& k, V3 r, const M3& R0, I6p& Mbb, P3& pb) {
-  if (!k.active) return;
-  i6p_add_contact(Mbb, r, row(R0, 2), k.hct, k.hbn);
-  const V3 f0b = tmul(R0, k.F0);
-  pb -= pair(cross(r, f0b), f0b);
-}
-// final (post-solve) force of a contact at rc on a link whose acceleration BEYOND the velocity products is d = (ang | lin)
-__device__ __forceinline__ V3 contact_force2(const RC2& k, V3 rc, const M3& Rw, const P3& d) {
-  const V3 aw = mul(Rw, hi(d) + cross(lo(d), rc));
-  return v3(k.F0.x - k.hct * aw.x, k.F0.y - k.hct * aw.y, k.F0.z - k.hbn * aw.z);  // (inactive: hct = hbn = 0, F0 = 0)
-}
-// one of the rarely touching spheres of link K: its contributions before the solve; the record the force after the solve needs
-template <int K>
-__device__ __forceinline__ RC2 rare_contact(const lt_cfg& c, float h, V3 r, float rho, float mu, const M3& Rw, V3 pwk, const P3& W, const P3& V,
-                                            const M3& R0, V3 p0, V3 ax0, V3 ax12, const V3 (&pw)[3], P3& Fk, LegSys2& S, I6p& Mbb) {
-  const V3 rc = r - rho * row(Rw, 2);
-  V3 Pc;
-  const RC2 k = contact_eval<true>(c, h, rc, mu, Rw, pwk, W, V, Pc);
-  if (k.active) leg_contact_add<K, false>(h, k, rc, Pc, Rw, R0, p0, ax0, ax12, pw, Fk, S, Mbb);
-  return k;
-}
-// =====================================================================================================
 // K2 physics: one integrator substep of length h (torques held).  Reference: PhysX (closed source) - this is the
 // engine's own model; executable spec: oracle/lt_oracle.c physics_substep; description: DESIGN.md "Physics model".
 // =====================================================================================================
@@ -785,73 +566,67 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
   PhysExt pe;
   if (!Ext::external && HAS_OBJ) pe.obj = object_part<TAC>(c, h, leg, B, O, X.trunk_mu);  // first: nothing else is live yet
   const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
-  const P3 WVb = tmul(R0, pair(B.w, B.u));
-  const V3 wb = lo(WVb), vb = hi(WVb);
-  // the base's packed motion: (omega | 0) and (v | +g z): gravity as a fictitious linear acceleration of the base
-  const P3 Wb = pair(wb, v3(0, 0, 0)), Vb = pair(vb, g * row(R0, 2));
-  P3 W[3], V[3];
-  joint_fk2<0>(Wb, Vb, LC[0].r, cq[0], sq[0], G.qd[0], W[0], V[0]);
-  joint_fk2<1>(W[0], V[0], LC[1].r, cq[1], sq[1], G.qd[1], W[1], V[1]);
-  joint_fk2<1>(W[1], V[1], LC[2].r, cq[2], sq[2], G.qd[2], W[2], V[2]);
+  const V3 wb = tmul(R0, B.w), vb = tmul(R0, B.u);
+  V3 om[3], vl[3], pw[3], ca[3], cl[3];
   M3 Rw[3];
-  V3 pw[3];
-  Rw[0] = mul_rot2<0>(R0, cq[0], sq[0]);    pw[0] = B.p + mul(R0, LC[0].r);
-  Rw[1] = mul_rot2<1>(Rw[0], cq[1], sq[1]); pw[1] = pw[0] + mul(Rw[0], LC[1].r);
-  Rw[2] = mul_rot2<1>(Rw[1], cq[2], sq[2]); pw[2] = pw[1] + mul(Rw[1], LC[2].r);
-  const V3 ax0 = col(Rw[0], 0), ax12 = col(Rw[1], 1);  // joint axes in world (thigh and calf axes are parallel)
+  joint_fk<0>(wb, vb, R0, B.p, LC[0].r, cq[0], sq[0], G.qd[0], om[0], vl[0], Rw[0], pw[0], ca[0], cl[0]);
+  joint_fk<1>(om[0], vl[0], Rw[0], pw[0], LC[1].r, cq[1], sq[1], G.qd[1], om[1], vl[1], Rw[1], pw[1], ca[1], cl[1]);
+  joint_fk<1>(om[1], vl[1], Rw[1], pw[1], LC[2].r, cq[2], sq[2], G.qd[2], om[2], vl[2], Rw[2], pw[2], ca[2], cl[2]);
+  // velocity-product spatial accelerations (base and joint accelerations zero)
+  V3 aa[3], al[3];
+  aa[0] = ca[0]; al[0] = cl[0];
+  aa[1] = rot_inv<1>(cq[1], sq[1], aa[0]) + ca[1];
+  al[1] = rot_inv<1>(cq[1], sq[1], al[0] + cross(aa[0], LC[1].r)) + cl[1];
+  aa[2] = rot_inv<1>(cq[2], sq[2], aa[1]) + ca[2];
+  al[2] = rot_inv<1>(cq[2], sq[2], al[1] + cross(aa[1], LC[2].r)) + cl[2];
+  const V3 axw[3] = {col(Rw[0], 0), col(Rw[1], 1), col(Rw[2], 1)};  // joint axes in world
 
-  // this lane's share of the base block / base bias wrench (moment | force)
-  P3 pb = both(v3(0, 0, 0));
+  // this lane's share of the base block / base bias wrench
+  I6 Mbb; Mbb.A = m3_zero(); Mbb.B = m3_zero(); Mbb.C = m3_zero();
+  F6 pb; pb.n = v3(0, 0, 0); pb.f = v3(0, 0, 0);
   rep.trunk_part = v3(0, 0, 0);
   rep.obj_part = v3(0, 0, 0);
 
-  // ---- RNEA forces of this leg's links (zero joint / base accelerations) + contacts ----
+  // ---- RNEA forces of this leg's links (zero accelerations) + contacts ----
   Rigid RB[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { RB[k].m = LC[k].m; RB[k].mc = LC[k].mc; RB[k].Io = LC[k].Io; }
-  P3 f[3];
+  F6 f[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) f[k] = rigid_bias2(RB[k], W[k], V[k]);
-  LegSys2 S;
-  I6p Mbb;
+  for (int k = 0; k < 3; ++k) f[k] = rigid_bias(RB[k], om[k], vl[k], aa[k], al[k], (-g) * row(Rw[k], 2));
+  LegSys S;
+  S.h00 = S.h01 = S.h02 = S.h11 = S.h12 = S.h22 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { S.bn[j] = v3(0, 0, 0); S.bl[j] = v3(0, 0, 0); }
   const float mu_foot = G.mu * c.ground_mu, mu_body = c.ground_mu;
   const V3 r_foot = v3(0.f, 0.f, -0.213f), r_calf = v3(0.f, 0.f, -0.1065f), r_knee = v3(0.f, 0.f, -0.213f);
   const V3 r_hip = v3(0.f, LT_MIRROR_HIP_CYL_Y * sgn[LT_MIRROR_HIP_CYL_Y_PAT], 0.f);
-  // the foot: straight-line code whose contributions initialise the joint system and the base block
-  const V3 rc_foot = r_foot - LT_FOOT_RADIUS * row(Rw[2], 2);
-  V3 Pc_foot;
-  const RC2 c_foot = contact_eval<false>(c, h, rc_foot, mu_foot, Rw[2], pw[2], W[2], V[2], Pc_foot);
-  leg_contact_add<2, true>(h, c_foot, rc_foot, Pc_foot, Rw[2], R0, B.p, ax0, ax12, pw, f[2], S, Mbb);
-  // The five spheres that rarely touch (calf, knee, hip, two trunk corners) sit behind ONE test of their heights: as five
-  // separate conditional regions they cost the common path ~440 operations of tests, accumulator copies and branch overhead
-  // per substep.  (height of a sphere's lowest point: p.z + z_b . r - rho, z_b = world z in link coordinates)
+  const RC c_foot = leg_contact<2>(c, h, r_foot, LT_FOOT_RADIUS, mu_foot, Rw[2], pw[2], om[2], vl[2], aa[2], al[2], R0, B.p, axw, pw, f[2], S, Mbb);
+  const RC c_calf = leg_contact<2>(c, h, r_calf, 0.012f, mu_body, Rw[2], pw[2], om[2], vl[2], aa[2], al[2], R0, B.p, axw, pw, f[2], S, Mbb);
+  const RC c_knee = leg_contact<1>(c, h, r_knee, 0.022f, mu_body, Rw[1], pw[1], om[1], vl[1], aa[1], al[1], R0, B.p, axw, pw, f[1], S, Mbb);
+  const RC c_hip = leg_contact<0>(c, h, r_hip, LT_HIP_CYL_RADIUS, mu_body, Rw[0], pw[0], om[0], vl[0], aa[0], al[0], R0, B.p, axw, pw, f[0], S, Mbb);
+  // trunk corners of this lane (base accelerations are the unknowns: no velocity-product part)
   const V3 r_tlo = trunk_corner(leg, false), r_thi = trunk_corner(leg, true);
-  const float z_calf = pw[2].z + dot(row(Rw[2], 2), r_calf) - 0.012f, z_knee = pw[1].z + dot(row(Rw[1], 2), r_knee) - 0.022f;
-  const float z_hip = pw[0].z + dot(row(Rw[0], 2), r_hip) - LT_HIP_CYL_RADIUS;
-  const float z_tlo = B.p.z + dot(row(R0, 2), r_tlo), z_thi = B.p.z + dot(row(R0, 2), r_thi);
-#ifdef LT_PROBE_NO_RARE  // instruction-count probe of the common path (tools/asm_profile.py); never shipped
-  const bool rare = false;
-#else
-  const bool rare = fminf(fminf(fminf(z_calf, z_knee), fminf(z_hip, z_tlo)), z_thi) < 0.f;
-#endif
-  RC2 k_calf = rc2_none(), k_knee = k_calf, k_hip = k_calf, k_tlo = k_calf, k_thi = k_calf;
-  if (rare) {
-    k_calf = rare_contact<2>(c, h, r_calf, 0.012f, mu_body, Rw[2], pw[2], W[2], V[2], R0, B.p, ax0, ax12, pw, f[2], S, Mbb);
-    k_knee = rare_contact<1>(c, h, r_knee, 0.022f, mu_body, Rw[1], pw[1], W[1], V[1], R0, B.p, ax0, ax12, pw, f[1], S, Mbb);
-    k_hip = rare_contact<0>(c, h, r_hip, LT_HIP_CYL_RADIUS, mu_body, Rw[0], pw[0], W[0], V[0], R0, B.p, ax0, ax12, pw, f[0], S, Mbb);
-    // trunk corners of this lane (base accelerations are the unknowns: no velocity-product part)
-    k_tlo = trunk_eval(c, h, r_tlo, mu_body, R0, B.p, wb, vb);
-    trunk_add(h, k_tlo, r_tlo, R0, Mbb, pb);
-    k_thi = trunk_eval(c, h, r_thi, mu_body, R0, B.p, wb, vb);
-    trunk_add(h, k_thi, r_thi, R0, Mbb, pb);
+  RC c_tlo, c_thi;
+  {
+    I6 dummyI = Mbb;
+    S6 pA; pA.a = pb.n; pA.l = pb.f;
+    c_tlo = ground_contact(c, h, r_tlo, 0.f, mu_body, R0, B.p, wb, vb, dummyI, pA);
+    c_thi = ground_contact(c, h, r_thi, 0.f, mu_body, R0, B.p, wb, vb, dummyI, pA);
+    Mbb = dummyI; pb.n = pA.a; pb.f = pA.l;
   }
   // backward force pass
-  f[1] += force_to_parent2<1>(f[2], cq[2], sq[2], LC[2].r);
-  f[0] += force_to_parent2<1>(f[1], cq[1], sq[1], LC[1].r);
-  pb += force_to_parent2<0>(f[0], cq[0], sq[0], LC[0].r);
-  S.rhs[0] = G.tau[0] - f[0].x.x;
-  S.rhs[1] = G.tau[1] - f[1].y.x;
-  S.rhs[2] = G.tau[2] - f[2].y.x;
+  {
+    const F6 t2 = force_to_parent<1>(f[2], cq[2], sq[2], LC[2].r);
+    f[1].n += t2.n; f[1].f += t2.f;
+    const F6 t1 = force_to_parent<1>(f[1], cq[1], sq[1], LC[1].r);
+    f[0].n += t1.n; f[0].f += t1.f;
+    const F6 t0 = force_to_parent<0>(f[0], cq[0], sq[0], LC[0].r);
+    pb.n += t0.n; pb.f += t0.f;
+  }
+  S.rhs[0] = G.tau[0] - f[0].n.x;
+  S.rhs[1] = G.tau[1] - f[1].n.y;
+  S.rhs[2] = G.tau[2] - f[2].n.y;
 
   // ---- the two parts that do not depend on this lane's leg dynamics: the carried cylinder (object_part) and the CRBA
   //      (crba_part) - computed here, or fetched from the helper waves that ran them beside the code above ----
@@ -861,7 +636,7 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
     pe.crba = crba_part(sgn, cq, sq);
   }
   if (HAS_OBJ) {
-    pb += pair(pe.obj.pb_n, pe.obj.pb_f);
+    pb.n += pe.obj.pb_n; pb.f += pe.obj.pb_f;
     rep.obj_part = pe.obj.obj_part;
     rep.trunk_part += pe.obj.trunk_part;
     if (TAC) rep.plate = pe.obj.plate;
@@ -870,11 +645,15 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
     const CrbaOut& cr = pe.crba;
     S.h00 += cr.h00; S.h01 += cr.h01; S.h02 += cr.h02; S.h11 += cr.h11; S.h12 += cr.h12; S.h22 += cr.h22;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) S.b[j] += pair(cr.bn[j], cr.bl[j]);
-    i6p_add_rigid(Mbb, cr.Io, cr.mc, cr.m);
+    for (int j = 0; j < 3; ++j) { S.bn[j] += cr.bn[j]; S.bl[j] += cr.bl[j]; }
+    Mbb.A.m[0] += cr.Io.xx; Mbb.A.m[1] += cr.Io.xy; Mbb.A.m[2] += cr.Io.xz;
+    Mbb.A.m[3] += cr.Io.xy; Mbb.A.m[4] += cr.Io.yy; Mbb.A.m[5] += cr.Io.yz;
+    Mbb.A.m[6] += cr.Io.xz; Mbb.A.m[7] += cr.Io.yz; Mbb.A.m[8] += cr.Io.zz;
+    Mbb.B += skew_of(cr.mc);
+    Mbb.C.m[0] += cr.m; Mbb.C.m[4] += cr.m; Mbb.C.m[8] += cr.m;
   }
 
-  // ---- eliminate this leg's joints: H = L L^T (3x3), Y = L^-1 H_lb (rows (moment | force)), z = L^-1 rhs ----
+  // ---- eliminate this leg's joints: H = L L^T (3x3), Y = L^-1 H_lb, z = L^-1 rhs ----
   float l10, l20, l21, i0, i1, i2;  // (only the inverse diagonal is ever used: one v_rsq_f32 each)
   {
     i0 = frsqrt(S.h00);
@@ -883,21 +662,26 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
     l21 = (S.h12 - l20 * l10) * i1;
     i2 = frsqrt(S.h22 - l20 * l20 - l21 * l21);
   }
-  P3 y[3];
+  V3 yn[3], yl[3];
   float z[3];
-  y[0] = i0 * S.b[0]; z[0] = S.rhs[0] * i0;
-  y[1] = i1 * (S.b[1] - l10 * y[0]); z[1] = (S.rhs[1] - l10 * z[0]) * i1;
-  y[2] = i2 * (S.b[2] - l20 * y[0] - l21 * y[1]); z[2] = (S.rhs[2] - l20 * z[0] - l21 * z[1]) * i2;
-  P3 rb = -pb;  // base rhs share: -(bias wrench) - Y^T z
+  yn[0] = i0 * S.bn[0]; yl[0] = i0 * S.bl[0]; z[0] = S.rhs[0] * i0;
+  yn[1] = i1 * (S.bn[1] - l10 * yn[0]); yl[1] = i1 * (S.bl[1] - l10 * yl[0]); z[1] = (S.rhs[1] - l10 * z[0]) * i1;
+  yn[2] = i2 * (S.bn[2] - l20 * yn[0] - l21 * yn[1]); yl[2] = i2 * (S.bl[2] - l20 * yl[0] - l21 * yl[1]);
+  z[2] = (S.rhs[2] - l20 * z[0] - l21 * z[1]) * i2;
+  V3 rb_n = -pb.n, rb_f = -pb.f;  // base rhs share: -(bias wrench) - Y^T z
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    i6p_rank1(Mbb, -y[j], y[j]);
-    rb -= z[j] * y[j];
+    Mbb.A -= outer(yn[j], yn[j]);
+    Mbb.B -= outer(yn[j], yl[j]);
+    Mbb.C -= outer(yl[j], yl[j]);
+    rb_n -= z[j] * yn[j];
+    rb_f -= z[j] * yl[j];
   }
 
   // ---- floating base: quad-sum the four shares, add the trunk's own rigid-body terms, solve 6x6 ----
-  I6p M = qsum6(Mbb);
-  P3 r0 = qsum(rb);
+  I6 M;
+  M.A = qsum_sym(Mbb.A); M.B = qsum_full(Mbb.B); M.C = qsum_sym(Mbb.C);
+  V3 r0a = qsum(rb_n), r0l = qsum(rb_f);
   {
     const float mt = LT_TRUNK_MASS + X.trunk_mass_add;
     Rigid T;
@@ -905,49 +689,41 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
     const V3 ctr = v3(k_trunk_com[0], k_trunk_com[1], k_trunk_com[2]);
     T.mc = mt * ctr;
     T.Io = s3_from(inertia_about_origin(mt, ctr, k_trunk_icom, mt / LT_TRUNK_MASS));
-    r0 -= rigid_bias2(T, Wb, Vb);
-    i6p_add_rigid(M, T.Io, T.mc, T.m);
+    const F6 ft = rigid_bias(T, wb, vb, v3(0, 0, 0), v3(0, 0, 0), (-g) * row(R0, 2));
+    r0a -= ft.n; r0l -= ft.f;
+    M.A.m[0] += T.Io.xx; M.A.m[1] += T.Io.xy; M.A.m[2] += T.Io.xz;
+    M.A.m[3] += T.Io.xy; M.A.m[4] += T.Io.yy; M.A.m[5] += T.Io.yz;
+    M.A.m[6] += T.Io.xz; M.A.m[7] += T.Io.yz; M.A.m[8] += T.Io.zz;
+    M.B += skew_of(T.mc);
+    M.C.m[0] += mt; M.C.m[4] += mt; M.C.m[8] += mt;
   }
   V3 a0a, a0l;
-  spd6_solve(M, r0, a0a, a0l);
+  spd6_solve(M, r0a, r0l, a0a, a0l);
 
   // ---- back-substitute the joints: qdd = L^-T (z - Y a_b) ----
   float qdd[3];
-  const P3 A0 = pair(a0a, a0l);
   {
-    const f2 d0 = dot(y[0], A0), d1 = dot(y[1], A0), d2 = dot(y[2], A0);
-    const float t0 = z[0] - d0.x - d0.y, t1 = z[1] - d1.x - d1.y, t2 = z[2] - d2.x - d2.y;
+    const float t0 = z[0] - dot(yn[0], a0a) - dot(yl[0], a0l);
+    const float t1 = z[1] - dot(yn[1], a0a) - dot(yl[1], a0l);
+    const float t2 = z[2] - dot(yn[2], a0a) - dot(yl[2], a0l);
     qdd[2] = t2 * i2;
     qdd[1] = (t1 - l21 * qdd[2]) * i1;
     qdd[0] = (t0 - l10 * qdd[1] - l20 * qdd[2]) * i0;
   }
-  // link accelerations beyond the velocity products (for the final contact forces): base and joint accelerations propagated
-  P3 dl[3];
-  {
-    P3 t = A0;
-    V3 cr = cross(a0a, LC[0].r);
-    t.x.y += cr.x; t.y.y += cr.y; t.z.y += cr.z;
-    dl[0] = rot_inv<0>(cq[0], sq[0], t); dl[0].x.x += qdd[0];
-    t = dl[0]; cr = cross(lo(dl[0]), LC[1].r);
-    t.x.y += cr.x; t.y.y += cr.y; t.z.y += cr.z;
-    dl[1] = rot_inv<1>(cq[1], sq[1], t); dl[1].y.x += qdd[1];
-    t = dl[1]; cr = cross(lo(dl[1]), LC[2].r);
-    t.x.y += cr.x; t.y.y += cr.y; t.z.y += cr.z;
-    dl[2] = rot_inv<1>(cq[2], sq[2], t); dl[2].y.x += qdd[2];
-  }
-  rep.body[3] = contact_force2(c_foot, rc_foot, Rw[2], dl[2]);
-  rep.body[2] = rep.body[1] = rep.body[0] = v3(0, 0, 0);
-  if (rare) {
-    // (the hip and thigh rotations again, from inputs the optimiser cannot tie to the first evaluation: 18 registers that do
-    //  not stay live across the solve)
-    const M3 Rh = mul_rot2<0>(R0, opaque(cq[0]), opaque(sq[0]));
-    const M3 Rt = mul_rot2<1>(Rh, opaque(cq[1]), opaque(sq[1]));
-    rep.body[2] = contact_force2(k_calf, r_calf - 0.012f * row(Rw[2], 2), Rw[2], dl[2]);
-    rep.body[1] = contact_force2(k_knee, r_knee - 0.022f * row(Rt, 2), Rt, dl[1]);
-    rep.body[0] = contact_force2(k_hip, r_hip - LT_HIP_CYL_RADIUS * row(Rh, 2), Rh, dl[0]);
-    rep.trunk_part += contact_force2(k_tlo, r_tlo, R0, A0);
-    rep.trunk_part += contact_force2(k_thi, r_thi, R0, A0);
-  }
+  // total link accelerations (for the final contact forces)
+  V3 ta[3], tl[3];
+  ta[0] = rot_inv<0>(cq[0], sq[0], a0a) + ca[0] + axis_scaled<0>(qdd[0]);
+  tl[0] = rot_inv<0>(cq[0], sq[0], a0l + cross(a0a, LC[0].r)) + cl[0];
+  ta[1] = rot_inv<1>(cq[1], sq[1], ta[0]) + ca[1] + axis_scaled<1>(qdd[1]);
+  tl[1] = rot_inv<1>(cq[1], sq[1], tl[0] + cross(ta[0], LC[1].r)) + cl[1];
+  ta[2] = rot_inv<1>(cq[2], sq[2], ta[1]) + ca[2] + axis_scaled<1>(qdd[2]);
+  tl[2] = rot_inv<1>(cq[2], sq[2], tl[1] + cross(ta[1], LC[2].r)) + cl[2];
+  rep.body[3] = ground_force(c_foot, h, r_foot, LT_FOOT_RADIUS, Rw[2], ta[2], tl[2]);
+  rep.body[2] = ground_force(c_calf, h, r_calf, 0.012f, Rw[2], ta[2], tl[2]);
+  rep.body[1] = ground_force(c_knee, h, r_knee, 0.022f, Rw[1], ta[1], tl[1]);
+  rep.body[0] = ground_force(c_hip, h, r_hip, LT_HIP_CYL_RADIUS, Rw[0], ta[0], tl[0]);
+  rep.trunk_part += ground_force(c_tlo, h, r_tlo, 0.f, R0, a0a, a0l);
+  rep.trunk_part += ground_force(c_thi, h, r_thi, 0.f, R0, a0a, a0l);
 
   // ---- semi-implicit Euler ----
 #pragma unroll
@@ -960,9 +736,8 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
   }
   {
     const V3 acl = a0l + cross(wb, vb);
-    const P3 d = mul(R0, pair(a0a, acl));
-    B.u += h * hi(d);
-    B.w += h * lo(d);
+    B.u += h * mul(R0, acl);
+    B.w += h * mul(R0, a0a);
     B.p += h * B.u;
     B.q = q_integrate(B.q, B.w, h);
   }

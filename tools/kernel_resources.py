@@ -8,7 +8,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 flags = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize", "-ffinite-math-only", "-fno-signed-zeros",
-         "-freciprocal-math", "-fno-math-errno", "-I", os.path.join(REPO, "include")] + sys.argv[3:]
+         "-freciprocal-math", "-fno-math-errno", "-mllvm", "-disable-vector-combine", "-I", os.path.join(REPO, "include")] + sys.argv[3:]
 out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/tmp/_kres.o"],
                      capture_output=True, text=True).stderr
 cur = None

@@ -16,6 +16,8 @@ for i, nm in enumerate(names):
     print(f"{nm:32s} mean {st[:, i].mean():10.0f} ticks  ({100 * st[:, i].mean() / tot:5.1f} %)   max {st[:, i].max():10.0f}")
 bw = env.field("LT_F_REWARD_TERMS")[::16, :2, 0].cpu()
 print(f"wave 0 waiting in physics barriers: A {bw[:, 0].mean():.0f} ticks, B {bw[:, 1].mean():.0f} ticks (4 substeps)")
+pr = env.field("LT_F_REWARD_TERMS")[::16, 4:7, 0].cpu()
+print(f"prologue: entry -> barrier B0 reached {pr[:, 0].mean():.0f} (max {pr[:, 0].max():.0f}); inside B0 (loads landed + all four waves arrived) {pr[:, 1].mean():.0f} (max {pr[:, 1].max():.0f}); B0 -> wave 0's own path {pr[:, 2].mean():.0f} (max {pr[:, 2].max():.0f})")
 print("total ticks", float(tot), "(s_memtime ticks at 100 MHz => us:", float(tot) / 100.0, ")")
 
 if n <= 4096:  # helper form: when does each wave of a tile finish, relative to its own entry?  (LT_F_REWARD_TERMS quad array 3 carries the stamps)
