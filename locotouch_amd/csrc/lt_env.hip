@@ -386,6 +386,20 @@ __device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P
   command_resample(c, P, rng4(c.seed, env, step, stream), rng4(c.seed, env, step, stream + 1), X);
 }
 
+// stores of the observation rows (LT_STORE_MODE: 0 plain, 1 non-temporal - the default: the rows are read next by another kernel on other XCDs,
+// measured 56.3 M against 54.1 M env-steps/s at 4096 envs -, 2 write-through sc0 sc1: slower)
+#ifndef LT_STORE_MODE
+#define LT_STORE_MODE 1
+#endif
+__device__ __forceinline__ void st_out(float* p, float v) {
+#if LT_STORE_MODE == 1
+  __builtin_nontemporal_store(v, p);
+#elif LT_STORE_MODE == 2
+  asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+#else
+  *p = v;
+#endif
+}
 // =====================================================================================================
 // the step kernel
 // =====================================================================================================
@@ -416,7 +430,7 @@ __device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P
 //        A: wave 0's inputs are in LDS          (helpers start)
 //        B: the helpers' results are in LDS     (wave 0 has meanwhile done FK / RNEA / contacts / the backward pass)
 //      `s_waitcnt lgkmcnt(0); s_barrier` only: no vmcnt drain (the history waves' DMA and wave 0's stores stay in flight).
-constexpr int MB_IN = 19, MB_CRBA = 34, MB_OBJ = 15, MB_OFIN = 13;
+constexpr int MB_IN = 22, MB_CRBA = 43, MB_OBJ = 15, MB_OFIN = 13;
 __device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifdef LT_STAMPS
 #define LT_TIMED_BARRIER(acc) do { unsigned long long t0_, t1_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); \
@@ -429,9 +443,9 @@ struct HelperParts {
   float (*in)[64]; float (*crba)[64]; float (*obj)[64];
   int lane;
   unsigned long long* wait;  // LT_STAMPS builds: cycles spent in barriers A ([0]) and B ([1])
-  __device__ __forceinline__ void publish(const float (&cq)[3], const float (&sq)[3], const Base& B) const {
+  __device__ __forceinline__ void publish(const float (&cq)[3], const float (&sq)[3], const float (&qd)[3], const Base& B) const {
     const float v[MB_IN] = {cq[0], cq[1], cq[2], sq[0], sq[1], sq[2], B.p.x, B.p.y, B.p.z, B.q.w, B.q.x, B.q.y, B.q.z,
-                            B.u.x, B.u.y, B.u.z, B.w.x, B.w.y, B.w.z};
+                            B.u.x, B.u.y, B.u.z, B.w.x, B.w.y, B.w.z, qd[0], qd[1], qd[2]};
 #pragma unroll
     for (int i = 0; i < MB_IN; ++i) in[i][lane] = v[i];
     LT_TIMED_BARRIER(wait);  // A
@@ -449,6 +463,8 @@ struct HelperParts {
     for (int j = 0; j < 3; ++j) { r.bn[j] = v3(c[6 + 3 * j], c[7 + 3 * j], c[8 + 3 * j]); r.bl[j] = v3(c[15 + 3 * j], c[16 + 3 * j], c[17 + 3 * j]); }
     r.Io.xx = c[24]; r.Io.xy = c[25]; r.Io.xz = c[26]; r.Io.yy = c[27]; r.Io.yz = c[28]; r.Io.zz = c[29];
     r.mc = v3(c[30], c[31], c[32]); r.m = c[33];
+    r.tb[0] = c[34]; r.tb[1] = c[35]; r.tb[2] = c[36];
+    r.pbn = v3(c[37], c[38], c[39]); r.pbf = v3(c[40], c[41], c[42]);
     ObjOut& q = e.obj;
     q.pb_n = v3(o[0], o[1], o[2]); q.pb_f = v3(o[3], o[4], o[5]); q.obj_part = v3(o[6], o[7], o[8]);
     q.trunk_part = v3(o[9], o[10], o[11]); q.plate = v3(o[12], o[13], o[14]);
@@ -511,6 +527,8 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     uint4* dst = (uint4*)&s_d;
     if (lane < STG) dst[lane] = stg0;
     if (lane + 64 < STG) dst[lane + 64] = stg1;
+  } else if (HELPERS && wave == 1) {  // the CRBA / bias helper adds the trunk's rigid body: its randomised mass
+    hot.env_params = *F(LT_F_ENV_PARAMS, 0);
   } else if (HELPERS && HAS_OBJ && wave == 2) {  // the object helper owns the object's state during the physics
     hot.obj_pos = *F(LT_F_OBJ_POS, 0); hot.obj_quat = *F(LT_F_OBJ_QUAT, 0);
     hot.obj_lin = *F(LT_F_OBJ_LIN_VEL_W, 0); hot.obj_ang = *F(LT_F_OBJ_ANG_VEL_W, 0);
@@ -530,7 +548,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     }
   };
   __shared__ int s_fill[16];
-  __shared__ short s_tab[HELPERS ? 2 : 1][704];  // observation history tables (src[352] | frame[352]), one copy per history wave
+  __shared__ short s_tab[1][704];  // observation history tables (src[352] | frame[352]) of the one-wave form
   __shared__ __attribute__((aligned(16))) float s_old[HELPERS ? 2 * 16 * OBS : 16 * OBS];  // old history rows (one-wave form: one group at a time)
   __shared__ float s_cur[HELPERS ? 64 * 5 : 1];  // wave 0 -> wave 3: this step's curriculum record per lane
   __shared__ float s_mb_in[HELPERS ? MB_IN : 1][64], s_mb_crba[HELPERS ? MB_CRBA : 1][64], s_mb_obj[HELPERS ? MB_OBJ : 1][64],
@@ -570,6 +588,21 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   const uint32_t ekey = (uint32_t)env + (uint32_t)c.env_index_offset;  // RNG stream key of this env (global index over all ranks)
 
   if (HELPERS && __builtin_expect(wave != 0, 0)) {  // (unlikely: keeps wave 0's path the fall-through behind B0 - see DESIGN.md "far jump")
+    // waves 1 / 2: per-lane column routing of history group g (lane l owns columns l, l + 64, ... of EVERY row, so the table
+    // lookups are done once per lane), and the group's rows
+    const int g = wave == 2 ? 1 : 0;
+    constexpr int NCH = (OBS + 63) / 64;
+    int src[NCH], frm[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int col = i * 64 + lane;
+      const int cc = col < OBS ? col : OBS - 1;
+      const ObsTable& tabc = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
+      src[i] = tabc.src[cc];    // >= 0: old column (one slot newer); < 0: newest frame element -src-1
+      frm[i] = tabc.frame[cc];  // newest-frame element of this column's term (rows that were just reset)
+    }
+    float* const rows = a.obs_next[g] + (long long)blockIdx.x * 16 * OBS;
+    const float* const old = s_old + g * 16 * OBS;
     // ---- physics helpers: as many (A, B) barrier pairs as wave 0 runs substeps ----
     {
       const int nsub = c.decimation * c.phys_substeps;
@@ -578,6 +611,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       const float sgnh[4] = {1.f, sxh, syh, sxh * syh};
       Obj Oh;
       float trunk_mu = 0.f;
+      const float trunk_mass_add_h = wave == 1 ? qbcast<0>(hot.env_params) : 0.f;
       float bank_mat_c = 0.f;
       GaitIO gio = {0.f, 0.f, 0.f, 0, v3(0, 0, 0), 0.f};
       if (wave == 1 && MODE == MODE_STEP) {  // the gait class state of this lane / env: wave 1 evaluates the gait term (below)
@@ -600,11 +634,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
         // history rows, step 0 (waves 1 / 2): the group's 16 old rows = one contiguous chunk of 16*OBS floats, fetched by LDS-DMA -
         // each wave-instruction moves 64 lanes x 16 B = 1 KiB, lane-linear in LDS, no VGPRs - NOW, so that it lands beside the
         // physics (the physics barriers wait for LDS traffic only; B0, a full barrier, is behind us).
-        const int g = wave - 1;
-        // (the routing tables first: their loads are waited for before the LDS copy, and vmcnt retires in order - behind the DMA
-        //  that wait would hold this wave until all 22 KB have landed, i.e. into the first substep)
-        const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
-        for (int i = lane; i < 352; i += 64) { s_tab[g][i] = tab.src[i]; s_tab[g][352 + i] = tab.frame[i]; }
+        // (the routing tables were read before: their loads must not queue behind the DMA - vmcnt retires in order)
         constexpr int CHUNK16 = 16 * OBS / 4;  // float4 count per group (OBS*16 is a multiple of 4 for both tasks)
         const float* gsrc = a.obs_prev[g] + (long long)blockIdx.x * 16 * OBS;
         for (int i = 0; i < (CHUNK16 + 63) / 64; ++i) {
@@ -627,11 +657,16 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
         if (wave == 1) {
           const float cqh[3] = {s_mb_in[0][lane], s_mb_in[1][lane], s_mb_in[2][lane]};
           const float sqh[3] = {s_mb_in[3][lane], s_mb_in[4][lane], s_mb_in[5][lane]};
-          const CrbaOut r = crba_part(sgnh, cqh, sqh);
+          const float qdh[3] = {s_mb_in[19][lane], s_mb_in[20][lane], s_mb_in[21][lane]};
+          // the base's packed motion, as physics_substep forms it: (omega | 0), (v | +g z) in base coordinates
+          const M3 R0h = quat_to_mat(s_mb_in[9][lane], s_mb_in[10][lane], s_mb_in[11][lane], s_mb_in[12][lane]);
+          const P3 WVh = tmul(R0h, pair(v3(s_mb_in[16][lane], s_mb_in[17][lane], s_mb_in[18][lane]), v3(s_mb_in[13][lane], s_mb_in[14][lane], s_mb_in[15][lane])));
+          const CrbaOut r = crba_part(sgnh, leg, cqh, sqh, qdh, pair(lo(WVh), v3(0, 0, 0)), pair(hi(WVh), c.gravity * row(R0h, 2)), trunk_mass_add_h);
           const float v[MB_CRBA] = {r.h00, r.h01, r.h02, r.h11, r.h12, r.h22,
                                     r.bn[0].x, r.bn[0].y, r.bn[0].z, r.bn[1].x, r.bn[1].y, r.bn[1].z, r.bn[2].x, r.bn[2].y, r.bn[2].z,
                                     r.bl[0].x, r.bl[0].y, r.bl[0].z, r.bl[1].x, r.bl[1].y, r.bl[1].z, r.bl[2].x, r.bl[2].y, r.bl[2].z,
-                                    r.Io.xx, r.Io.xy, r.Io.xz, r.Io.yy, r.Io.yz, r.Io.zz, r.mc.x, r.mc.y, r.mc.z, r.m};
+                                    r.Io.xx, r.Io.xy, r.Io.xz, r.Io.yy, r.Io.yz, r.Io.zz, r.mc.x, r.mc.y, r.mc.z, r.m,
+                                    r.tb[0], r.tb[1], r.tb[2], r.pbn.x, r.pbn.y, r.pbn.z, r.pbf.x, r.pbf.y, r.pbf.z};
 #pragma unroll
           for (int i = 0; i < MB_CRBA; ++i) s_mb_crba[i][lane] = v[i];
         } else if (HAS_OBJ && wave == 2) {
@@ -693,6 +728,24 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
           if (it < 4) noise_draw(it);
         }
         wg_barrier_lds();  // B
+        if (wave == 1 || wave == 2) {
+          // history rows, this substep's share: row(t) is built from row(t-1) - every term block shifts left by one frame and takes
+          // the newest frame from wave 0 at the end.  The shifted 5/6 of the rows go out HERE, between B and the next A, while
+          // wave 0 eliminates, solves and integrates (~2.4 k cycles in which the helpers have nothing else to do); as one pass
+          // behind the last substep it kept wave 0 waiting ~3 k cycles at barrier C.  In-place safety (rows updated in the arena):
+          // the DMA of the whole chunk has landed (vmcnt(0)) before this wave stores anything, and only this wave touches the
+          // group's rows.  (the builtin, not an asm: the waitcnt pass then knows the row DMA has landed; behind an opaque wait it
+          //  re-waits vmcnt(0) - for every store of the loop - before each LDS read of the staged rows.  0x0070 = vmcnt 0, lgkmcnt 0)
+          if (it == 0) __builtin_amdgcn_s_waitcnt(0x0070);
+          const int r0 = (16 * it) / nsub, r1 = (16 * (it + 1)) / nsub;
+          for (int r = r0; r < r1; ++r) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+              const int col = i * 64 + lane;
+              if (col < OBS && src[i] >= 0) st_out(&rows[r * OBS + col], old[r * OBS + src[i]]);
+            }
+          }
+        }
       }
       if (MODE == MODE_STEP) {
         // ---- D .. E: the gait term (wave 1) and the object terms (wave 2) beside wave 0's own terms ----
@@ -727,7 +780,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     if (wave == 3) {
       wg_barrier_lds();  // C: the uniforms are in LDS
       // ---- curriculum / population gate / step counter (lt_post.h) on the record wave 0 leaves in LDS ----
-      __syncthreads();  // B1
+      wg_barrier_lds();  // B1 (LDS traffic only: nobody behind it reads what a wave stored to global memory before it)
       CurIn in;
       in.valid = env < L.n;
       in.reset = s_cur[lane * 5 + 0] != 0.f; in.ep_len = s_cur[lane * 5 + 1];
@@ -743,31 +796,9 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     //      and takes the newest frame from wave 0.  Lane l owns columns l, l+64, ... of EVERY row, so the per-column routing
     //      (table lookups) is done once per lane.  In-place safety (rows updated in the arena): the DMA of the whole chunk
     //      has landed (vmcnt(0)) before this wave stores anything, and only this wave touches the group's rows. ----
-    const int g = wave - 1;
-    constexpr int NCH = (OBS + 63) / 64;
-    // (the builtin, not an asm: the waitcnt pass then knows the row DMA has landed; behind an opaque wait it re-waits vmcnt(0) - for
-    //  every store of the loops below - before each LDS read of the staged rows.  0x0070 = vmcnt 0, lgkmcnt 0, expcnt untouched)
-    __builtin_amdgcn_s_waitcnt(0x0070);
-    int src[NCH], frm[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int col = i * 64 + lane;
-      const int cc = col < OBS ? col : OBS - 1;
-      src[i] = s_tab[g][cc];         // >= 0: old column (one slot newer); < 0: newest frame element -src-1
-      frm[i] = s_tab[g][352 + cc];   // newest-frame element of this column's term (rows that were just reset)
-    }
-    float* const rows = a.obs_next[g] + (long long)blockIdx.x * 16 * OBS;
-    const float* const old = s_old + g * 16 * OBS;
-    // before the barrier (beside the physics): the shifted 5/6 of every row, as if no env reset
-    for (int r = 0; r < 16; ++r) {
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const int col = i * 64 + lane;
-        if (col < OBS && src[i] >= 0) rows[r * OBS + col] = old[r * OBS + src[i]];
-      }
-    }
+    // (the shifted 5/6 of every row went out between the physics substeps, above)
     wg_barrier_lds();  // C (wave 3's noise uniforms -> wave 0)
-    __syncthreads();  // B1: newest frame + reset flags are in LDS
+    wg_barrier_lds();  // B1: newest frame + reset flags are in LDS (no vmcnt drain: the ~100 row stores above stay in flight)
     // after B1: the newest-frame columns of every row (1/6 of the columns: each lane owns about one of its NCH), and whole rows
     // for envs that were just reset.  The per-lane column routing is loop-invariant, so the row loop is one LDS read + one store
     // per owned newest column; reset rows (rare) take the full pass.
@@ -780,7 +811,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       if (col < OBS && src[i] < 0) {
         const int fe = (-src[i] - 1) & 63;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rows[r * OBS + col] = s_frame[g][r][fe];
+        for (int r = 0; r < 16; ++r) st_out(&rows[r * OBS + col], s_frame[g][r][fe]);
       }
     }
     while (fills) {
@@ -789,7 +820,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const int col = i * 64 + lane;
-        if (col < OBS && src[i] >= 0) rows[r * OBS + col] = s_frame[g][r][frm[i] & 63];
+        if (col < OBS && src[i] >= 0) st_out(&rows[r * OBS + col], s_frame[g][r][frm[i] & 63]);
       }
     }
 #ifdef LT_STAMPS
@@ -1321,7 +1352,8 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       for (int i = 0; i < 13; ++i) fc[45 + i] = o[i];
     }
   }
-  __syncthreads();  // B1 (helper form): frame, reset flags and curriculum record are in LDS for waves 1-3
+  wg_barrier_lds();  // B1: frame, reset flags and curriculum record are in LDS (helper form: for waves 1-3).  LDS traffic only - a
+                     // full __syncthreads waited here for every global store issued so far
   LT_STAMP(5);
   if (!HELPERS)
   {
@@ -1363,7 +1395,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
           const int col = i * 64 + lane;
-          if (col < OBS) rows[r * OBS + col] = (fill || src[i] < 0) ? fv[i] : ov[i];
+          if (col < OBS) st_out(&rows[r * OBS + col], (fill || src[i] < 0) ? fv[i] : ov[i]);
         }
       }
     }

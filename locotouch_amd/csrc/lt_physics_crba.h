@@ -365,50 +365,6 @@ __device__ __forceinline__ RC leg_contact(const lt_cfg& c, float h, V3 r, float 
   return out;
 }
 
-// ---- CRBA on rigid composites: this leg's joint-space inertia, its coupling to the base and its rigid share of the base
-//      block.  A function of the joint angles alone, so a helper wave can run it beside the leg dynamics. ----
-struct CrbaOut {
-  float h00, h01, h02, h11, h12, h22;
-  V3 bn[3], bl[3];
-  S3 Io; V3 mc; float m;  // composite of the whole leg about the base origin
-};
-__device__ __forceinline__ CrbaOut crba_part(const float (&sgn)[4], const float (&cq)[3], const float (&sq)[3]) {
-  CrbaOut o;
-  const LinkC LC[3] = {make_link<0>(sgn), make_link<1>(sgn), make_link<2>(sgn)};
-  Rigid RB[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { RB[k].m = LC[k].m; RB[k].mc = LC[k].mc; RB[k].Io = LC[k].Io; }
-  {
-    const Rigid C3 = RB[2];
-    const Rigid C2 = rigid_add(RB[1], rigid_to_parent<1>(C3, cq[2], sq[2], LC[2].r));
-    const Rigid C1 = rigid_add(RB[0], rigid_to_parent<1>(C2, cq[1], sq[1], LC[1].r));
-    const Rigid Cb = rigid_to_parent<0>(C1, cq[0], sq[0], LC[0].r);
-    // joint 2 (calf, axis y)
-    const F6 F3 = rigid_col<1>(C3);
-    o.h22 = C3.Io.yy;
-    const F6 F32 = force_to_parent<1>(F3, cq[2], sq[2], LC[2].r);
-    o.h12 = F32.n.y;
-    const F6 F31 = force_to_parent<1>(F32, cq[1], sq[1], LC[1].r);
-    o.h02 = F31.n.x;
-    const F6 F30 = force_to_parent<0>(F31, cq[0], sq[0], LC[0].r);
-    o.bn[2] = F30.n; o.bl[2] = F30.f;
-    // joint 1 (thigh, axis y)
-    const F6 F2 = rigid_col<1>(C2);
-    o.h11 = C2.Io.yy;
-    const F6 F21 = force_to_parent<1>(F2, cq[1], sq[1], LC[1].r);
-    o.h01 = F21.n.x;
-    const F6 F20 = force_to_parent<0>(F21, cq[0], sq[0], LC[0].r);
-    o.bn[1] = F20.n; o.bl[1] = F20.f;
-    // joint 0 (hip, axis x)
-    const F6 F1 = rigid_col<0>(C1);
-    o.h00 = C1.Io.xx;
-    const F6 F10 = force_to_parent<0>(F1, cq[0], sq[0], LC[0].r);
-    o.bn[0] = F10.n; o.bl[0] = F10.f;
-    o.Io = Cb.Io; o.mc = Cb.mc; o.m = Cb.m;  // rigid share of the base block
-  }
-  return o;
-}
-
 // ---- the carried cylinder's share of a substep: its contacts with the plate (sample = lane) and the ground, its own 6x6
 //      solve, and its integration.  Couples to the robot only through the base STATE at the substep start (the plate
 //      reaction is an explicit wrench on the trunk), so a helper wave can run it beside the leg dynamics. ----
@@ -653,6 +609,78 @@ __device__ __forceinline__ P3 force_to_parent2(const P3& x, float c, float s, V3
   return o;
 }
 
+// ---- everything of a substep that depends on the joint ANGLES and the velocities but not on the contacts: CRBA on rigid
+//      composites (this leg's joint-space inertia, its coupling to the base, its rigid share of the base block) and the
+//      velocity-product / gravity bias (RNEA with zero accelerations: joint torques and the wrench on the base).  Lane 0 of the
+//      quad adds the trunk's own inertia and bias to its share.  A helper wave runs it beside the contacts (lt_env.hip). ----
+struct CrbaOut {
+  float h00, h01, h02, h11, h12, h22;
+  V3 bn[3], bl[3];
+  S3 Io; V3 mc; float m;  // composite of the whole leg (+ trunk, lane 0) about the base origin
+  float tb[3];            // bias torque of the three joints
+  V3 pbn, pbf;            // bias wrench on the base (moment, force), this lane's share
+};
+__device__ __forceinline__ CrbaOut crba_part(const float (&sgn)[4], int leg, const float (&cq)[3], const float (&sq)[3], const float (&qd)[3],
+                                             const P3& Wb, const P3& Vb, float trunk_mass_add) {
+  CrbaOut o;
+  const LinkC LC[3] = {make_link<0>(sgn), make_link<1>(sgn), make_link<2>(sgn)};
+  Rigid RB[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { RB[k].m = LC[k].m; RB[k].mc = LC[k].mc; RB[k].Io = LC[k].Io; }
+  {
+    const Rigid C3 = RB[2];
+    const Rigid C2 = rigid_add(RB[1], rigid_to_parent<1>(C3, cq[2], sq[2], LC[2].r));
+    const Rigid C1 = rigid_add(RB[0], rigid_to_parent<1>(C2, cq[1], sq[1], LC[1].r));
+    const Rigid Cb = rigid_to_parent<0>(C1, cq[0], sq[0], LC[0].r);
+    // joint 2 (calf, axis y): column of the composite, carried down to the base as a packed (moment | force)
+    const P3 F3 = pair(s3_col<1>(C3.Io), cross(axis_scaled<1>(1.f), C3.mc));
+    o.h22 = C3.Io.yy;
+    const P3 F32 = force_to_parent2<1>(F3, cq[2], sq[2], LC[2].r);
+    o.h12 = F32.y.x;
+    const P3 F31 = force_to_parent2<1>(F32, cq[1], sq[1], LC[1].r);
+    o.h02 = F31.x.x;
+    const P3 F30 = force_to_parent2<0>(F31, cq[0], sq[0], LC[0].r);
+    o.bn[2] = lo(F30); o.bl[2] = hi(F30);
+    // joint 1 (thigh, axis y)
+    const P3 F2 = pair(s3_col<1>(C2.Io), cross(axis_scaled<1>(1.f), C2.mc));
+    o.h11 = C2.Io.yy;
+    const P3 F21 = force_to_parent2<1>(F2, cq[1], sq[1], LC[1].r);
+    o.h01 = F21.x.x;
+    const P3 F20 = force_to_parent2<0>(F21, cq[0], sq[0], LC[0].r);
+    o.bn[1] = lo(F20); o.bl[1] = hi(F20);
+    // joint 0 (hip, axis x)
+    const P3 F1 = pair(s3_col<0>(C1.Io), cross(axis_scaled<0>(1.f), C1.mc));
+    o.h00 = C1.Io.xx;
+    const P3 F10 = force_to_parent2<0>(F1, cq[0], sq[0], LC[0].r);
+    o.bn[0] = lo(F10); o.bl[0] = hi(F10);
+    o.Io = Cb.Io; o.mc = Cb.mc; o.m = Cb.m;  // rigid share of the base block
+  }
+  // velocity-product / gravity bias of the three links (the same kinematics recursion as physics_substep's: inline, one copy)
+  P3 W[3], V[3];
+  joint_fk2<0>(Wb, Vb, LC[0].r, cq[0], sq[0], qd[0], W[0], V[0]);
+  joint_fk2<1>(W[0], V[0], LC[1].r, cq[1], sq[1], qd[1], W[1], V[1]);
+  joint_fk2<1>(W[1], V[1], LC[2].r, cq[2], sq[2], qd[2], W[2], V[2]);
+  P3 f2 = rigid_bias2(RB[2], W[2], V[2]);
+  P3 f1 = rigid_bias2(RB[1], W[1], V[1]) + force_to_parent2<1>(f2, cq[2], sq[2], LC[2].r);
+  P3 f0 = rigid_bias2(RB[0], W[0], V[0]) + force_to_parent2<1>(f1, cq[1], sq[1], LC[1].r);
+  P3 pb = force_to_parent2<0>(f0, cq[0], sq[0], LC[0].r);
+  o.tb[0] = f0.x.x; o.tb[1] = f1.y.x; o.tb[2] = f2.y.x;
+  {  // the trunk's own rigid body: once per env (lane 0's share)
+    const float on = leg == 0 ? 1.f : 0.f;
+    const float mt = (LT_TRUNK_MASS + trunk_mass_add) * on;
+    Rigid T;
+    T.m = mt;
+    const V3 ctr = v3(k_trunk_com[0], k_trunk_com[1], k_trunk_com[2]);
+    T.mc = mt * ctr;
+    T.Io = s3_from(inertia_about_origin(mt, ctr, k_trunk_icom, mt / LT_TRUNK_MASS));
+    pb += rigid_bias2(T, Wb, Vb);
+    o.Io.xx += T.Io.xx; o.Io.xy += T.Io.xy; o.Io.xz += T.Io.xz; o.Io.yy += T.Io.yy; o.Io.yz += T.Io.yz; o.Io.zz += T.Io.zz;
+    o.mc += T.mc; o.m += mt;
+  }
+  o.pbn = lo(pb); o.pbf = hi(pb);
+  return o;
+}
+
 struct LegSys2 {       // this lane's 3 joints: H (sym 3x3), coupling rows to the base (moment | force), right-hand side
   float h00, h01, h02, h11, h12, h22;
   P3 b[3];
@@ -770,7 +798,7 @@ __device__ __forceinline__ RC2 rare_contact(const lt_cfg& c, float h, V3 r, floa
 struct PhysExt { CrbaOut crba; ObjOut obj; };
 struct InlineParts {
   static constexpr bool external = false;
-  __device__ __forceinline__ void publish(const float (&)[3], const float (&)[3], const Base&) const {}
+  __device__ __forceinline__ void publish(const float (&)[3], const float (&)[3], const float (&)[3], const Base&) const {}
   __device__ __forceinline__ void fetch(PhysExt&) const {}
 };
 template <bool HAS_OBJ, bool TAC = false, class Ext = InlineParts>
@@ -781,7 +809,7 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
   float cq[3], sq[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { sq[k] = fsin(G.q[k]); cq[k] = fcos(G.q[k]); }
-  ext.publish(cq, sq, B);
+  ext.publish(cq, sq, G.qd, B);
   PhysExt pe;
   if (!Ext::external && HAS_OBJ) pe.obj = object_part<TAC>(c, h, leg, B, O, X.trunk_mu);  // first: nothing else is live yet
   const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
@@ -805,13 +833,9 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
   rep.trunk_part = v3(0, 0, 0);
   rep.obj_part = v3(0, 0, 0);
 
-  // ---- RNEA forces of this leg's links (zero joint / base accelerations) + contacts ----
-  Rigid RB[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { RB[k].m = LC[k].m; RB[k].mc = LC[k].mc; RB[k].Io = LC[k].Io; }
+  // ---- contact forces on this leg's links (the links' own bias forces come with the CRBA part) ----
   P3 f[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) f[k] = rigid_bias2(RB[k], W[k], V[k]);
+  f[0] = f[1] = f[2] = both(v3(0, 0, 0));
   LegSys2 S;
   I6p Mbb;
   const float mu_foot = G.mu * c.ground_mu, mu_body = c.ground_mu;
@@ -849,16 +873,13 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
   f[1] += force_to_parent2<1>(f[2], cq[2], sq[2], LC[2].r);
   f[0] += force_to_parent2<1>(f[1], cq[1], sq[1], LC[1].r);
   pb += force_to_parent2<0>(f[0], cq[0], sq[0], LC[0].r);
-  S.rhs[0] = G.tau[0] - f[0].x.x;
-  S.rhs[1] = G.tau[1] - f[1].y.x;
-  S.rhs[2] = G.tau[2] - f[2].y.x;
 
   // ---- the two parts that do not depend on this lane's leg dynamics: the carried cylinder (object_part) and the CRBA
   //      (crba_part) - computed here, or fetched from the helper waves that ran them beside the code above ----
   if (Ext::external) {
     ext.fetch(pe);
   } else {
-    pe.crba = crba_part(sgn, cq, sq);
+    pe.crba = crba_part(sgn, leg, cq, sq, G.qd, Wb, Vb, X.trunk_mass_add);
   }
   if (HAS_OBJ) {
     pb += pair(pe.obj.pb_n, pe.obj.pb_f);
@@ -872,6 +893,10 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
 #pragma unroll
     for (int j = 0; j < 3; ++j) S.b[j] += pair(cr.bn[j], cr.bl[j]);
     i6p_add_rigid(Mbb, cr.Io, cr.mc, cr.m);
+    pb += pair(cr.pbn, cr.pbf);
+    S.rhs[0] = G.tau[0] - f[0].x.x - cr.tb[0];
+    S.rhs[1] = G.tau[1] - f[1].y.x - cr.tb[1];
+    S.rhs[2] = G.tau[2] - f[2].y.x - cr.tb[2];
   }
 
   // ---- eliminate this leg's joints: H = L L^T (3x3), Y = L^-1 H_lb (rows (moment | force)), z = L^-1 rhs ----
@@ -895,19 +920,9 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
     rb -= z[j] * y[j];
   }
 
-  // ---- floating base: quad-sum the four shares, add the trunk's own rigid-body terms, solve 6x6 ----
-  I6p M = qsum6(Mbb);
-  P3 r0 = qsum(rb);
-  {
-    const float mt = LT_TRUNK_MASS + X.trunk_mass_add;
-    Rigid T;
-    T.m = mt;
-    const V3 ctr = v3(k_trunk_com[0], k_trunk_com[1], k_trunk_com[2]);
-    T.mc = mt * ctr;
-    T.Io = s3_from(inertia_about_origin(mt, ctr, k_trunk_icom, mt / LT_TRUNK_MASS));
-    r0 -= rigid_bias2(T, Wb, Vb);
-    i6p_add_rigid(M, T.Io, T.mc, T.m);
-  }
+  // ---- floating base: quad-sum the four shares (lane 0's carries the trunk's own rigid body), solve 6x6 ----
+  const I6p M = qsum6(Mbb);
+  const P3 r0 = qsum(rb);
   V3 a0a, a0l;
   spd6_solve(M, r0, a0a, a0l);
 
