@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 8
+#define LT_ABI_VERSION 9
 
 /* error codes */
 #define LT_OK 0
@@ -274,7 +274,7 @@ enum lt_field {
   LT_F_TIME_OUT,        /* uint8 [N] */
   LT_F_TERM_BITS,       /* int32 [N] which termination terms fired this step */
   LT_F_CMD_PARAMS,      /* float [LT_CMD_PARAMS_LEN], device-resident command/curriculum block */
-  LT_F_COUNTERS,        /* int64 [4]: (common_step_counter, _, scratch: step id whose chained population pass is final (lt_env_defer_gate mode 2),
+  LT_F_COUNTERS,        /* int64 [4]: (common_step_counter, error word: chained hand-offs that timed out (lt_env_check), scratch: step id whose chained population pass is final (lt_env_defer_gate mode 2),
                          *             number of curriculum passes so far = next LT_F_GATE_RING slot, mod LT_GATE_RING) */
   LT_F_GATE_RING,       /* float [LT_GATE_RING][8]: the population sums of the last curriculum passes, one row per pass:
                          * (envs with a non-zero command, envs reset this step, lin trackers not all reset, sum ep_len lin,
@@ -361,6 +361,13 @@ int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_pol
  * Results are identical in all modes.  Mode 0 can only be selected while no pass is outstanding. */
 int lt_env_defer_gate(lt_env* env, int mode);
 int lt_env_gate_update(lt_env* env, void* stream);
+/* Device-side error word (LT_F_COUNTERS[1]).  In a chained launch every workgroup polls - at most LT_CHAIN_POLL_MAX times, ~50 ms -
+ * for the announcement that the command block of its step is final; a launch that never sees it (host bookkeeping and the device's
+ * step counter disagree) counts itself there and goes on instead of hanging the GPU.  lt_env_check copies the word to the host
+ * (WAITS for `stream`), clears it, and returns LT_EHIP with a message if it was set, LT_OK otherwise.  The reference has no
+ * counterpart (its managers run on the host: on_policy_runner.py:154-214 is a Python loop).
+ * Test hook: lt_env_defer_gate(env, 3) selects mode 2 and makes the NEXT chained launch announce a wrong step id, once. */
+int lt_env_check(lt_env* env, void* stream);
 /* Profiling variant of lt_env_step: HIP events bracket the step kernel on `stream`; the call WAITS for them (host
  * sync - never use it inside a captured region) and returns the step kernel's duration in milliseconds. */
 int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float* step_kernel_ms);

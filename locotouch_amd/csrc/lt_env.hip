@@ -430,6 +430,9 @@ __device__ __forceinline__ void st_out(float* p, float v) {
 //        A: wave 0's inputs are in LDS          (helpers start)
 //        B: the helpers' results are in LDS     (wave 0 has meanwhile done FK / RNEA / contacts / the backward pass)
 //      `s_waitcnt lgkmcnt(0); s_barrier` only: no vmcnt drain (the history waves' DMA and wave 0's stores stay in flight).
+#ifndef LT_CHAIN_POLL_MAX
+#define LT_CHAIN_POLL_MAX (1 << 20)  // polls of the chained command-block hand-off before it is declared lost (s_sleep 2 = ~128 clocks each)
+#endif
 constexpr int MB_IN = 22, MB_CRBA = 43, MB_OBJ = 15, MB_OFIN = 13;
 __device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifdef LT_STAMPS
@@ -692,14 +695,24 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
           auto put = [&](int slot, const U4& u) { s_bank[slot][0][lane] = u.a; s_bank[slot][1][lane] = u.b; s_bank[slot][2][lane] = u.c; s_bank[slot][3][lane] = u.d; };
           const int last = nsub - 1;
           // chained steps: the previous step's population pass, once per launch, here - ~6 k cycles inside an 11 k-cycle substep
-          if (it == 0 && a.decide_first && blockIdx.x == 0) curriculum_decide(c, L, arena, 0, (long long)step, (int)((step - 1) & 1));
+          // (decide_first == 3: test hook of lt_env_defer_gate mode 3 - the publisher announces a wrong step id once, so the consumers'
+          //  bounded poll below times out and raises the error word)
+          if (it == 0 && a.decide_first && blockIdx.x == 0) curriculum_decide(c, L, arena, 0, (long long)step + (a.decide_first == 3 ? 1 : 0), (int)((step - 1) & 1));
           if (it == last) {
             // the command block of THIS step -> LDS.  Chained: wait until the launch's decision is final (it has been for ~35 us)
             // and read it with sc1 loads; nobody in this launch read the block earlier, so no cache of this XCD holds an older line.
             const float* const Pg = (const float*)(arena + L.off_cmd_params);
             if (a.decide_first) {
-              const long long* const flag = (const long long*)(arena + L.off_counters) + 2;
-              while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (long long)step) __builtin_amdgcn_s_sleep(2);
+              long long* const cnt = (long long*)(arena + L.off_counters);
+              // bounded poll: the flag has normally been up for ~30 us when this wave looks.  A host-side bookkeeping slip (a launch
+              // whose publisher announces another step id) must end as an ERROR, not as a hung GPU: after LT_CHAIN_POLL_MAX polls
+              // (~50 ms) the wave raises counters[1] - lt_env_check turns it into LT_EHIP - and goes on with the block as it is.
+              int polls = 0;
+              while (__hip_atomic_load(cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (long long)step && polls < LT_CHAIN_POLL_MAX) {
+                __builtin_amdgcn_s_sleep(2);
+                ++polls;
+              }
+              if (polls >= LT_CHAIN_POLL_MAX && lane == 0) __hip_atomic_fetch_add((unsigned long long*)cnt + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               if (lane < 31) s_P[lane] = __hip_atomic_load(Pg + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else if (lane < 31) {
               s_P[lane] = Pg[lane];
@@ -1561,10 +1574,11 @@ int launch_step(const lt_env* env, const float* actions, hipStream_t s, const fl
   const bool helpers = MODE == MODE_STEP && grid.x <= helpers_max;
   // population pass of the step (lt_post.h): its own one-wave launch behind the step kernel (mode 0), the caller's (mode 1), or
   // chained into the next step launch (mode 2; helper form only - larger grids fall back to mode 0 behaviour)
-  const int gate_mode = (MODE == MODE_STEP && with_gate) ? ((env->defer_gate == 2 && !helpers) ? 0 : env->defer_gate) : -1;
+  const int gate_mode = (MODE == MODE_STEP && with_gate) ? ((env->defer_gate == 2 && !helpers) ? 0 : env->defer_gate) : -1;  // (mode 3 is stored as 2)
   if (MODE == MODE_STEP) {
     k.step_offset = env->pending_steps;
-    k.decide_first = (helpers && env->gate_pending) ? 1 : 0;
+    k.decide_first = (helpers && env->gate_pending) ? (env->test_chain_skew ? 3 : 1) : 0;
+    if (k.decide_first == 3) env->test_chain_skew = 0;  // once
     if (env->gate_pending && !k.decide_first) {  // an outstanding pass this launch cannot absorb: run it now
       hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(64), 0, s, k, env->pending_steps);
       env->pending_steps = 0; env->gate_pending = 0; k.step_offset = 0;
@@ -1685,6 +1699,17 @@ int lt_launch_set_command_ranges(const lt_env* env, const float ranges[6], int z
   hipLaunchKernelGGL(lt_set_ranges_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, ranges[0], ranges[1], ranges[2], ranges[3],
                      ranges[4], ranges[5], zero_steps, rel_standing);
   return (int)hipGetLastError();
+}
+
+// the device-side error word (counters[1]: chained hand-offs that timed out): read, cleared, returned in *count.  Host sync.
+int lt_launch_check(const lt_env* env, void* stream, long long* count) {
+  hipStream_t s = (hipStream_t)stream;
+  long long* const word = (long long*)((char*)env->arena + env->layout.off_counters) + 1;
+  hipError_t e = hipMemcpyAsync(count, word, sizeof(long long), hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return (int)e;
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return (int)e;
+  if (*count != 0) e = hipMemsetAsync(word, 0, sizeof(long long), s);
+  return (int)e;
 }
 
 const char* lt_hip_error_string(int err) { return hipGetErrorString((hipError_t)err); }

@@ -200,9 +200,24 @@ int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_pol
 }
 
 int lt_env_defer_gate(lt_env* env, int mode) {
-  if (!env || mode < 0 || mode > 2) return LT_EINVAL;
+  if (!env || mode < 0 || mode > 3) return LT_EINVAL;
   if (env->gate_pending && mode == 0) { lt_set_error("lt_env_defer_gate: a population pass is outstanding - call lt_env_gate_update first"); return LT_EINVAL; }
+  if (mode == 3) { env->defer_gate = 2; env->test_chain_skew = 1; return LT_OK; }  // test hook (include/lt_env.h)
   env->defer_gate = mode;
+  return LT_OK;
+}
+
+int lt_env_check(lt_env* env, void* stream) {
+  if (!env) return LT_EINVAL;
+  if (!env->arena) { lt_set_error("lt_env_check: arena not bound"); return LT_EFAULT; }
+  long long lost = 0;
+  const int rc = finish(lt_launch_check(env, stream, &lost), "lt_env_check");
+  if (rc != LT_OK) return rc;
+  if (lost != 0) {
+    lt_set_error("lt_env_check: a chained step launch never saw its population pass announced (lt_env_defer_gate mode 2: host bookkeeping of "
+                 "step_offset / decide_first and the device's step counter disagree); the command block of that step may be stale");
+    return LT_EHIP;
+  }
   return LT_OK;
 }
 

@@ -17,6 +17,7 @@ struct lt_env {
   int defer_gate = 0;        // lt_env_defer_gate mode: 0 pass behind every step, 1 the caller's lt_env_gate_update, 2 chained (next step launch)
   mutable int pending_steps = 0;  // steps launched whose common_step_counter bump is outstanding (modes 1, 2)
   mutable int gate_pending = 0;   // a population pass is outstanding
+  mutable int test_chain_skew = 0;  // lt_env_defer_gate mode 3 (test hook): the next chained launch announces a wrong step id
 };
 
 // implemented in lt_env.hip -------------------------------------------------------------------------
@@ -34,6 +35,7 @@ int lt_launch_gate_decide(const lt_env* env, int bump_counter, void* stream);  /
 int lt_launch_set_command_ranges(const lt_env* env, const float ranges[6], int zero_steps, float rel_standing, void* stream);
 int lt_launch_curriculum_apply_global(const lt_env* env, const float* ring_sums, int nsteps, long long n_total, void* stream);
 int lt_launch_tactile(const lt_env* env, void* stream);  // lt_tactile.hip
+int lt_launch_check(const lt_env* env, void* stream, long long* count);
 const char* lt_hip_error_string(int err);
 
 void lt_set_error(const char* msg);

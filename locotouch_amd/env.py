@@ -204,6 +204,10 @@ class LocoTouchVecEnv:
         """The outstanding population pass, if any (lt_env_gate_update)."""
         _abi.check(self._lib.lt_env_gate_update(self._handle, self._stream()), "lt_env_gate_update")
 
+    def check(self) -> None:
+        """Raise if a chained step launch lost its population-pass announcement (lt_env_check; waits for the stream)."""
+        _abi.check(self._lib.lt_env_check(self._handle, self._stream()), "lt_env_check")
+
     @property
     def handle(self) -> ctypes.c_void_p:
         return self._handle

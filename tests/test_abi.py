@@ -154,7 +154,7 @@ def test_population_pass_placement_api():
     assert lib.lt_env_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
     for mode in (0, 1, 2, 0):
         assert lib.lt_env_defer_gate(h, mode) == 0
-    assert lib.lt_env_defer_gate(h, 3) == C["LT_EINVAL"] and lib.lt_env_defer_gate(h, -1) == C["LT_EINVAL"]
+    assert lib.lt_env_defer_gate(h, 4) == C["LT_EINVAL"] and lib.lt_env_defer_gate(h, -1) == C["LT_EINVAL"]  # (3 = mode 2 + the lost-announcement test hook)
     assert lib.lt_env_defer_gate(None, 0) == C["LT_EINVAL"]
     assert lib.lt_env_gate_update(h, None) == C["LT_EFAULT"] and b"not bound" in lib.lt_last_error()
     assert lib.lt_env_destroy(h) == 0

@@ -93,7 +93,9 @@ def test_registered_presets_and_explicit_cylinders_match_oracle():
     # student task: + tactile refresh cadence, plate samples, lt_tactile_kernel rows (405 = the registration's env count)
     ("student", 405, 100, 1, 0),
     # > 8192 envs: launch_step picks the register-path (PREFETCH=false) history variant, which shifts the rows in place
-    ("teacher", 8208, 16, 1, 45), ("locomotion", 8208, 12, 1, 45)])
+    ("teacher", 8208, 16, 1, 45), ("locomotion", 8208, 12, 1, 45),
+    # the headline grid itself: 4096 envs = 256 tiles, one per CU, four-wave form across all XCDs
+    ("teacher", 4096, 16, 1, 45), ("locomotion", 4096, 12, 1, 45)])
 def test_step_parity_resynced(task, n, steps, phys, pre):
     """Every step starts from byte-identical state (oracle arena copied to the device), then one step on each side.
     Covers contacts, object resting/rolling, resets with RNG, command resampling, pushes, history shifting.
@@ -118,7 +120,7 @@ def test_step_parity_resynced(task, n, steps, phys, pre):
         env.step(act.cuda())
         ora.step(act.numpy(), nthreads=8 if n > 1024 else 1)
         torch.cuda.synchronize()
-        res = compare_arenas(env, ora, what=f"{task} n={n} step {t}", max_flip_frac=0.05, max_event_frac=max(2.0 / n, 0.003))
+        res = compare_arenas(env, ora, what=f"{task} n={n} step {t}", max_flip_frac=0.05, max_event_frac=max(2.0 / n, 1e-3))
         tally.add(res)
         d = L.arr(ora.arena, "LT_F_DONES")[:n]
         n_reset += int(d.sum())
@@ -135,7 +137,8 @@ def test_step_parity_resynced(task, n, steps, phys, pre):
     assert n_reset > 0, "the sequence must include resets"
     assert n_shift > n_reset, "most rows must really shift (not fill)"
     assert tally.flips <= 0.01 * n * steps, f"too many thresholded-contact flips: {tally.flips}"
-    assert tally.events <= 0.003 * n * steps, f"too many discontinuous-event divergences: {tally.events}"
+    # observed: 1.5e-4 of the env-steps (r02: 14-19 events in 98-131 k env-steps at 8208 envs); the bound sits near it
+    assert tally.events <= max(2, 5e-4 * n * steps), f"too many discontinuous-event divergences: {tally.events}"
 
 
 @pytest.mark.parametrize("fmt,aux", [("LT_TACTILE_PROCESSED", 3), ("LT_TACTILE_DISCRETE", 0), ("LT_TACTILE_NORMALIZED", 1),
@@ -221,6 +224,67 @@ def test_global_gate_kernel_matches_oracle():
         bins.append(float(L.arr(ora.arena, "LT_F_CMD_PARAMS")[17] + L.arr(ora.arena, "LT_F_CMD_PARAMS")[18]))
     assert bins[-1] >= 3, bins
     assert int(L.arr(ora.arena, "LT_F_COUNTERS")[3]) == 30 * rollout
+
+
+def test_chained_steps_at_the_headline_grid_match_the_oracle():
+    """4096 envs (one tile per CU), lt_env_defer_gate mode 2: chains of 1-3 steps from byte-identical state against the ORACLE
+    (which runs its population pass behind every step) - compared after each chain has been closed by gate_update().  A chain is
+    not resynced inside, so a k-step chain is compared at k times the one-step event allowance."""
+    import torch
+
+    n = 4096
+    env = make_env("teacher", n)
+    ora = O.OracleEnv(env.cfg)
+    ora.reset_all()
+    g = torch.Generator().manual_seed(11)
+    for _ in range(30):
+        ora.step((0.6 * torch.randn(n, 12, generator=g)).numpy(), nthreads=8)
+    tally = Tally(n)
+    L = Layout(n, env.num_obs)
+    off = L.plain["LT_F_COUNTERS"][0] + 16  # counters[2]: the chain's scratch flag
+    nsteps = 0
+    for chain in (1, 2, 1, 3, 2, 1):
+        env._arena_aligned.copy_(torch.from_numpy(ora.arena))
+        env.defer_gate(2)
+        for _ in range(chain):
+            act = 0.6 * torch.randn(n, 12, generator=g)
+            a_dev = act.cuda()
+            env.step_rows_raw(a_dev.data_ptr(), 0, 0, 0, 0)
+            ora.step(act.numpy(), nthreads=8)
+            nsteps += 1
+        env.gate_update()
+        env.defer_gate(0)
+        torch.cuda.synchronize()
+        dev = device_arena_to_host(env)
+        dev[off:off + 8] = ora.arena[off:off + 8]
+        res = compare_host_arenas(env.cfg, dev, ora.arena, what=f"chain of {chain}", max_flip_frac=0.05 * chain, max_event_frac=2e-3 * chain * chain)
+        tally.add(res)
+    print(tally.line(f"chained teacher n={n} ({nsteps} steps in 6 chains)"))
+    assert tally.events <= 5e-4 * n * nsteps  # observed: 5 in 10 steps
+
+
+def test_lost_chain_announcement_is_an_error_not_a_hang():
+    """The consumers of a chained launch poll a bounded number of times for the announcement of their step's command block.  With
+    the publisher announcing a wrong step id once (lt_env_defer_gate mode 3, a test hook) the launch still ends, lt_env_check
+    reports LT_EHIP, and the env works again afterwards."""
+    import torch
+
+    n = 256
+    env = make_env("teacher", n)
+    act = torch.zeros(n, 12, device="cuda:0")
+    env.defer_gate(2)
+    env.step_rows_raw(act.data_ptr(), 0, 0, 0, 0)
+    env.check()  # a healthy chain raises nothing
+    env.defer_gate(3)
+    env.step_rows_raw(act.data_ptr(), 0, 0, 0, 0)  # its publisher announces step + 1: every other workgroup times out (~50 ms)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="lt_env_check"):
+        env.check()
+    env.gate_update()
+    env.defer_gate(0)
+    env.check()  # cleared
+    obs, rew, dones, _ = env.step(act)
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
 
 
 def test_chained_population_pass_equals_the_pass_behind_every_step():
