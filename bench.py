@@ -27,8 +27,14 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-ALGO_BYTES_PER_ENV_STEP = {"teacher": 6720, "locomotion": 5344}
-MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 MFMA peak (MI355X_MICROARCH.md)
+ALGO_BYTES_PER_ENV_STEP = {"teacher": 6720, "locomotion": 5344}  # 1680 / 1336 words of 4 bytes
+# bf16 observation rows (BASELINE config 5; state quad arrays stay f32): the 580 R + 696 W row words of the teacher table
+# (locomotion: 450 + 540) move as 2 bytes each: 6720 - 2 * 1276 = 4168 B, 5344 - 2 * 990 = 3364 B per env-step
+ALGO_BYTES_PER_ENV_STEP_BF16_ROWS = {"teacher": 4168, "locomotion": 3364}
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-INPUT MFMA peak (MI355X_MICROARCH.md): what an ideal f32-MFMA kernel could reach
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 MFMA peak: the pipe lt_mlp_kernel runs on, at 3 MFMAs per f32-equivalent MAC
+L2_STREAM_PEAK_GBS = 17800.0  # rows shared by every workgroup, served from the XCDs' L2s: 16.8-18.8 TB/s chip-wide (MI355X_MICROARCH.md, "Indexed rows")
+VALU_PEAK_GINST = 1024 * 2.4 / 4  # wave64 VALU instructions per ns the chip can issue: 1024 SIMDs x 2.4 GHz / 4 cycles
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling is 6290 GB/s
 TASKS = {"teacher": "Isaac-RandCylinderTransportTeacher-LocoTouch-v1", "locomotion": "Isaac-Locomotion-LocoTouch-v1"}
 POLICY_CFG = dict(init_noise_std=1.0, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], activation="elu")
@@ -111,6 +117,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--task", default="teacher", choices=list(TASKS))
+    ap.add_argument("--obs-dtype", default="f32", choices=["f32", "bf16"],
+                    help="element type of the observation rows, their history and the rollout-storage observations (bf16: BASELINE config 5; state stays f32)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager-torch", action="store_true", help="reference-shaped rollout (torch elementwise ops) instead of the fused kernels")
@@ -138,7 +146,8 @@ def main() -> None:
     torch.manual_seed(1234)  # identical random-init policy on every rank
     ac = ActorCritic(env.num_obs, env.num_obs, 12, **POLICY_CFG)
     alg = PPO(ac, device=dev, dist=dist, **PPO_CFG)
-    alg.init_storage(n, ROLLOUT, [env.num_obs], [env.num_obs], [12])
+    obs_dtype = torch.bfloat16 if args.obs_dtype == "bf16" else torch.float32
+    alg.init_storage(n, ROLLOUT, [env.num_obs], [env.num_obs], [12], obs_dtype=obs_dtype)
     obs, extras = env.get_observations()
     critic_obs = extras["observations"]["critic"]
 
@@ -210,22 +219,44 @@ def main() -> None:
     # ---- roofline of the dominant kernel: live HIP-event timing of lt_step_kernel on the launch stream ----
     with torch.inference_mode():
         act = alg.act(obs, critic_obs).clone()
+    if args.obs_dtype == "bf16":  # the kernel variant the rollout runs: bf16 rows from one storage slot into the next
+        st = alg.storage
+        env.set_row_format(torch.bfloat16)
+        prof = lambda: env.step_rows_profiled(act, st.observations[0], st.privileged_observations[0], st.observations[1], st.privileged_observations[1])  # noqa: E731
+    else:
+        prof = lambda: env.step_profiled(act)  # noqa: E731
     for _ in range(20):
-        env.step_profiled(act)
-    ms = [env.step_profiled(act) for _ in range(200)]
+        prof()
+    ms = [prof() for _ in range(200)]
+    if args.obs_dtype == "bf16":
+        env.set_row_format(torch.float32)
     k_ms = sum(ms) / len(ms)
-    algo_bytes = ALGO_BYTES_PER_ENV_STEP[args.task] * n
+    algo_bytes = (ALGO_BYTES_PER_ENV_STEP_BF16_ROWS if args.obs_dtype == "bf16" else ALGO_BYTES_PER_ENV_STEP)[args.task] * n
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+    key = f"{args.task}_{n}" + ("_bf16rows" if args.obs_dtype == "bf16" else "")
     traffic = None
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(f"{args.task}_{n}", {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": "lt_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes,
                 "env_only_steps_per_s": n / (k_ms * 1e-3)}
+    # what actually bounds the step kernel: VALU issue.  Wave-instructions per launch from the SQ counters of the same command
+    # (profiles/sq_counters.json, tools/pmc_sq.py) against what 1024 SIMDs can issue in the measured kernel time.
+    spath = os.path.join(REPO, "profiles", "sq_counters.json")
+    if os.path.exists(spath):
+        try:
+            valu = json.load(open(spath)).get(key, {}).get("valu_wave_insts_per_launch")
+        except Exception:
+            valu = None
+        if valu:
+            rate = valu / (k_ms * 1e6)  # G wave-instructions / s
+            roofline["valu"] = {"bound": "valu-issue", "kernel": "lt_step_kernel", "achieved": rate, "peak": VALU_PEAK_GINST,
+                                "unit": "G wave-inst/s", "frac": rate / VALU_PEAK_GINST, "valu_wave_insts_per_launch": valu,
+                                "note": "SQ_INSTS_VALU per launch / kernel time against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
     # the other launch of a rollout step: actor + critic MLPs + sampling in one kernel, against the dense f32 MFMA peak
     if fused is not None and fused.actor_mlp is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -240,9 +271,19 @@ def main() -> None:
         dims = [env.num_obs, 512, 256, 128]
         macs = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
         flop = 2.0 * n * (2 * macs + dims[-1] * (12 + 1))
-        roofline["mlp"] = {"bound": "mfma", "kernel": "lt_mlp_kernel (actor + critic + sampling)", "flop_per_launch": flop,
-                           "kernel_ms": mlp_ms, "achieved": flop / (mlp_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": flop / (mlp_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
+        # The kernel evaluates an f32-equivalent MAC as THREE f16 MFMAs (csrc/lt_mlp.hip), so its matrix-pipe peak is the f16
+        # peak / 3; what bounds it in practice is the weight stream every workgroup pulls from its XCD's L2 (2 f16 planes =
+        # 4 bytes per weight, once per workgroup of 32 rows).  Both fractions are <= 1 by construction.
+        tflops = flop / (mlp_ms * 1e-3) / 1e12
+        wg_per_net = (n + 31) // 32
+        stream_bytes = 2 * wg_per_net * 4.0 * (macs + dims[-1] * 6.5)  # actor (12 outputs) + critic (1): (12 + 1) / 2 per net
+        l2_rate = stream_bytes / (mlp_ms * 1e-3) / 1e9
+        roofline["mlp"] = {"bound": "l2-stream", "kernel": "lt_mlp_kernel (actor + critic + sampling)", "flop_per_launch": flop,
+                           "kernel_ms": mlp_ms, "achieved": tflops, "peak": MFMA_F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s (f32-equivalent)",
+                           "frac": tflops / (MFMA_F16_PEAK_TFLOPS / 3.0),
+                           "l2_stream": {"bytes_per_launch": stream_bytes, "achieved": l2_rate, "peak": L2_STREAM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": l2_rate / L2_STREAM_PEAK_GBS},
+                           "ideal_f32_mfma_kernel_tflops": MFMA_F32_PEAK_TFLOPS}
 
     extra = {}
     if args.update_iters > 0:  # rollout + GAE + PPO update with the gradient all-reduce (Perf/total_fps of the reference)
@@ -279,7 +320,10 @@ def main() -> None:
                "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{TASKS[args.task]} rollout (policy act + env step + storage), {n} envs/GPU, "
-                                      f"random-init ActorCritic [512,256,128], seed 42, env RNG keyed by global env index",
+                                      f"random-init ActorCritic [512,256,128], seed 42, env RNG keyed by global env index"
+                                      + ("; observation rows, their 6-deep history and the rollout-storage observations in bf16, all state "
+                                         "quad arrays and the arithmetic in f32" if args.obs_dtype == "bf16" else ""),
+                          "obs_dtype": args.obs_dtype,
                           "envs_per_gpu": n, "rollout_len": ROLLOUT, "hipgraph_replayed": launched["graph"] > 0 and launched["eager"] == 0,
                           "steps_replayed_from_graphs": launched["graph"], "steps_launched_eagerly": launched["eager"],
                           "fused_rollout": fused is not None, "launches_per_step": fused.launches_per_step if fused is not None else None},

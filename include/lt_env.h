@@ -349,6 +349,14 @@ int lt_env_step_rows(lt_env* env, const float* actions, const float* prev_policy
  * st_rewards[n] = reward + gamma * values * time_out, st_dones[n] = dones != 0.  `values` = V(obs_t), float[n]. */
 int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_policy, const float* prev_critic, float* next_policy,
                         float* next_critic, const float* values, float gamma, float* st_rewards, uint8_t* st_dones, void* stream);
+/* Element format of the observation rows behind the prev / next pointers of lt_env_step_rows and lt_env_step_rollout (BASELINE
+ * config 5: bf16 observation rows, history and rollout-storage observations; the arena's own rows and all state stay f32).
+ * LT_ROWS_BF16: rows are uint16 [n][obs_dim] (bf16 bit patterns); the newest frame is rounded to nearest-even as it enters a row,
+ * older frames are carried bit for bit, so a frame is rounded exactly once.  All four row pointers must then be given (LT_EHIP /
+ * invalid value otherwise); lt_env_step is unaffected.  Not available for the tactile tasks.  The reference keeps f32 everywhere
+ * (loco_rl/loco_rl/storage/rollout_storage.py:36-44). */
+enum lt_row_format { LT_ROWS_F32 = 0, LT_ROWS_BF16 = 1 };
+int lt_env_set_row_format(lt_env* env, int format);
 /* The population pass of a step - curriculum decision, population gate of rewards.py:190, common_step_counter += 1
  * (curriculums.py:184-275; csrc/lt_post.h) - needs sums over all envs; it is one wave of work.  lt_env_defer_gate(env, mode):
  *   0 (default) every step entry point launches it behind the step kernel: after a step the command block and the counters are final;
@@ -371,6 +379,9 @@ int lt_env_check(lt_env* env, void* stream);
 /* Profiling variant of lt_env_step: HIP events bracket the step kernel on `stream`; the call WAITS for them (host
  * sync - never use it inside a captured region) and returns the step kernel's duration in milliseconds. */
 int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float* step_kernel_ms);
+/* ... of lt_env_step_rows (rows in the format of lt_env_set_row_format): what bench.py times for the bf16-row configuration. */
+int lt_env_step_rows_profiled(lt_env* env, const float* actions, const float* prev_policy, const float* prev_critic, float* next_policy,
+                              float* next_critic, void* stream, float* step_kernel_ms);
 /* PPO minibatch loss with its gradients in one launch (reference loco_rl/loco_rl/algorithms/ppo.py:251-311; csrc/lt_ppo.hip).
  * mu, actions, old_mu, old_sigma: [M][A]; std: [A] (the policy's state-independent std); value, old_logp, adv, returns,
  * old_values: [M].  Outputs: dmu [M][A] and dvalue [M] = d loss / d mu, d loss / d value for
@@ -466,6 +477,8 @@ typedef struct lt_mlp_desc {
   int32_t num_layers;                   /* Linear layers */
   int32_t dims[LT_MLP_MAX_LAYERS + 1];  /* dims[0] = input width (<= LT_MLP_MAX_WIDTH), dims[l+1] = outputs of layer l (<= 512) */
   int32_t activation;                   /* lt_activation between layers (none after the last) */
+  int32_t input_format;                 /* lt_row_format of the input rows (x / obs): LT_ROWS_F32, or LT_ROWS_BF16 = uint16 [m][dims[0]]
+                                         * (bf16 bit patterns, widened exactly to f32 as they enter LDS; dims[0] % 4 == 0) */
 } lt_mlp_desc;
 /* Floats of the packed parameter buffer of a network. */
 int lt_mlp_packed_floats(const lt_mlp_desc* desc, size_t* floats);

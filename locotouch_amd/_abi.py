@@ -76,7 +76,7 @@ class LtView(ctypes.Structure):
 
 
 class LtMlpDesc(ctypes.Structure):
-    _fields_ = [("num_layers", ctypes.c_int32), ("dims", ctypes.c_int32 * (CONSTS["LT_MLP_MAX_LAYERS"] + 1)), ("activation", ctypes.c_int32)]
+    _fields_ = [("num_layers", ctypes.c_int32), ("dims", ctypes.c_int32 * (CONSTS["LT_MLP_MAX_LAYERS"] + 1)), ("activation", ctypes.c_int32), ("input_format", ctypes.c_int32)]
 
 
 _lib = None
@@ -107,10 +107,12 @@ def load() -> ctypes.CDLL:
     lib.lt_env_reset_all.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.lt_env_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.lt_env_step_profiled.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    lib.lt_env_step_rows_profiled.argtypes = [ctypes.c_void_p] * 7 + [ctypes.POINTER(ctypes.c_float)]
     lib.lt_env_eval_terms.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.lt_env_defer_gate.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.lt_env_gate_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.lt_env_check.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.lt_env_set_row_format.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.lt_env_tactile_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     _vp = ctypes.c_void_p
     lib.lt_gru_forward.argtypes = [_vp] * 5 + [ctypes.c_int] * 3 + [_vp] * 3
@@ -153,7 +155,7 @@ def load() -> ctypes.CDLL:
     return lib
 
 
-EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_preset", "lt_cfg_num_presets", "lt_cfg_preset_id", "lt_cfg_obs_dim", "lt_cfg_tactile_dim", "lt_env_create", "lt_env_tactile_update", "lt_env_defer_gate", "lt_env_gate_update", "lt_env_check", "lt_mlp_forward_pair", "lt_env_curriculum_apply_global", "lt_gru_forward", "lt_gru_backward", "lt_ppo_loss", "lt_elu_backward_bias", "lt_elu_backward_bias_ws_floats", "lt_adam_clip_step", "lt_adam_clip_step_ws_floats", "lt_gae", "lt_head_wgrad", "lt_head_wgrad_ws_floats",
+EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_preset", "lt_cfg_num_presets", "lt_cfg_preset_id", "lt_cfg_obs_dim", "lt_cfg_tactile_dim", "lt_env_create", "lt_env_tactile_update", "lt_env_defer_gate", "lt_env_gate_update", "lt_env_check", "lt_env_set_row_format", "lt_env_step_rows_profiled", "lt_mlp_forward_pair", "lt_env_curriculum_apply_global", "lt_gru_forward", "lt_gru_backward", "lt_ppo_loss", "lt_elu_backward_bias", "lt_elu_backward_bias_ws_floats", "lt_adam_clip_step", "lt_adam_clip_step_ws_floats", "lt_gae", "lt_head_wgrad", "lt_head_wgrad_ws_floats",
            "lt_env_destroy", "lt_env_state_bytes", "lt_env_bind", "lt_env_reset_all", "lt_env_step", "lt_env_step_profiled", "lt_env_eval_terms",
            "lt_env_curriculum_update", "lt_env_step_rows", "lt_env_step_rollout", "lt_env_get_view", "lt_env_set_command_ranges", "lt_rollout_act", "lt_rollout_record", "lt_mlp_packed_floats", "lt_mlp_pack", "lt_mlp_forward", "lt_rollout_policy", "lt_rollout_policy_value",
            "lt_env_kernel_name"]

@@ -400,6 +400,17 @@ __device__ __forceinline__ void st_out(float* p, float v) {
   *p = v;
 #endif
 }
+__device__ __forceinline__ void st_out(unsigned* p, unsigned v) {
+#if LT_STORE_MODE == 1
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ unsigned bf16_rne(float x) {  // round to nearest even (no NaNs on this path)
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
 // =====================================================================================================
 // the step kernel
 // =====================================================================================================
@@ -474,7 +485,9 @@ struct HelperParts {
   }
 };
 
-template <int TASK, int MODE, bool HELPERS>
+// RB: the observation rows behind a.obs_prev / a.obs_next are bf16 (rollout-storage slots of BASELINE config 5), two columns per
+// 32-bit word; the newest frame is rounded to nearest-even when it enters a row, older frames are carried bit for bit.
+template <int TASK, int MODE, bool HELPERS, bool RB = false>
 __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES_LARGE) void lt_step_kernel(const KArgs a) {
 #ifdef LT_STAMPS
   unsigned long long stamps_[8], bar_wait_[2] = {0, 0};
@@ -540,16 +553,22 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   __shared__ float s_frame[2][16][64];
   // the 16 old rows of history group g (one contiguous chunk of 16*OBS floats) -> LDS by LDS-DMA: each wave-instruction moves
   // 64 lanes x 16 B = 1 KiB, lane-linear in LDS, no VGPRs
-  auto dma_old_rows = [&](int g, float* dst) {
-    constexpr int CHUNK16 = 16 * OBS / 4;  // float4 count per group (OBS*16 is a multiple of 4 for both tasks)
-    const float* gsrc = a.obs_prev[g] + (long long)blockIdx.x * 16 * OBS;
+  constexpr int EB = RB ? 2 : 4;  // bytes per row element
+  // (`prev`: the group's previous rows, a.obs_prev[g] picked by the caller - indexing the by-value kernel argument struct with a
+  //  runtime g inside this lambda put the whole struct on the stack: 128 B of scratch in front of every launch)
+  auto dma_old_rows = [&](const float* prev, float* dst) __attribute__((always_inline)) {  // (a lambda called twice is a real call otherwise: scratch, vmcnt(0))
+    constexpr int CHUNK16 = 16 * OBS * EB / 16;  // 16-byte pieces per group (16 * OBS * EB is a multiple of 16 for both tasks)
+    const char* gsrc = (const char*)prev + (long long)blockIdx.x * 16 * OBS * EB;
     for (int i = 0; i < (CHUNK16 + 63) / 64; ++i) {
       const int v = i * 64 + lane;
       if (v < CHUNK16)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + v * 4),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + v * 16),
                                          (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
     }
   };
+  // bf16 rows: a lane owns column PAIRS p = lane, lane + 64, ... (columns 2p, 2p + 1: one 32-bit word) of every row
+  constexpr int NPC = (OBS / 2 + 63) / 64;
+  static_assert(OBS % 2 == 0, "bf16 rows are handled as column pairs");
   __shared__ int s_fill[16];
   __shared__ short s_tab[1][704];  // observation history tables (src[352] | frame[352]) of the one-wave form
   __shared__ __attribute__((aligned(16))) float s_old[HELPERS ? 2 * 16 * OBS : 16 * OBS];  // old history rows (one-wave form: one group at a time)
@@ -570,7 +589,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   if (!HELPERS) {
     const ObsTable& tab = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
     for (int i = lane; i < 352; i += 64) { s_tab[0][i] = tab.src[i]; s_tab[0][352 + i] = tab.frame[i]; }
-    dma_old_rows(0, s_old);  // the policy group's old history rows, behind the state loads (the critic group's follow at the end)
+    dma_old_rows(a.obs_prev[0], s_old);  // the policy group's old history rows, behind the state loads (the critic group's follow at the end)
   }
 #ifdef LT_STAMPS
   unsigned long long pro_a_, pro_b_;
@@ -604,8 +623,22 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       src[i] = tabc.src[cc];    // >= 0: old column (one slot newer); < 0: newest frame element -src-1
       frm[i] = tabc.frame[cc];  // newest-frame element of this column's term (rows that were just reset)
     }
-    float* const rows = a.obs_next[g] + (long long)blockIdx.x * 16 * OBS;
-    const float* const old = s_old + g * 16 * OBS;
+    float* const rows = (g ? a.obs_next[1] : a.obs_next[0]) + (long long)blockIdx.x * 16 * OBS * EB / 4;
+    const float* const old = s_old + g * (16 * OBS * EB / 4);
+    // bf16 rows: routing of this lane's column pairs (both halves), the rows as 32-bit words, the staged old rows as 16-bit elements
+    constexpr int NPR = RB ? NPC : 1;  // (no registers, no scratch in the f32 instantiation)
+    int psrc[NPR][2], pfrm[NPR][2];
+    if constexpr (RB) {
+#pragma unroll
+      for (int i = 0; i < NPR; ++i) {
+        const int pr = i * 64 + lane, c0 = 2 * (pr < OBS / 2 ? pr : OBS / 2 - 1);
+        const ObsTable& tabc = HAS_OBJ ? k_obs_tab_teacher : k_obs_tab_loco;
+        psrc[i][0] = tabc.src[c0]; psrc[i][1] = tabc.src[c0 + 1];
+        pfrm[i][0] = tabc.frame[c0]; pfrm[i][1] = tabc.frame[c0 + 1];
+      }
+    }
+    unsigned* const rows32 = (unsigned*)rows;
+    const unsigned short* const old16 = (const unsigned short*)old;
     // ---- physics helpers: as many (A, B) barrier pairs as wave 0 runs substeps ----
     {
       const int nsub = c.decimation * c.phys_substeps;
@@ -638,19 +671,12 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
         // each wave-instruction moves 64 lanes x 16 B = 1 KiB, lane-linear in LDS, no VGPRs - NOW, so that it lands beside the
         // physics (the physics barriers wait for LDS traffic only; B0, a full barrier, is behind us).
         // (the routing tables were read before: their loads must not queue behind the DMA - vmcnt retires in order)
-        constexpr int CHUNK16 = 16 * OBS / 4;  // float4 count per group (OBS*16 is a multiple of 4 for both tasks)
-        const float* gsrc = a.obs_prev[g] + (long long)blockIdx.x * 16 * OBS;
-        for (int i = 0; i < (CHUNK16 + 63) / 64; ++i) {
-          const int v = i * 64 + lane;
-          if (v < CHUNK16)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + v * 4),
-                                             (__attribute__((address_space(3))) void*)(s_old + g * 16 * OBS + i * 256), 16, 0, 0);
-        }
+        dma_old_rows(g ? a.obs_prev[1] : a.obs_prev[0], s_old + g * (16 * OBS * EB / 4));
       }
       // wave 3: the observation-noise uniforms of this step (Philox is ~1 k cycles per call).  Per lane: joint-pos and joint-vel noise of
       // its leg, object-noise block `leg`, base-noise block (legs 2, 3 -> RS_NOISE_BASE, + 1).  Same streams and keys as the
       // inline form: bit-identical draws.  Block i -> rows 4 i .. 4 i + 3 of s_mb_rng.
-      auto noise_draw = [&](int i) {
+      auto noise_draw = [&](int i) __attribute__((always_inline)) {
         const uint32_t stream = i == 0 ? RS_NOISE_JPOS + leg : (i == 1 ? RS_NOISE_JVEL + leg : (i == 2 ? RS_NOISE_OBJ + leg : RS_NOISE_BASE + (leg == 3 ? 1 : 0)));
         const U4 u = rng4(c.seed, ekey, step, stream);
         s_mb_rng[4 * i + 0][lane] = u.a; s_mb_rng[4 * i + 1][lane] = u.b; s_mb_rng[4 * i + 2][lane] = u.c; s_mb_rng[4 * i + 3][lane] = u.d;
@@ -752,10 +778,19 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
           if (it == 0) __builtin_amdgcn_s_waitcnt(0x0070);
           const int r0 = (16 * it) / nsub, r1 = (16 * (it + 1)) / nsub;
           for (int r = r0; r < r1; ++r) {
+            if constexpr (RB) {  // pairs whose two columns both come from the old row; a pair that takes a newest-frame column goes out behind B1
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-              const int col = i * 64 + lane;
-              if (col < OBS && src[i] >= 0) st_out(&rows[r * OBS + col], old[r * OBS + src[i]]);
+              for (int i = 0; i < NPR; ++i) {
+                const int pr = i * 64 + lane;
+                if (pr < OBS / 2 && psrc[i][0] >= 0 && psrc[i][1] >= 0)
+                  st_out(&rows32[r * (OBS / 2) + pr], (unsigned)old16[r * OBS + psrc[i][0]] | ((unsigned)old16[r * OBS + psrc[i][1]] << 16));
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < NCH; ++i) {
+                const int col = i * 64 + lane;
+                if (col < OBS && src[i] >= 0) st_out(&rows[r * OBS + col], old[r * OBS + src[i]]);
+              }
             }
           }
         }
@@ -818,6 +853,32 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     unsigned fills = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) fills |= (s_fill[r] != 0 ? 1u : 0u) << r;  // first push after a reset fills all 6 slots
+    if constexpr (RB) {
+      // the newest frame of this group -> bf16 bit patterns, once (in place; only this wave reads the group's frame from here on)
+      for (int idx = lane; idx < 16 * 64; idx += 64) s_frame[g][idx >> 6][idx & 63] = __uint_as_float(bf16_rne(s_frame[g][idx >> 6][idx & 63]));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < NPR; ++i) {
+        const int pr = i * 64 + lane;
+        if (pr < OBS / 2 && (psrc[i][0] < 0 || psrc[i][1] < 0)) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned lo16 = psrc[i][0] >= 0 ? (unsigned)old16[r * OBS + psrc[i][0]] : __float_as_uint(s_frame[g][r][(-psrc[i][0] - 1) & 63]);
+            const unsigned hi16 = psrc[i][1] >= 0 ? (unsigned)old16[r * OBS + psrc[i][1]] : __float_as_uint(s_frame[g][r][(-psrc[i][1] - 1) & 63]);
+            st_out(&rows32[r * (OBS / 2) + pr], lo16 | (hi16 << 16));
+          }
+        }
+      }
+      while (fills) {
+        const int r = __builtin_ctz(fills);
+        fills &= fills - 1;
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) {
+          const int pr = i * 64 + lane;
+          if (pr < OBS / 2) st_out(&rows32[r * (OBS / 2) + pr], __float_as_uint(s_frame[g][r][pfrm[i][0] & 63]) | (__float_as_uint(s_frame[g][r][pfrm[i][1] & 63]) << 16));
+        }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int col = i * 64 + lane;
@@ -835,6 +896,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
         const int col = i * 64 + lane;
         if (col < OBS && src[i] >= 0) st_out(&rows[r * OBS + col], s_frame[g][r][frm[i] & 63]);
       }
+    }
     }
 #ifdef LT_STAMPS
     LT_STAMP(1);
@@ -1389,12 +1451,44 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     for (int g = 0; g < 2; ++g) {
       if (g == 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the policy rows are done
-        dma_old_rows(1, s_old);
+        dma_old_rows(a.obs_prev[1], s_old);
       }
       // vmcnt(0) as the BUILTIN (0x0F70 = vmcnt 0, expcnt / lgkmcnt untouched): the waitcnt pass then knows the DMA has landed; behind
       // an opaque asm wait it re-waits vmcnt(0) - i.e. for every store of the loop below - before each LDS read of the staged rows
       __builtin_amdgcn_s_waitcnt(0x0F70);
-      float* const rows = a.obs_next[g] + (long long)blockIdx.x * 16 * OBS;
+      float* const rows = (g ? a.obs_next[1] : a.obs_next[0]) + (long long)blockIdx.x * 16 * OBS * EB / 4;
+      if constexpr (RB) {  // bf16 rows: one 32-bit word per column pair, old halves carried bit for bit, newest-frame halves rounded here
+        unsigned* const rows32 = (unsigned*)rows;
+        const unsigned short* const old16 = (const unsigned short*)s_old;
+        // the newest frame of this group -> bf16 bit patterns, once (in place)
+        for (int idx = lane; idx < 16 * 64; idx += 64) s_frame[g][idx >> 6][idx & 63] = __uint_as_float(bf16_rne(s_frame[g][idx >> 6][idx & 63]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int psrc[NPC][2], pfrm[NPC][2];
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+          const int pr = i * 64 + lane, c0 = 2 * (pr < OBS / 2 ? pr : OBS / 2 - 1);
+          psrc[i][0] = s_tab[0][c0]; psrc[i][1] = s_tab[0][c0 + 1];
+          pfrm[i][0] = s_tab[0][352 + c0]; pfrm[i][1] = s_tab[0][352 + c0 + 1];
+        }
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+          const bool fill = s_fill[r] != 0;
+#pragma unroll
+          for (int i = 0; i < NPC; ++i) {
+            const int pr = i * 64 + lane;
+            unsigned w[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              const int fi = (fill ? pfrm[i][hf] : (-psrc[i][hf] - 1)) & 63;
+              const int si = psrc[i][hf] >= 0 ? psrc[i][hf] : 0;
+              const unsigned nv = __float_as_uint(s_frame[g][r][fi]), ov = old16[r * OBS + si];
+              w[hf] = (fill || psrc[i][hf] < 0) ? nv : ov;
+            }
+            if (pr < OBS / 2) st_out(&rows32[r * (OBS / 2) + pr], w[0] | (w[1] << 16));
+          }
+        }
+        continue;
+      }
 #pragma unroll 4
       for (int r = 0; r < 16; ++r) {
         const bool fill = s_fill[r] != 0;  // first push after a reset fills all 6 slots
@@ -1584,7 +1678,18 @@ int launch_step(const lt_env* env, const float* actions, hipStream_t s, const fl
       env->pending_steps = 0; env->gate_pending = 0; k.step_offset = 0;
     }
   }
-  if (env->cfg.task == LT_TASK_LOCOMOTION) {
+  // bf16 rows (lt_env_set_row_format): only where the caller hands over both row pointers of both groups (rollout-storage slots)
+  const bool rb = MODE == MODE_STEP && env->rows_bf16 && prev && next && prev[0] && prev[1] && next[0] && next[1];
+  if (MODE == MODE_STEP && env->rows_bf16 && !rb) return (int)hipErrorInvalidValue;
+  if (rb && env->cfg.task == LT_TASK_LOCOMOTION) {
+    if (helpers) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE_STEP, true, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE_STEP, false, true>), grid, dim3(64), 0, s, k);
+  } else if (rb && !env->cfg.tactile_enabled) {
+    if (helpers) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE_STEP, true, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_TRANSPORT_TEACHER, MODE_STEP, false, true>), grid, dim3(64), 0, s, k);
+  } else if (rb) {
+    return (int)hipErrorInvalidValue;  // (tactile tasks keep f32 rows)
+  } else if (env->cfg.task == LT_TASK_LOCOMOTION) {
     if (helpers) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, MODE == MODE_STEP>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE, false>), grid, dim3(64), 0, s, k);
   } else if (env->cfg.tactile_enabled) {
@@ -1639,7 +1744,7 @@ int lt_launch_step_rows(const lt_env* env, const float* actions, const float* co
   return launch_step<MODE_STEP>(env, actions, (hipStream_t)stream, prev, next, st_rewards ? &rec : nullptr);
 }
 
-int lt_launch_step_profiled(lt_env* env, const float* actions, void* stream, float* ms) {
+int lt_launch_step_profiled(lt_env* env, const float* actions, const float* const* prev, float* const* next, void* stream, float* ms) {
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
   if (!env->ev_start) {
@@ -1649,7 +1754,7 @@ int lt_launch_step_profiled(lt_env* env, const float* actions, void* stream, flo
     env->ev_start = a; env->ev_stop = b;
   }
   if ((e = hipEventRecord((hipEvent_t)env->ev_start, s)) != hipSuccess) return (int)e;
-  int rc = launch_step<MODE_STEP>(env, actions, s, nullptr, nullptr, nullptr, false);  // the events bracket lt_step_kernel alone
+  int rc = launch_step<MODE_STEP>(env, actions, s, prev, next, nullptr, false);  // the events bracket lt_step_kernel alone
   if (rc != 0) return rc;
   if ((e = hipEventRecord((hipEvent_t)env->ev_stop, s)) != hipSuccess) return (int)e;
   if (!env->defer_gate && (rc = lt_launch_gate_decide(env, -1, s)) != 0) return rc;

@@ -207,6 +207,13 @@ int lt_env_defer_gate(lt_env* env, int mode) {
   return LT_OK;
 }
 
+int lt_env_set_row_format(lt_env* env, int format) {
+  if (!env || (format != LT_ROWS_F32 && format != LT_ROWS_BF16)) return LT_EINVAL;
+  if (format == LT_ROWS_BF16 && env->cfg.tactile_enabled) { lt_set_error("lt_env_set_row_format: the tactile tasks keep f32 rows"); return LT_EINVAL; }
+  env->rows_bf16 = format == LT_ROWS_BF16;
+  return LT_OK;
+}
+
 int lt_env_check(lt_env* env, void* stream) {
   if (!env) return LT_EINVAL;
   if (!env->arena) { lt_set_error("lt_env_check: arena not bound"); return LT_EFAULT; }
@@ -231,7 +238,16 @@ int lt_env_gate_update(lt_env* env, void* stream) {
 int lt_env_step_profiled(lt_env* env, const float* actions, void* stream, float* step_kernel_ms) {
   if (!env || !actions || !step_kernel_ms) return LT_EINVAL;
   if (!env->arena) { lt_set_error("lt_env_step_profiled: arena not bound"); return LT_EFAULT; }
-  return finish(lt_launch_step_profiled(env, actions, stream, step_kernel_ms), "lt_env_step_profiled");
+  return finish(lt_launch_step_profiled(env, actions, nullptr, nullptr, stream, step_kernel_ms), "lt_env_step_profiled");
+}
+
+int lt_env_step_rows_profiled(lt_env* env, const float* actions, const float* prev_policy, const float* prev_critic, float* next_policy,
+                              float* next_critic, void* stream, float* step_kernel_ms) {
+  if (!env || !actions || !step_kernel_ms) return LT_EINVAL;
+  if (!env->arena) { lt_set_error("lt_env_step_rows_profiled: arena not bound"); return LT_EFAULT; }
+  const float* prev[2] = {prev_policy, prev_critic};
+  float* next[2] = {next_policy, next_critic};
+  return finish(lt_launch_step_profiled(env, actions, prev, next, stream, step_kernel_ms), "lt_env_step_rows_profiled");
 }
 
 int lt_env_eval_terms(lt_env* env, void* stream) {

@@ -17,6 +17,7 @@ struct lt_env {
   int defer_gate = 0;        // lt_env_defer_gate mode: 0 pass behind every step, 1 the caller's lt_env_gate_update, 2 chained (next step launch)
   mutable int pending_steps = 0;  // steps launched whose common_step_counter bump is outstanding (modes 1, 2)
   mutable int gate_pending = 0;   // a population pass is outstanding
+  int rows_bf16 = 0;         // lt_env_set_row_format: the row pointers of lt_env_step_rows / _rollout are bf16 rows
   mutable int test_chain_skew = 0;  // lt_env_defer_gate mode 3 (test hook): the next chained launch announces a wrong step id
 };
 
@@ -27,7 +28,7 @@ int lt_launch_reset_all(const lt_env* env, void* stream);
 int lt_launch_step(const lt_env* env, const float* actions, void* stream);
 int lt_launch_step_rows(const lt_env* env, const float* actions, const float* const prev[2], float* const next[2], const float* values,
                         float gamma, float* st_rewards, unsigned char* st_dones, void* stream);
-int lt_launch_step_profiled(lt_env* env, const float* actions, void* stream, float* ms);
+int lt_launch_step_profiled(lt_env* env, const float* actions, const float* const* prev, float* const* next, void* stream, float* ms);
 int lt_launch_eval_terms(const lt_env* env, void* stream);
 void lt_release_events(lt_env* env);
 int lt_launch_curriculum(const lt_env* env, const float* records, void* stream);

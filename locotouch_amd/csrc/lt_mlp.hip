@@ -82,6 +82,7 @@ struct MlpArgs {
   int L;
   int dims[LT_MLP_MAX_LAYERS + 1];
   int activation;
+  int x_bf16;                 // the input rows are bf16 (uint16 [m][dims[0]])
   int mode;
   int stride;                 // LDS row stride in floats (== 4 mod 64: the 16 rows of a ds_read_b128 phase fall on distinct banks)
   int bias_total;             // floats of the bias block (sum of pad16(N_l))
@@ -122,6 +123,16 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi
     hi[i] = h;
     lo[i] = (_Float16)((x - (float)h) * LO_SCALE);
   }
+}
+
+// four consecutive input elements starting at element `off` of the input rows: f32, or bf16 widened exactly (read-once: nontemporal)
+__device__ __forceinline__ f32x4 load_in4(const MlpArgs& a, long long off) {
+  if (a.x_bf16) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 w = __builtin_nontemporal_load((const u32x2*)((const unsigned short*)a.x + off));
+    return f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xFFFF0000u)};
+  }
+  return __builtin_nontemporal_load((const f32x4*)(a.x + off));
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the weight
@@ -343,13 +354,29 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
   const int kv = K0p >> 2, k4 = K0 >> 2, total = ROWS * kv;
   f32x4 vin[B];
   if (vec_in) {
+    if (a.x_bf16) {  // (the format test outside the unrolled batch: one scalar branch, two straight-line load sequences)
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int u = 0; u < B; ++u) {
-      const int idx = tid + u * 64 * NW;
-      const int rr = idx / kv, cc = idx - rr * kv;
-      const long long e = row0 + rr;
-      vin[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (idx < total && cc < k4 && e < a.m) vin[u] = __builtin_nontemporal_load((const f32x4*)(a.x + e * K0 + 4 * cc));
+      for (int u = 0; u < B; ++u) {
+        const int idx = tid + u * 64 * NW;
+        const int rr = idx / kv, cc = idx - rr * kv;
+        const long long e = row0 + rr;
+        vin[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (idx < total && cc < k4 && e < a.m) {
+          // raw bits now, widened when they go to LDS: a conversion here would wait for the row load before the weight ring is requested
+          const u32x2 w = __builtin_nontemporal_load((const u32x2*)((const unsigned short*)a.x + e * K0 + 4 * cc));
+          vin[u] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), 0.f, 0.f};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        const int idx = tid + u * 64 * NW;
+        const int rr = idx / kv, cc = idx - rr * kv;
+        const long long e = row0 + rr;
+        vin[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (idx < total && cc < k4 && e < a.m) vin[u] = __builtin_nontemporal_load((const f32x4*)(a.x + e * K0 + 4 * cc));
+      }
     }
   }
   // weight stream: a full ring in flight.  Two row tiles need 128 accumulator registers per lane: a 16-slot ring then
@@ -369,20 +396,27 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
       for (int u = 0; u < B; ++u) {
         const int idx = tid + u * 64 * NW;
         const int rr = idx / kv, cc = idx - rr * kv;
-        if (idx < total) *(f32x4*)(s_act + rr * S + 4 * cc) = vin[u];
+        if (idx < total) {
+          f32x4 v = vin[u];
+          if (a.x_bf16) {
+            const unsigned w0 = __float_as_uint(v[0]), w1 = __float_as_uint(v[1]);
+            v = f32x4{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xFFFF0000u), __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xFFFF0000u)};
+          }
+          *(f32x4*)(s_act + rr * S + 4 * cc) = v;
+        }
       }
       for (int base = tid + B * 64 * NW; base < total; base += 64 * NW) {  // inputs wider than one batch
         const int rr = base / kv, cc = base - rr * kv;
         const long long e = row0 + rr;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (cc < k4 && e < a.m) v = __builtin_nontemporal_load((const f32x4*)(a.x + e * K0 + 4 * cc));
+        if (cc < k4 && e < a.m) v = load_in4(a, e * K0 + 4 * cc);
         *(f32x4*)(s_act + rr * S + 4 * cc) = v;
       }
     } else {
       for (int idx = tid; idx < ROWS * K0p; idx += 64 * NW) {
         const int rr = idx / K0p, cc = idx - rr * K0p;
         const long long e = row0 + rr;
-        s_act[rr * S + cc] = (cc < K0 && e < a.m) ? a.x[e * K0 + cc] : 0.f;
+        s_act[rr * S + cc] = (cc < K0 && e < a.m) ? (a.x_bf16 ? __uint_as_float((unsigned)((const unsigned short*)a.x)[e * K0 + cc] << 16) : a.x[e * K0 + cc]) : 0.f;
       }
     }
   }
@@ -452,6 +486,7 @@ __global__ void lt_mlp_pack_kernel(const PackAll all) {
 
 bool desc_ok(const lt_mlp_desc* d) {
   if (!d || d->num_layers < 1 || d->num_layers > LT_MLP_MAX_LAYERS) return false;
+  if (d->input_format != LT_ROWS_F32 && !(d->input_format == LT_ROWS_BF16 && (d->dims[0] & 3) == 0)) return false;
   if (d->activation < LT_ACT_NONE || d->activation > LT_ACT_TANH) return false;
   for (int l = 0; l <= d->num_layers; ++l)
     if (d->dims[l] < 1 || d->dims[l] > LT_MLP_MAX_WIDTH) return false;
@@ -490,6 +525,7 @@ Geometry geometry(const lt_mlp_desc* d) {
 void fill_args(const lt_mlp_desc* d, MlpArgs& a) {
   a.L = d->num_layers;
   a.activation = d->activation;
+  a.x_bf16 = d->input_format == LT_ROWS_BF16;
   int widest = 0;
   for (int l = 0; l <= d->num_layers; ++l) {
     a.dims[l] = d->dims[l];

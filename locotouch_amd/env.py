@@ -204,6 +204,14 @@ class LocoTouchVecEnv:
         """The outstanding population pass, if any (lt_env_gate_update)."""
         _abi.check(self._lib.lt_env_gate_update(self._handle, self._stream()), "lt_env_gate_update")
 
+    def set_row_format(self, dtype) -> None:
+        """Element format of the rows behind step_rows_raw / step_rollout_raw pointers: torch.float32 or torch.bfloat16
+        (lt_env_set_row_format; the arena's own rows stay f32)."""
+        import torch
+
+        fmt = {torch.float32: _abi.CONSTS["LT_ROWS_F32"], torch.bfloat16: _abi.CONSTS["LT_ROWS_BF16"]}[dtype]
+        _abi.check(self._lib.lt_env_set_row_format(self._handle, fmt), "lt_env_set_row_format")
+
     def check(self) -> None:
         """Raise if a chained step launch lost its population-pass announcement (lt_env_check; waits for the stream)."""
         _abi.check(self._lib.lt_env_check(self._handle, self._stream()), "lt_env_check")
@@ -217,6 +225,15 @@ class LocoTouchVecEnv:
         ms = ctypes.c_float()
         _abi.check(self._lib.lt_env_step_profiled(self._handle, ctypes.c_void_p(actions.data_ptr()), self._stream(), ctypes.byref(ms)),
                    "lt_env_step_profiled")
+        return float(ms.value)
+
+    def step_rows_profiled(self, actions: torch.Tensor, prev_policy: torch.Tensor, prev_critic: torch.Tensor, next_policy: torch.Tensor,
+                           next_critic: torch.Tensor) -> float:
+        """lt_env_step_rows with HIP events around the step kernel (rows in the current row format); duration in ms."""
+        ms = ctypes.c_float()
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        _abi.check(self._lib.lt_env_step_rows_profiled(self._handle, p(actions), p(prev_policy), p(prev_critic), p(next_policy),
+                                                       p(next_critic), self._stream(), ctypes.byref(ms)), "lt_env_step_rows_profiled")
         return float(ms.value)
 
     def eval_terms(self) -> None:

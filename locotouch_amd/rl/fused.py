@@ -53,6 +53,18 @@ class FusedRollout:
 
             if describe(ac.actor) is not None and describe(ac.critic) is not None and env.num_actions == 12:
                 self.actor_mlp, self.critic_mlp = PackedMLP(ac.actor), PackedMLP(ac.critic)
+        # bf16 observation rows (BASELINE config 5): the storage slots hold bf16 rows; the env kernel reads slot t and writes slot
+        # t + 1 as bf16 (the newest frame rounded once, older frames carried bit for bit), the policy kernel widens them in LDS.
+        # The rows behind the LAST step go to two extra bf16 buffers and from there to the arena's f32 rows (exact).
+        self.obs_dtype = alg.storage.observations.dtype
+        self._tail_rows = None
+        if self.obs_dtype == torch.bfloat16:
+            if self.actor_mlp is None or not self.rows_in_storage:
+                raise ValueError("bf16 observation rows need the packed MLP path and num_envs % 16 == 0")
+            self.actor_mlp.set_input_format(torch.bfloat16)
+            self.critic_mlp.set_input_format(torch.bfloat16)
+            st = alg.storage
+            self._tail_rows = (torch.zeros_like(st.observations[0]), torch.zeros_like(st.privileged_observations[0]))
 
     @staticmethod
     def _p(t: torch.Tensor) -> ctypes.c_void_p:
@@ -70,7 +82,10 @@ class FusedRollout:
         env, st = self.env, self.alg.storage
         if not self.rows_in_storage:
             return env.obs_policy, env.obs_critic, 0, 0
-        nxt = (0, 0) if last else (st.observations[t + 1].data_ptr(), st.privileged_observations[t + 1].data_ptr())
+        if last and self._tail_rows is not None:
+            nxt = (self._tail_rows[0].data_ptr(), self._tail_rows[1].data_ptr())
+        else:
+            nxt = (0, 0) if last else (st.observations[t + 1].data_ptr(), st.privileged_observations[t + 1].data_ptr())
         return st.observations[t], st.privileged_observations[t], nxt[0], nxt[1]
 
     @property
@@ -153,6 +168,8 @@ class FusedRollout:
             chain = not env.tactile  # (the tactile kernel keys its draws by the step counter, which lags inside a chain)
             if chain:
                 env.defer_gate(2)
+            if self._tail_rows is not None:
+                env.set_row_format(torch.bfloat16)
             try:
                 for t in range(num_steps):
                     self.step(t, last=t == num_steps - 1)
@@ -160,3 +177,7 @@ class FusedRollout:
                 if chain:
                     env.gate_update()
                     env.defer_gate(0)
+                if self._tail_rows is not None:
+                    env.set_row_format(torch.float32)
+                    env.obs_policy.copy_(self._tail_rows[0])
+                    env.obs_critic.copy_(self._tail_rows[1])

@@ -83,9 +83,18 @@ class PackedMLP:
                 raise ValueError("Linear.weight must be contiguous")
         _abi.check(self.lib.lt_mlp_pack(ctypes.byref(self.desc), w, b, ctypes.c_void_p(self.packed.data_ptr()), self._stream()), "lt_mlp_pack")
 
+    def set_input_format(self, dtype: torch.dtype) -> None:
+        """float32 rows (default) or bfloat16 rows (BASELINE config 5: widened exactly to f32 inside the kernel)."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("input rows are float32 or bfloat16")
+        if dtype == torch.bfloat16 and self.in_features % 4:
+            raise ValueError("bfloat16 input rows need in_features % 4 == 0")
+        self.desc.input_format = _abi.CONSTS["LT_ROWS_BF16"] if dtype == torch.bfloat16 else _abi.CONSTS["LT_ROWS_F32"]
+        self.in_dtype = dtype
+
     def forward(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        if x.dim() != 2 or x.shape[1] != self.in_features or x.dtype != torch.float32 or not x.is_contiguous():
-            raise ValueError("x must be a contiguous float32 [m, in_features] tensor")
+        if x.dim() != 2 or x.shape[1] != self.in_features or x.dtype != getattr(self, "in_dtype", torch.float32) or not x.is_contiguous():
+            raise ValueError("x must be a contiguous [m, in_features] tensor of the input format")
         m = x.shape[0]
         if out is None:
             out = torch.empty(m, self.out_features, device=x.device, dtype=torch.float32)

@@ -17,9 +17,6 @@ from .dist import Dist
 from .modules import ActorCritic
 from .storage import RolloutStorage
 
-import os as _os
-_NO_FENCE = bool(_os.environ.get("LT_PPO_NO_FENCE"))  # diagnostic (tools/ppo_graph_probe.py)
-
 
 class PPO:
     def __init__(self, actor_critic: ActorCritic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998,
@@ -30,24 +27,10 @@ class PPO:
         self.dist = dist or Dist()
         self.actor_critic = actor_critic.to(device)
         on_gpu = torch.device(device).type == "cuda"
-        # Two optional forms of the update, both OFF by default (measured, tools/ppo_graph_probe.py, bench.py):
-        #  * `device_update`: no host syncs - the reference reads the KL on the host every minibatch step (ppo.py:273-281) and
-        #    three loss values with it; here the same learning-rate rule runs on a device scalar that a capturable Adam reads,
-        #    statistics are read once per update.  Equal results (tests/test_hip_ppo_graph.py) but the capturable / tensor-lr
-        #    Adam kernels cost more than the syncs they save: 60 ms per iteration against 53 ms.
-        self.device_update = on_gpu and bool(unused.get("device_update", False))
         self.fused_loss = on_gpu and bool(unused.get("fused_loss", True))  # csrc/lt_ppo.hip: the loss chain and its backward in one launch
         self.packed_forward = on_gpu and bool(unused.get("packed_forward", True))  # csrc/lt_mlp.hip: both networks' training forward in one launch
         self._pair = None
-        self._lr_t = None
-        #  * `graph_update`: that minibatch step captured once and replayed 20x per iteration from a hipGraph: 46 ms per
-        #    iteration, but on this stack (ROCm 7.0 PyTorch) back-to-back replays are not stream-ordered with each other and the
-        #    results depend on which hipBLASLt kernels ran eagerly in between - not trusted, kept for study.
-        self.graph_update = on_gpu and bool(unused.get("graph_update", False))
-        self.optimizer = torch.optim.Adam(self.actor_critic.parameters(), lr=learning_rate,
-                                          capturable=self.device_update or self.graph_update)
-        self._g = None
-        self._g_iterations_seen = 0
+        self.optimizer = torch.optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
         self.storage: RolloutStorage | None = None
         self.learning_rate = learning_rate
         self.schedule, self.desired_kl = schedule, desired_kl
@@ -61,7 +44,7 @@ class PPO:
         # clip_grad_norm_ + Adam.step() in two launches on flat buffers (rl/flat_adam.py); the tensors the module and the optimizer
         # hold become views of those buffers, checkpoints keep the reference's layout
         self._flat_adam = None
-        use_flat_adam = on_gpu and bool(unused.get("fused_adam", True)) and not (self.device_update or self.graph_update)
+        use_flat_adam = on_gpu and bool(unused.get("fused_adam", True))
         if self.dist.world_size > 1:
             if not use_flat_adam:
                 self._make_flat_grad_bucket()
@@ -87,9 +70,10 @@ class PPO:
             self.dist.broadcast_(t.data, src=0)
 
     # ---- rollout -----------------------------------------------------------------------------------
-    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape) -> None:
+    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape,
+                     obs_dtype: torch.dtype = torch.float32) -> None:
         self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape[0], critic_obs_shape[0],
-                                      action_shape[0], self.device)
+                                      action_shape[0], self.device, obs_dtype=obs_dtype)
 
     def test_mode(self) -> None:
         self.actor_critic.eval()
@@ -164,7 +148,10 @@ class PPO:
         pair = self._packed_pair()
         for idx in st.mini_batch_indices(self.num_mini_batches, self.num_learning_epochs):
             # both networks' forward in one launch of the MFMA MLP kernel where their shape allows (rl/mlp.py PackedPair)
-            mu, value = pair(obs[idx], cobs[idx]) if pair is not None else (ac.actor(obs[idx]), ac.critic(cobs[idx]))
+            o, co = obs[idx], cobs[idx]
+            if o.dtype != torch.float32:  # bf16 observation storage (BASELINE config 5): the update computes in f32
+                o, co = o.float(), co.float()
+            mu, value = pair(o, co) if pair is not None else (ac.actor(o), ac.critic(co))
             loss, surrogate_loss, value_loss, ent, kl_mean = fused_ppo_loss(
                 mu, ac.std, value, *small, self.clip_param, self.value_loss_coef, self.entropy_coef,
                 self.use_clipped_value_loss, idx=idx)
@@ -197,166 +184,8 @@ class PPO:
         for group in self.optimizer.param_groups:
             group["lr"] = self.learning_rate
 
-    # ---- hipGraph-replayed update -------------------------------------------------------------------
-    def _graph_ok(self) -> bool:
-        return (self.graph_update and self.dist.world_size == 1 and self.desired_kl is not None and self.schedule == "adaptive"
-                and self.storage is not None and self.storage.observations.is_cuda)
-
-    def _minibatch_step_on_device(self, flat, idx, lr_t, sums):
-        """The body of `update()`'s loop with the learning-rate rule on a device scalar (same thresholds and factors)."""
-        ac = self.actor_critic
-        eager = not torch.cuda.is_current_stream_capturing()
-        obs, cobs, actions, values_b, adv, returns, logp_b, mu_b, sigma_b = [x[idx] for x in flat]
-        if self.normalize_advantage_per_mini_batch:
-            with torch.no_grad():
-                adv = (adv - adv.mean()) / (adv.std() + 1e-8)
-        ac.update_distribution(obs)
-        log_prob = ac.get_actions_log_prob(actions)
-        value = ac.evaluate(cobs)
-        mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
-        with torch.no_grad():
-            kl = torch.sum(torch.log(sigma / sigma_b + 1.0e-5)
-                           + (torch.square(sigma_b) + torch.square(mu_b - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
-            kl_mean = torch.mean(kl)
-            if eager and self.dist.world_size > 1:
-                kl_mean = self.dist.all_reduce_mean_(kl_mean.clone())
-            down = torch.clamp_min(lr_t / 1.5, 1e-5)
-            up = torch.clamp_max(lr_t * 1.5, 1e-2)
-            lr_t.copy_(torch.where(kl_mean > self.desired_kl * 2.0, down,
-                                   torch.where((kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0), up, lr_t)))
-        ratio = torch.exp(log_prob - torch.squeeze(logp_b))
-        a = torch.squeeze(adv)
-        surrogate_loss = torch.max(-a * ratio, -a * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
-        if self.use_clipped_value_loss:
-            clipped = values_b + (value - values_b).clamp(-self.clip_param, self.clip_param)
-            value_loss = torch.max((value - returns).pow(2), (clipped - returns).pow(2)).mean()
-        else:
-            value_loss = (returns - value).pow(2).mean()
-        ent = entropy.mean()
-        loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * ent
-        if eager:
-            if self._flat_grad is not None:
-                self._flat_grad.zero_()
-            else:
-                self.optimizer.zero_grad()
-        loss.backward()
-        if eager and self._flat_grad is not None:
-            self.dist.all_reduce_mean_(self._flat_grad)  # RCCL all-reduce of the policy gradients over xGMI
-        nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm, foreach=True)
-        self.optimizer.step()
-        with torch.no_grad():
-            sums.add_(torch.stack([value_loss.detach(), surrogate_loss.detach(), ent.detach()]))
-
-    def _build_graph(self):
-        st = self.storage
-        adv = torch.empty_like(st.advantages)  # compute_returns REBINDS storage.advantages every iteration: replay from a copy
-        flat = [x.flatten(0, 1) for x in (st.observations, st.privileged_observations, st.actions, st.values, adv,
-                                          st.returns, st.actions_log_prob, st.mu, st.sigma)]
-        self._g_ptrs = [x.data_ptr() for x in (st.observations, st.privileged_observations, st.actions, st.values, st.returns,
-                                               st.actions_log_prob, st.mu, st.sigma)]
-        mb = (st.num_envs * st.num_steps) // self.num_mini_batches
-        dev = st.observations.device
-        idx = torch.zeros(mb, dtype=torch.int64, device=dev)
-        lr_t = torch.tensor(float(self.learning_rate), device=dev)
-        sums = torch.zeros(3, device=dev)
-        for g in self.optimizer.param_groups:
-            g["lr"] = lr_t
-        graph = torch.cuda.CUDAGraph()
-        self.optimizer.zero_grad(set_to_none=True)
-        from .linear import Linear
-
-        Linear.force_split_k = True  # the stock weight-gradient GEMM misbehaves under graph replay at some shapes (rl/linear.py)
-        try:
-            with torch.cuda.graph(graph, stream=self._g_stream):
-                self._minibatch_step_on_device(flat, idx, lr_t, sums)
-        finally:
-            Linear.force_split_k = False
-        return dict(graph=graph, idx=idx, lr=lr_t, sums=sums, mb=mb, storage=st, adv=adv)
-
-    def _graph_update(self):
-        g = self._g
-        st = self.storage
-        n = self.num_learning_epochs * self.num_mini_batches
-        perm = torch.randperm(self.num_mini_batches * g["mb"], device=st.observations.device)
-        assert self._g_ptrs == [x.data_ptr() for x in (st.observations, st.privileged_observations, st.actions, st.values, st.returns,
-                                                       st.actions_log_prob, st.mu, st.sigma)], "rollout storage was reallocated"
-        g["adv"].copy_(st.advantages)
-        g["sums"].zero_()
-        g["lr"].fill_(float(self.learning_rate))
-        for grp in self.optimizer.param_groups:  # (a checkpoint load puts a float back)
-            grp["lr"] = g["lr"]
-        for _ in range(self.num_learning_epochs):
-            for i in range(self.num_mini_batches):
-                g["idx"].copy_(perm[i * g["mb"]:(i + 1) * g["mb"]])
-                g["graph"].replay()
-                # Back-to-back replays of this graph are NOT serialised by the stream on this stack (ROCm 7.0 PyTorch): without
-                # a fence replay k+1 starts before replay k's tail has finished (tools/ppo_graph_probe.py: results diverge from the
-                # second replayed iteration on; with it they equal the eager update).  A captured backward has side branches,
-                # and a kernel between the launches does not order them - a host-side stream sync does (~30 us per step).
-                if not _NO_FENCE:
-                    torch.cuda.synchronize()
-        v, s_, e = (g["sums"] / n).tolist()  # the one host read of the update
-        self.learning_rate = float(g["lr"])
-        st.clear()
-        return v, s_, e, None, None
-
     def update(self):
-        if self._graph_ok():
-            if self._g is not None and self._g["storage"] is self.storage:
-                return self._graph_update()
-            self._g_iterations_seen += 1
-            if self._g_iterations_seen < 2:
-                # the first update runs eagerly and is the capture's warm-up - on a side stream, as capture will: autograd's
-                # AccumulateGrad nodes remember the stream they were created on
-                self._g_stream = torch.cuda.Stream()  # the SAME stream captures later (no AccumulateGrad stream mismatch)
-                self._g_stream.wait_stream(torch.cuda.current_stream())
-                from .linear import Linear
-
-                Linear.force_split_k = bool(_os.environ.get("LT_PPO_WARM_FORCE"))
-                with torch.cuda.stream(self._g_stream):
-                    out = self._eager_update()
-                Linear.force_split_k = False
-                torch.cuda.current_stream().wait_stream(self._g_stream)
-                return out
-            if self._g_iterations_seen >= 2:
-                try:
-                    self._g = self._build_graph()
-                    return self._graph_update()
-                except Exception as e:  # noqa: BLE001  (an optimisation: fall back loudly, keep training)
-                    print(f"[WARN] hipGraph capture of the PPO update failed ({type(e).__name__}: {e}); updating eagerly")
-                    self.graph_update, self._g = False, None
-                    torch.cuda.synchronize()
-                    for grp in self.optimizer.param_groups:
-                        grp["lr"] = self.learning_rate
-        if (self.device_update and self.desired_kl is not None and self.schedule == "adaptive" and self.storage.observations.is_cuda
-                and (self.dist.world_size == 1 or self.dist.backend == "nccl")):
-            return self._device_update()
         return self._eager_update()
-
-    def _device_update(self):
-        """`_eager_update` without host syncs: learning rate on the device, statistics read once."""
-        st = self.storage
-        dev = st.observations.device
-        if self._lr_t is None:
-            self._lr_t = torch.tensor(float(self.learning_rate), device=dev)
-        self._lr_t.fill_(float(self.learning_rate))
-        for grp in self.optimizer.param_groups:
-            grp["lr"] = self._lr_t
-        flat = [x.flatten(0, 1) for x in (st.observations, st.privileged_observations, st.actions, st.values, st.advantages,
-                                          st.returns, st.actions_log_prob, st.mu, st.sigma)]
-        mb = (st.num_envs * st.num_steps) // self.num_mini_batches
-        perm = torch.randperm(self.num_mini_batches * mb, device=dev)
-        sums = torch.zeros(3, device=dev)
-        for _ in range(self.num_learning_epochs):
-            for i in range(self.num_mini_batches):
-                self._minibatch_step_on_device(flat, perm[i * mb:(i + 1) * mb], self._lr_t, sums)
-        n = self.num_learning_epochs * self.num_mini_batches
-        v, s_, e = (sums / n).tolist()  # the one host read of the update
-        self.learning_rate = float(self._lr_t)
-        for grp in self.optimizer.param_groups:
-            grp["lr"] = self.learning_rate
-        st.clear()
-        return v, s_, e, None, None
 
     def _eager_update(self):
         ac = self.actor_critic

@@ -28,11 +28,14 @@ class Batch(NamedTuple):
 
 
 class RolloutStorage:
-    def __init__(self, num_envs: int, num_steps: int, obs_dim: int, critic_obs_dim: int, num_actions: int, device="cpu"):
+    def __init__(self, num_envs: int, num_steps: int, obs_dim: int, critic_obs_dim: int, num_actions: int, device="cpu",
+                 obs_dtype: torch.dtype = torch.float32):
+        """`obs_dtype`: torch.float32 (the reference's, rollout_storage.py:36-44) or torch.bfloat16 (BASELINE config 5: the env
+        kernel writes bf16 rows straight into the slots, the policy kernel reads them; the update widens its minibatches to f32)."""
         self.num_envs, self.num_steps, self.device = num_envs, num_steps, device
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, device=device, dtype=dtype)  # noqa: E731
-        self.observations = z(num_steps, num_envs, obs_dim)
-        self.privileged_observations = z(num_steps, num_envs, critic_obs_dim)
+        self.observations = z(num_steps, num_envs, obs_dim, dtype=obs_dtype)
+        self.privileged_observations = z(num_steps, num_envs, critic_obs_dim, dtype=obs_dtype)
         self.actions = z(num_steps, num_envs, num_actions)
         self.mu = z(num_steps, num_envs, num_actions)
         self.sigma = z(num_steps, num_envs, num_actions)
@@ -121,7 +124,10 @@ class RolloutStorage:
         for _ in range(num_epochs):
             for i in range(num_mini_batches):
                 idx = perm[i * mb:(i + 1) * mb]
-                yield Batch(*[x[idx] for x in flat])
+                b = [x[idx] for x in flat]
+                if b[0].dtype != torch.float32:  # bf16 observation storage: the update computes in f32
+                    b[0], b[1] = b[0].float(), b[1].float()
+                yield Batch(*b)
 
     def mini_batch_indices(self, num_mini_batches: int, num_epochs: int) -> Iterator[torch.Tensor]:
         """The row indices `mini_batches` gathers with (same single `randperm`, same order), for consumers that gather themselves

@@ -118,42 +118,6 @@ def test_update_with_fused_loss_equals_update_with_torch_ops():
         assert float((pa - pb).abs().mean()) < 3e-4
 
 
-def test_device_side_update_equals_host_side_update():
-    import torch
-
-    from locotouch_amd.rl import PPO, ActorCritic
-    from tests.rl_synth import N_ACT, N_OBS, POLICY_CFG, PPO_CFG
-
-    n, T = 512, 24
-    cfg = dict(PPO_CFG, num_learning_epochs=2, num_mini_batches=4)
-
-    def make(graph):
-        torch.manual_seed(0)
-        alg = PPO(ActorCritic(N_OBS, N_OBS, N_ACT, **POLICY_CFG), device="cuda:0", device_update=graph, fused_loss=False, **cfg)
-        alg.init_storage(n, T, [N_OBS], [N_OBS], [N_ACT])
-        return alg
-
-    def fill(alg, seed):
-        _fill(alg, seed, n, T)
-
-    a, b = make(True), make(False)
-    lrs = []
-    for it in range(4):
-        outs = []
-        for alg in (a, b):
-            fill(alg, 100 + it)
-            torch.manual_seed(7 + it)  # same minibatch permutation on both sides
-            outs.append(alg.update())
-        lrs.append((a.learning_rate, b.learning_rate))
-        for x, y in zip(outs[0][:3], outs[1][:3]):
-            assert abs(x - y) <= 2e-4 * max(1.0, abs(y)), (it, outs)
-        assert abs(a.learning_rate - b.learning_rate) <= 1e-9 + 1e-6 * b.learning_rate, lrs
-    assert a._lr_t is not None and b._lr_t is None, "side a must really have run the device-side path"
-    assert len({round(x, 9) for x, _ in lrs}) > 1, "the adaptive rule must have moved the learning rate"
-    for pa, pb in zip(a.actor_critic.parameters(), b.actor_critic.parameters()):
-        torch.testing.assert_close(pa, pb, rtol=5e-3, atol=5e-4)
-
-
 @pytest.mark.parametrize("m,n", [(24576, 512), (4100, 256), (5000, 128), (4096, 400), (4097, 4)])
 def test_linear_elu_node_matches_torch(m, n):
     """`MLPSequential`'s fused Linear -> ELU node (csrc/lt_ppo.hip lt_elu_backward_bias) against nn.Linear + nn.ELU."""
