@@ -35,8 +35,11 @@ if g("SQ_WAVE_CYCLES") and g("SQ_ACTIVE_INST_VALU"):
 if g("SQ_WAVE_CYCLES") and g("SQ_BUSY_CYCLES"):
     der["mean_waves_per_busy_sq_cycle"] = g("SQ_WAVE_CYCLES") / g("SQ_BUSY_CYCLES")
 d["derived"] = der
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{rnd}_sq_counters.json")
-data = json.load(open(path)) if os.path.exists(path) else {}
-data[key] = d
-json.dump(data, open(path, "w"), indent=1)
+if g("SQ_INSTS_VALU"):
+    d["valu_wave_insts_per_launch"] = g("SQ_INSTS_VALU")  # what bench.py's roofline.valu divides by the measured kernel time
+root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+for path in (os.path.join(root, f"{rnd}_sq_counters.json"), os.path.join(root, "sq_counters.json")):  # per round + the one bench.py reads
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data[key] = d
+    json.dump(data, open(path, "w"), indent=1)
 print(key, json.dumps(der))
