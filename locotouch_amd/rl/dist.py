@@ -72,6 +72,21 @@ class Dist:
             t.div_(self.world_size)
         return t
 
+    def all_reduce_mean_begin(self, t: torch.Tensor):
+        """Start `all_reduce_mean_` and return a handle for `all_reduce_mean_end` (RCCL: asynchronous - its latency hides under
+        whatever the caller enqueues before the end call; gloo rehearsal / one rank: done here)."""
+        if self.world_size > 1 and self.backend == "nccl":
+            return (t, td.all_reduce(t, op=td.ReduceOp.SUM, async_op=True))
+        self.all_reduce_mean_(t)
+        return (t, None)
+
+    def all_reduce_mean_end(self, handle) -> torch.Tensor:
+        t, work = handle
+        if work is not None:
+            work.wait()
+            t.div_(self.world_size)
+        return t
+
     def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1:
             self._collective(t, lambda x: td.all_reduce(x, op=td.ReduceOp.MAX))

@@ -155,10 +155,14 @@ class PPO:
             loss, surrogate_loss, value_loss, ent, kl_mean = fused_ppo_loss(
                 mu, ac.std, value, *small, self.clip_param, self.value_loss_coef, self.entropy_coef,
                 self.use_clipped_value_loss, idx=idx)
-            if adaptive:
-                self._apply_kl(kl_mean)
+            # the 1-float KL all-reduce starts here and its host read waits until the backward pass is enqueued: the collective's
+            # latency (and the host round trip of the learning-rate rule, ppo.py:273-281) hides under the backward GEMMs; the
+            # decision still precedes this step's optimizer update, as in the reference
+            kl_handle = self.dist.all_reduce_mean_begin(kl_mean.detach().clone()) if adaptive else None
             self._zero_grad()
             loss.backward()
+            if adaptive:
+                self._apply_kl(self.dist.all_reduce_mean_end(kl_handle), reduced=True)
             self._optim_step()
             stats = stats + torch.stack((value_loss, surrogate_loss, ent.detach()))
         n = self.num_learning_epochs * self.num_mini_batches
@@ -172,9 +176,9 @@ class PPO:
                            + (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
             self._apply_kl(torch.mean(kl))
 
-    def _apply_kl(self, kl_mean) -> None:
+    def _apply_kl(self, kl_mean, reduced: bool = False) -> None:
         with torch.inference_mode():
-            if self.dist.world_size > 1:
+            if self.dist.world_size > 1 and not reduced:
                 kl_mean = self.dist.all_reduce_mean_(kl_mean.clone())
             kl_mean = float(kl_mean)  # host decision, as in the reference (ppo.py:273-281)
         if kl_mean > self.desired_kl * 2.0:
