@@ -69,6 +69,13 @@ class LtCfg(ctypes.Structure):
         ctypes.memmove(ctypes.byref(new), ctypes.byref(self), ctypes.sizeof(self))
         return new
 
+    def to_dict(self) -> dict:
+        """Plain-Python form (scalars and nested lists) for params/env.{yaml,pkl}."""
+        def py(v):
+            return [py(x) for x in v] if hasattr(v, "__len__") else v
+
+        return {name: py(getattr(self, name)) for name, *_ in self._fields_ if not name.startswith("_")}
+
 
 class LtView(ctypes.Structure):
     _fields_ = [("ptr", ctypes.c_void_p), ("dtype", ctypes.c_int32), ("ndim", ctypes.c_int32),

@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m locotouch_amd.scripts.train --task ... (one rank per GPU)
 
 Flags follow the reference CLI (locotouch/scripts/cli_args.py:11-33, train.py:17-29); `--headless` / `--video` are accepted
-and ignored (there is no renderer).  Logs: logs/rsl_rl/<experiment>/<timestamp>/{progress.jsonl, model_<it>.pt, params/agent.yaml}.
+and ignored (there is no renderer).  Logs: logs/rsl_rl/<experiment>/<timestamp>/{progress.jsonl, model_<it>.pt, params/{env,agent}.{yaml,pkl}}.
 """
 from __future__ import annotations
 
@@ -14,6 +14,23 @@ import datetime
 import os
 
 import torch
+
+
+def dump_params(log_dir: str, env_cfg: dict, agent_cfg: dict) -> None:
+    """params/env.yaml, agent.yaml, env.pkl, agent.pkl (reference locotouch/scripts/train.py:150-153, isaaclab.utils.io.dump_yaml /
+    dump_pickle [DEP]).  The env config is the resolved lt_cfg the kernels run on, as a plain dict (the reference pickles its
+    cfg object; a dict loads without this package)."""
+    import pickle
+
+    import yaml
+
+    d = os.path.join(log_dir, "params")
+    os.makedirs(d, exist_ok=True)
+    for name, obj in (("env", env_cfg), ("agent", agent_cfg)):
+        with open(os.path.join(d, name + ".yaml"), "w") as f:
+            yaml.safe_dump(obj, f)
+        with open(os.path.join(d, name + ".pkl"), "wb") as f:
+            pickle.dump(obj, f)
 
 
 def main() -> None:
@@ -58,12 +75,8 @@ def main() -> None:
             os.path.join(args.log_root, cfg["experiment_name"]), args.load_run or ".*", args.checkpoint or "model_.*.pt")
         print(f"[INFO]: Loading model checkpoint from: {ckpt}")
         runner.load(ckpt)
-    if dist.is_main:
-        os.makedirs(os.path.join(log_dir, "params"), exist_ok=True)
-        import yaml
-
-        with open(os.path.join(log_dir, "params", "agent.yaml"), "w") as f:
-            yaml.safe_dump(cfg, f)
+    if dist.is_main:  # train.py:150-153 of the reference: params/{env,agent}.{yaml,pkl}
+        dump_params(log_dir, dict(env.cfg.to_dict(), gym_id=args.task), cfg)
     runner.learn(cfg["max_iterations"], init_at_random_ep_len=True)
     if dist.is_main and runner.history:
         last = runner.history[-1]

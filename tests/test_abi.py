@@ -158,3 +158,23 @@ def test_population_pass_placement_api():
     assert lib.lt_env_defer_gate(None, 0) == C["LT_EINVAL"]
     assert lib.lt_env_gate_update(h, None) == C["LT_EFAULT"] and b"not bound" in lib.lt_last_error()
     assert lib.lt_env_destroy(h) == 0
+
+
+def test_train_script_dumps_env_and_agent_params(tmp_path):
+    """params/{env,agent}.{yaml,pkl} (reference locotouch/scripts/train.py:150-153): the resolved lt_cfg and the agent cfg as dicts."""
+    import pickle
+
+    import yaml
+
+    from locotouch_amd import _abi as A
+    from locotouch_amd.agents import train_cfg
+    from locotouch_amd.scripts.train import dump_params
+
+    task = "Isaac-RandCylinderTransportTeacher-LocoTouch-v1"
+    cfg = A.preset_cfg(task, num_envs=128)
+    dump_params(str(tmp_path), dict(cfg.to_dict(), gym_id=task), train_cfg(task))
+    assert sorted(os.listdir(tmp_path / "params")) == ["agent.pkl", "agent.yaml", "env.pkl", "env.yaml"]
+    env = yaml.safe_load(open(tmp_path / "params" / "env.yaml"))
+    assert env["num_envs"] == 128 and env["gym_id"] == task and len(env["reward_weight"]) >= 25
+    assert pickle.load(open(tmp_path / "params" / "env.pkl", "rb")) == env
+    assert pickle.load(open(tmp_path / "params" / "agent.pkl", "rb")) == yaml.safe_load(open(tmp_path / "params" / "agent.yaml"))
