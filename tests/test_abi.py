@@ -1,6 +1,7 @@
 """CPU-only checks of the C-ABI boundary: the library loads, exports every symbol include/lt_env.h declares,
 the ctypes mirror matches, and the Python layout mirror agrees with lt_env_get_view.  No compute calls."""
 import ctypes
+import os
 import re
 
 import numpy as np
