@@ -67,6 +67,8 @@ class LtCfg(ctypes.Structure):
     def copy(self) -> "LtCfg":
         new = LtCfg()
         ctypes.memmove(ctypes.byref(new), ctypes.byref(self), ctypes.sizeof(self))
+        if hasattr(self, "extra_reward_terms"):  # (compat/cfg_translate.py: user reward terms for the slow torch path)
+            new.extra_reward_terms = list(self.extra_reward_terms)
         return new
 
     def to_dict(self) -> dict:

@@ -101,7 +101,10 @@ TACTILE_FORMATS = {"BinaryTactileSignals": "LT_TACTILE_BINARY", "NormalizedTacti
                    "ProcessedTactileSignals": "LT_TACTILE_PROCESSED", "TactileSignals": "LT_TACTILE_ORIGINAL"}
 
 
-def translate(env_cfg, seed: int | None = None, omit_groups: tuple = ()) -> "_abi.LtCfg":
+def translate(env_cfg, seed: int | None = None, omit_groups: tuple = (), collect_unknown_rewards: bool = False) -> "_abi.LtCfg":
+    """`collect_unknown_rewards`: a reward term the fused kernels do not know is not an error - it is returned in
+    `cfg.extra_reward_terms` [(name, func, weight, params)] for the slow torch path (compat/scene_views.py: evaluated on
+    IsaacLab-layout views after every step and added to the kernel's reward)."""
     kind = task_kind(env_cfg)
     has_obj = kind != C["LT_TASK_LOCOMOTION"]
     cfg = _abi.default_cfg(kind, num_envs=int(env_cfg.scene.num_envs), seed=int(seed if seed is not None else (getattr(env_cfg, "seed", None) or 42)))
@@ -167,7 +170,12 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = ()) -> "_ab
     # ---- rewards (mdp/rewards.py; RewardManager: weight * dt, zero weight = skipped) ----
     rt = _terms(env_cfg.rewards)
     sigma = {}
+    extra_terms = []
     for name, term in rt.items():
+        if name not in _REWARDS and collect_unknown_rewards:
+            if float(term.weight) != 0.0:
+                extra_terms.append((name, term.func, float(term.weight), dict(term.params or {})))
+            continue
         _need(name in _REWARDS, f"reward term {name!r} has no fused implementation")
         enum, funcs = _REWARDS[name]
         w = float(term.weight)
@@ -395,6 +403,7 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = ()) -> "_ab
         cfg.cur_reward_threshold[1] = math.exp(-float(p["error_threshold_ang"]) / float(ang.params["sigma"])) * float(ang.weight) * cfg.episode_length_s  # :200
         cfg.cur_repeat_times[0], cfg.cur_repeat_times[1] = int(p["repeat_times_lin"]), int(p["repeat_times_ang"])
         cfg.cur_max_distance_bins = int(p["max_distance_bins"])
+    cfg.extra_reward_terms = extra_terms  # (a Python attribute beside the C struct: empty unless collect_unknown_rewards)
     return cfg
 
 

@@ -87,8 +87,39 @@ class ManagedEnv:
     """What `gym.make` returns: the HIP env behind the attribute surface the scripts and `RslRlVecEnvWrapper` touch
     (`unwrapped`, `cfg`, `num_envs`, `device`, `step_dt`, `max_episode_length`, `episode_length_buf`, `close`)."""
 
-    def __init__(self, task_id: str, cfg, vec_env):
+    def __init__(self, task_id: str, cfg, vec_env, extra_rewards=()):
         self.task_id, self.cfg, self.vec = task_id, cfg, vec_env
+        # reward terms the fused kernels do not know: evaluated in torch on IsaacLab-layout views after every step and added to
+        # the kernel's reward (compat/scene_views.py; the slow path of SURVEY.md §8(b) B3)
+        self.extra = None
+        if extra_rewards:
+            from .scene_views import ExtraTerms
+
+            self.extra = ExtraTerms(vec_env)
+            for name, func, weight, params in extra_rewards:
+                self.extra.add_reward(name, func, weight, params)
+
+    def add_reward_term(self, name: str, func, weight: float, params: dict | None = None) -> None:
+        """Attach a user reward term `func(env, **params) -> (N,)` (reference term signature, mdp/rewards.py:15-20)."""
+        if self.extra is None:
+            from .scene_views import ExtraTerms
+
+            self.extra = ExtraTerms(self.vec)
+        self.extra.add_reward(name, func, weight, params)
+
+    @property
+    def scene(self):
+        if self.extra is None:
+            from .scene_views import ExtraTerms
+
+            self.extra = ExtraTerms(self.vec)
+        return self.extra.env.scene
+
+    def step(self, actions):
+        obs, rew, dones, extras = self.vec.step(actions)
+        if self.extra:
+            rew = self.extra.apply(rew, dones)
+        return obs, rew, dones, extras
 
     @property
     def unwrapped(self):
@@ -118,7 +149,7 @@ def translate_env_cfg(task_id: str, cfg):
 
     if cfg is None:
         return _abi.preset_cfg(task_id), None
-    lt = cfg_translate.translate(cfg)
+    lt = cfg_translate.translate(cfg, collect_unknown_rewards=True)
     sizes = None
     spawn = getattr(getattr(cfg.scene, "object", None), "spawn", None)
     if spawn is not None and type(spawn).__name__ == "MultiAssetSpawnerCfg":
@@ -137,12 +168,14 @@ def translate_env_cfg(task_id: str, cfg):
 
 def make_env(task_id: str, cfg):
     if _env_factory is not None:
-        return ManagedEnv(task_id, cfg, _env_factory(task_id, cfg))
+        vec = _env_factory(task_id, cfg)
+        return ManagedEnv(task_id, cfg, vec, extra_rewards=getattr(getattr(vec, "cfg", None), "extra_reward_terms", ()))
     from ..env import LocoTouchVecEnv
 
     lt, sizes = translate_env_cfg(task_id, cfg)
     device = getattr(getattr(cfg, "sim", None), "device", None) or "cuda:0"
-    return ManagedEnv(task_id, cfg, LocoTouchVecEnv(task_id, device=device, cfg=lt, object_sizes=sizes))
+    return ManagedEnv(task_id, cfg, LocoTouchVecEnv(task_id, device=device, cfg=lt, object_sizes=sizes),
+                      extra_rewards=getattr(lt, "extra_reward_terms", ()))
 
 
 # ---------------------------------------------------------------------------------------------------------

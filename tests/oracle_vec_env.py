@@ -36,6 +36,11 @@ class OracleVecEnv:
     def _arr(self, name: str) -> np.ndarray:
         return self.layout.arr(self.o.arena, name)[: self.num_envs]
 
+    def field(self, name: str) -> torch.Tensor:
+        """Quad field as [N, Q, 4] (component c = q*4 + lane), like LocoTouchVecEnv.field (a copy: the host arena is quad-major)."""
+        v = self.layout.vec(self.o.arena, name)
+        return torch.from_numpy(v).reshape(self.num_envs, -1, 4)
+
     @property
     def unwrapped(self):
         return self
