@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
   for (int l = 0; l < a.L; ++l) {
     const int T = tiles_per_wave(pad16(a.dims[l + 1]) / 16);
     const bool last = l == a.L - 1;
-    if (T == 8) mlp_layer<8, RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);
+    if (NW <= 4 && T == 8) mlp_layer<(NW <= 4 ? 8 : 4), RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);  // (eight waves: at most 4 tiles each)
     else if (T == 4) mlp_layer<4, RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);
     else if (T == 2) mlp_layer<2, RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);
     else mlp_layer<1, RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);
