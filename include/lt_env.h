@@ -469,7 +469,8 @@ int lt_rollout_record(int64_t n, float gamma, const float* reward, const int64_t
                       float* st_rewards, uint8_t* st_dones, float* st_values, int64_t* bump_counter, void* stream);
 /* ---- fused fp32 MLP inference (actor / critic evaluation inside the rollout loop; reference
  * loco_rl/loco_rl/modules/actor_critic.py:113-131: self.actor(obs), self.critic(critic_obs) - Linear layers with one activation between).
- * One launch per network on the f32-input MFMA; weights are re-packed from the torch.nn.Linear layout once per policy update. ---- */
+ * One launch per network (or both) on the f16 MFMA with error-compensated operand splitting - three MFMAs per f32-equivalent MAC, csrc/lt_mlp.hip;
+ * weights are re-packed from the torch.nn.Linear layout once per policy update. ---- */
 #define LT_MLP_MAX_LAYERS 6
 #define LT_MLP_MAX_WIDTH 1008
 enum lt_activation { LT_ACT_NONE = 0, LT_ACT_ELU = 1, LT_ACT_RELU = 2, LT_ACT_TANH = 3 };

@@ -4,15 +4,16 @@
 //   action term -> 4 x (DC-motor PD -> ABA forward dynamics with implicit penalty contacts -> contact sensors)
 //   -> terminations -> 23 reward terms (incl. the adaptive symmetric-gait class) -> masked reset (events, RNG)
 //   -> command term -> interval pushes -> observation frame + 6-deep history -> outputs.
-// The velocity curriculum, the population gates and the step counter run at the kernel's tail (lt_post.h: per-wave partials,
-// the last-arriving wave decides) - one launch per env step, no host synchronisation, hipGraph-capturable.
+// The per-tile half of the velocity curriculum / population gate runs at the kernel's tail, the one-wave global half behind it or
+// chained into the next launch (lt_post.h) - no host synchronisation, hipGraph-capturable.
 //
-// Lane mapping: 4 lanes per env (lane&3 = leg FR/FL/RR/RL, each lane owns the hip-thigh-calf chain of its leg),
-// 16 envs per wave64, one wave per workgroup.  Tree-level coupling (floating base, carried cylinder) and all
-// per-env reductions go through DPP quad butterflies - no LDS, no barriers in the physics.  All persistent
-// state is SoA "quad arrays" float[N][4] (include/lt_layout.h), so every state access of a wave is one
-// coalesced 256-byte transaction.  The roofline that bounds the kernel is HBM: 6720 algorithmic bytes per
-// env-step; see DESIGN.md for the per-field breakdown.
+// Lane mapping: 4 lanes per env (lane&3 = leg FR/FL/RR/RL, each lane owns the hip-thigh-calf chain of its leg), 16 envs per wave64.
+// Tree-level coupling (floating base, carried cylinder) and all per-env reductions go through DPP quad butterflies.  Grids of at
+// most one 16-env tile per CU (4096 envs) run FOUR waves per tile - leg dynamics, CRBA + bias, carried cylinder, random numbers -
+// that meet at two LDS-only barriers per physics substep; larger grids run one wave per tile (template parameter HELPERS).
+// All persistent state is SoA "quad arrays" float[N][4] (include/lt_layout.h), so every state access of a wave is one coalesced
+// 256-byte transaction.  The roofline the kernel is REPORTED against is HBM (6720 algorithmic bytes per env-step);
+// what bounds it is VALU issue on one wave per SIMD - DESIGN.md §4 has both.
 //
 // Reference citations use paths relative to the reference repo (locotouch/...).
 #include <hip/hip_runtime.h>

@@ -40,6 +40,9 @@ class FusedRollout:
         self.env, self.alg, self.lib = env, alg, _abi.load()
         self.device = env.device
         self.actions = torch.zeros(env.num_envs, 12, device=self.device)
+        # Philox key of the policy noise: the kernels key the draws by the LOCAL row index, so rank r (env_index_offset = r * N) gets its
+        # own key - with the population's seed alone every rank would explore with the same noise on its env i (offset 0: the seed itself)
+        self._noise_seed = (int(env.cfg.seed) + 0x9E3779B97F4A7C15 * int(env.cfg.env_index_offset)) & 0xFFFFFFFFFFFFFFFF
         self.side = torch.cuda.Stream(device=self.device)
         # policy-noise RNG key: a copy of the env's common step counter (refreshed at every rollout start, advanced by
         # lt_rollout_record) so that lt_rollout_act never has to wait for the overlapped post kernel
@@ -100,7 +103,7 @@ class FusedRollout:
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _abi.check(self.lib.lt_rollout_policy_value(
             ctypes.byref(self.actor_mlp.desc), p(self.actor_mlp.packed), p(obs), ctypes.byref(self.critic_mlp.desc),
-            p(self.critic_mlp.packed), p(cobs), p(st.values[t]), env.num_envs, int(env.cfg.seed), p(self._act_counter), t,
+            p(self.critic_mlp.packed), p(cobs), p(st.values[t]), env.num_envs, self._noise_seed, p(self._act_counter), t,
             p(alg.actor_critic.std.data), p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), p(st.actions_log_prob[t]), p(self.actions), stream),
             "lt_rollout_policy_value")
 
@@ -117,7 +120,7 @@ class FusedRollout:
             st.privileged_observations[t].copy_(cobs)
         _abi.check(self.lib.lt_rollout_policy_value(
             ctypes.byref(self.actor_mlp.desc), p(self.actor_mlp.packed), p(obs), ctypes.byref(self.critic_mlp.desc),
-            p(self.critic_mlp.packed), p(cobs), p(st.values[t]), n, int(env.cfg.seed), p(self._act_counter), t, p(ac.std.data),
+            p(self.critic_mlp.packed), p(cobs), p(st.values[t]), n, self._noise_seed, p(self._act_counter), t, p(ac.std.data),
             p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), p(st.actions_log_prob[t]), p(self.actions), stream),
             "lt_rollout_policy_value")
         prev = (obs.data_ptr(), cobs.data_ptr()) if self.rows_in_storage else (0, 0)
@@ -136,7 +139,7 @@ class FusedRollout:
         obs, cobs, nxt_p, nxt_c = self._rows(t, last)
         mu = ac.actor(obs)
         rows = (null, null, null, null) if self.rows_in_storage else (p(obs), p(cobs), p(st.observations[t]), p(st.privileged_observations[t]))
-        _abi.check(self.lib.lt_rollout_act(n, env.num_obs, int(env.cfg.seed), p(self._act_counter), p(mu), p(ac.std.data), null,
+        _abi.check(self.lib.lt_rollout_act(n, env.num_obs, self._noise_seed, p(self._act_counter), p(mu), p(ac.std.data), null,
                                            *rows, p(st.actions[t]), p(st.mu[t]), p(st.sigma[t]), null,
                                            p(st.actions_log_prob[t]), p(self.actions), stream), "lt_rollout_act")
         self.side.wait_stream(main)

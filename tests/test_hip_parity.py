@@ -688,7 +688,7 @@ def test_training_loop_runs_and_checkpoints(tmp_path):
 @pytest.mark.parametrize("dims,act,m", [((348, 512, 256, 128, 12), "elu", 4096), ((348, 512, 256, 128, 1), "elu", 1000),
                                         ((45, 64, 64, 7), "relu", 37), ((270, 256, 128, 128, 12), "tanh", 50), ((33, 20), "elu", 16)])
 def test_fused_mlp_matches_torch(dims, act, m):
-    """lt_mlp_forward (f32-input MFMA, one launch) against the torch fp32 modules it replaces; tolerance 2e-5 * scale
+    """lt_mlp_forward (f16 MFMA with error-compensated operand splitting, one launch) against the torch fp32 modules it replaces; tolerance 2e-5 * scale
     (both are fp32 accumulations, only the summation order differs)."""
     import torch
     from locotouch_amd.rl.mlp import PackedMLP
