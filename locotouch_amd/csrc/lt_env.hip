@@ -457,7 +457,17 @@ struct HelperParts {
   static constexpr bool external = true;
   float (*in)[64]; float (*crba)[64]; float (*obj)[64];
   int lane;
-  unsigned long long* wait;  // LT_STAMPS builds: cycles spent in barriers A ([0]) and B ([1])
+  unsigned long long* wait;  // LT_STAMPS builds: cycles spent in barriers A ([0]) and B ([1]); [2] last mark, [3..10] phase sums
+  __device__ __forceinline__ void mark(int i) const {
+#ifdef LT_STAMPS
+    unsigned long long t_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+    if (i > 0) wait[3 + i] += t_ - wait[2];
+    wait[2] = t_;
+#else
+    (void)i;
+#endif
+  }
   __device__ __forceinline__ void publish(const float (&cq)[3], const float (&sq)[3], const float (&qd)[3], const Base& B) const {
     const float v[MB_IN] = {cq[0], cq[1], cq[2], sq[0], sq[1], sq[2], B.p.x, B.p.y, B.p.z, B.q.w, B.q.x, B.q.y, B.q.z,
                             B.u.x, B.u.y, B.u.z, B.w.x, B.w.y, B.w.z, qd[0], qd[1], qd[2]};
@@ -491,7 +501,7 @@ struct HelperParts {
 template <int TASK, int MODE, bool HELPERS, bool RB = false>
 __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES_LARGE) void lt_step_kernel(const KArgs a) {
 #ifdef LT_STAMPS
-  unsigned long long stamps_[8], bar_wait_[2] = {0, 0};
+  unsigned long long stamps_[8], bar_wait_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 8; ++i) stamps_[i] = 0;
 #endif
   LT_STAMP(0);
@@ -1558,6 +1568,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   if (lane == 0)
     for (int q = 0; q < 7; ++q) *F(LT_F_LAST_EPISODE_SUMS, q) = (float)(long long)(stamps_[q + 1] - stamps_[q]);
   if (lane == 0) { *F(LT_F_REWARD_TERMS, 0) = (float)(long long)bar_wait_[0]; *F(LT_F_REWARD_TERMS, 1) = (float)(long long)bar_wait_[1]; }
+  if (lane == 1) { for (int q = 0; q < 7; ++q) *F(LT_F_REWARD_TERMS, q) = (float)(long long)bar_wait_[4 + q]; }  // phase sums of the substeps (lane 1)
   if (lane == 0) { *F(LT_F_REWARD_TERMS, 4) = (float)(long long)(pro_a_ - stamps_[0]); *F(LT_F_REWARD_TERMS, 5) = (float)(long long)(pro_b_ - pro_a_); *F(LT_F_REWARD_TERMS, 6) = (float)(long long)(pro_c_ - pro_b_); }
   if (lane == 0) ((float*)(arena + L.quad_off[LT_F_REWARD_TERMS]) + 3 * L.npad * 4 + (long long)blockIdx.x * 64)[0] = (float)(long long)(stamps_[7] - stamps_[0]);
 #endif

@@ -58,15 +58,30 @@ constexpr int RING = 32;               // chunk granularity of the packed stream
 constexpr int NW = LT_MLP_WAVES;       // waves per workgroup (one per SIMD)
 constexpr unsigned RS_POLICY = 0x400;  // same Philox stream id as lt_rollout_act
 constexpr int MODE_FORWARD = 0, MODE_POLICY = 1;
-constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
-constexpr float F16_CLAMP = 60000.f;   // |x| beyond the f16 range saturates instead of turning into inf - inf
+#ifndef LT_MLP_ONE_ACC
+#define LT_MLP_ONE_ACC 0
+#endif
+// One accumulator per output tile (module header, "Arithmetic"): the low parts carry a 2^6 scale and so does the main
+// product's activation operand, so all three MFMAs sum into the same registers.  0: the two-accumulator form (2^11 scale).
+constexpr bool ONE_ACC = LT_MLP_ONE_ACC != 0;
+constexpr float LO_SCALE = ONE_ACC ? 64.f : 2048.f, LO_INV = 1.f / LO_SCALE;
+// |x| beyond the range saturates instead of turning into inf - inf (one accumulator: 64 x must stay an f16 number)
+constexpr float F16_CLAMP = ONE_ACC ? 1000.f : 60000.f;
 
 __host__ __device__ inline int pad16(int x) { return (x + 15) & ~15; }
 __host__ __device__ inline int pad32(int x) { return (x + 31) & ~31; }
-// Tiles per wave of a layer with `ntiles` 16-feature output tiles: the smallest of {1, 2, 4, 8} that covers ntiles with NW waves.
+// Tiles per wave of a layer with `ntiles` 16-feature output tiles: the smallest of {MIN_TILES, .., 8} that covers ntiles with
+// NW waves.  Not below MIN_TILES = 2: a narrow last layer (12 actions = one tile) then runs through the loop code the layer
+// before it has just pulled into the instruction cache, instead of through a one-tile instantiation fetched cold (the
+// second tile is zero weights; 8 KB more in one wave's stream).
+#ifndef LT_MLP_MIN_TILES
+#define LT_MLP_MIN_TILES 2
+#endif
+constexpr int MIN_TILES = LT_MLP_MIN_TILES;
 __host__ __device__ inline int tiles_per_wave(int ntiles) {
   const int per = (ntiles + NW - 1) / NW;
-  return per > 4 ? 8 : (per > 2 ? 4 : (per > 1 ? 2 : 1));
+  const int t = per > 4 ? 8 : (per > 2 ? 4 : (per > 1 ? 2 : 1));
+  return t < MIN_TILES ? MIN_TILES : t;
 }
 // chunks of one layer in the stream of an ACTIVE wave: one item of 2T chunks per 32-wide k-group, padded to whole ring rounds
 __host__ __device__ inline int layer_chunks(int K, int N) {
@@ -86,6 +101,8 @@ struct MlpArgs {
   int mode;
   int stride;                 // LDS row stride in floats (== 4 mod 64: the 16 rows of a ds_read_b128 phase fall on distinct banks)
   int bias_total;             // floats of the bias block (sum of pad16(N_l))
+  int noise_off;              // MODE_POLICY: float offset inside the LDS image of the [rows][16] block of N(0,1) draws (launch())
+  unsigned in_magic;          // dims[0] % 4 == 0: floor(2^32 / (dims[0] / 4)) + 1, the reciprocal the input staging divides by; else 0
   long long bias_chunk;       // chunk offset of the bias block inside `packed`
   long long wave_base[NW];    // chunk offset of each wave's stream inside `packed`
   const float* packed;
@@ -152,6 +169,9 @@ __device__ unsigned long long g_mlp_stamps[1024 * 8 * NW];
 // Tiles up to the next layer's k padding (32) are written even when they lie beyond N (zero weights and bias give
 // activation(0) = 0; an inactive wave writes plain zeros): the next layer multiplies those columns by zero weights, and
 // 0 x (stale LDS bits) could be 0 x NaN.
+// a finished accumulator pair -> the layer's pre-activation (without bias)
+__device__ __forceinline__ float acc_value(float main, float corr) { return ONE_ACC ? main * LO_INV : main + corr * LO_INV; }
+
 template <int KIND, int T, int RT>
 __device__ __forceinline__ void write_back(const f32x4 (&am)[RT][T], const f32x4 (&ac)[RT][T], bool active, float* s_act, const float* s_bias,
                                            int r, int q, int S, int tile0, int nwrite) {
@@ -165,7 +185,7 @@ __device__ __forceinline__ void write_back(const f32x4 (&am)[RT][T], const f32x4
       f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
       if (active) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = activate<KIND>(am[rt][t][i] + ac[rt][t][i] * LO_INV + bias[i]);
+        for (int i = 0; i < 4; ++i) o[i] = activate<KIND>(acc_value(am[rt][t][i], ac[rt][t][i]) + bias[i]);
       }
       *(f32x4*)(s_act + (r + 16 * rt) * S + n0) = o;
     }
@@ -175,13 +195,41 @@ __device__ __forceinline__ void write_back(const f32x4 (&am)[RT][T], const f32x4
   }
 }
 
+// Policy head, first half: the standard-normal draws of this workgroup's rows and the log-density of the sample
+// (Normal.log_prob summed over the 12 actions needs z and sigma only, not mu).  Wave 0 runs it in the prologue, between
+// requesting the weight ring and the arrival of the input rows - ~250 instructions that would otherwise sit, fetched cold,
+// behind the last layer where nothing overlaps them.  Lane (r, q) owns actions 4q..4q+3 of row r (q == 3: padding).
+template <int RT>
+__device__ __forceinline__ void policy_noise(const MlpArgs& a, long long row0, int lane, float* s_noise) {
+  const int r = lane & 15, q = lane >> 4;
+  if (q >= 3) return;
+  const unsigned long long step = (unsigned long long)(a.step_counter[0] + a.step_offset);
+  const float4 sg = *(const float4*)(a.std12 + 4 * q);
+  const float sgv[4] = {sg.x, sg.y, sg.z, sg.w};
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const long long e = row0 + 16 * rt + r;
+    const U4 u = rng4(a.seed, (unsigned)e, step, RS_POLICY + q);
+    const float ra = sqrtf(-2.f * __logf(1.f - u.a)), rb = sqrtf(-2.f * __logf(1.f - u.c));  // 1-u in (0,1]: never log(0)
+    float sa, ca, sb, cb;
+    __sincosf(6.28318530717958647692f * u.b, &sa, &ca);
+    __sincosf(6.28318530717958647692f * u.d, &sb, &cb);
+    const float z[4] = {ra * ca, ra * sa, rb * cb, rb * sb};
+    float lp = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lp += -(z[i] * z[i]) * 0.5f - __logf(sgv[i]) - 0.91893853320467274178f;  // Normal.log_prob
+    *(float4*)(s_noise + (16 * rt + r) * 16 + 4 * q) = make_float4(z[0], z[1], z[2], z[3]);
+    s_noise[(16 * rt + r) * 16 + 12 + q] = lp;
+  }
+}
+
 // One layer for this wave.  `ring` slot s holds chunk c0 + s of the wave's stream; the layer consumes its items in order
 // (item i = k-group i: T x (hi chunk, lo chunk)) and leaves the ring positioned on the next layer's first chunk.
 // RT row tiles (16 rows each) share every weight chunk: RT x the MFMA work per byte streamed from L2.
 // RG = ring slots (chunks in flight per wave): 32, or 16 where the accumulators need the registers (RG divides RING, so a
 // ring round never straddles a layer).
 template <int T, int RT, int RG>
-__device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, float* s_act, const float* s_bias, int wave, int lane,
+__device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, float* s_act, const float* s_bias, const float* s_noise, int wave, int lane,
                                           long long row_block, float4 (&ring)[RG], const float4* __restrict__ stream, long long& c0) {
   constexpr int C = 2 * T;      // chunks per item
   constexpr int R = RG / C;     // items per ring round
@@ -233,12 +281,22 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
             const f16x8 bh = xh[j & 1][rt], bl = xl[j & 1][rt];
+            if (ONE_ACC) {
+              const f16x8 bs = bh * (_Float16)LO_SCALE;  // exact: |x| <= F16_CLAMP
 #pragma unroll
-            for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bh, am[rt][t], 0, 0, 0);
+              for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bs, am[rt][t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < T; ++t) ac[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bl, ac[rt][t], 0, 0, 0);
+              for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bl, am[rt][t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < T; ++t) ac[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t + 1]), bh, ac[rt][t], 0, 0, 0);
+              for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t + 1]), bh, am[rt][t], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bh, am[rt][t], 0, 0, 0);
+#pragma unroll
+              for (int t = 0; t < T; ++t) ac[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bl, ac[rt][t], 0, 0, 0);
+#pragma unroll
+              for (int t = 0; t < T; ++t) ac[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t + 1]), bh, ac[rt][t], 0, 0, 0);
+            }
           }
         }
         // refill the slots just consumed (pad items included: the ring invariant must hold for the next layer)
@@ -274,7 +332,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
     for (int t = 0; t < T; ++t) {
       const f32x4 bias = active ? *(const f32x4*)(s_bias + 16 * (tile0 + t) + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) out[t][i] = active ? am[rt][t][i] + ac[rt][t][i] * LO_INV + bias[i] : 0.f;
+      for (int i = 0; i < 4; ++i) out[t][i] = active ? acc_value(am[rt][t][i], ac[rt][t][i]) + bias[i] : 0.f;
     }
     if (a.mode == MODE_FORWARD) {
       if (active && e < a.m) {
@@ -292,23 +350,12 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
       if (wave == 0) {
         float lp = 0.f;
         if (q < 3 && e < a.m) {
-          const unsigned long long step = (unsigned long long)(a.step_counter[0] + a.step_offset);
-          const U4 u = rng4(a.seed, (unsigned)e, step, RS_POLICY + q);
-          const float ra = sqrtf(-2.f * __logf(1.f - u.a)), rb = sqrtf(-2.f * __logf(1.f - u.c));  // 1-u in (0,1]: never log(0)
-          float sa, ca, sb, cb;
-          __sincosf(6.28318530717958647692f * u.b, &sa, &ca);
-          __sincosf(6.28318530717958647692f * u.d, &sb, &cb);
-          const float z[4] = {ra * ca, ra * sa, rb * cb, rb * sb};
+          // the N(0,1) draws and their log-density were made while the input rows were in flight (policy_noise)
+          const float4 zz = *(const float4*)(s_noise + (16 * rt + r) * 16 + 4 * q);
+          lp = s_noise[(16 * rt + r) * 16 + 12 + q];
           const float4 sg = *(const float4*)(a.std12 + 4 * q);
-          const float sgv[4] = {sg.x, sg.y, sg.z, sg.w};
-          float xv[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            xv[i] = out[0][i] + sgv[i] * z[i];
-            lp += -(z[i] * z[i]) * 0.5f - __logf(sgv[i]) - 0.91893853320467274178f;  // Normal.log_prob
-          }
           const long long o = e * 12 + 4 * q;
-          const float4 xo = make_float4(xv[0], xv[1], xv[2], xv[3]);
+          const float4 xo = make_float4(out[0][0] + sg.x * zz.x, out[0][1] + sg.y * zz.y, out[0][2] + sg.z * zz.z, out[0][3] + sg.w * zz.w);
           *(float4*)(a.st_actions + o) = xo;
           *(float4*)(a.actions_out + o) = xo;
           *(float4*)(a.st_mu + o) = make_float4(out[0][0], out[0][1], out[0][2], out[0][3]);
@@ -347,73 +394,86 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
   float* const s_bias = s_img + ROWS * S;
   // Input rows first: their loads enter the memory queue AHEAD of the weight ring (vmcnt retires in order - behind 128 KiB
   // of weight chunks the 45 KB of rows would arrive ~2 us later).  Read-once rows: nontemporal, so they do not push the
-  // weight stream out of the XCD's L2.  Pad columns and rows beyond m are zero.
+  // weight stream out of the XCD's L2.
+  // This prologue runs once per launch, i.e. at instruction-fetch speed (~14 cycles per instruction on cold caches): it is
+  // written for instruction COUNT.  Thread t takes float4 number t, t + 256, ... of the workgroup's ROWS x K0/4 real input
+  // (index -> (row, column) by a host-made reciprocal, no predicates: indices past the end re-read the last float4 and store
+  // it where it already is; rows beyond m re-read row m - 1 - rows never mix in the MFMA and those results are not stored);
+  // the k padding (columns K0 .. pad32(K0), zero weights) is zeroed separately - 0 x stale LDS bits could be 0 x NaN.
   const int K0 = a.dims[0], K0p = pad32(K0);
-  const bool vec_in = (K0 & 3) == 0;
+  const bool vec_in = a.in_magic != 0;  // K0 % 4 == 0 (fill_args)
   constexpr int B = 12;  // float4 in flight per thread: one batch covers a 348-wide input (11 per thread at two row tiles)
-  const int kv = K0p >> 2, k4 = K0 >> 2, total = ROWS * kv;
+  constexpr int NT = 64 * NW;
+  const int kv = K0p >> 2, k4 = K0 >> 2;
+  const unsigned tv = ROWS * k4;
+  const long long left = a.m - row0;
+  if (left <= 0) return;  // (launch() starts no such workgroup)
+  const unsigned rmax = left < ROWS ? (unsigned)left - 1u : ROWS - 1u;
   f32x4 vin[B];
+  unsigned lds_at[B];
   if (vec_in) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const char* const xb = (const char*)a.x + row0 * K0 * (a.x_bf16 ? 2 : 4);
     if (a.x_bf16) {  // (the format test outside the unrolled batch: one scalar branch, two straight-line load sequences)
-      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int u = 0; u < B; ++u) {
-        const int idx = tid + u * 64 * NW;
-        const int rr = idx / kv, cc = idx - rr * kv;
-        const long long e = row0 + rr;
-        vin[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (idx < total && cc < k4 && e < a.m) {
-          // raw bits now, widened when they go to LDS: a conversion here would wait for the row load before the weight ring is requested
-          const u32x2 w = __builtin_nontemporal_load((const u32x2*)((const unsigned short*)a.x + e * K0 + 4 * cc));
-          vin[u] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), 0.f, 0.f};
-        }
+        const unsigned idx = min((unsigned)tid + u * NT, tv - 1u);
+        const unsigned rr = __umulhi(idx, a.in_magic), cc = idx - rr * k4;
+        lds_at[u] = rr * S + 4 * cc;
+        // raw bits now, widened when they go to LDS: a conversion here would wait for the row load before the weight ring is requested
+        const u32x2 w = __builtin_nontemporal_load((const u32x2*)(xb + 2u * (min(rr, rmax) * K0 + 4 * cc)));
+        vin[u] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), 0.f, 0.f};
       }
     } else {
 #pragma unroll
       for (int u = 0; u < B; ++u) {
-        const int idx = tid + u * 64 * NW;
-        const int rr = idx / kv, cc = idx - rr * kv;
-        const long long e = row0 + rr;
-        vin[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (idx < total && cc < k4 && e < a.m) vin[u] = __builtin_nontemporal_load((const f32x4*)(a.x + e * K0 + 4 * cc));
+        const unsigned idx = min((unsigned)tid + u * NT, tv - 1u);
+        const unsigned rr = __umulhi(idx, a.in_magic), cc = idx - rr * k4;
+        lds_at[u] = rr * S + 4 * cc;
+        vin[u] = __builtin_nontemporal_load((const f32x4*)(xb + 4u * (min(rr, rmax) * K0 + 4 * cc)));
       }
     }
   }
+  // biases: requested before the weight ring as well (behind it they would wait for every chunk of it)
+  constexpr int BB = 4;
+  const float* const bsrc = a.packed + a.bias_chunk * 256;
+  float bv[BB];
+#pragma unroll
+  for (int u = 0; u < BB; ++u) bv[u] = bsrc[min(tid + u * NT, a.bias_total - 1)];
   // weight stream: a full ring in flight.  Two row tiles need 128 accumulator registers per lane: a 16-slot ring then
   // keeps the allocation clear of spills (a scratch reload in a layer epilogue would sit behind the whole ring in the queue).
-  constexpr int RG = RT >= 2 ? 16 : 32;
+#ifndef LT_MLP_RING2
+#define LT_MLP_RING2 (LT_MLP_ONE_ACC ? 32 : 16)  // ring slots at two row tiles
+#endif
+  constexpr int RG = RT >= 2 ? LT_MLP_RING2 : 32;
   const float4* __restrict__ stream = (const float4*)a.packed + a.wave_base[wave] * 64 + lane;
   float4 ring[RG];
 #pragma unroll
   for (int s = 0; s < RG; ++s) ring[s] = stream[s * 64];
   long long c0 = 0;
+  float* const s_noise = s_img + a.noise_off;
+  if (a.mode == MODE_POLICY && wave == 0) policy_noise<RT>(a, row0, lane, s_noise);
   {
-    // biases -> LDS
-    const float* bsrc = a.packed + a.bias_chunk * 256;
-    for (int i = tid; i < a.bias_total; i += 64 * NW) s_bias[i] = bsrc[i];
+#pragma unroll
+    for (int u = 0; u < BB; ++u) s_bias[min(tid + u * NT, a.bias_total - 1)] = bv[u];
+    for (int i = tid + BB * NT; i < a.bias_total; i += NT) s_bias[i] = bsrc[i];
     if (vec_in) {
 #pragma unroll
       for (int u = 0; u < B; ++u) {
-        const int idx = tid + u * 64 * NW;
-        const int rr = idx / kv, cc = idx - rr * kv;
-        if (idx < total) {
-          f32x4 v = vin[u];
-          if (a.x_bf16) {
-            const unsigned w0 = __float_as_uint(v[0]), w1 = __float_as_uint(v[1]);
-            v = f32x4{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xFFFF0000u), __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xFFFF0000u)};
-          }
-          *(f32x4*)(s_act + rr * S + 4 * cc) = v;
+        f32x4 v = vin[u];
+        if (a.x_bf16) {
+          const unsigned w0 = __float_as_uint(v[0]), w1 = __float_as_uint(v[1]);
+          v = f32x4{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xFFFF0000u), __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xFFFF0000u)};
         }
+        *(f32x4*)(s_act + lds_at[u]) = v;
       }
-      for (int base = tid + B * 64 * NW; base < total; base += 64 * NW) {  // inputs wider than one batch
-        const int rr = base / kv, cc = base - rr * kv;
-        const long long e = row0 + rr;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (cc < k4 && e < a.m) v = load_in4(a, e * K0 + 4 * cc);
-        *(f32x4*)(s_act + rr * S + 4 * cc) = v;
+      for (unsigned idx = tid + B * NT; idx < tv; idx += NT) {  // inputs wider than one batch
+        const unsigned rr = idx / k4, cc = idx - rr * k4;
+        *(f32x4*)(s_act + rr * S + 4 * cc) = load_in4(a, (row0 + min(rr, rmax)) * K0 + 4 * cc);
       }
+      for (int i = tid; i < ROWS * (kv - k4); i += NT) *(f32x4*)(s_act + (i & (ROWS - 1)) * S + 4 * (k4 + i / ROWS)) = f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
-      for (int idx = tid; idx < ROWS * K0p; idx += 64 * NW) {
+      for (int idx = tid; idx < ROWS * K0p; idx += NT) {
         const int rr = idx / K0p, cc = idx - rr * K0p;
         const long long e = row0 + rr;
         s_act[rr * S + cc] = (cc < K0 && e < a.m) ? (a.x_bf16 ? __uint_as_float((unsigned)((const unsigned short*)a.x)[e * K0 + cc] << 16) : a.x[e * K0 + cc]) : 0.f;
@@ -426,10 +486,10 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
   for (int l = 0; l < a.L; ++l) {
     const int T = tiles_per_wave(pad16(a.dims[l + 1]) / 16);
     const bool last = l == a.L - 1;
-    if (NW <= 4 && T == 8) mlp_layer<(NW <= 4 ? 8 : 4), RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);  // (eight waves: at most 4 tiles each)
-    else if (T == 4) mlp_layer<4, RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);
-    else if (T == 2) mlp_layer<2, RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);
-    else mlp_layer<1, RT, RG>(a, l, last, s_act, s_bias + boff, wave, lane, row_block, ring, stream, c0);
+    if (NW <= 4 && T == 8) mlp_layer<(NW <= 4 ? 8 : 4), RT, RG>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);  // (eight waves: at most 4 tiles each)
+    else if (T == 4) mlp_layer<4, RT, RG>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);
+    else if (MIN_TILES >= 2 || T == 2) mlp_layer<(MIN_TILES > 2 ? MIN_TILES : 2), RT, RG>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);
+    else mlp_layer<1, RT, RG>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);
     boff += pad16(a.dims[l + 1]);
     MLP_STAMP(2 + l);
     // training forward (lt_mlp_forward_pair): the layer's activations, still in LDS, also go to memory for the backward pass -
@@ -535,6 +595,8 @@ void fill_args(const lt_mlp_desc* d, MlpArgs& a) {
   for (int w = 0; w < NW; ++w) a.wave_base[w] = g.wave_base[w];
   a.stride = pad32(widest) + 4;
   a.bias_total = g.bias_total;
+  // exact for every index below ROWS x K0/4 as long as ROWS (K0/4)^2 < 2^32 - LDS holds no such row; K0 = 4 has no 32-bit reciprocal
+  a.in_magic = (d->dims[0] % 4 == 0 && d->dims[0] >= 8) ? (unsigned)(0x100000000ull / (unsigned)(d->dims[0] / 4)) + 1u : 0u;
   a.bias_chunk = g.bias_chunk;
 }
 
@@ -556,8 +618,10 @@ int launch(DualArgs& d, int nets, hipStream_t s) {
   const long long t0 = (d.net[0].m + 15) / 16, t1 = nets == 2 ? (d.net[1].m + 15) / 16 : 0;
   int rt = pick_row_tiles(t0 + t1);
   if (const char* o = getenv("LT_MLP_ROW_TILES")) rt = atoi(o) == 2 ? 2 : 1;  // diagnostic override
-  while (rt > 1 && (size_t)16 * rt * row_bytes + bias_bytes > 160 * 1024) rt /= 2;  // one workgroup's activations must fit the LDS
-  const size_t lds = (size_t)16 * rt * row_bytes + bias_bytes;
+  // one workgroup's activations (+ the policy head's [rows][12 draws + 3 log-density partials + pad] block) must fit the LDS
+  while (rt > 1 && (size_t)16 * rt * row_bytes + bias_bytes + (size_t)16 * rt * 64 > 160 * 1024) rt /= 2;
+  const size_t lds = (size_t)16 * rt * row_bytes + bias_bytes + (size_t)16 * rt * 64;
+  for (int n = 0; n < nets; ++n) d.net[n].noise_off = 16 * rt * stride + bias;
   const long long b0 = (t0 + rt - 1) / rt, b1 = (t1 + rt - 1) / rt;
   d.split = (int)b0;
   // Two networks of equal row count: split them by XCD instead of by block range.  Each XCD's 4 MiB L2 then holds ONE

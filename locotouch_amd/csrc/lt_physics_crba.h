@@ -800,6 +800,7 @@ struct InlineParts {
   static constexpr bool external = false;
   __device__ __forceinline__ void publish(const float (&)[3], const float (&)[3], const float (&)[3], const Base&) const {}
   __device__ __forceinline__ void fetch(PhysExt&) const {}
+  __device__ __forceinline__ void mark(int) const {}  // (phase stamps of the LT_STAMPS build, helper form)
 };
 template <bool HAS_OBJ, bool TAC = false, class Ext = InlineParts>
 __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int leg, const float (&sgn)[4], Base& B, Leg& G, Obj& O,
@@ -809,7 +810,9 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
   float cq[3], sq[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { sq[k] = fsin(G.q[k]); cq[k] = fcos(G.q[k]); }
+  ext.mark(0);
   ext.publish(cq, sq, G.qd, B);
+  ext.mark(1);
   PhysExt pe;
   if (!Ext::external && HAS_OBJ) pe.obj = object_part<TAC>(c, h, leg, B, O, X.trunk_mu);  // first: nothing else is live yet
   const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
@@ -876,6 +879,7 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
 
   // ---- the two parts that do not depend on this lane's leg dynamics: the carried cylinder (object_part) and the CRBA
   //      (crba_part) - computed here, or fetched from the helper waves that ran them beside the code above ----
+  ext.mark(2);
   if (Ext::external) {
     ext.fetch(pe);
   } else {
@@ -899,6 +903,7 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
     S.rhs[2] = G.tau[2] - f[2].y.x - cr.tb[2];
   }
 
+  ext.mark(3);
   // ---- eliminate this leg's joints: H = L L^T (3x3), Y = L^-1 H_lb (rows (moment | force)), z = L^-1 rhs ----
   float l10, l20, l21, i0, i1, i2;  // (only the inverse diagonal is ever used: one v_rsq_f32 each)
   {
@@ -920,11 +925,14 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
     rb -= z[j] * y[j];
   }
 
+  ext.mark(4);
   // ---- floating base: quad-sum the four shares (lane 0's carries the trunk's own rigid body), solve 6x6 ----
   const I6p M = qsum6(Mbb);
   const P3 r0 = qsum(rb);
+  ext.mark(5);
   V3 a0a, a0l;
   spd6_solve(M, r0, a0a, a0l);
+  ext.mark(6);
 
   // ---- back-substitute the joints: qdd = L^-T (z - Y a_b) ----
   float qdd[3];
@@ -964,6 +972,7 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
     rep.trunk_part += contact_force2(k_thi, r_thi, R0, A0);
   }
 
+  ext.mark(7);
   // ---- semi-implicit Euler ----
 #pragma unroll
   for (int k = 0; k < 3; ++k) {

@@ -42,7 +42,10 @@ def test_two_rank_fused_update_replicas_are_bit_equal_and_match_one_process(tmp_
             # one minibatch per epoch: the mean of the two shards' gradients is the single process's full-batch gradient, the KL and
             # the advantage moments are all-reduced -> the same update up to the rounding of differently ordered sums
             assert float(r0["lr"]) == float(one["lr"])
-            np.testing.assert_allclose(r0["params"], one["params"], rtol=3e-4, atol=3e-5)
+            # (Adam divides by sqrt(v): a parameter whose gradient sits at the rounding level can move by a visible fraction of one
+            # step either way - a handful out of 687 513 - so: all within one learning-rate step, all but 1e-5 of them tight)
+            tight = d <= 3e-5 + 3e-4 * np.abs(one["params"])
+            assert d.max() < 1e-3 and (~tight).mean() < 1e-5, (d.max(), int((~tight).sum()))
         else:
             # several minibatches: each rank permutes its own shard, the partitions differ -> agreement to the size of an Adam step
             assert d.max() < 8e-3 and d.mean() < 1.5e-3, (d.max(), d.mean())

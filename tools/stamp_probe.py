@@ -18,6 +18,12 @@ bw = env.field("LT_F_REWARD_TERMS")[::16, :2, 0].cpu()
 print(f"wave 0 waiting in physics barriers: A {bw[:, 0].mean():.0f} ticks, B {bw[:, 1].mean():.0f} ticks (4 substeps)")
 pr = env.field("LT_F_REWARD_TERMS")[::16, 4:7, 0].cpu()
 print(f"prologue: entry -> barrier B0 reached {pr[:, 0].mean():.0f} (max {pr[:, 0].max():.0f}); inside B0 (loads landed + all four waves arrived) {pr[:, 1].mean():.0f} (max {pr[:, 1].max():.0f}); B0 -> wave 0's own path {pr[:, 2].mean():.0f} (max {pr[:, 2].max():.0f})")
+ph = env.field("LT_F_REWARD_TERMS")[::16, :7, 1].cpu()  # lane 1 of every wave: phase sums over the step's substeps
+if n <= 4096:
+    names2 = ["publish + barrier A", "kinematics, foot, guarded spheres, backward pass", "barrier B + fetch + merge", "3x3 Cholesky, Y, Schur update", "quad sums (54 DPP adds)", "6x6 solve", "back-substitution, link accelerations, contact forces"]
+    print("substep phases of wave 0 (sum over the step's substeps):")
+    for i, nm in enumerate(names2):
+        print(f"   {nm:56s} {ph[:, i].mean():8.0f}")
 print("total ticks", float(tot), "(s_memtime ticks at 100 MHz => us:", float(tot) / 100.0, ")")
 
 if n <= 4096:  # helper form: when does each wave of a tile finish, relative to its own entry?  (LT_F_REWARD_TERMS quad array 3 carries the stamps)
