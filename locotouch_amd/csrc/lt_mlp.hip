@@ -180,6 +180,29 @@ __device__ __forceinline__ void write_back(const f32x4 (&am)[RT][T], const f32x4
     const int n0 = 16 * (tile0 + t) + 4 * q;  // this lane's 4 consecutive output features = next layer's k
     if (16 * (tile0 + t) >= nwrite) continue;
     const f32x4 bias = active ? *(const f32x4*)(s_bias + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (KIND == LT_ACT_ELU && !active) {  // (wave-uniform)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) *(f32x4*)(s_act + (r + 16 * rt) * S + n0) = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if (KIND == LT_ACT_ELU) {
+      // stage by stage over the tile's 4 x RT values, on float4 (-> v_pk_*_f32 pairs): value by value the eight dependent
+      // instructions of one ELU issue back to back at the dependent-issue rate (2.5 us for the 64 values of the widest layer).
+      // elu(x) = max(x, 0) + (exp(min(x, 0)) - 1): the same bits as  x > 0 ? x : exp(x) - 1  without compare / select.
+      const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 x[RT], e[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) x[rt] = (ONE_ACC ? am[rt][t] * LO_INV : am[rt][t] + ac[rt][t] * LO_INV) + bias;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) e[rt] = __builtin_elementwise_min(x[rt], zero) * 1.44269504088896340736f;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[rt][i] = __builtin_amdgcn_exp2f(e[rt][i]);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const f32x4 o = __builtin_elementwise_max(x[rt], zero) + (e[rt] - 1.f);
+        *(f32x4*)(s_act + (r + 16 * rt) * S + n0) = o;
+      }
+    } else {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -188,6 +211,7 @@ __device__ __forceinline__ void write_back(const f32x4 (&am)[RT][T], const f32x4
         for (int i = 0; i < 4; ++i) o[i] = activate<KIND>(acc_value(am[rt][t][i], ac[rt][t][i]) + bias[i]);
       }
       *(f32x4*)(s_act + (r + 16 * rt) * S + n0) = o;
+    }
     }
     // one tile at a time: left alone, the scheduler reads ALL accumulators out of the AGPRs up front (128 more live
     // registers beside the weight ring) and spills - and a scratch reload queues behind the 32 KiB of weight loads in flight
@@ -228,7 +252,7 @@ __device__ __forceinline__ void policy_noise(const MlpArgs& a, long long row0, i
 // RT row tiles (16 rows each) share every weight chunk: RT x the MFMA work per byte streamed from L2.
 // RG = ring slots (chunks in flight per wave): 32, or 16 where the accumulators need the registers (RG divides RING, so a
 // ring round never straddles a layer).
-template <int T, int RT, int RG>
+template <int T, int RT, int RG, int KIND>
 __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, float* s_act, const float* s_bias, const float* s_noise, int wave, int lane,
                                           long long row_block, float4 (&ring)[RG], const float4* __restrict__ stream, long long& c0) {
   constexpr int C = 2 * T;      // chunks per item
@@ -315,9 +339,13 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
   if (l == 0) MLP_STAMP(6);
 #endif
   lds_barrier();  // every wave is done reading this layer's input
+#ifdef LT_MLP_STAMPS
+  if (l == 0) MLP_STAMP(7);
+#endif
   if (!last) {
     const int nwrite = pad32(N);
-    if (a.activation == LT_ACT_ELU) write_back<LT_ACT_ELU, T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
+    if (KIND >= 0) write_back<(KIND >= 0 ? KIND : 0), T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
+    else if (a.activation == LT_ACT_ELU) write_back<LT_ACT_ELU, T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
     else if (a.activation == LT_ACT_RELU) write_back<LT_ACT_RELU, T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
     else if (a.activation == LT_ACT_TANH) write_back<LT_ACT_TANH, T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
     else write_back<LT_ACT_NONE, T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
@@ -369,7 +397,9 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
   }
 }
 
-template <int RT>
+// KIND: the hidden activation as a compile-time constant (the one every LocoTouch network uses gets its own, smaller kernel:
+// the epilogues run once per layer, at instruction-fetch speed), or -1 = read it from the arguments.
+template <int RT, int KIND>
 __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
   extern __shared__ __attribute__((aligned(16))) float s_img[];
   constexpr int ROWS = 16 * RT;
@@ -486,10 +516,10 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
   for (int l = 0; l < a.L; ++l) {
     const int T = tiles_per_wave(pad16(a.dims[l + 1]) / 16);
     const bool last = l == a.L - 1;
-    if (NW <= 4 && T == 8) mlp_layer<(NW <= 4 ? 8 : 4), RT, RG>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);  // (eight waves: at most 4 tiles each)
-    else if (T == 4) mlp_layer<4, RT, RG>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);
-    else if (MIN_TILES >= 2 || T == 2) mlp_layer<(MIN_TILES > 2 ? MIN_TILES : 2), RT, RG>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);
-    else mlp_layer<1, RT, RG>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);
+    if (NW <= 4 && T == 8) mlp_layer<(NW <= 4 ? 8 : 4), RT, RG, KIND>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);  // (eight waves: at most 4 tiles each)
+    else if (T == 4) mlp_layer<4, RT, RG, KIND>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);
+    else if (MIN_TILES >= 2 || T == 2) mlp_layer<(MIN_TILES > 2 ? MIN_TILES : 2), RT, RG, KIND>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);
+    else mlp_layer<1, RT, RG, KIND>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);
     boff += pad16(a.dims[l + 1]);
     MLP_STAMP(2 + l);
     // training forward (lt_mlp_forward_pair): the layer's activations, still in LDS, also go to memory for the backward pass -
@@ -635,11 +665,19 @@ int launch(DualArgs& d, int nets, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {  // more than the default 64 KB of dynamic LDS
     attr_set = true;
-    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<1, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<2, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<1, LT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<2, LT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  if (rt == 2) hipLaunchKernelGGL(lt_mlp_kernel<2>, grid, block, lds, s, d);
-  else hipLaunchKernelGGL(lt_mlp_kernel<1>, grid, block, lds, s, d);
+  const bool elu = d.net[0].activation == LT_ACT_ELU && (nets == 1 || d.net[1].activation == LT_ACT_ELU);
+  if (rt == 2) {
+    if (elu) hipLaunchKernelGGL((lt_mlp_kernel<2, LT_ACT_ELU>), grid, block, lds, s, d);
+    else hipLaunchKernelGGL((lt_mlp_kernel<2, -1>), grid, block, lds, s, d);
+  } else {
+    if (elu) hipLaunchKernelGGL((lt_mlp_kernel<1, LT_ACT_ELU>), grid, block, lds, s, d);
+    else hipLaunchKernelGGL((lt_mlp_kernel<1, -1>), grid, block, lds, s, d);
+  }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;
