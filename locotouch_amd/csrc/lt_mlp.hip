@@ -8,13 +8,18 @@
 //
 // Arithmetic.  The reference rolls out in fp32, and gfx950 has no TF32-like mode: the f32-input MFMA runs at the f32 vector
 // rate (157 TF), 1/16 of the f16/bf16 MFMA.  Every f32 operand x is therefore split into two f16 numbers,
-//     x = hi + lo * 2^-11,   hi = f16(x),  lo = f16((x - hi) * 2^11)      (22 significand bits; x - hi is exact in f32)
-// and a product sum  sum_k w_k x_k  is evaluated as three f16 MFMAs with f32 accumulation:
-//     main += w_hi x_hi          corr += w_hi x_lo + w_lo x_hi          result = main + corr * 2^-11
-// (the dropped w_lo x_lo term is 2^-22 relative).  f16 x f16 products are exact in the f32 accumulator, so the only errors
-// are the 2^-22 operand truncation and the f32 accumulation itself - measured against an fp64 reference the result is as
-// close as PyTorch's own fp32 GEMM chain (tests/test_hip_parity.py::test_fused_mlp_matches_torch keeps the round-1
-// tolerance).  3 MFMAs at 16x the f32-MFMA rate: 5.3x less matrix-pipe time than the exact-f32 form.
+//     x = hi + lo * 2^-6,   hi = f16(x),  lo = f16((x - hi) * 2^6)       (x - hi is exact in f32)
+// and a product sum  sum_k w_k x_k  is evaluated as three f16 MFMAs into ONE f32 accumulator that holds 2^6 x the result:
+//     acc += w_hi (2^6 x_hi)  +  w_hi x_lo  +  w_lo x_hi                  result = acc * 2^-6
+// (2^6 x_hi is exact: |x| is clamped to 1000; the dropped w_lo x_lo term is 2^-22 relative).  The scale is 2^6 rather than
+// the 2^11 that would normalise lo: with it the main operand stays an f16 number up to |x| = 1000, and lo = 2^6 (x - hi)
+// keeps its full 11 bits down to |x| = 2^-8 - below that it goes subnormal with an ABSOLUTE error of 2^-30, nothing against
+// the f32 rounding of the sum.  One accumulator set instead of (main, corr) halves the accumulator registers - what makes
+// four row tiles per workgroup fit - and the layer epilogues read half as many AGPRs.  f16 x f16 products are exact in
+// the f32 accumulator, so the only errors are the 2^-22 operand truncation and the f32 accumulation itself - measured
+// against an fp64 reference the result is as close as PyTorch's own fp32 GEMM chain
+// (tests/test_hip_parity.py::test_fused_mlp_matches_torch keeps the round-1 tolerance).  3 MFMAs at 16x the f32-MFMA rate:
+// 5.3x less matrix-pipe time than the exact-f32 form.
 //
 // Structure:
 //   * a workgroup (NW = 4 waves, one per SIMD) owns 16 * RT batch rows; their activations live in LDS as f32 rows
@@ -24,16 +29,21 @@
 //   * out^T = W . act^T on v_mfma_f32_16x16x32_f16: the weight tile is the A operand (16 output features x 32 k), the
 //     activations are the B operand (32 k x 16 rows), so a lane ends up with 4 CONSECUTIVE output features of ONE row ->
 //     the next layer's input is written back with one ds_write_b128;
-//   * each wave owns T = N/(16 NW) output tiles x RT row tiles (independent accumulators);
+//   * each wave owns T = N/(16 NW) output tiles x RT row tiles (independent accumulators); RT = 2 from 8192 rows per launch
+//     (every CU still gets a workgroup), 4 from 16384 (several rounds of workgroups, each streaming the weights again);
 //   * the weights are pre-packed once per policy update (lt_mlp_pack) - already split into (hi, lo) f16 - into ONE LINEAR
 //     STREAM PER WAVE of 1-KiB chunks (64 lanes x 16 B) in exactly the order the wave consumes them, across layers: per
-//     32-wide k-group one item of T x (hi chunk, lo chunk).  The kernel keeps a 32-chunk register ring per wave and refills
-//     a slot right after its MFMAs, so 32 KiB per wave are always in flight and the first weights of layer l+1 are already
+//     32-wide k-group one item of T x (hi chunk, lo chunk).  The kernel keeps a register ring per wave (32 chunks at one row
+//     tile, 16 above) and refills a slot right after its MFMAs, so 16-32 KiB per wave are always in flight and the first weights of layer l+1 are already
 //     on their way while layer l finishes.  Every wave-instruction of the stream is one fully coalesced
 //     global_load_dwordx4; all workgroups stream the same ~1.5 MB per network from L2.  That stream is what bounds the
 //     kernel: a CU draws ~30 B/clk from L2 however many CUs stream (MI355X_MICROARCH.md, indexed rows from L2), i.e.
 //     ~20 us per network - the MFMAs of 32 rows take 7 us;
-//   * biases live in LDS (staged once) and are added in the epilogue.
+//   * biases live in LDS (staged once) and are added in the epilogue;
+//   * everything outside the layer loops runs ONCE per launch, i.e. on cold instruction caches (~14 cycles per instruction):
+//     the prologue and the epilogues are written for instruction count and independent issue, the policy head's noise is
+//     drawn in the prologue under the latency of the input rows, and a narrow last layer goes through the two-tile loop
+//     the layer before it has just run instead of a one-tile instantiation of its own.
 //
 // The policy network's last layer carries the sampling epilogue of lt_rollout_act (a = mu + sigma N(0,1), log-prob,
 // storage-slot writes), so the actor side of a rollout step needs no further launch.
@@ -58,15 +68,11 @@ constexpr int RING = 32;               // chunk granularity of the packed stream
 constexpr int NW = LT_MLP_WAVES;       // waves per workgroup (one per SIMD)
 constexpr unsigned RS_POLICY = 0x400;  // same Philox stream id as lt_rollout_act
 constexpr int MODE_FORWARD = 0, MODE_POLICY = 1;
-#ifndef LT_MLP_ONE_ACC
-#define LT_MLP_ONE_ACC 0
-#endif
-// One accumulator per output tile (module header, "Arithmetic"): the low parts carry a 2^6 scale and so does the main
-// product's activation operand, so all three MFMAs sum into the same registers.  0: the two-accumulator form (2^11 scale).
-constexpr bool ONE_ACC = LT_MLP_ONE_ACC != 0;
-constexpr float LO_SCALE = ONE_ACC ? 64.f : 2048.f, LO_INV = 1.f / LO_SCALE;
-// |x| beyond the range saturates instead of turning into inf - inf (one accumulator: 64 x must stay an f16 number)
-constexpr float F16_CLAMP = ONE_ACC ? 1000.f : 60000.f;
+// scale of the low parts - and of the main product's activation operand, so that all three MFMAs of the split sum into ONE
+// accumulator (module header, "Arithmetic")
+constexpr float LO_SCALE = 64.f, LO_INV = 1.f / LO_SCALE;
+// |x| beyond this saturates (64 x must stay an f16 number, and inf - inf must not appear)
+constexpr float F16_CLAMP = 1000.f;
 
 __host__ __device__ inline int pad16(int x) { return (x + 15) & ~15; }
 __host__ __device__ inline int pad32(int x) { return (x + 31) & ~31; }
@@ -131,7 +137,7 @@ __device__ __forceinline__ float activate(float x) {
   if (KIND == LT_ACT_TANH) return tanhf(x);
   return x;
 }
-// 8 consecutive f32 activations -> the (hi, lo) f16 B-fragments:  x = hi + lo / 2048  (module header)
+// 8 consecutive f32 activations -> the (hi, lo) f16 B-fragments:  x = hi + lo / 64  (module header)
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -169,11 +175,8 @@ __device__ unsigned long long g_mlp_stamps[1024 * 8 * NW];
 // Tiles up to the next layer's k padding (32) are written even when they lie beyond N (zero weights and bias give
 // activation(0) = 0; an inactive wave writes plain zeros): the next layer multiplies those columns by zero weights, and
 // 0 x (stale LDS bits) could be 0 x NaN.
-// a finished accumulator pair -> the layer's pre-activation (without bias)
-__device__ __forceinline__ float acc_value(float main, float corr) { return ONE_ACC ? main * LO_INV : main + corr * LO_INV; }
-
 template <int KIND, int T, int RT>
-__device__ __forceinline__ void write_back(const f32x4 (&am)[RT][T], const f32x4 (&ac)[RT][T], bool active, float* s_act, const float* s_bias,
+__device__ __forceinline__ void write_back(const f32x4 (&am)[RT][T], bool active, float* s_act, const float* s_bias,
                                            int r, int q, int S, int tile0, int nwrite) {
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -190,7 +193,7 @@ __device__ __forceinline__ void write_back(const f32x4 (&am)[RT][T], const f32x4
       const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 x[RT], e[RT];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) x[rt] = (ONE_ACC ? am[rt][t] * LO_INV : am[rt][t] + ac[rt][t] * LO_INV) + bias;
+      for (int rt = 0; rt < RT; ++rt) x[rt] = am[rt][t] * LO_INV + bias;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) e[rt] = __builtin_elementwise_min(x[rt], zero) * 1.44269504088896340736f;
 #pragma unroll
@@ -208,7 +211,7 @@ __device__ __forceinline__ void write_back(const f32x4 (&am)[RT][T], const f32x4
       f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
       if (active) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = activate<KIND>(acc_value(am[rt][t][i], ac[rt][t][i]) + bias[i]);
+        for (int i = 0; i < 4; ++i) o[i] = activate<KIND>(am[rt][t][i] * LO_INV + bias[i]);
       }
       *(f32x4*)(s_act + (r + 16 * rt) * S + n0) = o;
     }
@@ -266,11 +269,11 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
   const int tile0 = wave * T;
   const bool active = wave < active_waves(N);
   const float* const xrow = s_act + r * S + 8 * q;  // row tile rt: + 16 * rt * S; k-group g: + 32 g
-  f32x4 am[RT][T], ac[RT][T];
+  f32x4 am[RT][T];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int t = 0; t < T; ++t) { am[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < T; ++t) am[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (active) {
     // software pipeline over items: raw f32 of item i+2 in flight from LDS, item i+1 being split on the VALU, item i in the MFMAs
     f32x4 raw[RT][2];
@@ -302,25 +305,18 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
             raw[rt][0] = *(const f32x4*)(xrow + 16 * rt * S + 32 * gx);
             raw[rt][1] = *(const f32x4*)(xrow + 16 * rt * S + 32 * gx + 4);
           }
+          // the three products of the split, all into the one accumulator (product-major order - two MFMAs on the same
+          // accumulator T x RT apart instead of T - measured the same within noise)
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
             const f16x8 bh = xh[j & 1][rt], bl = xl[j & 1][rt];
-            if (ONE_ACC) {
-              const f16x8 bs = bh * (_Float16)LO_SCALE;  // exact: |x| <= F16_CLAMP
+            const f16x8 bs1 = bh * (_Float16)LO_SCALE;  // exact: |x| <= F16_CLAMP
 #pragma unroll
-              for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bs, am[rt][t], 0, 0, 0);
+            for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bs1, am[rt][t], 0, 0, 0);
 #pragma unroll
-              for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bl, am[rt][t], 0, 0, 0);
+            for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bl, am[rt][t], 0, 0, 0);
 #pragma unroll
-              for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t + 1]), bh, am[rt][t], 0, 0, 0);
-            } else {
-#pragma unroll
-              for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bh, am[rt][t], 0, 0, 0);
-#pragma unroll
-              for (int t = 0; t < T; ++t) ac[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bl, ac[rt][t], 0, 0, 0);
-#pragma unroll
-              for (int t = 0; t < T; ++t) ac[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t + 1]), bh, ac[rt][t], 0, 0, 0);
-            }
+            for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t + 1]), bh, am[rt][t], 0, 0, 0);
           }
         }
         // refill the slots just consumed (pad items included: the ring invariant must hold for the next layer)
@@ -344,11 +340,11 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
 #endif
   if (!last) {
     const int nwrite = pad32(N);
-    if (KIND >= 0) write_back<(KIND >= 0 ? KIND : 0), T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
-    else if (a.activation == LT_ACT_ELU) write_back<LT_ACT_ELU, T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
-    else if (a.activation == LT_ACT_RELU) write_back<LT_ACT_RELU, T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
-    else if (a.activation == LT_ACT_TANH) write_back<LT_ACT_TANH, T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
-    else write_back<LT_ACT_NONE, T, RT>(am, ac, active, s_act, s_bias, r, q, S, tile0, nwrite);
+    if (KIND >= 0) write_back<(KIND >= 0 ? KIND : 0), T, RT>(am, active, s_act, s_bias, r, q, S, tile0, nwrite);
+    else if (a.activation == LT_ACT_ELU) write_back<LT_ACT_ELU, T, RT>(am, active, s_act, s_bias, r, q, S, tile0, nwrite);
+    else if (a.activation == LT_ACT_RELU) write_back<LT_ACT_RELU, T, RT>(am, active, s_act, s_bias, r, q, S, tile0, nwrite);
+    else if (a.activation == LT_ACT_TANH) write_back<LT_ACT_TANH, T, RT>(am, active, s_act, s_bias, r, q, S, tile0, nwrite);
+    else write_back<LT_ACT_NONE, T, RT>(am, active, s_act, s_bias, r, q, S, tile0, nwrite);
     lds_barrier();
     return;
   }
@@ -360,7 +356,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
     for (int t = 0; t < T; ++t) {
       const f32x4 bias = active ? *(const f32x4*)(s_bias + 16 * (tile0 + t) + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) out[t][i] = active ? acc_value(am[rt][t][i], ac[rt][t][i]) + bias[i] : 0.f;
+      for (int i = 0; i < 4; ++i) out[t][i] = active ? am[rt][t][i] * LO_INV + bias[i] : 0.f;
     }
     if (a.mode == MODE_FORWARD) {
       if (active && e < a.m) {
@@ -432,7 +428,7 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
   // the k padding (columns K0 .. pad32(K0), zero weights) is zeroed separately - 0 x stale LDS bits could be 0 x NaN.
   const int K0 = a.dims[0], K0p = pad32(K0);
   const bool vec_in = a.in_magic != 0;  // K0 % 4 == 0 (fill_args)
-  constexpr int B = 12;  // float4 in flight per thread: one batch covers a 348-wide input (11 per thread at two row tiles)
+  constexpr int B = 6 * RT;  // float4 in flight per thread: one batch covers a 348-wide input (5.4 per thread and row tile)
   constexpr int NT = 64 * NW;
   const int kv = K0p >> 2, k4 = K0 >> 2;
   const unsigned tv = ROWS * k4;
@@ -473,7 +469,7 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
   // weight stream: a full ring in flight.  Two row tiles need 128 accumulator registers per lane: a 16-slot ring then
   // keeps the allocation clear of spills (a scratch reload in a layer epilogue would sit behind the whole ring in the queue).
 #ifndef LT_MLP_RING2
-#define LT_MLP_RING2 (LT_MLP_ONE_ACC ? 32 : 16)  // ring slots at two row tiles
+#define LT_MLP_RING2 16  // ring slots at two or more row tiles
 #endif
   constexpr int RG = RT >= 2 ? LT_MLP_RING2 : 32;
   const float4* __restrict__ stream = (const float4*)a.packed + a.wave_base[wave] * 64 + lane;
@@ -634,7 +630,20 @@ void fill_args(const lt_mlp_desc* d, MlpArgs& a) {
 // from L2 per FLOP, and the kernel is bound by L2 -> CU bandwidth (every workgroup streams the whole network), not by the
 // MFMA rate.  (4 row tiles = 256 accumulator + 128 ring registers per lane: past the point where the allocator spills.)
 int pick_row_tiles(long long rows_total_blocks16) {
+  if (rows_total_blocks16 / 4 >= 256) return 4;  // large batches: several rounds of workgroups - each round streams the weights again
   return rows_total_blocks16 / 2 >= 256 ? 2 : 1;
+}
+
+template <int RT>
+void launch_rt(const DualArgs& d, bool elu, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {  // more than the default 64 KB of dynamic LDS
+    attr_set = true;
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<RT, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<RT, LT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  if (elu) hipLaunchKernelGGL((lt_mlp_kernel<RT, LT_ACT_ELU>), grid, block, lds, s, d);
+  else hipLaunchKernelGGL((lt_mlp_kernel<RT, -1>), grid, block, lds, s, d);
 }
 
 int launch(DualArgs& d, int nets, hipStream_t s) {
@@ -647,7 +656,7 @@ int launch(DualArgs& d, int nets, hipStream_t s) {
   const size_t bias_bytes = (size_t)bias * sizeof(float);
   const long long t0 = (d.net[0].m + 15) / 16, t1 = nets == 2 ? (d.net[1].m + 15) / 16 : 0;
   int rt = pick_row_tiles(t0 + t1);
-  if (const char* o = getenv("LT_MLP_ROW_TILES")) rt = atoi(o) == 2 ? 2 : 1;  // diagnostic override
+  if (const char* o = getenv("LT_MLP_ROW_TILES")) rt = atoi(o) == 4 ? 4 : (atoi(o) == 2 ? 2 : 1);  // diagnostic override
   // one workgroup's activations (+ the policy head's [rows][12 draws + 3 log-density partials + pad] block) must fit the LDS
   while (rt > 1 && (size_t)16 * rt * row_bytes + bias_bytes + (size_t)16 * rt * 64 > 160 * 1024) rt /= 2;
   const size_t lds = (size_t)16 * rt * row_bytes + bias_bytes + (size_t)16 * rt * 64;
@@ -662,22 +671,11 @@ int launch(DualArgs& d, int nets, hipStream_t s) {
   d.blocks_per_net = (int)b0;
   const long long nblocks = d.xcd_split ? (b0 + 3) / 4 * 8 : b0 + b1;
   const dim3 grid((unsigned)nblocks), block(64 * NW);
-  static bool attr_set = false;
-  if (!attr_set) {  // more than the default 64 KB of dynamic LDS
-    attr_set = true;
-    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<1, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<2, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<1, LT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<2, LT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
   const bool elu = d.net[0].activation == LT_ACT_ELU && (nets == 1 || d.net[1].activation == LT_ACT_ELU);
-  if (rt == 2) {
-    if (elu) hipLaunchKernelGGL((lt_mlp_kernel<2, LT_ACT_ELU>), grid, block, lds, s, d);
-    else hipLaunchKernelGGL((lt_mlp_kernel<2, -1>), grid, block, lds, s, d);
-  } else {
-    if (elu) hipLaunchKernelGGL((lt_mlp_kernel<1, LT_ACT_ELU>), grid, block, lds, s, d);
-    else hipLaunchKernelGGL((lt_mlp_kernel<1, -1>), grid, block, lds, s, d);
-  }
+  if (rt == 4) {
+    launch_rt<4>(d, elu, grid, block, lds, s);
+  } else if (rt == 2) launch_rt<2>(d, elu, grid, block, lds, s);
+  else launch_rt<1>(d, elu, grid, block, lds, s);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;
