@@ -63,7 +63,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int RING = 32;               // chunk granularity of the packed streams (layers are padded to multiples of it)
 #ifndef LT_MLP_WAVES
-#define LT_MLP_WAVES 4
+#define LT_MLP_WAVES 8
 #endif
 constexpr int NW = LT_MLP_WAVES;       // waves per workgroup (one per SIMD)
 constexpr unsigned RS_POLICY = 0x400;  // same Philox stream id as lt_rollout_act
@@ -137,15 +137,37 @@ __device__ __forceinline__ float activate(float x) {
   if (KIND == LT_ACT_TANH) return tanhf(x);
   return x;
 }
-// 8 consecutive f32 activations -> the (hi, lo) f16 B-fragments:  x = hi + lo / 64  (module header)
-__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+// The LDS image of the activations: row r at s_act + r * S floats; inside a row, GROUP j (elements 8j .. 8j + 7) occupies
+// floats [8j, 8j + 8): first the eight hi halves (16 B), then the eight lo halves (16 B),  x = hi + lo / 64  (module header).
+// A lane's B fragment of a k-group - 8 consecutive k of one row - is therefore two ds_read_b128 at consecutive addresses, the
+// same bytes an f32 row would take: the split is made ONCE per element, by whoever stages it (input rows: the prologue;
+// hidden activations: convert_pass), not by each of the NW waves in front of its MFMAs.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4(const f32x4& v, f16x4& hi, f16x4& lo) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float x = fminf(fmaxf(i < 4 ? a[i] : b[i - 4], -F16_CLAMP), F16_CLAMP);
+  for (int i = 0; i < 4; ++i) {
+    const float x = fminf(fmaxf(v[i], -F16_CLAMP), F16_CLAMP);
     const _Float16 h = (_Float16)x;
     hi[i] = h;
     lo[i] = (_Float16)((x - (float)h) * LO_SCALE);
   }
+}
+
+// byte offset inside the image of the hi halves of elements 4 c4 .. 4 c4 + 3 of row rr (their lo halves: + 16)
+__device__ __forceinline__ unsigned half_group_at(unsigned rr, unsigned c4, int S) { return (rr * (unsigned)S + (c4 >> 1) * 8u) * 4u + (c4 & 1u) * 8u; }
+__device__ __forceinline__ void store_split4(float* s_act, unsigned at, const f32x4& v) {
+  f16x4 hi, lo;
+  split4(v, hi, lo);
+  *(f16x4*)((char*)s_act + at) = hi;
+  *(f16x4*)((char*)s_act + at + 16) = lo;
+}
+// one element (inputs whose width is not a multiple of 4)
+__device__ __forceinline__ void store_split1(float* s_act, int rr, int col, int S, float v) {
+  const float x = fminf(fmaxf(v, -F16_CLAMP), F16_CLAMP);
+  const _Float16 h = (_Float16)x;
+  _Float16* const g = (_Float16*)(s_act + rr * S + (col >> 3) * 8);
+  g[col & 7] = h;
+  g[8 + (col & 7)] = (_Float16)((x - (float)h) * LO_SCALE);
 }
 
 // four consecutive input elements starting at element `off` of the input rows: f32, or bf16 widened exactly (read-once: nontemporal)
@@ -170,55 +192,82 @@ __device__ unsigned long long g_mlp_stamps[1024 * 8 * NW];
 #define MLP_STAMP(i) do { } while (0)
 #endif
 
-// Epilogue of a hidden layer: bias + compensation + activation, written back as the next layer's f32 input.  KIND is a
-// compile-time constant per call site (a runtime `kind` inside the loop gets if-converted into computing EVERY activation).
-// Tiles up to the next layer's k padding (32) are written even when they lie beyond N (zero weights and bias give
-// activation(0) = 0; an inactive wave writes plain zeros): the next layer multiplies those columns by zero weights, and
-// 0 x (stale LDS bits) could be 0 x NaN.
-template <int KIND, int T, int RT>
-__device__ __forceinline__ void write_back(const f32x4 (&am)[RT][T], bool active, float* s_act, const float* s_bias,
-                                           int r, int q, int S, int tile0, int nwrite) {
+// Epilogue of a hidden layer, first half: the accumulators go to the image RAW (f32, still scaled by 2^6), each lane's 4
+// consecutive output features of a row with one ds_write_b128 at its f32 position - T x RT stores and no arithmetic in this
+// once-per-layer, instruction-cache-cold code.  Only tiles that start below the next layer's k padding (32) are written.
+template <int T, int RT>
+__device__ __forceinline__ void raw_store(const f32x4 (&am)[RT][T], float* s_act, int r, int q, int S, int tile0, int nwrite) {
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const int n0 = 16 * (tile0 + t) + 4 * q;  // this lane's 4 consecutive output features = next layer's k
     if (16 * (tile0 + t) >= nwrite) continue;
-    const f32x4 bias = active ? *(const f32x4*)(s_bias + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
-    if (KIND == LT_ACT_ELU && !active) {  // (wave-uniform)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) *(f32x4*)(s_act + (r + 16 * rt) * S + n0) = f32x4{0.f, 0.f, 0.f, 0.f};
-    } else if (KIND == LT_ACT_ELU) {
-      // stage by stage over the tile's 4 x RT values, on float4 (-> v_pk_*_f32 pairs): value by value the eight dependent
-      // instructions of one ELU issue back to back at the dependent-issue rate (2.5 us for the 64 values of the widest layer).
-      // elu(x) = max(x, 0) + (exp(min(x, 0)) - 1): the same bits as  x > 0 ? x : exp(x) - 1  without compare / select.
-      const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 x[RT], e[RT];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) x[rt] = am[rt][t] * LO_INV + bias;
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) e[rt] = __builtin_elementwise_min(x[rt], zero) * 1.44269504088896340736f;
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e[rt][i] = __builtin_amdgcn_exp2f(e[rt][i]);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const f32x4 o = __builtin_elementwise_max(x[rt], zero) + (e[rt] - 1.f);
-        *(f32x4*)(s_act + (r + 16 * rt) * S + n0) = o;
-      }
+    for (int rt = 0; rt < RT; ++rt) *(f32x4*)(s_act + (r + 16 * rt) * S + n0) = am[rt][t];
+    // one tile at a time: left alone, the scheduler reads ALL accumulators out of the AGPRs up front and spills
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// Second half, by ALL threads of the workgroup, as ONE rolled loop with ONE copy in the kernel (the layer loop calls it from a
+// single site): everything in this kernel that is not a hot loop runs at instruction-fetch speed (~14 cycles per instruction
+// on cold caches, every launch), so the body is fetched once, behind the first layer, and runs hot behind the others.  (Unrolled
+// four groups deep it was slower: 2 cold trips of 450 instructions.  Started by a warm-up trip in the prologue, or fed the
+// input rows as well, it was slower too: the input rows are there before the trip ends.)  A thread takes whole groups - 8
+// consecutive features of a row, 32 bytes - reads the raw sums, applies scale + bias + activation, and writes the (hi, lo)
+// halves back over the same 32 bytes (in place: nobody else touches the group).  Features N .. pad32(N) become zeros (the next
+// layer multiplies them by zero weights, and 0 x stale bits could be 0 x NaN).  The training forward's copy of the activations
+// for the backward pass (act_out) leaves from here as well, from registers.
+template <int KIND, int ROWS>
+__device__ __forceinline__ void convert_pass(const MlpArgs& a, int l, float* s_act, const float* s_bias, int tid, long long row0) {
+  const int S = a.stride;
+  const int N = a.dims[l + 1];
+  const int total = ROWS * (pad32(N) >> 3);
+  float* const dst = a.act_out[l];
+#pragma unroll 1
+  for (int idx = tid; idx < total; idx += 64 * NW) {
+    const int rr = idx & (ROWS - 1), j = idx / ROWS;  // consecutive lanes = consecutive rows: conflict-free (S == 4 mod 64)
+    const int n0 = 8 * j;
+    float* const g = s_act + rr * S + n0;
+    f32x4 x[2];
+    if (n0 + 8 <= N) {
+      x[0] = *(const f32x4*)g * LO_INV + *(const f32x4*)(s_bias + n0);
+      x[1] = *(const f32x4*)(g + 4) * LO_INV + *(const f32x4*)(s_bias + n0 + 4);
     } else {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (active) {
+      for (int i = 0; i < 8; ++i) x[i >> 2][i & 3] = n0 + i < N ? g[i] * LO_INV + s_bias[n0 + i] : 0.f;
+    }
+    {
+      const int kind = KIND >= 0 ? KIND : a.activation;
+      if (kind == LT_ACT_ELU) {
+        // stage by stage on float4 (-> v_pk_*_f32 pairs).  elu(x) = max(x, 0) + (exp(min(x, 0)) - 1): the same bits as
+        // x > 0 ? x : exp(x) - 1  without compare / select; elu(0) = 0 keeps the padding features zero.
+        const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 e[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = activate<KIND>(am[rt][t][i] * LO_INV + bias[i]);
+        for (int h = 0; h < 2; ++h) e[h] = __builtin_elementwise_min(x[h], zero) * 1.44269504088896340736f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i >> 2][i & 3] = __builtin_amdgcn_exp2f(e[i >> 2][i & 3]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) x[h] = __builtin_elementwise_max(x[h], zero) + (e[h] - 1.f);
+      } else if (kind == LT_ACT_RELU) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) x[h] = __builtin_elementwise_max(x[h], f32x4{0.f, 0.f, 0.f, 0.f});
+      } else if (kind == LT_ACT_TANH) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i >> 2][i & 3] = tanhf(x[i >> 2][i & 3]);  // (tanh(0) = 0: the padding stays zero)
       }
-      *(f32x4*)(s_act + (r + 16 * rt) * S + n0) = o;
     }
+    f16x4 hi[2], lo[2];
+    split4(x[0], hi[0], lo[0]);
+    split4(x[1], hi[1], lo[1]);
+    *(f16x4*)g = hi[0]; *((f16x4*)g + 1) = hi[1];
+    *((f16x4*)g + 2) = lo[0]; *((f16x4*)g + 3) = lo[1];
+    if (dst) {  // (hidden widths of such networks are multiples of 4: lt_mlp_forward_pair)
+      const long long e = row0 + rr;
+      if (e < a.m) {
+        if (n0 < N) *(f32x4*)(dst + e * N + n0) = x[0];
+        if (n0 + 4 < N) *(f32x4*)(dst + e * N + n0 + 4) = x[1];
+      }
     }
-    // one tile at a time: left alone, the scheduler reads ALL accumulators out of the AGPRs up front (128 more live
-    // registers beside the weight ring) and spills - and a scratch reload queues behind the 32 KiB of weight loads in flight
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -275,17 +324,12 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
 #pragma unroll
     for (int t = 0; t < T; ++t) am[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (active) {
-    // software pipeline over items: raw f32 of item i+2 in flight from LDS, item i+1 being split on the VALU, item i in the MFMAs
-    f32x4 raw[RT][2];
+    // software pipeline over items: the (hi, lo) fragments of item i+1 in flight from LDS while item i is in the MFMAs
     f16x8 xh[2][RT], xl[2][RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      raw[rt][0] = *(const f32x4*)(xrow + 16 * rt * S);
-      raw[rt][1] = *(const f32x4*)(xrow + 16 * rt * S + 4);
-      split8(raw[rt][0], raw[rt][1], xh[0][rt], xl[0][rt]);
-      const int g1 = G > 1 ? 1 : 0;
-      raw[rt][0] = *(const f32x4*)(xrow + 16 * rt * S + 32 * g1);
-      raw[rt][1] = *(const f32x4*)(xrow + 16 * rt * S + 32 * g1 + 4);
+      xh[0][rt] = *(const f16x8*)(xrow + 16 * rt * S);
+      xl[0][rt] = *(const f16x8*)(xrow + 16 * rt * S + 4);
     }
     // items incl. the zero-weight pad items of the last RING round: they are walked (refill only) to leave the ring on the
     // next layer's first chunk - except behind the last layer, where nothing follows
@@ -296,14 +340,12 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
         const int i = i0 + j;  // item = k-group
         const int sl = (j % R) * C;  // first ring slot of the item
         if (i < G) {
-          // split item i+1 (its raw values were fetched during item i-1), then fetch the raw values of item i+2
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) split8(raw[rt][0], raw[rt][1], xh[(j & 1) ^ 1][rt], xl[(j & 1) ^ 1][rt]);
-          const int gx = i + 2 < G ? i + 2 : G - 1;
+          // fetch item i+1's fragments (the last item re-reads itself)
+          const int gx = i + 1 < G ? i + 1 : G - 1;
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
-            raw[rt][0] = *(const f32x4*)(xrow + 16 * rt * S + 32 * gx);
-            raw[rt][1] = *(const f32x4*)(xrow + 16 * rt * S + 32 * gx + 4);
+            xh[(j & 1) ^ 1][rt] = *(const f16x8*)(xrow + 16 * rt * S + 32 * gx);
+            xl[(j & 1) ^ 1][rt] = *(const f16x8*)(xrow + 16 * rt * S + 32 * gx + 4);
           }
           // the three products of the split, all into the one accumulator (product-major order - two MFMAs on the same
           // accumulator T x RT apart instead of T - measured the same within noise)
@@ -339,13 +381,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
   if (l == 0) MLP_STAMP(7);
 #endif
   if (!last) {
-    const int nwrite = pad32(N);
-    if (KIND >= 0) write_back<(KIND >= 0 ? KIND : 0), T, RT>(am, active, s_act, s_bias, r, q, S, tile0, nwrite);
-    else if (a.activation == LT_ACT_ELU) write_back<LT_ACT_ELU, T, RT>(am, active, s_act, s_bias, r, q, S, tile0, nwrite);
-    else if (a.activation == LT_ACT_RELU) write_back<LT_ACT_RELU, T, RT>(am, active, s_act, s_bias, r, q, S, tile0, nwrite);
-    else if (a.activation == LT_ACT_TANH) write_back<LT_ACT_TANH, T, RT>(am, active, s_act, s_bias, r, q, S, tile0, nwrite);
-    else write_back<LT_ACT_NONE, T, RT>(am, active, s_act, s_bias, r, q, S, tile0, nwrite);
-    lds_barrier();
+    if (active) raw_store<T, RT>(am, s_act, r, q, S, tile0, pad32(N));
     return;
   }
 #pragma unroll
@@ -428,7 +464,7 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
   // the k padding (columns K0 .. pad32(K0), zero weights) is zeroed separately - 0 x stale LDS bits could be 0 x NaN.
   const int K0 = a.dims[0], K0p = pad32(K0);
   const bool vec_in = a.in_magic != 0;  // K0 % 4 == 0 (fill_args)
-  constexpr int B = 6 * RT;  // float4 in flight per thread: one batch covers a 348-wide input (5.4 per thread and row tile)
+  constexpr int B = (6 * RT * 4 + NW - 1) / NW;  // float4 in flight per thread: one batch covers a 348-wide input (5.4 per thread and row tile at four waves)
   constexpr int NT = 64 * NW;
   const int kv = K0p >> 2, k4 = K0 >> 2;
   const unsigned tv = ROWS * k4;
@@ -445,7 +481,7 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
       for (int u = 0; u < B; ++u) {
         const unsigned idx = min((unsigned)tid + u * NT, tv - 1u);
         const unsigned rr = __umulhi(idx, a.in_magic), cc = idx - rr * k4;
-        lds_at[u] = rr * S + 4 * cc;
+        lds_at[u] = half_group_at(rr, cc, S);
         // raw bits now, widened when they go to LDS: a conversion here would wait for the row load before the weight ring is requested
         const u32x2 w = __builtin_nontemporal_load((const u32x2*)(xb + 2u * (min(rr, rmax) * K0 + 4 * cc)));
         vin[u] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), 0.f, 0.f};
@@ -455,7 +491,7 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
       for (int u = 0; u < B; ++u) {
         const unsigned idx = min((unsigned)tid + u * NT, tv - 1u);
         const unsigned rr = __umulhi(idx, a.in_magic), cc = idx - rr * k4;
-        lds_at[u] = rr * S + 4 * cc;
+        lds_at[u] = half_group_at(rr, cc, S);
         vin[u] = __builtin_nontemporal_load((const f32x4*)(xb + 4u * (min(rr, rmax) * K0 + 4 * cc)));
       }
     }
@@ -469,16 +505,20 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
   // weight stream: a full ring in flight.  Two row tiles need 128 accumulator registers per lane: a 16-slot ring then
   // keeps the allocation clear of spills (a scratch reload in a layer epilogue would sit behind the whole ring in the queue).
 #ifndef LT_MLP_RING2
-#define LT_MLP_RING2 16  // ring slots at two or more row tiles
+#define LT_MLP_RING2 16  // ring slots at two row tiles (32 fits without scratch and measured slower: 35.5 against 33.7 us at 4096 rows)
 #endif
-  constexpr int RG = RT >= 2 ? LT_MLP_RING2 : 32;
+#ifndef LT_MLP_RING4
+#define LT_MLP_RING4 16  // ring slots at four row tiles
+#endif
+  constexpr int RG = RT >= 4 ? LT_MLP_RING4 : (RT >= 2 ? LT_MLP_RING2 : (NW > 4 ? 16 : 32));  // (two waves per SIMD: 256 registers each)
   const float4* __restrict__ stream = (const float4*)a.packed + a.wave_base[wave] * 64 + lane;
   float4 ring[RG];
 #pragma unroll
   for (int s = 0; s < RG; ++s) ring[s] = stream[s * 64];
   long long c0 = 0;
   float* const s_noise = s_img + a.noise_off;
-  if (a.mode == MODE_POLICY && wave == 0) policy_noise<RT>(a, row0, lane, s_noise);
+  // The policy head's noise: by the last wave (idle in the narrow layers), under the latency of the input rows.
+  if (a.mode == MODE_POLICY && wave == NW - 1) policy_noise<RT>(a, row0, lane, s_noise);
   {
 #pragma unroll
     for (int u = 0; u < BB; ++u) s_bias[min(tid + u * NT, a.bias_total - 1)] = bv[u];
@@ -491,44 +531,44 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
           const unsigned w0 = __float_as_uint(v[0]), w1 = __float_as_uint(v[1]);
           v = f32x4{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xFFFF0000u), __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xFFFF0000u)};
         }
-        *(f32x4*)(s_act + lds_at[u]) = v;
+        store_split4(s_act, lds_at[u], v);
       }
       for (unsigned idx = tid + B * NT; idx < tv; idx += NT) {  // inputs wider than one batch
         const unsigned rr = idx / k4, cc = idx - rr * k4;
-        *(f32x4*)(s_act + rr * S + 4 * cc) = load_in4(a, (row0 + min(rr, rmax)) * K0 + 4 * cc);
+        store_split4(s_act, half_group_at(rr, cc, S), load_in4(a, (row0 + min(rr, rmax)) * K0 + 4 * cc));
       }
-      for (int i = tid; i < ROWS * (kv - k4); i += NT) *(f32x4*)(s_act + (i & (ROWS - 1)) * S + 4 * (k4 + i / ROWS)) = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = tid; i < ROWS * (kv - k4); i += NT) {  // the k padding: zero halves
+        const unsigned at = half_group_at(i & (ROWS - 1), k4 + i / ROWS, S);
+        *(f16x4*)((char*)s_act + at) = f16x4{0, 0, 0, 0};
+        *(f16x4*)((char*)s_act + at + 16) = f16x4{0, 0, 0, 0};
+      }
     } else {
       for (int idx = tid; idx < ROWS * K0p; idx += NT) {
         const int rr = idx / K0p, cc = idx - rr * K0p;
         const long long e = row0 + rr;
-        s_act[rr * S + cc] = (cc < K0 && e < a.m) ? (a.x_bf16 ? __uint_as_float((unsigned)((const unsigned short*)a.x)[e * K0 + cc] << 16) : a.x[e * K0 + cc]) : 0.f;
+        store_split1(s_act, rr, cc, S, (cc < K0 && e < a.m) ? (a.x_bf16 ? __uint_as_float((unsigned)((const unsigned short*)a.x)[e * K0 + cc] << 16) : a.x[e * K0 + cc]) : 0.f);
       }
     }
   }
-  __syncthreads();
+  lds_barrier();  // (not __syncthreads: that would drain the weight ring as well)
   MLP_STAMP(1);
+  // per layer: hot loop, raw sums -> image, conversion pass (one copy: above)
   int boff = 0;
+#pragma unroll 1
   for (int l = 0; l < a.L; ++l) {
     const int T = tiles_per_wave(pad16(a.dims[l + 1]) / 16);
     const bool last = l == a.L - 1;
-    if (NW <= 4 && T == 8) mlp_layer<(NW <= 4 ? 8 : 4), RT, RG, KIND>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);  // (eight waves: at most 4 tiles each)
-    else if (T == 4) mlp_layer<4, RT, RG, KIND>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);
-    else if (MIN_TILES >= 2 || T == 2) mlp_layer<(MIN_TILES > 2 ? MIN_TILES : 2), RT, RG, KIND>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);
-    else mlp_layer<1, RT, RG, KIND>(a, l, last, s_act, s_bias + boff, s_noise, wave, lane, row_block, ring, stream, c0);
-    boff += pad16(a.dims[l + 1]);
+    const float* const bias_l = s_bias + boff;
+    if (NW <= 4 && T == 8) mlp_layer<(NW <= 4 ? 8 : 4), RT, RG, KIND>(a, l, last, s_act, bias_l, s_noise, wave, lane, row_block, ring, stream, c0);  // (eight waves: at most 4 tiles each)
+    else if (T == 4) mlp_layer<4, RT, RG, KIND>(a, l, last, s_act, bias_l, s_noise, wave, lane, row_block, ring, stream, c0);
+    else if (MIN_TILES >= 2 || T == 2) mlp_layer<(MIN_TILES > 2 ? MIN_TILES : 2), RT, RG, KIND>(a, l, last, s_act, bias_l, s_noise, wave, lane, row_block, ring, stream, c0);
+    else mlp_layer<1, RT, RG, KIND>(a, l, last, s_act, bias_l, s_noise, wave, lane, row_block, ring, stream, c0);
     MLP_STAMP(2 + l);
-    // training forward (lt_mlp_forward_pair): the layer's activations, still in LDS, also go to memory for the backward pass -
-    // a cooperative, coalesced copy between the layers, where no accumulator is live (write_back itself is at the register limit)
-    if (!last && a.act_out[l]) {
-      const int N = a.dims[l + 1], n4 = N >> 2;
-      float* const dst = a.act_out[l];
-      for (int idx = tid; idx < ROWS * n4; idx += 64 * NW) {
-        const int rr = idx / n4, c4 = idx - rr * n4;
-        const long long e = row0 + rr;
-        if (e < a.m) *(f32x4*)(dst + e * N + 4 * c4) = *(const f32x4*)(s_act + rr * S + 4 * c4);
-      }
-    }
+    if (last) break;
+    lds_barrier();  // the raw sums of the whole layer are in the image
+    convert_pass<KIND, ROWS>(a, l, s_act, bias_l, tid, row0);
+    boff += pad16(a.dims[l + 1]);
+    lds_barrier();
   }
 }
 
