@@ -22,28 +22,33 @@
 // 5.3x less matrix-pipe time than the exact-f32 form.
 //
 // Structure:
-//   * a workgroup (NW = 4 waves, one per SIMD) owns 16 * RT batch rows; their activations live in LDS as f32 rows
-//     ([rows][S], S = widest layer + 4 floats) and never visit HBM between layers.  The (hi, lo) split of the activations
-//     happens in the HOT loop, on the VALU slots the MFMAs leave idle - not in the per-layer epilogues: straight-line code
-//     that runs once per layer is instruction-cache-cold, and measured 3 x slower per instruction than the loop body;
+//   * a workgroup (NW = 8 waves, two per SIMD) owns 16 * RT batch rows; their activations live in LDS ([rows][S] slots of 4
+//     bytes per element, S = widest layer + 4) and never visit HBM between layers.  The image holds them ALREADY SPLIT: a
+//     group of 8 consecutive elements is 16 B of hi halves + 16 B of lo halves, made once per element - by the prologue for
+//     the input rows, by convert_pass (all threads, in place over the raw f32 sums) behind a hidden layer.  (Round 2 split
+//     them in the hot loop, every wave for itself in front of its MFMAs, to keep arithmetic out of the once-per-layer code: the
+//     narrow layers then ran at the VALU rate of NW redundant conversions, and the epilogues stayed cold all the same.)
+//   * WHAT BOUNDS THE SMALL-BATCH LAUNCH.  A 4096-env rollout step gives every CU 32 rows of one network: 1.37 MB of weights
+//     through the CU's L2 port (60-90 GB/s per CU: ~16 us) and, around that, code that runs ONCE per launch - prologue, layer
+//     epilogues, the narrow last layers, the policy head - at instruction-fetch speed on cold caches (~14 cycles per
+//     instruction; the step kernel between two launches replaces the instruction cache's contents).  Hence: eight waves (the
+//     once-through phases are latency-bound, and a second wave per SIMD fills them: 33.0 -> 30.2 us), ONE rolled copy of the
+//     conversion loop shared by all layers (30.2 -> 29.8 us) instead of one unrolled epilogue per layer shape;
 //   * out^T = W . act^T on v_mfma_f32_16x16x32_f16: the weight tile is the A operand (16 output features x 32 k), the
 //     activations are the B operand (32 k x 16 rows), so a lane ends up with 4 CONSECUTIVE output features of ONE row ->
-//     the next layer's input is written back with one ds_write_b128;
+//     the raw sums go back into the image with one ds_write_b128 per tile;
 //   * each wave owns T = N/(16 NW) output tiles x RT row tiles (independent accumulators); RT = 2 from 8192 rows per launch
 //     (every CU still gets a workgroup), 4 from 16384 (several rounds of workgroups, each streaming the weights again);
 //   * the weights are pre-packed once per policy update (lt_mlp_pack) - already split into (hi, lo) f16 - into ONE LINEAR
 //     STREAM PER WAVE of 1-KiB chunks (64 lanes x 16 B) in exactly the order the wave consumes them, across layers: per
-//     32-wide k-group one item of T x (hi chunk, lo chunk).  The kernel keeps a register ring per wave (32 chunks at one row
-//     tile, 16 above) and refills a slot right after its MFMAs, so 16-32 KiB per wave are always in flight and the first weights of layer l+1 are already
-//     on their way while layer l finishes.  Every wave-instruction of the stream is one fully coalesced
-//     global_load_dwordx4; all workgroups stream the same ~1.5 MB per network from L2.  That stream is what bounds the
-//     kernel: a CU draws ~30 B/clk from L2 however many CUs stream (MI355X_MICROARCH.md, indexed rows from L2), i.e.
-//     ~20 us per network - the MFMAs of 32 rows take 7 us;
-//   * biases live in LDS (staged once) and are added in the epilogue;
-//   * everything outside the layer loops runs ONCE per launch, i.e. on cold instruction caches (~14 cycles per instruction):
-//     the prologue and the epilogues are written for instruction count and independent issue, the policy head's noise is
-//     drawn in the prologue under the latency of the input rows, and a narrow last layer goes through the two-tile loop
-//     the layer before it has just run instead of a one-tile instantiation of its own.
+//     32-wide k-group one item of T x (hi chunk, lo chunk).  The kernel keeps a register ring of 16 chunks per wave (128 KiB
+//     in flight per CU) and refills a slot right after its MFMAs, so the first weights of layer l+1 are already on their way
+//     while layer l finishes.  Every wave-instruction of the stream is one fully coalesced global_load_dwordx4; all
+//     workgroups stream the same ~1.4 MB per network from L2 (measured with stamps: 89 GB/s per CU in the first layer);
+//   * biases live in LDS (staged once) and are added by the conversion pass;
+//   * the policy head's noise is drawn in the prologue by the last wave under the latency of the input rows, and a narrow
+//     last layer goes through the two-tile loop the layer before it has just run instead of a one-tile instantiation of its
+//     own, on waves that had no share in the layer before it (first_wave).
 //
 // The policy network's last layer carries the sampling epilogue of lt_rollout_act (a = mu + sigma N(0,1), log-prob,
 // storage-slot writes), so the actor side of a rollout step needs no further launch.
@@ -65,7 +70,7 @@ constexpr int RING = 32;               // chunk granularity of the packed stream
 #ifndef LT_MLP_WAVES
 #define LT_MLP_WAVES 8
 #endif
-constexpr int NW = LT_MLP_WAVES;       // waves per workgroup (one per SIMD)
+constexpr int NW = LT_MLP_WAVES;       // waves per workgroup (two per SIMD)
 constexpr unsigned RS_POLICY = 0x400;  // same Philox stream id as lt_rollout_act
 constexpr int MODE_FORWARD = 0, MODE_POLICY = 1;
 // scale of the low parts - and of the main product's activation operand, so that all three MFMAs of the split sum into ONE
@@ -97,6 +102,16 @@ __host__ __device__ inline int layer_chunks(int K, int N) {
 __host__ __device__ inline int active_waves(int N) {
   const int nt = pad16(N) / 16, T = tiles_per_wave(nt);
   return (nt + T - 1) / T;
+}
+
+// First wave of a layer's active range [first, first + active_waves).  The LAST layer, when it and the layer before it leave
+// waves free, takes the waves BEHIND the previous layer's: such a wave has no chunks in the layer before, so its ring turns
+// to the last layer's weights one layer early and they are in registers when the layer starts (on the previous layer's
+// waves the narrow last layer began with a full L2 round trip: ~1 us).
+__host__ __device__ inline int first_wave(const int* dims, int L, int l) {
+  if (l != L - 1 || l == 0) return 0;
+  const int prev = active_waves(dims[l]), mine = active_waves(dims[l + 1]);
+  return prev + mine <= NW ? prev : 0;
 }
 
 struct MlpArgs {
@@ -143,16 +158,23 @@ __device__ __forceinline__ float activate(float x) {
 // same bytes an f32 row would take: the split is made ONCE per element, by whoever stages it (input rows: the prologue;
 // hidden activations: convert_pass), not by each of the NW waves in front of its MFMAs.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (written on pairs: one v_cvt_pk_f16_f32 rounds two values, and the residual is one v_pk_add_f32 + one v_pk_mul_f32 per pair -
+//  value by value the compiler converts every hi half twice, once for the residual and once for the packed store)
 __device__ __forceinline__ void split4(const f32x4& v, f16x4& hi, f16x4& lo) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float x = fminf(fmaxf(v[i], -F16_CLAMP), F16_CLAMP);
-    const _Float16 h = (_Float16)x;
-    hi[i] = h;
-    lo[i] = (_Float16)((x - (float)h) * LO_SCALE);
+  for (int p = 0; p < 2; ++p) {
+    f32x2 x;
+    x[0] = __builtin_amdgcn_fmed3f(v[2 * p], -F16_CLAMP, F16_CLAMP);
+    x[1] = __builtin_amdgcn_fmed3f(v[2 * p + 1], -F16_CLAMP, F16_CLAMP);
+    const f16x2 h = __builtin_convertvector(x, f16x2);
+    const f32x2 d = (x - __builtin_convertvector(h, f32x2)) * LO_SCALE;
+    const f16x2 l = __builtin_convertvector(d, f16x2);
+    hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
+    lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
   }
 }
-
 // byte offset inside the image of the hi halves of elements 4 c4 .. 4 c4 + 3 of row rr (their lo halves: + 16)
 __device__ __forceinline__ unsigned half_group_at(unsigned rr, unsigned c4, int S) { return (rr * (unsigned)S + (c4 >> 1) * 8u) * 4u + (c4 & 1u) * 8u; }
 __device__ __forceinline__ void store_split4(float* s_act, unsigned at, const f32x4& v) {
@@ -185,6 +207,9 @@ __device__ __forceinline__ f32x4 load_in4(const MlpArgs& a, long long off) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #ifdef LT_MLP_STAMPS
+#ifndef LT_MLP_STAMP_L
+#define LT_MLP_STAMP_L 0  // the layer whose loop end (6) and barrier exit (7) are stamped
+#endif
 __device__ unsigned long long g_mlp_stamps[1024 * 8 * NW];
 #define MLP_STAMP(i) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
   if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_mlp_stamps[blockIdx.x * 8 * NW + (threadIdx.x >> 6) * 8 + (i)] = t_; } while (0)
@@ -315,8 +340,9 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
   const int S = a.stride;
   const int G = pad32(a.dims[l]) / 32;
   const int N = a.dims[l + 1];
-  const int tile0 = wave * T;
-  const bool active = wave < active_waves(N);
+  const int first = first_wave(a.dims, a.L, l);
+  const int tile0 = (wave - first) * T;
+  const bool active = wave >= first && wave < first + active_waves(N);
   const float* const xrow = s_act + r * S + 8 * q;  // row tile rt: + 16 * rt * S; k-group g: + 32 g
   f32x4 am[RT][T];
 #pragma unroll
@@ -374,11 +400,11 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
     }
   }
 #ifdef LT_MLP_STAMPS
-  if (l == 0) MLP_STAMP(6);
+  if (l == LT_MLP_STAMP_L) MLP_STAMP(6);
 #endif
   lds_barrier();  // every wave is done reading this layer's input
 #ifdef LT_MLP_STAMPS
-  if (l == 0) MLP_STAMP(7);
+  if (l == LT_MLP_STAMP_L) MLP_STAMP(7);
 #endif
   if (!last) {
     if (active) raw_store<T, RT>(am, s_act, r, q, S, tile0, pad32(N));
@@ -407,7 +433,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
       }
     } else {
       // policy head: N == 12 -> one tile, held by wave 0; lane (r, q) owns actions 4q..4q+3 of env e (q == 3: padding)
-      if (wave == 0) {
+      if (wave == first) {
         float lp = 0.f;
         if (q < 3 && e < a.m) {
           // the N(0,1) draws and their log-density were made while the input rows were in flight (policy_noise)
@@ -502,8 +528,9 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
   float bv[BB];
 #pragma unroll
   for (int u = 0; u < BB; ++u) bv[u] = bsrc[min(tid + u * NT, a.bias_total - 1)];
-  // weight stream: a full ring in flight.  Two row tiles need 128 accumulator registers per lane: a 16-slot ring then
-  // keeps the allocation clear of spills (a scratch reload in a layer epilogue would sit behind the whole ring in the queue).
+  // weight stream: a full ring in flight.  Two waves per SIMD leave a wave 256 registers: accumulators (16 RT at the widest
+  // layer), fragments (16 RT) and a 16-slot ring (64) fit without scratch at two row tiles (a scratch reload in a layer
+  // epilogue would sit behind the whole ring in the queue); four row tiles spill 88 bytes.
 #ifndef LT_MLP_RING2
 #define LT_MLP_RING2 16  // ring slots at two row tiles (32 fits without scratch and measured slower: 35.5 against 33.7 us at 4096 rows)
 #endif
@@ -524,14 +551,15 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
     for (int u = 0; u < BB; ++u) s_bias[min(tid + u * NT, a.bias_total - 1)] = bv[u];
     for (int i = tid + BB * NT; i < a.bias_total; i += NT) s_bias[i] = bsrc[i];
     if (vec_in) {
+      if (a.x_bf16) {  // (uniform: two straight-line sequences, not a select per value)
 #pragma unroll
-      for (int u = 0; u < B; ++u) {
-        f32x4 v = vin[u];
-        if (a.x_bf16) {
-          const unsigned w0 = __float_as_uint(v[0]), w1 = __float_as_uint(v[1]);
-          v = f32x4{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xFFFF0000u), __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xFFFF0000u)};
+        for (int u = 0; u < B; ++u) {
+          const unsigned w0 = __float_as_uint(vin[u][0]), w1 = __float_as_uint(vin[u][1]);
+          store_split4(s_act, lds_at[u], f32x4{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xFFFF0000u), __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xFFFF0000u)});
         }
-        store_split4(s_act, lds_at[u], v);
+      } else {
+#pragma unroll
+        for (int u = 0; u < B; ++u) store_split4(s_act, lds_at[u], vin[u]);
       }
       for (unsigned idx = tid + B * NT; idx < tv; idx += NT) {  // inputs wider than one batch
         const unsigned rr = idx / k4, cc = idx - rr * k4;
@@ -577,6 +605,7 @@ struct PackArgs {
   const float* w; const float* b;
   int K, N;
   long long chunk_off[NW];  // first chunk of this layer in each wave's stream (absolute, in chunks)
+  int first;                // first active wave of the layer (first_wave)
   long long bias_float_off; // first float of this layer's (pad16(N)) bias slice
   float* packed;
 };
@@ -607,7 +636,7 @@ __global__ void lt_mlp_pack_kernel(const PackAll all) {
     }
     out = __builtin_bit_cast(float4, h);
   }
-  *(float4*)(p.packed + ((p.chunk_off[wv] + c) * 64 + lane) * 4) = out;
+  *(float4*)(p.packed + ((p.chunk_off[p.first + wv] + c) * 64 + lane) * 4) = out;
 }
 
 bool desc_ok(const lt_mlp_desc* d) {
@@ -617,7 +646,7 @@ bool desc_ok(const lt_mlp_desc* d) {
   for (int l = 0; l <= d->num_layers; ++l)
     if (d->dims[l] < 1 || d->dims[l] > LT_MLP_MAX_WIDTH) return false;
   for (int l = 1; l <= d->num_layers; ++l)
-    if (d->dims[l] > 512) return false;  // 8 output tiles per wave at most (NW = 4)
+    if (d->dims[l] > 512) return false;  // 4 output tiles per wave at most (NW = 8; 8 at NW = 4)
   return true;
 }
 
@@ -637,7 +666,8 @@ Geometry geometry(const lt_mlp_desc* d) {
     long long off = 0;
     for (int l = 0; l < d->num_layers; ++l) {
       g.layer_off[l][w] = base + off;
-      if (w < active_waves(d->dims[l + 1])) off += layer_chunks(d->dims[l], d->dims[l + 1]);
+      const int first = first_wave(d->dims, d->num_layers, l);
+      if (w >= first && w < first + active_waves(d->dims[l + 1])) off += layer_chunks(d->dims[l], d->dims[l + 1]);
     }
     base += off + RING;
   }
@@ -667,8 +697,8 @@ void fill_args(const lt_mlp_desc* d, MlpArgs& a) {
 }
 
 // Row tiles per workgroup: the most (of 1, 2) that still leaves every CU a workgroup - doubling halves the bytes streamed
-// from L2 per FLOP, and the kernel is bound by L2 -> CU bandwidth (every workgroup streams the whole network), not by the
-// MFMA rate.  (4 row tiles = 256 accumulator + 128 ring registers per lane: past the point where the allocator spills.)
+// from L2 per FLOP (every workgroup streams the whole network) - and 4 once the grid has several rounds of workgroups anyway
+// (measured, policy + value launch: 8192 envs 52.1 us against 58.5 at two row tiles, 16384: 97.5 / 112.5, 32768: 187.5 / 219.6).
 int pick_row_tiles(long long rows_total_blocks16) {
   if (rows_total_blocks16 / 4 >= 256) return 4;  // large batches: several rounds of workgroups - each round streams the weights again
   return rows_total_blocks16 / 2 >= 256 ? 2 : 1;
@@ -763,6 +793,7 @@ int lt_mlp_pack(const lt_mlp_desc* desc, const float* const* weights, const floa
     PackArgs& p = all.layer[l];
     p.w = weights[l]; p.b = biases[l]; p.K = desc->dims[l]; p.N = desc->dims[l + 1]; p.packed = packed;
     for (int w = 0; w < NW; ++w) p.chunk_off[w] = g.layer_off[l][w];
+    p.first = first_wave(desc->dims, desc->num_layers, l);
     p.bias_float_off = g.bias_chunk * 256 + bias_off;
     bias_off += pad16(p.N);
     long long total = (long long)active_waves(p.N) * layer_chunks(p.K, p.N) * 64;

@@ -40,7 +40,7 @@ for m in [int(a) for a in sys.argv[1:]] or [4096]:
         print("stamps (10 ns ticks -> ns), mean over blocks, per wave 0..3; times since kernel start")
         names = ["start", "input staged"] + [f"layer {l} done" for l in range(L)]
         for i, nm in enumerate(names):
-            print(f"   {nm:16s}", " ".join(f"{(st[:, w, i] - t0).mean() * 10:8.0f}" for w in range(4)))
-        print(f"   {'L0 barrier passed':16s}", " ".join(f"{(st[:, w, 7] - t0).mean() * 10:8.0f}" for w in range(4)))
-        print(f"   {'L0 loop done':16s}", " ".join(f"{(st[:, w, 6] - t0).mean() * 10:8.0f}" for w in range(4)))
+            print(f"   {nm:16s}", " ".join(f"{(st[:, w, i] - t0).mean() * 10:8.0f}" for w in range(NWV)))
+        print(f"   {'Lx barrier passed':16s}", " ".join(f"{(st[:, w, 7] - t0).mean() * 10:8.0f}" for w in range(NWV)))
+        print(f"   {'Lx loop done':16s}", " ".join(f"{(st[:, w, 6] - t0).mean() * 10:8.0f}" for w in range(NWV)))
         print("   last block end - first start:", (st[:, :, L + 1].max() - t0) * 10, "ns")
