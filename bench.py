@@ -273,14 +273,17 @@ def main() -> None:
         flop = 2.0 * n * (2 * macs + dims[-1] * (12 + 1))
         # The kernel evaluates an f32-equivalent MAC as THREE f16 MFMAs (csrc/lt_mlp.hip), so its matrix-pipe peak is the f16
         # peak / 3; what bounds it in practice is the weight stream every workgroup pulls from its XCD's L2 (2 f16 planes =
-        # 4 bytes per weight, once per workgroup of 32 rows).  Both fractions are <= 1 by construction.
+        # 4 bytes per weight, once per workgroup of 16 x rt rows).  Both fractions are <= 1 by construction.
         tflops = flop / (mlp_ms * 1e-3) / 1e12
-        wg_per_net = (n + 31) // 32
+        t16 = 2 * ((n + 15) // 16)  # 16-row tiles of both networks; row tiles per workgroup as csrc/lt_mlp.hip::pick_row_tiles
+        rt = 4 if t16 // 4 >= 256 else (2 if t16 // 2 >= 256 else 1)
+        wg_per_net = (n + 16 * rt - 1) // (16 * rt)
         stream_bytes = 2 * wg_per_net * 4.0 * (macs + dims[-1] * 6.5)  # actor (12 outputs) + critic (1): (12 + 1) / 2 per net
         l2_rate = stream_bytes / (mlp_ms * 1e-3) / 1e9
         roofline["mlp"] = {"bound": "l2-stream", "kernel": "lt_mlp_kernel (actor + critic + sampling)", "flop_per_launch": flop,
                            "kernel_ms": mlp_ms, "achieved": tflops, "peak": MFMA_F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s (f32-equivalent)",
                            "frac": tflops / (MFMA_F16_PEAK_TFLOPS / 3.0),
+                           "rows_per_workgroup": 16 * rt,
                            "l2_stream": {"bytes_per_launch": stream_bytes, "achieved": l2_rate, "peak": L2_STREAM_PEAK_GBS, "unit": "GB/s",
                                          "frac": l2_rate / L2_STREAM_PEAK_GBS},
                            "ideal_f32_mfma_kernel_tflops": MFMA_F32_PEAK_TFLOPS}

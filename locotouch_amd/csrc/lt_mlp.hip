@@ -124,6 +124,7 @@ struct MlpArgs {
   int bias_total;             // floats of the bias block (sum of pad16(N_l))
   int noise_off;              // MODE_POLICY: float offset inside the LDS image of the [rows][16] block of N(0,1) draws (launch())
   unsigned in_magic;          // dims[0] % 4 == 0: floor(2^32 / (dims[0] / 4)) + 1, the reciprocal the input staging divides by; else 0
+  unsigned in_magic2;         // dims[0] % 4 == 2 (f32 rows): the same for pairs, floor(2^32 / (dims[0] / 2)) + 1; else 0
   long long bias_chunk;       // chunk offset of the bias block inside `packed`
   long long wave_base[NW];    // chunk offset of each wave's stream inside `packed`
   const float* packed;
@@ -175,6 +176,17 @@ __device__ __forceinline__ void split4(const f32x4& v, f16x4& hi, f16x4& lo) {
     lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
   }
 }
+// a pair of consecutive elements (inputs whose width is 2 mod 4, e.g. the locomotion task's 270): hi halves at `at`, lo at + 16
+__device__ __forceinline__ void store_split2(float* s_act, unsigned at, f32x2 v) {
+  f32x2 x;
+  x[0] = __builtin_amdgcn_fmed3f(v[0], -F16_CLAMP, F16_CLAMP);
+  x[1] = __builtin_amdgcn_fmed3f(v[1], -F16_CLAMP, F16_CLAMP);
+  const f16x2 h = __builtin_convertvector(x, f16x2);
+  const f32x2 d = (x - __builtin_convertvector(h, f32x2)) * LO_SCALE;
+  *(f16x2*)((char*)s_act + at) = h;
+  *(f16x2*)((char*)s_act + at + 16) = __builtin_convertvector(d, f16x2);
+}
+__device__ __forceinline__ unsigned pair_at(unsigned rr, unsigned c2, int S) { return (rr * (unsigned)S + (c2 >> 2) * 8u) * 4u + (c2 & 3u) * 4u; }
 // byte offset inside the image of the hi halves of elements 4 c4 .. 4 c4 + 3 of row rr (their lo halves: + 16)
 __device__ __forceinline__ unsigned half_group_at(unsigned rr, unsigned c4, int S) { return (rr * (unsigned)S + (c4 >> 1) * 8u) * 4u + (c4 & 1u) * 8u; }
 __device__ __forceinline__ void store_split4(float* s_act, unsigned at, const f32x4& v) {
@@ -522,6 +534,24 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
       }
     }
   }
+  // widths that are 2 mod 4 (f32 rows): the same scheme on pairs - two 8-byte loads per float4 slot
+  const bool vec2_in = a.in_magic2 != 0;
+  const unsigned p2 = K0 >> 1, tv2 = ROWS * p2;
+  unsigned lds_at2[B];
+  if (vec2_in) {
+    const char* const xb = (const char*)a.x + row0 * K0 * 4;
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned idx = min((unsigned)tid + (2 * u + h) * NT, tv2 - 1u);
+        const unsigned rr = __umulhi(idx, a.in_magic2), c2 = idx - rr * p2;
+        (h ? lds_at2[u] : lds_at[u]) = pair_at(rr, c2, S);
+        const f32x2 w = __builtin_nontemporal_load((const f32x2*)(xb + 4u * (min(rr, rmax) * K0 + 2 * c2)));
+        vin[u][2 * h] = w[0]; vin[u][2 * h + 1] = w[1];
+      }
+    }
+  }
   // biases: requested before the weight ring as well (behind it they would wait for every chunk of it)
   constexpr int BB = 4;
   const float* const bsrc = a.packed + a.bias_chunk * 256;
@@ -569,6 +599,21 @@ __global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
         const unsigned at = half_group_at(i & (ROWS - 1), k4 + i / ROWS, S);
         *(f16x4*)((char*)s_act + at) = f16x4{0, 0, 0, 0};
         *(f16x4*)((char*)s_act + at + 16) = f16x4{0, 0, 0, 0};
+      }
+    } else if (vec2_in) {
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        store_split2(s_act, lds_at[u], f32x2{vin[u][0], vin[u][1]});
+        store_split2(s_act, lds_at2[u], f32x2{vin[u][2], vin[u][3]});
+      }
+      for (unsigned idx = tid + 2 * B * NT; idx < tv2; idx += NT) {  // inputs wider than one batch
+        const unsigned rr = idx / p2, c2 = idx - rr * p2;
+        store_split2(s_act, pair_at(rr, c2, S), __builtin_nontemporal_load((const f32x2*)(a.x + (row0 + min(rr, rmax)) * K0 + 2 * c2)));
+      }
+      for (int i = tid; i < ROWS * ((K0p >> 1) - (int)p2); i += NT) {  // the k padding: zero halves
+        const unsigned at = pair_at(i & (ROWS - 1), p2 + i / ROWS, S);
+        *(f16x2*)((char*)s_act + at) = f16x2{0, 0};
+        *(f16x2*)((char*)s_act + at + 16) = f16x2{0, 0};
       }
     } else {
       for (int idx = tid; idx < ROWS * K0p; idx += NT) {
@@ -693,6 +738,7 @@ void fill_args(const lt_mlp_desc* d, MlpArgs& a) {
   a.bias_total = g.bias_total;
   // exact for every index below ROWS x K0/4 as long as ROWS (K0/4)^2 < 2^32 - LDS holds no such row; K0 = 4 has no 32-bit reciprocal
   a.in_magic = (d->dims[0] % 4 == 0 && d->dims[0] >= 8) ? (unsigned)(0x100000000ull / (unsigned)(d->dims[0] / 4)) + 1u : 0u;
+  a.in_magic2 = (d->dims[0] % 4 == 2 && d->dims[0] >= 6 && d->input_format == LT_ROWS_F32) ? (unsigned)(0x100000000ull / (unsigned)(d->dims[0] / 2)) + 1u : 0u;
   a.bias_chunk = g.bias_chunk;
 }
 

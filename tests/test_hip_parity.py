@@ -686,7 +686,11 @@ def test_training_loop_runs_and_checkpoints(tmp_path):
 
 
 @pytest.mark.parametrize("dims,act,m", [((348, 512, 256, 128, 12), "elu", 4096), ((348, 512, 256, 128, 1), "elu", 1000),
-                                        ((45, 64, 64, 7), "relu", 37), ((270, 256, 128, 128, 12), "tanh", 50), ((33, 20), "elu", 16)])
+                                        ((45, 64, 64, 7), "relu", 37), ((270, 256, 128, 128, 12), "tanh", 50), ((33, 20), "elu", 16),
+                                        # the locomotion task's width (2 mod 4: pair-wise input staging) at two and four row tiles, and inputs
+                                        # wider than one staging batch on the pair-wise and the float4 path
+                                        ((270, 512, 256, 128, 12), "elu", 9000), ((270, 512, 256, 128, 1), "elu", 40000),
+                                        ((774, 64, 8), "elu", 300), ((1000, 40, 4), "elu", 100)])
 def test_fused_mlp_matches_torch(dims, act, m):
     """lt_mlp_forward (f16 MFMA with error-compensated operand splitting, one launch) against the torch fp32 modules it replaces; tolerance 2e-5 * scale
     (both are fp32 accumulations, only the summation order differs)."""
