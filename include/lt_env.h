@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 9
+#define LT_ABI_VERSION 10
 
 /* error codes */
 #define LT_OK 0
@@ -76,6 +76,13 @@ enum lt_term_bit {
   LT_T_TIME_OUT = 0, LT_T_BASE_ORIENTATION, LT_T_BASE_HEIGHT, LT_T_BASE_CONTACT, LT_T_HIP_CONTACT,
   LT_T_OBJECT_BELOW_ROBOT, LT_T_OBJECT_BAD_ROLL, LT_NUM_TERM_BITS
 };
+/* Termination terms outside the fused set (a cfg's own TerminationTermCfg, time_out = False - the TerminationManager ORs every
+ * term into `terminated` [DEP]; reference cfg: locomotion_base_env_cfg.py:296-313): the caller evaluates the term on the state a step
+ * left (lt_env_get_view) and sets LT_TERM_REQUEST_BIT in LT_F_TERM_BITS of the envs it fires for; the NEXT lt_env_step* reads the
+ * bit before it rewrites the word, reports LT_T_USER among that step's bits and terminates the env (dones, the `alive` term and the
+ * reset like any other termination) - one env step later than a fused term would.  LT_T_USER has no `term_enabled` entry. */
+#define LT_T_USER 7
+#define LT_TERM_REQUEST_BIT 30
 
 /*
  * Environment configuration.  Every member after `seed` is a 4-byte int32_t or float (arrays of them), so

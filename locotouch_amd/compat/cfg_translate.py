@@ -103,7 +103,8 @@ TACTILE_FORMATS = {"BinaryTactileSignals": "LT_TACTILE_BINARY", "NormalizedTacti
 
 def translate(env_cfg, seed: int | None = None, omit_groups: tuple = (), collect_unknown_rewards: bool = False) -> "_abi.LtCfg":
     """`collect_unknown_rewards`: a reward term the fused kernels do not know is not an error - it is returned in
-    `cfg.extra_reward_terms` [(name, func, weight, params)] for the slow torch path (compat/scene_views.py: evaluated on
+    `cfg.extra_reward_terms` [(name, func, weight, params)], an unknown termination term (time_out = False) in
+    `cfg.extra_termination_terms` [(name, func, params)], for the slow torch path (compat/scene_views.py: evaluated on
     IsaacLab-layout views after every step and added to the kernel's reward)."""
     kind = task_kind(env_cfg)
     has_obj = kind != C["LT_TASK_LOCOMOTION"]
@@ -224,7 +225,11 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = (), collect
         _need(has_obj, "gait-with-object needs an object in the scene")
 
     # ---- terminations (locomotion_base_env_cfg.py:296-313, mdp/terminations.py) ----
+    extra_terminations = []
     for name, term in _terms(env_cfg.terminations).items():
+        if name not in _TERMINATIONS and collect_unknown_rewards and not bool(term.time_out):
+            extra_terminations.append((name, term.func, dict(term.params or {})))  # slow path: compat/scene_views.py (LT_T_USER)
+            continue
         _need(name in _TERMINATIONS, f"termination term {name!r} has no fused implementation")
         enum, fn = _TERMINATIONS[name]
         _need(_name(term.func) == fn, f"termination {name!r}: func {_name(term.func)} != {fn}")
@@ -404,6 +409,7 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = (), collect
         cfg.cur_repeat_times[0], cfg.cur_repeat_times[1] = int(p["repeat_times_lin"]), int(p["repeat_times_ang"])
         cfg.cur_max_distance_bins = int(p["max_distance_bins"])
     cfg.extra_reward_terms = extra_terms  # (a Python attribute beside the C struct: empty unless collect_unknown_rewards)
+    cfg.extra_termination_terms = extra_terminations
     return cfg
 
 

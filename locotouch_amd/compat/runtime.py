@@ -87,7 +87,7 @@ class ManagedEnv:
     """What `gym.make` returns: the HIP env behind the attribute surface the scripts and `RslRlVecEnvWrapper` touch
     (`unwrapped`, `cfg`, `num_envs`, `device`, `step_dt`, `max_episode_length`, `episode_length_buf`, `close`)."""
 
-    def __init__(self, task_id: str, cfg, vec_env, extra_rewards=()):
+    def __init__(self, task_id: str, cfg, vec_env, extra_rewards=(), extra_terminations=()):
         self.task_id, self.cfg, self.vec = task_id, cfg, vec_env
         # reward terms the fused kernels do not know: evaluated in torch on IsaacLab-layout views after every step and added to
         # the kernel's reward (compat/scene_views.py; the slow path of SURVEY.md §8(b) B3)
@@ -98,6 +98,8 @@ class ManagedEnv:
             self.extra = ExtraTerms(vec_env)
             for name, func, weight, params in extra_rewards:
                 self.extra.add_reward(name, func, weight, params)
+        for name, func, params in extra_terminations:
+            self.add_termination_term(name, func, params)
 
     def add_reward_term(self, name: str, func, weight: float, params: dict | None = None) -> None:
         """Attach a user reward term `func(env, **params) -> (N,)` (reference term signature, mdp/rewards.py:15-20)."""
@@ -106,6 +108,15 @@ class ManagedEnv:
 
             self.extra = ExtraTerms(self.vec)
         self.extra.add_reward(name, func, weight, params)
+
+    def add_termination_term(self, name: str, func, params: dict | None = None) -> None:
+        """Attach a user termination term `func(env, **params) -> bool (N,)` (mdp/terminations.py:10-23); it takes effect one env
+        step after it fires (include/lt_env.h, LT_T_USER)."""
+        if self.extra is None:
+            from .scene_views import ExtraTerms
+
+            self.extra = ExtraTerms(self.vec)
+        self.extra.add_termination(name, func, params)
 
     @property
     def scene(self):
@@ -118,7 +129,10 @@ class ManagedEnv:
     def step(self, actions):
         obs, rew, dones, extras = self.vec.step(actions)
         if self.extra:
-            rew = self.extra.apply(rew, dones)
+            if self.extra.terms:
+                rew = self.extra.apply(rew, dones)
+            if self.extra.terminations:
+                self.extra.request_terminations(dones)
         return obs, rew, dones, extras
 
     @property
@@ -169,13 +183,14 @@ def translate_env_cfg(task_id: str, cfg):
 def make_env(task_id: str, cfg):
     if _env_factory is not None:
         vec = _env_factory(task_id, cfg)
-        return ManagedEnv(task_id, cfg, vec, extra_rewards=getattr(getattr(vec, "cfg", None), "extra_reward_terms", ()))
+        return ManagedEnv(task_id, cfg, vec, extra_rewards=getattr(getattr(vec, "cfg", None), "extra_reward_terms", ()),
+                          extra_terminations=getattr(getattr(vec, "cfg", None), "extra_termination_terms", ()))
     from ..env import LocoTouchVecEnv
 
     lt, sizes = translate_env_cfg(task_id, cfg)
     device = getattr(getattr(cfg, "sim", None), "device", None) or "cuda:0"
     return ManagedEnv(task_id, cfg, LocoTouchVecEnv(task_id, device=device, cfg=lt, object_sizes=sizes),
-                      extra_rewards=getattr(lt, "extra_reward_terms", ()))
+                      extra_rewards=getattr(lt, "extra_reward_terms", ()), extra_terminations=getattr(lt, "extra_termination_terms", ()))
 
 
 # ---------------------------------------------------------------------------------------------------------

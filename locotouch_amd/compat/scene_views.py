@@ -9,8 +9,9 @@ the arena views on every access, on the env's device - and `ExtraTerms` evaluate
 Limits, stated: the step kernel resets finished envs inside the step, so a user term sees the post-reset state of an env that just
 finished and its value is dropped there (the fused terms are evaluated before the reset, as the RewardManager does [DEP]);
 contact forces are stored as norms - `net_forces_w_history` carries each body's |F| in the z component (norm-exact, direction not
-kept); air / contact timers exist for the four feet.  User TERMINATION terms are not supported (a reset has to happen inside the
-step kernel) and still raise UnsupportedCfg.
+kept); air / contact timers exist for the four feet.  User TERMINATION terms (time_out = False) are evaluated on the state a step
+left and take effect through the kernel's own termination stage one env step LATER (LT_T_USER in include/lt_env.h: the reset has to
+happen inside the step kernel); user time-out terms still raise UnsupportedCfg.
 """
 from __future__ import annotations
 
@@ -174,10 +175,13 @@ class ExtraTerms:
 
     def __init__(self, vec):
         self.env = TermEnv(vec)
+        self.vec = vec
         self.terms: list = []  # (name, callable, weight, params)
         self.sums: dict = {}
+        self.terminations: list = []  # (name, callable, params)
+        self.term_counts: dict = {}   # name -> envs terminated by the term since the last episode_log read
 
-    def add_reward(self, name: str, func, weight: float, params: dict | None = None) -> None:
+    def _bind(self, func, params, weight=0.0):
         params = dict(params or {})
         for v in params.values():  # SceneEntityCfg-like parameters: names -> ids against this scene (the manager does that at load [DEP])
             if hasattr(v, "resolve") and hasattr(v, "name"):
@@ -185,11 +189,34 @@ class ExtraTerms:
         if isinstance(func, type):  # class term (ManagerTermBase): built with (cfg, env), called like a function
             cfg = type("Cfg", (), {"params": params, "weight": weight, "func": func})()
             func = func(cfg, self.env)
+        return func, params
+
+    def add_termination(self, name: str, func, params: dict | None = None) -> None:
+        """A termination term `func(env, **params) -> bool (N,)` (reference signature, mdp/terminations.py:10-23)."""
+        func, params = self._bind(func, params)
+        self.terminations.append((name, func, params))
+        self.term_counts[name] = 0
+
+    def request_terminations(self, dones: torch.Tensor) -> torch.Tensor:
+        """Evaluate the user termination terms on the state the step left; envs they fire for (and that did not just finish)
+        are terminated by the NEXT step (LocoTouchVecEnv.request_termination).  Returns the mask."""
+        fired = torch.zeros(self.env.num_envs, dtype=torch.bool, device=self.env.device)
+        alive = dones == 0
+        for name, func, params in self.terminations:
+            m = func(self.env, **params).to(torch.bool) & alive
+            self.term_counts[name] += int(m.sum())
+            fired |= m
+        if bool(fired.any()):
+            self.vec.request_termination(fired)
+        return fired
+
+    def add_reward(self, name: str, func, weight: float, params: dict | None = None) -> None:
+        func, params = self._bind(func, params, weight)
         self.terms.append((name, func, float(weight), params))
         self.sums[name] = torch.zeros(self.env.num_envs, device=self.env.device)
 
     def __bool__(self) -> bool:
-        return bool(self.terms)
+        return bool(self.terms) or bool(self.terminations)
 
     def apply(self, reward: torch.Tensor, dones: torch.Tensor) -> torch.Tensor:
         """reward + sum_i weight_i * dt * term_i(env) for the envs that did not just finish (in place on a copy of `reward`)."""

@@ -1055,12 +1055,14 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   LT_STAMP(2);
   // ---- late loads: state the physics never touches (compiler barrier: keep these below the decimation loop) ----
   asm volatile("" ::: "memory");
+  int req_bits = 0;
   {
     float t;
     t = *F(LT_F_CMD, 0); X.cmd = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.cmd_time_left = qbcast<3>(t);
     t = *F(LT_F_CMD_BUF, 0); X.cmd_buf = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.cmd_standing = qbcast<3>(t);
     t = *F(LT_F_EVENT_TIMERS, 0); X.push_robot_left = qbcast<0>(t); X.push_obj_left = qbcast<1>(t);
     X.ep_len = ((const long long*)(arena + L.off_ep_len))[env];
+    if (MODE == MODE_STEP) req_bits = ((const int*)(arena + L.off_term_bits))[env];  // last step's word: carries the caller's termination request (LT_T_USER)
     if (!(HELPERS && MODE == MODE_STEP)) {  // (helper form: wave 1 holds the gait class state and hands it back with the gait term)
       t = *F(LT_F_GAIT_CMD, 0); X.gait_cmd = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.gait_step = qbcast<3>(t);
       G.g_last_air = *F(LT_F_GAIT_LAST_AIR, 0); G.g_last_con = *F(LT_F_GAIT_LAST_CONTACT, 0);
@@ -1131,6 +1133,8 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
           if (fabsf(asinf(go.y)) > c.term_object_roll_limit) bits |= 1 << LT_T_OBJECT_BAD_ROLL;
         }
       }
+      // a termination the caller requested on the state the previous step left (include/lt_env.h, LT_T_USER)
+      if ((req_bits >> LT_TERM_REQUEST_BIT) & 1) bits |= 1 << LT_T_USER;
       time_out = bits & 1;
       terminated = (bits & ~1) != 0;
     }

@@ -236,6 +236,12 @@ class LocoTouchVecEnv:
                                                        p(next_critic), self._stream(), ctypes.byref(ms)), "lt_env_step_rows_profiled")
         return float(ms.value)
 
+    def request_termination(self, mask: torch.Tensor) -> None:
+        """Terminate the envs of `mask` (bool [N]) in the NEXT step: sets LT_TERM_REQUEST_BIT in their LT_F_TERM_BITS word
+        (include/lt_env.h, LT_T_USER - the hook of termination terms outside the fused set, compat/scene_views.py)."""
+        bits = self.view(C["LT_F_TERM_BITS"])
+        bits.bitwise_or_(mask.to(device=self.device, dtype=torch.int32) << C["LT_TERM_REQUEST_BIT"])
+
     def eval_terms(self) -> None:
         _abi.check(self._lib.lt_env_eval_terms(self._handle, self._stream()), "lt_env_eval_terms")
 

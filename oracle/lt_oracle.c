@@ -1653,6 +1653,8 @@ static void step_one(const lt_cfg* cfg, void* arena, const lt_layout* L, const f
     lt_term_in in;
     term_in_from_env(&E, 0, &in);
     bits = lt_oracle_terminations(cfg, &in, E.ep_len, max_len);
+    /* a termination the caller requested on the state the previous step left (include/lt_env.h, LT_T_USER) */
+    if (mode == LT_ORACLE_MODE_STEP && ((((const int32_t*)((char*)arena + L->off_term_bits))[e] >> LT_TERM_REQUEST_BIT) & 1)) bits |= 1 << LT_T_USER;
     time_out = bits & 1;
     terminated = (bits & ~1) != 0;
     ((int32_t*)((char*)arena + L->off_term_bits))[e] = bits;

@@ -83,5 +83,12 @@ class OracleVecEnv:
         extras["log"] = {}
         return obs, torch.from_numpy(self._arr("LT_F_REWARD")), torch.from_numpy(self._arr("LT_F_DONES")), extras
 
+    def request_termination(self, mask: torch.Tensor) -> None:
+        """LocoTouchVecEnv.request_termination on the host arena."""
+        from locotouch_amd import _abi
+
+        bits = self._arr("LT_F_TERM_BITS")
+        bits |= (mask.cpu().numpy().astype(np.int32) << _abi.CONSTS["LT_TERM_REQUEST_BIT"])
+
     def close(self):
         pass

@@ -113,3 +113,50 @@ def test_views_follow_the_isaaclab_layouts():
     assert te.scene["object"].data.root_pos_w.shape == (16, 3) and te.command_manager.get_command("base_velocity").shape == (16, 3)
     ids, names = te.scene["contact_forces"].find_bodies(".*hip")
     assert ids == [1, 2, 3, 4]
+
+
+def base_too_fast_user(env, limit: float, asset_cfg):
+    """a user termination in the reference's style (mdp/terminations.py:10-23): reads asset.data, returns bool (N,)"""
+    asset = env.scene[asset_cfg.name]
+    return torch.norm(asset.data.root_lin_vel_w[:, :2], dim=1) > limit
+
+
+def test_reference_cfg_with_a_user_termination_term_terminates_one_step_later(rt):
+    """B3, terminations: the reference's env cfg with one extra TerminationTermCfg translates; the term is evaluated on the state a
+    step left and the NEXT step terminates the env through the kernel's own termination stage (LT_T_USER, include/lt_env.h)."""
+    from isaaclab.managers import SceneEntityCfg
+    from isaaclab.managers import TerminationTermCfg as DoneTerm
+
+    from locotouch_amd.compat import cfg_translate as T
+    from locotouch_amd.compat.runtime import ManagedEnv
+    from tests.oracle_vec_env import OracleVecEnv
+
+    C = _abi.CONSTS
+    cfg = rt.load_cfg_from_registry(TASK, "env_cfg_entry_point")
+    cfg.scene.num_envs = 64
+    cfg.terminations.base_too_fast = DoneTerm(func=base_too_fast_user, params={"limit": 0.35, "asset_cfg": SceneEntityCfg("robot")})
+    with pytest.raises(T.UnsupportedCfg):
+        T.translate(cfg)  # the strict form still refuses
+    cfg.terminations.user_time_out = DoneTerm(func=base_too_fast_user, time_out=True, params={"limit": 9.0, "asset_cfg": SceneEntityCfg("robot")})
+    with pytest.raises(T.UnsupportedCfg):
+        rt.translate_env_cfg(TASK, cfg)  # a user TIME-OUT term is still outside what the kernels can honour
+    del cfg.terminations.user_time_out
+    lt, sizes = rt.translate_env_cfg(TASK, cfg)
+    assert [t[0] for t in lt.extra_termination_terms] == ["base_too_fast"] and not lt.extra_reward_terms
+    vec = OracleVecEnv(TASK, cfg=lt, object_sizes=sizes)
+    env = ManagedEnv(TASK, cfg, vec, extra_terminations=lt.extra_termination_terms)
+    g = torch.Generator().manual_seed(1)
+    pending = torch.zeros(64, dtype=torch.bool)
+    fired_total = 0
+    for _ in range(40):
+        act = 0.8 * torch.randn(64, 12, generator=g)
+        _, _, dones, _ = env.step(act)
+        bits = torch.from_numpy(vec._arr("LT_F_TERM_BITS").copy())
+        user = ((bits >> C["LT_T_USER"]) & 1).bool()
+        assert torch.equal(user, pending), "exactly the envs requested after the previous step terminate by LT_T_USER in this one"
+        assert bool((dones[user] != 0).all()) and bool((torch.from_numpy(vec._arr("LT_F_TERMINATED").copy())[user] != 0).all())
+        pending = ((bits >> C["LT_TERM_REQUEST_BIT"]) & 1).bool()  # what the slow path requested on the state this step left
+        v = vec.field("LT_F_ROOT_LIN_VEL_W")[:, 0, :2]
+        assert torch.equal(pending, (v.norm(dim=1) > 0.35) & (dones == 0))
+        fired_total += int(user.sum())
+    assert fired_total > 5 and env.extra.term_counts["base_too_fast"] >= fired_total

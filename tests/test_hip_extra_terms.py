@@ -48,3 +48,54 @@ def test_views_and_a_user_reward_term_over_the_hip_env():
         torch.testing.assert_close(rew, want, rtol=1e-5, atol=1e-6)
         changed += int((rew != rew0).sum())
     assert changed > n
+
+
+def test_a_requested_termination_matches_the_oracle_and_resets_in_the_next_step():
+    """LT_T_USER (include/lt_env.h): envs whose LT_F_TERM_BITS word carries LT_TERM_REQUEST_BIT terminate in the next step - HIP
+    kernel (both forms) and oracle from byte-identical arenas - and a user termination term attached through ManagedEnv drives it."""
+    import numpy as np
+    import torch
+
+    from locotouch_amd import _abi
+    from locotouch_amd.compat.runtime import ManagedEnv
+    from locotouch_amd.env import LocoTouchVecEnv
+    from tests import oracle_lib
+    from tests.parity_util import compare_arenas
+
+    C = _abi.CONSTS
+    for n in (128, 8208):  # helper form / one-wave form of the step kernel
+        env = LocoTouchVecEnv(TASK, num_envs=n, device="cuda:0", seed=9, debug_terms=1)
+        ora = oracle_lib.OracleEnv(env.cfg)
+        ora.reset_all()
+        g = torch.Generator().manual_seed(3)
+        for t in range(4):
+            act = 0.5 * torch.randn(n, 12, generator=g)
+            env._arena_aligned.copy_(torch.from_numpy(ora.arena))  # identical start state
+            want = torch.zeros(n, dtype=torch.bool)
+            want[t::7] = True
+            env.request_termination(want.to("cuda:0"))
+            ora.arena[:] = env._arena_aligned.cpu().numpy()  # the request bits travel with the bytes
+            env.step(act.to("cuda:0"))
+            ora.step(act.numpy())
+            torch.cuda.synchronize()
+            compare_arenas(env, ora, what=f"n={n} step {t} with termination requests", max_flip_frac=0.05, max_event_frac=max(2.0 / n, 1e-3))  # (the allowances of test_hip_parity.py)
+            bits = env.field("LT_F_TERM_BITS").cpu()
+            assert torch.equal(((bits >> C["LT_T_USER"]) & 1).bool(), want) and not bool(((bits >> C["LT_TERM_REQUEST_BIT"]) & 1).any())
+            assert bool((env.field("LT_F_DONES").cpu()[want] != 0).all()) and bool((env.episode_length_buf.cpu()[want] == 0).all())
+    # the slow path end to end: a term on the views, one step of delay
+    n = 256
+    vec = LocoTouchVecEnv(TASK, num_envs=n, device="cuda:0", seed=4)
+    env = ManagedEnv(TASK, None, vec)
+    env.add_termination_term("tilted", lambda e, limit: e.scene["robot"].data.projected_gravity_b[:, 2] > -limit, {"limit": 0.985})
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    pending = torch.zeros(n, dtype=torch.bool, device="cuda:0")
+    total = 0
+    for _ in range(30):
+        _, _, dones, _ = env.step(0.8 * torch.randn(n, 12, device="cuda:0", generator=g))
+        bits = vec.field("LT_F_TERM_BITS")
+        user = ((bits >> C["LT_T_USER"]) & 1).bool()
+        assert torch.equal(user, pending) and bool((dones[user] != 0).all())
+        pending = ((bits >> C["LT_TERM_REQUEST_BIT"]) & 1).bool()
+        total += int(user.sum())
+    assert total > 0
+    _ = np
