@@ -230,10 +230,10 @@ __device__ __forceinline__ V3 qapply_inv(Q4 q, V3 v) {
   return v - q.w * t + cross(qv, t);
 }
 __device__ __forceinline__ Q4 q_from_euler(float roll, float pitch, float yaw) {
-  float sy, cy, sr, cr, sp, cp;
-  sincosf(yaw * 0.5f, &sy, &cy);
-  sincosf(roll * 0.5f, &sr, &cr);
-  sincosf(pitch * 0.5f, &sp, &cp);
+  // half angles within [-pi, pi]: v_sin_f32 / v_cos_f32 (lt_device_prims.h; |err| ~1e-6, the parity bands are 5e-5).  sincosf
+  // is ~95 instructions a call, 13 calls in the step kernel - on the reset path and in the object-state row, i.e. in once-through
+  // code that runs at instruction-fetch speed on the tiles that end the launch.
+  const float sy = fsin(yaw * 0.5f), cy = fcos(yaw * 0.5f), sr = fsin(roll * 0.5f), cr = fcos(roll * 0.5f), sp = fsin(pitch * 0.5f), cp = fcos(pitch * 0.5f);
   Q4 o;
   o.w = cy * cr * cp + sy * sr * sp;
   o.x = cy * sr * cp - sy * cr * sp;

@@ -227,7 +227,7 @@ __device__ __forceinline__ float gait_reward(const lt_cfg& c, Gait& G, V3 cmd, f
   }
   // task performance score :202-213, :372-392
   const float e_lin = nonzero ? lin_err : 0.f, e_ang = nonzero ? ang_err : 0.f;
-  const float vel_score = (expf(-(e_lin / c.gait_vel_sigma)) + expf(-(e_ang / c.gait_vel_sigma))) / 2.f;
+  const float vel_score = (__expf(-(e_lin / c.gait_vel_sigma)) + __expf(-(e_ang / c.gait_vel_sigma))) / 2.f;  // (v_exp_f32: ~2e-7 relative)
   float score = vel_score;
   if (c.gait_with_object) {
     const float sx = clampf(1.f - fabsf(ox) / c.danger_x_max, 0.f, 1.f);
@@ -1116,7 +1116,13 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     {
       const V3 gq = qapply_inv(B.q, v3(0.f, 0.f, -1.f));
       if (c.term_enabled[LT_T_TIME_OUT] && X.ep_len >= (long long)c.max_episode_length) bits |= 1 << LT_T_TIME_OUT;
-      if (c.term_enabled[LT_T_BASE_ORIENTATION] && acosf(-gq.z) > c.term_orientation_limit) bits |= 1 << LT_T_BASE_ORIENTATION;
+      // acos(x) > L  <=>  x < cos(L): the inverse function (~50 instructions of once-through code) only inside a band around the
+      // threshold, where the two forms could round differently - the oracle's decision bit for bit, the common path two compares
+      if (c.term_enabled[LT_T_BASE_ORIENTATION]) {
+        const float x = -gq.z, cl = fcos(c.term_orientation_limit);
+        const bool over = fabsf(x - cl) > 1e-4f ? x < cl : acosf(x) > c.term_orientation_limit;
+        if (over) bits |= 1 << LT_T_BASE_ORIENTATION;
+      }
       if (c.term_enabled[LT_T_BASE_HEIGHT] && B.p.z < c.term_min_height) bits |= 1 << LT_T_BASE_HEIGHT;
       if (c.term_enabled[LT_T_BASE_CONTACT]) {
         const float mx = fmaxf(X.trunk_fh[0], fmaxf(X.trunk_fh[1], X.trunk_fh[2]));
@@ -1130,7 +1136,8 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
         if (c.term_enabled[LT_T_OBJECT_BELOW_ROBOT] && O.p.z < B.p.z) bits |= 1 << LT_T_OBJECT_BELOW_ROBOT;
         if (c.term_enabled[LT_T_OBJECT_BAD_ROLL]) {
           const V3 go = qapply_inv(O.q, v3(0.f, 0.f, -1.f));
-          if (fabsf(asinf(go.y)) > c.term_object_roll_limit) bits |= 1 << LT_T_OBJECT_BAD_ROLL;
+          const float ay = fabsf(go.y), sl = fsin(c.term_object_roll_limit);  // |asin(y)| > L  <=>  |y| > sin(L), as above
+          if (fabsf(ay - sl) > 1e-4f ? ay > sl : fabsf(asinf(go.y)) > c.term_object_roll_limit) bits |= 1 << LT_T_OBJECT_BAD_ROLL;
         }
       }
       // a termination the caller requested on the state the previous step left (include/lt_env.h, LT_T_USER)
@@ -1149,8 +1156,8 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     // independent dependency chains interleave - a lone wave issues a DEPENDENT VALU operation only every 7 cycles.
     auto on = [&](int i, float v) { return w[i] != 0.f ? v : 0.f; };
     terms[LT_R_ALIVE] = on(LT_R_ALIVE, alive_in ? 0.f : 1.f);
-    terms[LT_R_TRACK_LIN_VEL_XY] = on(LT_R_TRACK_LIN_VEL_XY, expf(-(lin_err / c.track_sigma)));                 // :15-20
-    terms[LT_R_TRACK_ANG_VEL_Z] = on(LT_R_TRACK_ANG_VEL_Z, expf(-(ang_err / c.track_sigma)));                   // :22-27
+    terms[LT_R_TRACK_LIN_VEL_XY] = on(LT_R_TRACK_LIN_VEL_XY, __expf(-(lin_err / c.track_sigma)));                 // :15-20
+    terms[LT_R_TRACK_ANG_VEL_Z] = on(LT_R_TRACK_ANG_VEL_Z, __expf(-(ang_err / c.track_sigma)));                   // :22-27
     const float foot_pv = fsqrt(G.foot_v.x * G.foot_v.x + G.foot_v.y * G.foot_v.y);
     {                                                                                                         // :31-42
       const float mx = fmaxf(G.fh[0][3], fmaxf(G.fh[1][3], G.fh[2][3]));

@@ -71,6 +71,9 @@ constexpr int RING = 32;               // chunk granularity of the packed stream
 #define LT_MLP_WAVES 8
 #endif
 constexpr int NW = LT_MLP_WAVES;       // waves per workgroup (two per SIMD)
+#ifndef LT_MLP_MIN_WAVES_PER_SIMD
+#define LT_MLP_MIN_WAVES_PER_SIMD (LT_MLP_WAVES / 4)  // register budget: 512 / this per wave (probe builds: four waves at 2 = two workgroups per CU)
+#endif
 constexpr unsigned RS_POLICY = 0x400;  // same Philox stream id as lt_rollout_act
 constexpr int MODE_FORWARD = 0, MODE_POLICY = 1;
 // scale of the low parts - and of the main product's activation operand, so that all three MFMAs of the split sum into ONE
@@ -470,7 +473,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
 // KIND: the hidden activation as a compile-time constant (the one every LocoTouch network uses gets its own, smaller kernel:
 // the epilogues run once per layer, at instruction-fetch speed), or -1 = read it from the arguments.
 template <int RT, int KIND>
-__global__ __launch_bounds__(64 * NW) void lt_mlp_kernel(const DualArgs d) {
+__global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_kernel(const DualArgs d) {
   extern __shared__ __attribute__((aligned(16))) float s_img[];
   constexpr int ROWS = 16 * RT;
   bool second;
