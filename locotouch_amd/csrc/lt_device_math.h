@@ -241,11 +241,16 @@ __device__ __forceinline__ Q4 q_from_euler(float roll, float pitch, float yaw) {
   o.z = sy * cr * cp - cy * sr * sp;
   return o;
 }
-__device__ __forceinline__ float q_yaw_2pi(Q4 q) {  // euler_xyz_from_quat(...)[2], python `% (2*pi)`
-  float yaw = atan2f(2.f * (q.w * q.z + q.x * q.y), 1.f - 2.f * (q.y * q.y + q.z * q.z));
-  const float two_pi = 6.28318530717958647692f;
-  float m = fmodf(yaw, two_pi);
-  return m < 0.f ? m + two_pi : m;
+// (cos, sin) of a quaternion's yaw (euler_xyz_from_quat(...)[2] = atan2(2(wz + xy), 1 - 2(y^2 + z^2))) WITHOUT the angle: what the
+// reference builds from the angle - yaw_quat rotations, yaw differences - needs only this pair (atan2f + fmodf + a sincos per use
+// were ~200 instructions; atan2(0, 0) = 0 keeps the degenerate case)
+__device__ __forceinline__ void q_yaw_cs(Q4 q, float& c, float& s) {
+  const float sn = 2.f * (q.w * q.z + q.x * q.y), cn = 1.f - 2.f * (q.y * q.y + q.z * q.z);
+  const float n2 = sn * sn + cn * cn;
+  const bool ok = n2 > 1e-24f;
+  const float inv = frsqrt(ok ? n2 : 1.f);
+  c = ok ? cn * inv : 1.f;
+  s = ok ? sn * inv : 0.f;
 }
 __device__ __forceinline__ Q4 q_normalize(Q4 q) {
   float inv = frsqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);

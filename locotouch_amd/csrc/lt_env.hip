@@ -287,9 +287,11 @@ __device__ __forceinline__ float gait_term(const lt_cfg& c, int leg, float cur_a
   GT.last_cmd = io.cmd; GT.step_from_change = io.step;
   float ox = 0.f, oy = 0.f;
   if (HAS_OBJ && c.gait_with_object) {                                                                      // :372-385
-    const Q4 qy = q_from_euler(0.f, 0.f, q_yaw_2pi(bq));
-    const V3 o = qapply_inv(qy, op - bp);
-    ox = o.x; oy = o.y;
+    // quat_apply_inverse(yaw_quat(base), object - base): a planar rotation by -yaw (q_yaw_cs: no angle, no trigonometry)
+    float cy, sy;
+    q_yaw_cs(bq, cy, sy);
+    const V3 d = op - bp;
+    ox = cy * d.x + sy * d.y; oy = cy * d.y - sy * d.x;
   }
   const float term = gait_reward(c, GT, cmd, lin_err, ang_err, ox, oy, any_nonzero_cmd, step_dt);
   // scatter the class state back: lane (leg) owns column {0:0, 1:2, 2:3, 3:1}
@@ -320,10 +322,13 @@ __device__ __forceinline__ void object_terms(const lt_cfg& c, const Base& B, con
   }
   t[LT_R_OBJECT_ROLL_PITCH_VELOCITY - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_ROLL_PITCH_VELOCITY, ar.x * ar.x);                // :535-543
   {                                                                                                         // :545-567
-    const Q4 qr = q_from_euler(0.f, 0.f, q_yaw_2pi(B.q)), qo = q_from_euler(0.f, 0.f, q_yaw_2pi(O.q));
-    float yd = q_yaw_2pi(qmul(qconj(qr), qo));
+    // yaw of conj(yaw_quat(robot)) * yaw_quat(object), wrapped to (-pi, pi]: the angle between the two yaw directions, from
+    // their (cos, sin) pairs - one atan2f instead of three, no sincos, no quaternion product
+    float cr, sr, co, so;
+    q_yaw_cs(B.q, cr, sr);
+    q_yaw_cs(O.q, co, so);
+    float yd = atan2f(so * cr - co * sr, co * cr + so * sr);
     const float pi = 3.14159265358979323846f;
-    yd = yd > pi ? yd - 2.f * pi : yd;
     yd = yd > 0.5f * pi ? yd - pi : yd;
     yd = yd <= -0.5f * pi ? yd + pi : yd;
     t[LT_R_OBJECT_YAW_ALIGNMENT - LT_R_OBJECT_XY_POSITION] = on(LT_R_OBJECT_YAW_ALIGNMENT, yd * yd * (cn > 0.f ? 1.f : 0.f));
