@@ -48,7 +48,7 @@
 //   * biases live in LDS (staged once) and are added by the conversion pass;
 //   * the policy head's noise is drawn in the prologue by the last wave under the latency of the input rows, and a narrow
 //     last layer goes through the two-tile loop the layer before it has just run instead of a one-tile instantiation of its
-//     own, on waves that had no share in the layer before it (first_wave).
+//     own, on waves that had no share in the layer before it; a narrow hidden layer is dealt twice, by halves of k (Plan).
 //
 // The policy network's last layer carries the sampling epilogue of lt_rollout_act (a = mu + sigma N(0,1), log-prob,
 // storage-slot writes), so the actor side of a rollout step needs no further launch.
@@ -66,7 +66,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int RING = 32;               // chunk granularity of the packed streams (layers are padded to multiples of it)
 #ifndef LT_MLP_WAVES
 #define LT_MLP_WAVES 8
 #endif
@@ -74,6 +73,7 @@ constexpr int NW = LT_MLP_WAVES;       // waves per workgroup (two per SIMD)
 #ifndef LT_MLP_MIN_WAVES_PER_SIMD
 #define LT_MLP_MIN_WAVES_PER_SIMD (LT_MLP_WAVES / 4)  // register budget: 512 / this per wave (probe builds: four waves at 2 = two workgroups per CU)
 #endif
+constexpr int RING = NW > 4 ? 16 : 32;  // chunk granularity of the packed streams (layers are padded to multiples of it) = the largest ring
 constexpr unsigned RS_POLICY = 0x400;  // same Philox stream id as lt_rollout_act
 constexpr int MODE_FORWARD = 0, MODE_POLICY = 1;
 // scale of the low parts - and of the main product's activation operand, so that all three MFMAs of the split sum into ONE
@@ -97,24 +97,44 @@ __host__ __device__ inline int tiles_per_wave(int ntiles) {
   const int t = per > 4 ? 8 : (per > 2 ? 4 : (per > 1 ? 2 : 1));
   return t < MIN_TILES ? MIN_TILES : t;
 }
-// chunks of one layer in the stream of an ACTIVE wave: one item of 2T chunks per 32-wide k-group, padded to whole ring rounds
-__host__ __device__ inline int layer_chunks(int K, int N) {
-  const int T = tiles_per_wave(pad16(N) / 16), G = pad32(K) / 32, R = RING / (2 * T);
-  return (G + R - 1) / R * RING;
-}
 __host__ __device__ inline int active_waves(int N) {
   const int nt = pad16(N) / 16, T = tiles_per_wave(nt);
   return (nt + T - 1) / T;
 }
-
-// First wave of a layer's active range [first, first + active_waves).  The LAST layer, when it and the layer before it leave
-// waves free, takes the waves BEHIND the previous layer's: such a wave has no chunks in the layer before, so its ring turns
-// to the last layer's weights one layer early and they are in registers when the layer starts (on the previous layer's
-// waves the narrow last layer began with a full L2 round trip: ~1 us).
-__host__ __device__ inline int first_wave(const int* dims, int L, int l) {
-  if (l != L - 1 || l == 0) return 0;
-  const int prev = active_waves(dims[l]), mine = active_waves(dims[l + 1]);
-  return prev + mine <= NW ? prev : 0;
+// How a layer is dealt to the waves.  `nact` waves share the output tiles (T each).  K-SPLIT: a hidden layer narrow enough to
+// leave half of the waves idle is dealt twice - waves [first, first + nact) take the first half of the k-groups, the next nact
+// waves the second half of the SAME tiles; both halves put their raw sums into the image side by side (columns n and koff + n)
+// and the conversion pass adds them.  A wave's share of such a layer is then one ring of chunks, all of them requested while the
+// layer before it was still running: without it the third layer of the LocoTouch networks (256 -> 128: four active waves of
+// eight, 32 chunks each behind a 16-slot ring) began with an L2 round trip for its second half (2.3 us for 0.3 us of MFMAs).
+// The LAST layer, when it and the layer before it leave waves free, takes the waves BEHIND the previous layer's: such a wave
+// has no chunks in the layer before, so its ring turns to the last layer's weights one layer early.
+struct Plan {
+  int T, nact, ks, G, Gl, first, waves, koff;
+};
+__host__ __device__ inline Plan plan_of(const int* dims, int L, int l, bool with_first = true) {
+  Plan p;
+  const int K = dims[l], N = dims[l + 1];
+  p.T = tiles_per_wave(pad16(N) / 16);
+  p.nact = active_waves(N);
+  p.G = pad32(K) / 32;
+  int widest = 0;
+  for (int i = 0; i <= L; ++i) widest = dims[i] > widest ? dims[i] : widest;
+  p.ks = (l < L - 1 && 2 * p.nact <= NW && p.G >= 2 && (p.G & 1) == 0 && 2 * pad32(N) <= pad32(widest)) ? 2 : 1;
+  p.Gl = p.G / p.ks;
+  p.waves = p.nact * p.ks;
+  p.koff = pad32(N);
+  p.first = 0;
+  if (with_first && l == L - 1 && l > 0) {
+    const Plan q = plan_of(dims, L, l - 1, false);
+    if (q.waves + p.waves <= NW) p.first = q.waves;
+  }
+  return p;
+}
+// chunks of one layer in the stream of an ACTIVE wave: one item of 2T chunks per 32-wide k-group of its share, padded to whole ring rounds
+__host__ __device__ inline int layer_chunks(const Plan& p) {
+  const int R = RING / (2 * p.T);
+  return (p.Gl + R - 1) / R * RING;
 }
 
 struct MlpArgs {
@@ -127,6 +147,7 @@ struct MlpArgs {
   int bias_total;             // floats of the bias block (sum of pad16(N_l))
   int noise_off;              // MODE_POLICY: float offset inside the LDS image of the [rows][16] block of N(0,1) draws (launch())
   unsigned in_magic;          // dims[0] % 4 == 0: floor(2^32 / (dims[0] / 4)) + 1, the reciprocal the input staging divides by; else 0
+  signed char l_first[LT_MLP_MAX_LAYERS], l_ks[LT_MLP_MAX_LAYERS];  // per layer: first active wave, k-split factor (plan_of, host side)
   unsigned in_magic2;         // dims[0] % 4 == 2 (f32 rows): the same for pairs, floor(2^32 / (dims[0] / 2)) + 1; else 0
   long long bias_chunk;       // chunk offset of the bias block inside `packed`
   long long wave_base[NW];    // chunk offset of each wave's stream inside `packed`
@@ -262,6 +283,8 @@ __device__ __forceinline__ void convert_pass(const MlpArgs& a, int l, float* s_a
   const int N = a.dims[l + 1];
   const int total = ROWS * (pad32(N) >> 3);
   float* const dst = a.act_out[l];
+  const bool ksplit = a.l_ks[l] > 1;
+  const int koff = pad32(N);
 #pragma unroll 1
   for (int idx = tid; idx < total; idx += 64 * NW) {
     const int rr = idx & (ROWS - 1), j = idx / ROWS;  // consecutive lanes = consecutive rows: conflict-free (S == 4 mod 64)
@@ -269,11 +292,17 @@ __device__ __forceinline__ void convert_pass(const MlpArgs& a, int l, float* s_a
     float* const g = s_act + rr * S + n0;
     f32x4 x[2];
     if (n0 + 8 <= N) {
-      x[0] = *(const f32x4*)g * LO_INV + *(const f32x4*)(s_bias + n0);
-      x[1] = *(const f32x4*)(g + 4) * LO_INV + *(const f32x4*)(s_bias + n0 + 4);
+      x[0] = *(const f32x4*)g;
+      x[1] = *(const f32x4*)(g + 4);
+      if (ksplit) {  // (uniform) the second half of the k-groups left its sums koff columns to the right (Plan)
+        x[0] += *(const f32x4*)(g + koff);
+        x[1] += *(const f32x4*)(g + koff + 4);
+      }
+      x[0] = x[0] * LO_INV + *(const f32x4*)(s_bias + n0);
+      x[1] = x[1] * LO_INV + *(const f32x4*)(s_bias + n0 + 4);
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[i >> 2][i & 3] = n0 + i < N ? g[i] * LO_INV + s_bias[n0 + i] : 0.f;
+      for (int i = 0; i < 8; ++i) x[i >> 2][i & 3] = n0 + i < N ? (g[i] + (ksplit ? g[koff + i] : 0.f)) * LO_INV + s_bias[n0 + i] : 0.f;
     }
     {
       const int kind = KIND >= 0 ? KIND : a.activation;
@@ -353,12 +382,15 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
   static_assert(R >= 1 && RING % RG == 0, "ring geometry");
   const int r = lane & 15, q = lane >> 4;
   const int S = a.stride;
-  const int G = pad32(a.dims[l]) / 32;
   const int N = a.dims[l + 1];
-  const int first = first_wave(a.dims, a.L, l);
-  const int tile0 = (wave - first) * T;
-  const bool active = wave >= first && wave < first + active_waves(N);
-  const float* const xrow = s_act + r * S + 8 * q;  // row tile rt: + 16 * rt * S; k-group g: + 32 g
+  // the layer's deal (Plan): `nact` waves share the tiles; k-split layers are dealt twice, the second half of the k-groups to the
+  // next nact waves, whose raw sums go `koff` columns to the right
+  const int first = a.l_first[l], ks = a.l_ks[l], nact = active_waves(N);
+  const int rel = wave - first, kh = rel >= nact ? 1 : 0;
+  const int G = pad32(a.dims[l]) / 32 / ks;  // this wave's k-groups: [kh G, (kh + 1) G)
+  const int tile0 = (rel - kh * nact) * T;
+  const bool active = rel >= 0 && rel < nact * ks;
+  const float* const xrow = s_act + r * S + 8 * q + 32 * G * kh;  // row tile rt: + 16 * rt * S; k-group g of this wave's share: + 32 g
   f32x4 am[RT][T];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -402,11 +434,13 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
             for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t + 1]), bh, am[rt][t], 0, 0, 0);
           }
         }
-        // refill the slots just consumed (pad items included: the ring invariant must hold for the next layer)
-        if (!last || i < G) {
+        // refill the slots just consumed (pad items included: the ring invariant must hold for the next layer).  UNCONDITIONAL:
+        // behind a branch the compiler cannot count these loads, and its s_waitcnt in front of the NEXT item's MFMAs then
+        // waits for all of them - vmcnt(3), (1), (0) instead of (12+) - which made the ring one item deep (every item paid an
+        // L2 round trip: 350 ns per item in the narrow layers, 730 ns in the first).  The last layer's surplus refills land in
+        // the ring of zero chunks behind every stream (geometry()).
 #pragma unroll
-          for (int s = 0; s < C; ++s) ring[sl + s] = stream[(c0 + RG + (j / R) * RG + sl + s) * 64];
-        }
+        for (int s = 0; s < C; ++s) ring[sl + s] = stream[(c0 + RG + (j / R) * RG + sl + s) * 64];
         // keep the refill HERE: left alone, the scheduler sinks it behind the next item's MFMAs to save registers, which
         // collapses the ring to one item in flight
         __builtin_amdgcn_sched_barrier(0);
@@ -422,7 +456,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
   if (l == LT_MLP_STAMP_L) MLP_STAMP(7);
 #endif
   if (!last) {
-    if (active) raw_store<T, RT>(am, s_act, r, q, S, tile0, pad32(N));
+    if (active) raw_store<T, RT>(am, s_act + kh * pad32(N), r, q, S, tile0, pad32(N));
     return;
   }
 #pragma unroll
@@ -448,7 +482,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
       }
     } else {
       // policy head: N == 12 -> one tile, held by wave 0; lane (r, q) owns actions 4q..4q+3 of env e (q == 3: padding)
-      if (wave == first) {
+      if (rel == 0) {
         float lp = 0.f;
         if (q < 3 && e < a.m) {
           // the N(0,1) draws and their log-density were made while the input rows were in flight (policy_noise)
@@ -653,7 +687,7 @@ struct PackArgs {
   const float* w; const float* b;
   int K, N;
   long long chunk_off[NW];  // first chunk of this layer in each wave's stream (absolute, in chunks)
-  int first;                // first active wave of the layer (first_wave)
+  Plan plan;                // how the layer is dealt to the waves
   long long bias_float_off; // first float of this layer's (pad16(N)) bias slice
   float* packed;
 };
@@ -661,19 +695,21 @@ struct PackArgs {
 struct PackAll { PackArgs layer[LT_MLP_MAX_LAYERS]; };
 __global__ void lt_mlp_pack_kernel(const PackAll all) {
   const PackArgs& p = all.layer[blockIdx.y];
-  const int T = tiles_per_wave(pad16(p.N) / 16), G = pad32(p.K) / 32, C = 2 * T;
-  const int chunks = layer_chunks(p.K, p.N), nact = active_waves(p.N);
+  const Plan& pl = p.plan;
+  const int T = pl.T, G = pl.Gl, C = 2 * T;
+  const int chunks = layer_chunks(pl), nact = pl.waves;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (wave, chunk, lane)
   if (idx < pad16(p.N)) p.packed[p.bias_float_off + idx] = idx < p.N ? p.b[idx] : 0.f;
   if (idx >= (long long)nact * chunks * 64) return;
   const int lane = (int)(idx & 63);
   const int c = (int)((idx >> 6) % chunks), wv = (int)((idx >> 6) / chunks);
+  const int kh = wv / pl.nact, tw = wv - kh * pl.nact;  // k half, tile wave
   const int r = lane & 15, q = lane >> 4;
   const int g = c / C, slot = c - g * C;
   float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g < G) {
     const int t = slot >> 1, comp = slot & 1;
-    const int n = 16 * (wv * T + t) + r, k0 = 32 * g + 8 * q;
+    const int n = 16 * (tw * T + t) + r, k0 = 32 * (kh * G + g) + 8 * q;
     f16x8 h;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -684,7 +720,7 @@ __global__ void lt_mlp_pack_kernel(const PackAll all) {
     }
     out = __builtin_bit_cast(float4, h);
   }
-  *(float4*)(p.packed + ((p.chunk_off[p.first + wv] + c) * 64 + lane) * 4) = out;
+  *(float4*)(p.packed + ((p.chunk_off[pl.first + wv] + c) * 64 + lane) * 4) = out;
 }
 
 bool desc_ok(const lt_mlp_desc* d) {
@@ -714,8 +750,8 @@ Geometry geometry(const lt_mlp_desc* d) {
     long long off = 0;
     for (int l = 0; l < d->num_layers; ++l) {
       g.layer_off[l][w] = base + off;
-      const int first = first_wave(d->dims, d->num_layers, l);
-      if (w >= first && w < first + active_waves(d->dims[l + 1])) off += layer_chunks(d->dims[l], d->dims[l + 1]);
+      const Plan pl = plan_of(d->dims, d->num_layers, l);
+      if (w >= pl.first && w < pl.first + pl.waves) off += layer_chunks(pl);
     }
     base += off + RING;
   }
@@ -737,6 +773,10 @@ void fill_args(const lt_mlp_desc* d, MlpArgs& a) {
   }
   const Geometry g = geometry(d);
   for (int w = 0; w < NW; ++w) a.wave_base[w] = g.wave_base[w];
+  for (int l = 0; l < d->num_layers; ++l) {
+    const Plan pl = plan_of(d->dims, d->num_layers, l);
+    a.l_first[l] = (signed char)pl.first; a.l_ks[l] = (signed char)pl.ks;
+  }
   a.stride = pad32(widest) + 4;
   a.bias_total = g.bias_total;
   // exact for every index below ROWS x K0/4 as long as ROWS (K0/4)^2 < 2^32 - LDS holds no such row; K0 = 4 has no 32-bit reciprocal
@@ -842,10 +882,10 @@ int lt_mlp_pack(const lt_mlp_desc* desc, const float* const* weights, const floa
     PackArgs& p = all.layer[l];
     p.w = weights[l]; p.b = biases[l]; p.K = desc->dims[l]; p.N = desc->dims[l + 1]; p.packed = packed;
     for (int w = 0; w < NW; ++w) p.chunk_off[w] = g.layer_off[l][w];
-    p.first = first_wave(desc->dims, desc->num_layers, l);
+    p.plan = plan_of(desc->dims, desc->num_layers, l);
     p.bias_float_off = g.bias_chunk * 256 + bias_off;
     bias_off += pad16(p.N);
-    long long total = (long long)active_waves(p.N) * layer_chunks(p.K, p.N) * 64;
+    long long total = (long long)p.plan.waves * layer_chunks(p.plan) * 64;
     total = total < pad16(p.N) ? pad16(p.N) : total;  // (the bias slice is written by the first pad16(N) threads)
     most = total > most ? total : most;
   }
