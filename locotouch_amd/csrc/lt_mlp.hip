@@ -73,7 +73,10 @@ constexpr int NW = LT_MLP_WAVES;       // waves per workgroup (two per SIMD)
 #ifndef LT_MLP_MIN_WAVES_PER_SIMD
 #define LT_MLP_MIN_WAVES_PER_SIMD (LT_MLP_WAVES / 4)  // register budget: 512 / this per wave (probe builds: four waves at 2 = two workgroups per CU)
 #endif
-constexpr int RING = NW > 4 ? 16 : 32;  // chunk granularity of the packed streams (layers are padded to multiples of it) = the largest ring
+#ifndef LT_MLP_RING_GRAIN
+#define LT_MLP_RING_GRAIN (LT_MLP_WAVES > 4 ? 16 : 32)
+#endif
+constexpr int RING = LT_MLP_RING_GRAIN;  // chunk granularity of the packed streams (layers are padded to multiples of it) = the largest ring
 constexpr unsigned RS_POLICY = 0x400;  // same Philox stream id as lt_rollout_act
 constexpr int MODE_FORWARD = 0, MODE_POLICY = 1;
 // scale of the low parts - and of the main product's activation operand, so that all three MFMAs of the split sum into ONE
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
   // layer), fragments (16 RT) and a 16-slot ring (64) fit without scratch at two row tiles (a scratch reload in a layer
   // epilogue would sit behind the whole ring in the queue); four row tiles spill 88 bytes.
 #ifndef LT_MLP_RING2
-#define LT_MLP_RING2 16  // ring slots at two row tiles (32 fits without scratch and measured slower: 35.5 against 33.7 us at 4096 rows)
+#define LT_MLP_RING2 16  // ring slots at two row tiles (32 at eight waves: 352 B of scratch)
 #endif
 #ifndef LT_MLP_RING4
 #define LT_MLP_RING4 16  // ring slots at four row tiles
