@@ -622,9 +622,14 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
 #endif
   const lt_cfg& c = s_d.cfg;
   const lt_layout& L = s_d.layout;
-  // the command block: global memory, or - helper form - the copy wave 3 leaves in LDS beside the last physics substep
-  __shared__ float s_P[HELPERS ? 32 : 1];
-  const float* P = (HELPERS && MODE == MODE_STEP) ? (const float*)s_P : (const float*)(arena + L.off_cmd_params);
+  // the command block: a copy in LDS - helper form: wave 3 leaves it there beside the last physics substep; one-wave form: requested
+  // here, stored behind the physics (below).  Read from global memory it cost the resetting / resampling waves of the one-wave form a
+  // dozen DEPENDENT loads (commands.py:517-559 branches on the block's values), each behind an `s_waitcnt vmcnt(0)`.  (The terms-only
+  // and reset-all launches read it where it is.)
+  __shared__ float s_P[MODE == MODE_STEP ? 32 : 1];
+  const float* P = MODE == MODE_STEP ? (const float*)s_P : (const float*)(arena + L.off_cmd_params);
+  float p_own = 0.f;
+  if (!HELPERS && MODE == MODE_STEP) p_own = ((const float*)(arena + L.off_cmd_params))[lane & 31];
   const uint64_t step = MODE == MODE_RESET_ALL ? 0ull : (uint64_t)(((const long long*)(arena + L.off_counters))[0] + (MODE == MODE_STEP ? a.step_offset : 0));
   const float step_dt = c.sim_dt * (float)c.decimation;
   const uint32_t ekey = (uint32_t)env + (uint32_t)c.env_index_offset;  // RNG stream key of this env (global index over all ranks)
@@ -1057,6 +1062,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     }
     foot_kinematics(sgn, B, G);
   }
+  if (!HELPERS && MODE == MODE_STEP) s_P[lane & 31] = p_own;  // (LT_CMD_PARAMS_LEN = 32 floats; both half-waves hold the same values)
   LT_STAMP(2);
   // ---- late loads: state the physics never touches (compiler barrier: keep these below the decimation loop) ----
   asm volatile("" ::: "memory");
