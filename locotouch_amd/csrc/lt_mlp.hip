@@ -509,7 +509,12 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
 
 // KIND: the hidden activation as a compile-time constant (the one every LocoTouch network uses gets its own, smaller kernel:
 // the epilogues run once per layer, at instruction-fetch speed), or -1 = read it from the arguments.
-template <int RT, int KIND>
+// IN: how the input rows are staged, as a compile-time constant - f32 rows by float4, bf16 rows by 4 elements, f32 rows by pairs
+// (widths 2 mod 4) - or IN_ANY = decided at run time (odd widths, and networks of the generic-activation kernel).  With the three
+// forms behind run-time branches the loaded registers met in PHI copies at the join: the copies waited for the input rows, and
+// the bias and weight-ring requests behind them left ~3 us late.
+constexpr int IN_ANY = 0, IN_F32X4 = 1, IN_BF16X4 = 2, IN_F32X2 = 3;
+template <int RT, int KIND, int IN>
 __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_kernel(const DualArgs d) {
   extern __shared__ __attribute__((aligned(16))) float s_img[];
   constexpr int ROWS = 16 * RT;
@@ -541,7 +546,8 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
   // it where it already is; rows beyond m re-read row m - 1 - rows never mix in the MFMA and those results are not stored);
   // the k padding (columns K0 .. pad32(K0), zero weights) is zeroed separately - 0 x stale LDS bits could be 0 x NaN.
   const int K0 = a.dims[0], K0p = pad32(K0);
-  const bool vec_in = a.in_magic != 0;  // K0 % 4 == 0 (fill_args)
+  const bool vec_in = IN == IN_ANY ? a.in_magic != 0 : (IN == IN_F32X4 || IN == IN_BF16X4);  // K0 % 4 == 0 (fill_args)
+  const bool is_bf16 = IN == IN_ANY ? a.x_bf16 != 0 : IN == IN_BF16X4;
   constexpr int B = (6 * RT * 4 + NW - 1) / NW;  // float4 in flight per thread: one batch covers a 348-wide input (5.4 per thread and row tile at four waves)
   constexpr int NT = 64 * NW;
   const int kv = K0p >> 2, k4 = K0 >> 2;
@@ -553,8 +559,8 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
   unsigned lds_at[B];
   if (vec_in) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const char* const xb = (const char*)a.x + row0 * K0 * (a.x_bf16 ? 2 : 4);
-    if (a.x_bf16) {  // (the format test outside the unrolled batch: one scalar branch, two straight-line load sequences)
+    const char* const xb = (const char*)a.x + row0 * K0 * (is_bf16 ? 2 : 4);
+    if (is_bf16) {  // (the format test outside the unrolled batch: one scalar branch, two straight-line load sequences)
 #pragma unroll
       for (int u = 0; u < B; ++u) {
         const unsigned idx = min((unsigned)tid + u * NT, tv - 1u);
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
     }
   }
   // widths that are 2 mod 4 (f32 rows): the same scheme on pairs - two 8-byte loads per float4 slot
-  const bool vec2_in = a.in_magic2 != 0;
+  const bool vec2_in = IN == IN_ANY ? a.in_magic2 != 0 : IN == IN_F32X2;
   const unsigned p2 = K0 >> 1, tv2 = ROWS * p2;
   unsigned lds_at2[B];
   if (vec2_in) {
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
     for (int u = 0; u < BB; ++u) s_bias[min(tid + u * NT, a.bias_total - 1)] = bv[u];
     for (int i = tid + BB * NT; i < a.bias_total; i += NT) s_bias[i] = bsrc[i];
     if (vec_in) {
-      if (a.x_bf16) {  // (uniform: two straight-line sequences, not a select per value)
+      if (is_bf16) {  // (uniform: two straight-line sequences, not a select per value)
 #pragma unroll
         for (int u = 0; u < B; ++u) {
           const unsigned w0 = __float_as_uint(vin[u][0]), w1 = __float_as_uint(vin[u][1]);
@@ -796,16 +802,26 @@ int pick_row_tiles(long long rows_total_blocks16) {
   return rows_total_blocks16 / 2 >= 256 ? 2 : 1;
 }
 
+int input_kind(const MlpArgs& a) {
+  if (a.in_magic) return a.x_bf16 ? IN_BF16X4 : IN_F32X4;
+  return a.in_magic2 ? IN_F32X2 : IN_ANY;
+}
 template <int RT>
-void launch_rt(const DualArgs& d, bool elu, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+void launch_rt(const DualArgs& d, bool elu, int in, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {  // more than the default 64 KB of dynamic LDS
     attr_set = true;
-    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<RT, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<RT, LT_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<RT, -1, IN_ANY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<RT, LT_ACT_ELU, IN_ANY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<RT, LT_ACT_ELU, IN_F32X4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<RT, LT_ACT_ELU, IN_BF16X4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<RT, LT_ACT_ELU, IN_F32X2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  if (elu) hipLaunchKernelGGL((lt_mlp_kernel<RT, LT_ACT_ELU>), grid, block, lds, s, d);
-  else hipLaunchKernelGGL((lt_mlp_kernel<RT, -1>), grid, block, lds, s, d);
+  if (!elu) hipLaunchKernelGGL((lt_mlp_kernel<RT, -1, IN_ANY>), grid, block, lds, s, d);
+  else if (in == IN_F32X4) hipLaunchKernelGGL((lt_mlp_kernel<RT, LT_ACT_ELU, IN_F32X4>), grid, block, lds, s, d);
+  else if (in == IN_BF16X4) hipLaunchKernelGGL((lt_mlp_kernel<RT, LT_ACT_ELU, IN_BF16X4>), grid, block, lds, s, d);
+  else if (in == IN_F32X2) hipLaunchKernelGGL((lt_mlp_kernel<RT, LT_ACT_ELU, IN_F32X2>), grid, block, lds, s, d);
+  else hipLaunchKernelGGL((lt_mlp_kernel<RT, LT_ACT_ELU, IN_ANY>), grid, block, lds, s, d);
 }
 
 int launch(DualArgs& d, int nets, hipStream_t s) {
@@ -834,10 +850,13 @@ int launch(DualArgs& d, int nets, hipStream_t s) {
   const long long nblocks = d.xcd_split ? (b0 + 3) / 4 * 8 : b0 + b1;
   const dim3 grid((unsigned)nblocks), block(64 * NW);
   const bool elu = d.net[0].activation == LT_ACT_ELU && (nets == 1 || d.net[1].activation == LT_ACT_ELU);
+  // the input-staging form as a compile-time constant when both networks of the launch take the same one
+  int in = input_kind(d.net[0]);
+  if (nets == 2 && input_kind(d.net[1]) != in) in = IN_ANY;
   if (rt == 4) {
-    launch_rt<4>(d, elu, grid, block, lds, s);
-  } else if (rt == 2) launch_rt<2>(d, elu, grid, block, lds, s);
-  else launch_rt<1>(d, elu, grid, block, lds, s);
+    launch_rt<4>(d, elu, in, grid, block, lds, s);
+  } else if (rt == 2) launch_rt<2>(d, elu, in, grid, block, lds, s);
+  else launch_rt<1>(d, elu, in, grid, block, lds, s);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;
