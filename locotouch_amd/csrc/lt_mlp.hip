@@ -344,7 +344,7 @@ __device__ __forceinline__ void convert_pass(const MlpArgs& a, int l, float* s_a
 }
 
 // Policy head, first half: the standard-normal draws of this workgroup's rows and the log-density of the sample
-// (Normal.log_prob summed over the 12 actions needs z and sigma only, not mu).  Wave 0 runs it in the prologue, between
+// (Normal.log_prob summed over the 12 actions needs z and sigma only, not mu).  The last wave runs it in the prologue, between
 // requesting the weight ring and the arrival of the input rows - ~250 instructions that would otherwise sit, fetched cold,
 // behind the last layer where nothing overlaps them.  Lane (r, q) owns actions 4q..4q+3 of row r (q == 3: padding).
 template <int RT>
@@ -484,7 +484,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
         }
       }
     } else {
-      // policy head: N == 12 -> one tile, held by wave 0; lane (r, q) owns actions 4q..4q+3 of env e (q == 3: padding)
+      // policy head: N == 12 -> one tile, held by the layer's first active wave; lane (r, q) owns actions 4q..4q+3 of env e (q == 3: padding)
       if (rel == 0) {
         float lp = 0.f;
         if (q < 3 && e < a.m) {
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
   const int K0 = a.dims[0], K0p = pad32(K0);
   const bool vec_in = IN == IN_ANY ? a.in_magic != 0 : (IN == IN_F32X4 || IN == IN_BF16X4);  // K0 % 4 == 0 (fill_args)
   const bool is_bf16 = IN == IN_ANY ? a.x_bf16 != 0 : IN == IN_BF16X4;
-  constexpr int B = (6 * RT * 4 + NW - 1) / NW;  // float4 in flight per thread: one batch covers a 348-wide input (5.4 per thread and row tile at four waves)
+  constexpr int B = (6 * RT * 4 + NW - 1) / NW;  // float4 in flight per thread: one batch covers a 348-wide input (5.4 per thread and row tile at four waves, 2.7 at eight)
   constexpr int NT = 64 * NW;
   const int kv = K0p >> 2, k4 = K0 >> 2;
   const unsigned tv = ROWS * k4;
