@@ -613,7 +613,10 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
 #ifndef LT_MLP_RING4
 #define LT_MLP_RING4 16  // ring slots at four row tiles
 #endif
-  constexpr int RG = RT >= 4 ? LT_MLP_RING4 : (RT >= 2 ? LT_MLP_RING2 : (NW > 4 ? 16 : 32));  // (two waves per SIMD: 256 registers each)
+#ifndef LT_MLP_RING1
+#define LT_MLP_RING1 (LT_MLP_WAVES > 4 ? 16 : 32)  // ring slots at one row tile
+#endif
+  constexpr int RG = RT >= 4 ? LT_MLP_RING4 : (RT >= 2 ? LT_MLP_RING2 : LT_MLP_RING1);  // (two waves per SIMD: 256 registers each)
   const float4* __restrict__ stream = (const float4*)a.packed + a.wave_base[wave] * 64 + lane;
   float4 ring[RG];
 #pragma unroll
