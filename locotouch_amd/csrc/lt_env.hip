@@ -1467,6 +1467,52 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   wg_barrier_lds();  // B1: frame, reset flags and curriculum record are in LDS (helper form: for waves 1-3).  LDS traffic only - a
                      // full __syncthreads waited here for every global store issued so far
   LT_STAMP(5);
+  // ---- store state ---- (a lambda with ONE live call site per kernel form: at the kernel's end, or - one-wave form with bf16 rows -
+  // between the request for the critic group's old rows and the wait for them, where the ~80 stores and their address arithmetic run
+  // under a DMA latency that nothing covered: 32768 envs 109.9 -> 102.8 us.  With f32 rows the same move cost 1.5 %: twice the row
+  // stores are in flight in front of the wait.)
+  auto store_state = [&]() __attribute__((always_inline)) {
+    ST_STATE(F(LT_F_ROOT_POS, 0), sel4(leg, B.p.x, B.p.y, B.p.z, 0.f));
+    ST_STATE(F(LT_F_ROOT_QUAT, 0), sel4(leg, B.q.w, B.q.x, B.q.y, B.q.z));
+    ST_STATE(F(LT_F_ROOT_LIN_VEL_W, 0), sel4(leg, B.u.x, B.u.y, B.u.z, 0.f));
+    ST_STATE(F(LT_F_ROOT_ANG_VEL_W, 0), sel4(leg, B.w.x, B.w.y, B.w.z, 0.f));
+    if (HAS_OBJ || MODE == MODE_RESET_ALL) {
+      ST_STATE(F(LT_F_OBJ_POS, 0), sel4(leg, O.p.x, O.p.y, O.p.z, 0.f));
+      ST_STATE(F(LT_F_OBJ_QUAT, 0), sel4(leg, O.q.w, O.q.x, O.q.y, O.q.z));
+      ST_STATE(F(LT_F_OBJ_LIN_VEL_W, 0), sel4(leg, O.u.x, O.u.y, O.u.z, 0.f));
+      ST_STATE(F(LT_F_OBJ_ANG_VEL_W, 0), sel4(leg, O.w.x, O.w.y, O.w.z, 0.f));
+      ST_STATE(F(LT_F_OBJ_TIMERS, 0), sel4(leg, O.cur_air, O.cur_con, O.last_air, O.last_con));
+      ST_STATE(F(LT_F_OBJ_PARAMS, 0), sel4(leg, O.rad, O.len, O.mass, O.mu));
+    }
+    ST_STATE(F(LT_F_ENV_PARAMS, 0), sel4(leg, X.trunk_mass_add, X.trunk_mu, X.trunk_rest, X.obj_rest));
+    ST_STATE(F(LT_F_TRUNK_FORCE_HIST, 0), sel4(leg, X.trunk_fh[0], X.trunk_fh[1], X.trunk_fh[2], 0.f));
+    ST_STATE(F(LT_F_CMD, 0), sel4(leg, X.cmd.x, X.cmd.y, X.cmd.z, X.cmd_time_left));
+    ST_STATE(F(LT_F_CMD_BUF, 0), sel4(leg, X.cmd_buf.x, X.cmd_buf.y, X.cmd_buf.z, X.cmd_standing));
+    ST_STATE(F(LT_F_EVENT_TIMERS, 0), sel4(leg, X.push_robot_left, X.push_obj_left, 0.f, 0.f));
+    ST_STATE(F(LT_F_GAIT_CMD, 0), sel4(leg, X.gait_cmd.x, X.gait_cmd.y, X.gait_cmd.z, X.gait_step));
+    if (leg == 0) ((long long*)(arena + L.off_ep_len))[env] = X.ep_len;
+    if (TAC && tac_new) { ST_STATE(F(LT_F_PLATE_SAMPLES, 0), tac.x); ST_STATE(F(LT_F_PLATE_SAMPLES, 1), tac.y); ST_STATE(F(LT_F_PLATE_SAMPLES, 2), tac.z); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      ST_STATE(F(LT_F_JOINT_POS, k), G.q[k]); ST_STATE(F(LT_F_JOINT_VEL, k), G.qd[k]);
+      ST_STATE(F(LT_F_JOINT_ACC, k), G.qdd[k]); ST_STATE(F(LT_F_APPLIED_TORQUE, k), G.tau[k]);
+      ST_STATE(F(LT_F_ACT_RAW, k), G.raw[k]); ST_STATE(F(LT_F_ACT_PREV_RAW, k), G.prev[k]); ST_STATE(F(LT_F_ACT_PREV_PREV_RAW, k), G.prev2[k]);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int ty = 0; ty < 4; ++ty) ST_STATE(F(LT_F_FORCE_HIST, s * 4 + ty), G.fh[s][ty]);
+    ST_STATE(F(LT_F_FOOT_CUR_AIR, 0), G.cur_air); ST_STATE(F(LT_F_FOOT_CUR_CONTACT, 0), G.cur_con);
+    ST_STATE(F(LT_F_FOOT_LAST_AIR, 0), G.last_air); ST_STATE(F(LT_F_FOOT_LAST_CONTACT, 0), G.last_con);
+    ST_STATE(F(LT_F_FOOT_FRICTION, 0), G.mu);
+    ST_STATE(F(LT_F_FOOT_POS_W, 0), G.foot_p.x); ST_STATE(F(LT_F_FOOT_POS_W, 1), G.foot_p.y); ST_STATE(F(LT_F_FOOT_POS_W, 2), G.foot_p.z);
+    ST_STATE(F(LT_F_FOOT_VEL_W, 0), G.foot_v.x); ST_STATE(F(LT_F_FOOT_VEL_W, 1), G.foot_v.y); ST_STATE(F(LT_F_FOOT_VEL_W, 2), G.foot_v.z);
+    ST_STATE(F(LT_F_GAIT_LAST_AIR, 0), G.g_last_air); ST_STATE(F(LT_F_GAIT_LAST_CONTACT, 0), G.g_last_con);
+    ST_STATE(F(LT_F_GAIT_VALID_LAST_AIR, 0), G.g_valid);
+    *(int*)F(LT_F_GAIT_FLAGS, 0) = G.g_flags;
+#pragma unroll
+    for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) ST_STATE(F(LT_F_EPISODE_SUMS, q), sums[q]);
+  };
   if (!HELPERS)
   {
     // History rows (one-wave form).  The 16 env rows of this wave are one contiguous chunk of 16*OBS floats per group.  Row(t) is
@@ -1489,6 +1535,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       if (g == 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the policy rows are done
         dma_old_rows(a.obs_prev[1], s_old);
+        if (RB) store_state();
       }
       // vmcnt(0) as the BUILTIN (0x0F70 = vmcnt 0, expcnt / lgkmcnt untouched): the waitcnt pass then knows the DMA has landed; behind
       // an opaque asm wait it re-waits vmcnt(0) - i.e. for every store of the loop below - before each LDS read of the staged rows
@@ -1546,49 +1593,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
   }
 
   LT_STAMP(6);
-  // ---- store state ----
-  {
-    ST_STATE(F(LT_F_ROOT_POS, 0), sel4(leg, B.p.x, B.p.y, B.p.z, 0.f));
-    ST_STATE(F(LT_F_ROOT_QUAT, 0), sel4(leg, B.q.w, B.q.x, B.q.y, B.q.z));
-    ST_STATE(F(LT_F_ROOT_LIN_VEL_W, 0), sel4(leg, B.u.x, B.u.y, B.u.z, 0.f));
-    ST_STATE(F(LT_F_ROOT_ANG_VEL_W, 0), sel4(leg, B.w.x, B.w.y, B.w.z, 0.f));
-    if (HAS_OBJ || MODE == MODE_RESET_ALL) {
-      ST_STATE(F(LT_F_OBJ_POS, 0), sel4(leg, O.p.x, O.p.y, O.p.z, 0.f));
-      ST_STATE(F(LT_F_OBJ_QUAT, 0), sel4(leg, O.q.w, O.q.x, O.q.y, O.q.z));
-      ST_STATE(F(LT_F_OBJ_LIN_VEL_W, 0), sel4(leg, O.u.x, O.u.y, O.u.z, 0.f));
-      ST_STATE(F(LT_F_OBJ_ANG_VEL_W, 0), sel4(leg, O.w.x, O.w.y, O.w.z, 0.f));
-      ST_STATE(F(LT_F_OBJ_TIMERS, 0), sel4(leg, O.cur_air, O.cur_con, O.last_air, O.last_con));
-      ST_STATE(F(LT_F_OBJ_PARAMS, 0), sel4(leg, O.rad, O.len, O.mass, O.mu));
-    }
-    ST_STATE(F(LT_F_ENV_PARAMS, 0), sel4(leg, X.trunk_mass_add, X.trunk_mu, X.trunk_rest, X.obj_rest));
-    ST_STATE(F(LT_F_TRUNK_FORCE_HIST, 0), sel4(leg, X.trunk_fh[0], X.trunk_fh[1], X.trunk_fh[2], 0.f));
-    ST_STATE(F(LT_F_CMD, 0), sel4(leg, X.cmd.x, X.cmd.y, X.cmd.z, X.cmd_time_left));
-    ST_STATE(F(LT_F_CMD_BUF, 0), sel4(leg, X.cmd_buf.x, X.cmd_buf.y, X.cmd_buf.z, X.cmd_standing));
-    ST_STATE(F(LT_F_EVENT_TIMERS, 0), sel4(leg, X.push_robot_left, X.push_obj_left, 0.f, 0.f));
-    ST_STATE(F(LT_F_GAIT_CMD, 0), sel4(leg, X.gait_cmd.x, X.gait_cmd.y, X.gait_cmd.z, X.gait_step));
-    if (leg == 0) ((long long*)(arena + L.off_ep_len))[env] = X.ep_len;
-    if (TAC && tac_new) { ST_STATE(F(LT_F_PLATE_SAMPLES, 0), tac.x); ST_STATE(F(LT_F_PLATE_SAMPLES, 1), tac.y); ST_STATE(F(LT_F_PLATE_SAMPLES, 2), tac.z); }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      ST_STATE(F(LT_F_JOINT_POS, k), G.q[k]); ST_STATE(F(LT_F_JOINT_VEL, k), G.qd[k]);
-      ST_STATE(F(LT_F_JOINT_ACC, k), G.qdd[k]); ST_STATE(F(LT_F_APPLIED_TORQUE, k), G.tau[k]);
-      ST_STATE(F(LT_F_ACT_RAW, k), G.raw[k]); ST_STATE(F(LT_F_ACT_PREV_RAW, k), G.prev[k]); ST_STATE(F(LT_F_ACT_PREV_PREV_RAW, k), G.prev2[k]);
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-#pragma unroll
-      for (int ty = 0; ty < 4; ++ty) ST_STATE(F(LT_F_FORCE_HIST, s * 4 + ty), G.fh[s][ty]);
-    ST_STATE(F(LT_F_FOOT_CUR_AIR, 0), G.cur_air); ST_STATE(F(LT_F_FOOT_CUR_CONTACT, 0), G.cur_con);
-    ST_STATE(F(LT_F_FOOT_LAST_AIR, 0), G.last_air); ST_STATE(F(LT_F_FOOT_LAST_CONTACT, 0), G.last_con);
-    ST_STATE(F(LT_F_FOOT_FRICTION, 0), G.mu);
-    ST_STATE(F(LT_F_FOOT_POS_W, 0), G.foot_p.x); ST_STATE(F(LT_F_FOOT_POS_W, 1), G.foot_p.y); ST_STATE(F(LT_F_FOOT_POS_W, 2), G.foot_p.z);
-    ST_STATE(F(LT_F_FOOT_VEL_W, 0), G.foot_v.x); ST_STATE(F(LT_F_FOOT_VEL_W, 1), G.foot_v.y); ST_STATE(F(LT_F_FOOT_VEL_W, 2), G.foot_v.z);
-    ST_STATE(F(LT_F_GAIT_LAST_AIR, 0), G.g_last_air); ST_STATE(F(LT_F_GAIT_LAST_CONTACT, 0), G.g_last_con);
-    ST_STATE(F(LT_F_GAIT_VALID_LAST_AIR, 0), G.g_valid);
-    *(int*)F(LT_F_GAIT_FLAGS, 0) = G.g_flags;
-#pragma unroll
-    for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) ST_STATE(F(LT_F_EPISODE_SUMS, q), sums[q]);
-  }
+  if (HELPERS || !RB) store_state();  // (one-wave form with bf16 rows: stored beside the critic rows' DMA, above)
 #ifdef LT_STAMPS
   LT_STAMP(7);
   if (lane == 0)
