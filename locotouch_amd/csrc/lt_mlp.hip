@@ -288,6 +288,73 @@ __device__ __forceinline__ void convert_pass(const MlpArgs& a, int l, float* s_a
   float* const dst = a.act_out[l];
   const bool ksplit = a.l_ks[l] > 1;
   const int koff = pad32(N);
+  // Four row tiles (several rounds of workgroups per CU: the loop's code stays in the instruction cache from the second round
+  // on): TWO groups per trip, phase by phase - one group's chain (LDS read, exp, three conversions) is ~600 ns of latency for
+  // the two waves of a SIMD; at one or two row tiles the launch runs the loop once per layer and the longer body costs more
+  // in instruction fetch than it hides.
+  if (ROWS >= 64 && (N & 31) == 0 && (KIND == LT_ACT_ELU || KIND == LT_ACT_NONE)) {
+    constexpr int NT = 64 * NW;
+#pragma unroll 1
+    for (int base = tid; base < total; base += 2 * NT) {
+      float* g[2];
+      int n0[2], row[2];
+      bool ok[2];
+      f32x4 x[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = base + u * NT;
+        ok[u] = idx < total;
+        const int id = ok[u] ? idx : base;  // (a surplus slot re-reads the first group and stores nothing)
+        row[u] = id & (ROWS - 1);
+        n0[u] = 8 * (id / ROWS);
+        g[u] = s_act + row[u] * S + n0[u];
+        x[u][0] = *(const f32x4*)g[u];
+        x[u][1] = *(const f32x4*)(g[u] + 4);
+      }
+      if (ksplit) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { x[u][0] += *(const f32x4*)(g[u] + koff); x[u][1] += *(const f32x4*)(g[u] + koff + 4); }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        x[u][0] = x[u][0] * LO_INV + *(const f32x4*)(s_bias + n0[u]);
+        x[u][1] = x[u][1] * LO_INV + *(const f32x4*)(s_bias + n0[u] + 4);
+      }
+      if (KIND == LT_ACT_ELU) {
+        const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 e[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) e[u][h] = __builtin_elementwise_min(x[u][h], zero) * 1.44269504088896340736f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) e[u][i >> 2][i & 3] = __builtin_amdgcn_exp2f(e[u][i >> 2][i & 3]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) x[u][h] = __builtin_elementwise_max(x[u][h], zero) + (e[u][h] - 1.f);
+      }
+      f16x4 hi[2][2], lo[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { split4(x[u][0], hi[u][0], lo[u][0]); split4(x[u][1], hi[u][1], lo[u][1]); }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (!ok[u]) continue;
+        *(f16x4*)g[u] = hi[u][0]; *((f16x4*)g[u] + 1) = hi[u][1];
+        *((f16x4*)g[u] + 2) = lo[u][0]; *((f16x4*)g[u] + 3) = lo[u][1];
+        if (dst) {
+          const long long e = row0 + row[u];
+          if (e < a.m) {
+            *(f32x4*)(dst + e * N + n0[u]) = x[u][0];
+            *(f32x4*)(dst + e * N + n0[u] + 4) = x[u][1];
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll 1
   for (int idx = tid; idx < total; idx += 64 * NW) {
     const int rr = idx & (ROWS - 1), j = idx / ROWS;  // consecutive lanes = consecutive rows: conflict-free (S == 4 mod 64)
