@@ -46,3 +46,20 @@ for mode in ("plain", "upload"):
         torch.cuda.synchronize(dev)
         ts.append((time.perf_counter() - t0) * 1e6)
     print(mode, "replay wall us:", " ".join(f"{t:8.1f}" for t in ts), f"  -> per step {ts[0] / K:.2f} first, {min(ts) / K:.2f} best")
+
+# how the host learns that the replay is done: torch.cuda.synchronize() alone, or an event-query spin in front of it
+g = capture(K, False)
+for mode in ("sync", "spin+sync"):
+    ts = []
+    for i in range(8):
+        torch.cuda.synchronize(dev)
+        ev = torch.cuda.Event()
+        t0 = time.perf_counter()
+        g.replay()
+        if mode != "sync":
+            ev.record()
+            while not ev.query():
+                pass
+        torch.cuda.synchronize(dev)
+        ts.append((time.perf_counter() - t0) * 1e6)
+    print(mode, "replay wall us:", " ".join(f"{t:8.1f}" for t in ts[1:]), f"  -> best per step {min(ts) / K:.2f}")
