@@ -461,6 +461,17 @@ class RslRlVecEnvWrapper:
         obs, rew, dones, extras = self.env.unwrapped.step(actions)
         return ObsTensor.wrap(obs, extras["observations"]), rew, dones, extras
 
+    def fused_target(self):
+        """The HIP env itself when nothing between the trainer and it changes a step - no action clipping here, no user terms on
+        the ManagedEnv - so that `OnPolicyRunner` can run its fused rollout (hipGraph, two launches per step) through the import
+        surface of the unmodified launch scripts as well; None otherwise (the trainer then steps through `step`)."""
+        if self.clip_actions is not None:
+            return None
+        managed = self.env.unwrapped
+        if getattr(managed, "extra", None):
+            return None
+        return getattr(managed, "vec", None)
+
     def seed(self, seed: int = -1) -> int:
         return seed
 

@@ -162,13 +162,16 @@ class OnPolicyRunner:
             from .fused import FusedRollout
         except Exception:
             return None
-        if not isinstance(self.env, LocoTouchVecEnv) or self.cfg.get("fused_rollout", True) is False:
+        target = self.env
+        if not isinstance(target, LocoTouchVecEnv):  # the scripts' wrapper (compat/runtime.py) hands the HIP env over when it adds nothing to a step
+            target = getattr(self.env, "fused_target", lambda: None)()
+        if not isinstance(target, LocoTouchVecEnv) or self.cfg.get("fused_rollout", True) is False:
             return None
         if getattr(self.alg.actor_critic, "noise_std_type", "scalar") != "scalar" or type(self.alg.actor_critic) is not ActorCritic:
             return None  # the fused rollout packs the plain feed-forward actor / critic MLPs
         if self.empirical_normalization:  # the fused rollout feeds raw observation rows to the MLP kernel
             return None
-        return FusedRollout(self.env, self.alg)
+        return FusedRollout(target, self.alg)
 
     # ---- checkpoints (reference on_policy_runner.py:369-422) -------------------------------------------
     def save(self, path: str, infos=None) -> None:

@@ -49,6 +49,14 @@ def test_runner_learns_through_the_wrapper(tmp_path):
     agent = train_cfg(TEACHER)
     agent["save_interval"] = 1
     runner = OnPolicyRunner(w, agent, log_dir=str(tmp_path), device="cuda:0")
+    # the wrapper adds nothing to a step here, so the trainer runs its fused rollout (hipGraph, two launches per step) on the HIP env
+    # behind it; action clipping in the wrapper or a user term on the ManagedEnv sends it through `step` instead
+    assert w.fused_target() is vec and runner._make_fused() is not None
+    from locotouch_amd.compat.runtime import RslRlVecEnvWrapper
+    assert RslRlVecEnvWrapper(w.env, clip_actions=1.0).fused_target() is None
+    w.env.add_reward_term("zero", lambda e: e.scene["robot"].data.joint_vel[:, 0] * 0.0, 1.0)
+    assert w.fused_target() is None
+    w.env.extra = None
     runner.learn(num_learning_iterations=2, init_at_random_ep_len=True)
     assert sorted(os.path.basename(p) for p in glob.glob(str(tmp_path / "model_*.pt")))[-1] == "model_1.pt"
     assert all(torch.isfinite(p).all() for p in runner.alg.actor_critic.parameters())
