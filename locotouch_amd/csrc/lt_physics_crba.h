@@ -365,136 +365,6 @@ __device__ __forceinline__ RC leg_contact(const lt_cfg& c, float h, V3 r, float 
   return out;
 }
 
-// ---- the carried cylinder's share of a substep: its contacts with the plate (sample = lane) and the ground, its own 6x6
-//      solve, and its integration.  Couples to the robot only through the base STATE at the substep start (the plate
-//      reaction is an explicit wrench on the trunk), so a helper wave can run it beside the leg dynamics. ----
-struct ObjOut {
-  V3 pb_n, pb_f;      // this lane's share of the base bias wrench (reaction of its plate sample)
-  V3 obj_part;        // ... of the net contact force on the object (world)
-  V3 trunk_part;      // ... of the net contact force on the trunk (world), plate part
-  V3 plate;           // tactile tasks: this lane's plate sample (x, y in the trunk frame, normal force)
-};
-template <bool TAC>
-__device__ __forceinline__ ObjOut object_part(const lt_cfg& c, float h, int leg, const Base& B, Obj& O, float trunk_mu) {
-  ObjOut out;
-  out.pb_n = v3(0, 0, 0); out.pb_f = v3(0, 0, 0); out.obj_part = v3(0, 0, 0); out.trunk_part = v3(0, 0, 0); out.plate = v3(0, 0, 0);
-  const float g = c.gravity;
-  const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
-  // ---- carried cylinder: free body, implicit contacts with the plate (sample = lane) and the ground ----
-  V3 obj_aa = v3(0, 0, 0), obj_al = v3(0, 0, 0);
-  {
-    const M3 Ro = quat_to_mat(O.q.w, O.q.x, O.q.y, O.q.z);
-    const V3 ay = col(Ro, 1);
-    const float rad = O.rad, half = 0.5f * O.len;
-    const float mu_plate = 0.5f * (trunk_mu + O.mu);
-    const V3 ct = tmul(R0, O.p - B.p), at = tmul(R0, ay);
-    const float hx = LT_BACK_HALF_X, hy = LT_RAIL_Y + LT_RAIL_RADIUS, zp = LT_BACK_TOP_Z;
-    float s0 = -half, s1 = half;
-    bool ok = true;
-    {
-      const float cc[2] = {ct.x, ct.y}, dd[2] = {at.x, at.y}, lim[2] = {hx, hy};
-#pragma unroll
-      for (int ax = 0; ax < 2; ++ax) {
-        if (ok) {
-          if (fabsf(dd[ax]) < 1e-9f) { if (fabsf(cc[ax]) > lim[ax]) ok = false; }
-          else {
-            float ta = (-lim[ax] - cc[ax]) / dd[ax], tb = (lim[ax] - cc[ax]) / dd[ax];
-            if (ta > tb) { const float t = ta; ta = tb; tb = t; }
-            s0 = ta > s0 ? ta : s0;
-            s1 = tb < s1 ? tb : s1;
-            if (s0 > s1) ok = false;
-          }
-        }
-      }
-    }
-    I6 Mo; Mo.A = m3_zero(); Mo.B = m3_zero(); Mo.C = m3_zero();
-    V3 rhs_a = v3(0, 0, 0), rhs_l = v3(0, 0, 0);
-    Law lp; lp.active = false; lp.fx = lp.fy = lp.fn = lp.cte = lp.Bn = 0.f;
-    V3 Pw_p = v3(0, 0, 0), rho_p = v3(0, 0, 0), F0_p = v3(0, 0, 0);
-    const V3 nw = col(R0, 2);
-    out.plate = v3(0, 0, 0);
-    if (ok) {
-      const float nza = at.z;
-      const V3 up = v3(-nza * at.x, -nza * at.y, 1.f - nza * at.z);
-      const float un = norm(up);
-      const float inv = 1.f / (un > 1e-6f ? un : 1e-6f);
-      const float sk = s0 + (s1 - s0) * (float)leg / 3.f;
-      const V3 Pt = v3(ct.x + sk * at.x - rad * up.x * inv, ct.y + sk * at.y - rad * up.y * inv, ct.z + sk * at.z - rad * up.z * inv);
-      const float d = zp - Pt.z;
-      if (TAC) { out.plate.x = Pt.x; out.plate.y = Pt.y; }
-      if (d > 0.f) {
-        Pw_p = B.p + mul(R0, Pt);
-        rho_p = Pw_p - O.p;
-        const V3 vo = O.u + cross(O.w, rho_p);
-        const V3 vt = B.u + cross(B.w, Pw_p - B.p);
-        const V3 vrel = tmul(R0, vo - vt);
-        lp = contact_law(d, vrel, c.plate_kn / 4, c.plate_cn / 4, c.plate_ct / 4, mu_plate, c.contact_ramp, h);
-        if (lp.active) {
-          F0_p = mul(R0, v3(lp.fx, lp.fy, lp.fn));
-          add_contact_inertia(Mo, rho_p, nw, lp.cte, lp.Bn, h);
-          rhs_a += cross(rho_p, F0_p);
-          rhs_l += F0_p;
-        }
-      }
-    }
-    Law lg; lg.active = false; lg.fx = lg.fy = lg.fn = lg.cte = lg.Bn = 0.f;
-    V3 rho_g = v3(0, 0, 0), F0_g = v3(0, 0, 0);
-    if (leg < 2) {
-      const float nza = ay.z;
-      const V3 up = v3(-nza * ay.x, -nza * ay.y, 1.f - nza * ay.z);
-      const float un = norm(up);
-      const float inv = 1.f / (un > 1e-6f ? un : 1e-6f);
-      const float sk = leg == 0 ? -half : half;
-      const V3 Pw = v3(O.p.x + sk * ay.x - rad * up.x * inv, O.p.y + sk * ay.y - rad * up.y * inv, O.p.z + sk * ay.z - rad * up.z * inv);
-      if (Pw.z < 0.f) {
-        rho_g = Pw - O.p;
-        const V3 vo = O.u + cross(O.w, rho_g);
-        lg = contact_law(-Pw.z, vo, c.ground_kn, c.ground_cn, c.ground_ct, O.mu * c.ground_mu, c.contact_ramp, h);
-        if (lg.active) {
-          F0_g = v3(lg.fx, lg.fy, lg.fn);
-          add_contact_inertia(Mo, rho_g, v3(0, 0, 1), lg.cte, lg.Bn, h);
-          rhs_a += cross(rho_g, F0_g);
-          rhs_l += F0_g;
-        }
-      }
-    }
-    I6 M;
-    M.A = qsum_sym(Mo.A); M.B = qsum_full(Mo.B); M.C = qsum_sym(Mo.C);
-    rhs_a = qsum(rhs_a); rhs_l = qsum(rhs_l);
-    const float m = O.mass;
-    const float Iyy = 0.5f * m * rad * rad, Ixx = m * (3.f * rad * rad + O.len * O.len) / 12.f;
-    M3 Iw = m3_diag(Ixx);
-    Iw += outer((Iyy - Ixx) * ay, ay);
-    M.A += Iw;
-    M.C += m3_diag(m);
-    rhs_a -= cross(O.w, mul(Iw, O.w));
-    rhs_l.z -= m * g;
-    spd6_solve(M, rhs_a, rhs_l, obj_aa, obj_al);
-    if (lp.active) {
-      const V3 ap = obj_al + cross(obj_aa, rho_p);
-      const float an = dot(nw, ap);
-      const V3 F = F0_p - h * (lp.cte * ap + ((lp.Bn - lp.cte) * an) * nw);
-      out.obj_part += F;
-      if (TAC) out.plate.z = dot(nw, F);  // the cylinder presses the taxels with the plate-normal part of its contact force
-      const V3 Fn = -F;
-      const V3 rb = tmul(R0, Pw_p - B.p), fb = tmul(R0, Fn);
-      out.pb_n -= cross(rb, fb);
-      out.pb_f -= fb;
-      out.trunk_part += Fn;
-    }
-    if (lg.active) {
-      const V3 ap = obj_al + cross(obj_aa, rho_g);
-      out.obj_part += v3(F0_g.x - h * lg.cte * ap.x, F0_g.y - h * lg.cte * ap.y, F0_g.z - h * lg.Bn * ap.z);
-    }
-  }
-
-  O.w += h * obj_aa;
-  O.u += h * obj_al;
-  O.p += h * O.u;
-  O.q = q_integrate(O.q, O.w, h);
-  return out;
-}
-
 // =====================================================================================================
 // Packed-pair formulation of the leg dynamics (lt_device_math.h "packed pairs").  What is paired:
 //   * (omega | velocity-product angular acceleration) and (v | velocity-product linear acceleration) of every link: the
@@ -558,6 +428,137 @@ __device__ __forceinline__ void spd6_solve(const I6p& M, const P3& b, V3& xa, V3
   F.B.m[0] = M.bd[0]; F.B.m[4] = M.bd[1]; F.B.m[8] = M.bd[2];
   F.B.m[1] = M.bo[0].x; F.B.m[3] = M.bo[0].y; F.B.m[2] = M.bo[1].x; F.B.m[6] = M.bo[1].y; F.B.m[5] = M.bo[2].x; F.B.m[7] = M.bo[2].y;
   spd6_solve(F, lo(b), hi(b), xa, xl);
+}
+
+// ---- the carried cylinder's share of a substep: its contacts with the plate (sample = lane) and the ground, its own 6x6
+//      solve, and its integration.  Couples to the robot only through the base STATE at the substep start (the plate
+//      reaction is an explicit wrench on the trunk), so a helper wave can run it beside the leg dynamics. ----
+struct ObjOut {
+  V3 pb_n, pb_f;      // this lane's share of the base bias wrench (reaction of its plate sample)
+  V3 obj_part;        // ... of the net contact force on the object (world)
+  V3 trunk_part;      // ... of the net contact force on the trunk (world), plate part
+  V3 plate;           // tactile tasks: this lane's plate sample (x, y in the trunk frame, normal force)
+};
+template <bool TAC>
+__device__ __forceinline__ ObjOut object_part(const lt_cfg& c, float h, int leg, const Base& B, Obj& O, float trunk_mu) {
+  ObjOut out;
+  out.pb_n = v3(0, 0, 0); out.pb_f = v3(0, 0, 0); out.obj_part = v3(0, 0, 0); out.trunk_part = v3(0, 0, 0); out.plate = v3(0, 0, 0);
+  const float g = c.gravity;
+  const M3 R0 = quat_to_mat(B.q.w, B.q.x, B.q.y, B.q.z);
+  // ---- carried cylinder: free body, implicit contacts with the plate (sample = lane) and the ground ----
+  V3 obj_aa = v3(0, 0, 0), obj_al = v3(0, 0, 0);
+  {
+    const M3 Ro = quat_to_mat(O.q.w, O.q.x, O.q.y, O.q.z);
+    const V3 ay = col(Ro, 1);
+    const float rad = O.rad, half = 0.5f * O.len;
+    const float mu_plate = 0.5f * (trunk_mu + O.mu);
+    const V3 ct = tmul(R0, O.p - B.p), at = tmul(R0, ay);
+    const float hx = LT_BACK_HALF_X, hy = LT_RAIL_Y + LT_RAIL_RADIUS, zp = LT_BACK_TOP_Z;
+    float s0 = -half, s1 = half;
+    bool ok = true;
+    {
+      const float cc[2] = {ct.x, ct.y}, dd[2] = {at.x, at.y}, lim[2] = {hx, hy};
+#pragma unroll
+      for (int ax = 0; ax < 2; ++ax) {
+        if (ok) {
+          if (fabsf(dd[ax]) < 1e-9f) { if (fabsf(cc[ax]) > lim[ax]) ok = false; }
+          else {
+            float ta = (-lim[ax] - cc[ax]) / dd[ax], tb = (lim[ax] - cc[ax]) / dd[ax];
+            if (ta > tb) { const float t = ta; ta = tb; tb = t; }
+            s0 = ta > s0 ? ta : s0;
+            s1 = tb < s1 ? tb : s1;
+            if (s0 > s1) ok = false;
+          }
+        }
+      }
+    }
+    I6p Mo = i6p_zero();  // (the packed block layout of the leg dynamics: a contact's h J^T B J is ~30 operations instead of ~90)
+    V3 rhs_a = v3(0, 0, 0), rhs_l = v3(0, 0, 0);
+    Law lp; lp.active = false; lp.fx = lp.fy = lp.fn = lp.cte = lp.Bn = 0.f;
+    V3 Pw_p = v3(0, 0, 0), rho_p = v3(0, 0, 0), F0_p = v3(0, 0, 0);
+    const V3 nw = col(R0, 2);
+    out.plate = v3(0, 0, 0);
+    if (ok) {
+      const float nza = at.z;
+      const V3 up = v3(-nza * at.x, -nza * at.y, 1.f - nza * at.z);
+      const float un = norm(up);
+      const float inv = 1.f / (un > 1e-6f ? un : 1e-6f);
+      const float sk = s0 + (s1 - s0) * (float)leg / 3.f;
+      const V3 Pt = v3(ct.x + sk * at.x - rad * up.x * inv, ct.y + sk * at.y - rad * up.y * inv, ct.z + sk * at.z - rad * up.z * inv);
+      const float d = zp - Pt.z;
+      if (TAC) { out.plate.x = Pt.x; out.plate.y = Pt.y; }
+      if (d > 0.f) {
+        Pw_p = B.p + mul(R0, Pt);
+        rho_p = Pw_p - O.p;
+        const V3 vo = O.u + cross(O.w, rho_p);
+        const V3 vt = B.u + cross(B.w, Pw_p - B.p);
+        const V3 vrel = tmul(R0, vo - vt);
+        lp = contact_law(d, vrel, c.plate_kn / 4, c.plate_cn / 4, c.plate_ct / 4, mu_plate, c.contact_ramp, h);
+        if (lp.active) {
+          F0_p = mul(R0, v3(lp.fx, lp.fy, lp.fn));
+          i6p_add_contact(Mo, rho_p, nw, h * lp.cte, h * lp.Bn);
+          rhs_a += cross(rho_p, F0_p);
+          rhs_l += F0_p;
+        }
+      }
+    }
+    Law lg; lg.active = false; lg.fx = lg.fy = lg.fn = lg.cte = lg.Bn = 0.f;
+    V3 rho_g = v3(0, 0, 0), F0_g = v3(0, 0, 0);
+    // (the two rim points: only when the cylinder can reach the ground at all - its lowest point lies above p.z - half - rad;
+    //  on the robot's back that is ~0.3 m, and the ~50 operations of the points' construction were paid every substep)
+    if (leg < 2 && O.p.z - half - rad < 0.f) {
+      const float nza = ay.z;
+      const V3 up = v3(-nza * ay.x, -nza * ay.y, 1.f - nza * ay.z);
+      const float un = norm(up);
+      const float inv = 1.f / (un > 1e-6f ? un : 1e-6f);
+      const float sk = leg == 0 ? -half : half;
+      const V3 Pw = v3(O.p.x + sk * ay.x - rad * up.x * inv, O.p.y + sk * ay.y - rad * up.y * inv, O.p.z + sk * ay.z - rad * up.z * inv);
+      if (Pw.z < 0.f) {
+        rho_g = Pw - O.p;
+        const V3 vo = O.u + cross(O.w, rho_g);
+        lg = contact_law(-Pw.z, vo, c.ground_kn, c.ground_cn, c.ground_ct, O.mu * c.ground_mu, c.contact_ramp, h);
+        if (lg.active) {
+          F0_g = v3(lg.fx, lg.fy, lg.fn);
+          i6p_add_contact(Mo, rho_g, v3(0, 0, 1), h * lg.cte, h * lg.Bn);
+          rhs_a += cross(rho_g, F0_g);
+          rhs_l += F0_g;
+        }
+      }
+    }
+    I6p M = qsum6(Mo);
+    rhs_a = qsum(rhs_a); rhs_l = qsum(rhs_l);
+    const float m = O.mass;
+    const float Iyy = 0.5f * m * rad * rad, Ixx = m * (3.f * rad * rad + O.len * O.len) / 12.f;
+    M3 Iw = m3_diag(Ixx);
+    Iw += outer((Iyy - Ixx) * ay, ay);
+    M.ac[0] += mk2(Iw.m[0], m); M.ac[1].x += Iw.m[1]; M.ac[2].x += Iw.m[2];
+    M.ac[3] += mk2(Iw.m[4], m); M.ac[4].x += Iw.m[5]; M.ac[5] += mk2(Iw.m[8], m);
+    rhs_a -= cross(O.w, mul(Iw, O.w));
+    rhs_l.z -= m * g;
+    spd6_solve(M, pair(rhs_a, rhs_l), obj_aa, obj_al);
+    if (lp.active) {
+      const V3 ap = obj_al + cross(obj_aa, rho_p);
+      const float an = dot(nw, ap);
+      const V3 F = F0_p - h * (lp.cte * ap + ((lp.Bn - lp.cte) * an) * nw);
+      out.obj_part += F;
+      if (TAC) out.plate.z = dot(nw, F);  // the cylinder presses the taxels with the plate-normal part of its contact force
+      const V3 Fn = -F;
+      const V3 rb = tmul(R0, Pw_p - B.p), fb = tmul(R0, Fn);
+      out.pb_n -= cross(rb, fb);
+      out.pb_f -= fb;
+      out.trunk_part += Fn;
+    }
+    if (lg.active) {
+      const V3 ap = obj_al + cross(obj_aa, rho_g);
+      out.obj_part += v3(F0_g.x - h * lg.cte * ap.x, F0_g.y - h * lg.cte * ap.y, F0_g.z - h * lg.Bn * ap.z);
+    }
+  }
+
+  O.w += h * obj_aa;
+  O.u += h * obj_al;
+  O.p += h * O.u;
+  O.q = q_integrate(O.q, O.w, h);
+  return out;
 }
 
 // child link's (omega | aa) and (v | al) from the parent's: rotate both halves, add the joint rate to omega and the
