@@ -678,7 +678,7 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
 #define LT_MLP_RING2 16  // ring slots at two row tiles (32 at eight waves: 352 B of scratch)
 #endif
 #ifndef LT_MLP_RING4
-#define LT_MLP_RING4 16  // ring slots at four row tiles
+#define LT_MLP_RING4 8   // ring slots at four row tiles: one item of the widest layer - 16 slots spill 72 bytes and measured slower (177 against 171 us at 32768 envs: the launch is not stream-bound there)
 #endif
 #ifndef LT_MLP_RING1
 #define LT_MLP_RING1 (LT_MLP_WAVES > 4 ? 16 : 32)  // ring slots at one row tile
