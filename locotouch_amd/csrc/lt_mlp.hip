@@ -41,9 +41,9 @@
 //     (every CU still gets a workgroup), 4 from 16384 (several rounds of workgroups, each streaming the weights again);
 //   * the weights are pre-packed once per policy update (lt_mlp_pack) - already split into (hi, lo) f16 - into ONE LINEAR
 //     STREAM PER WAVE of 1-KiB chunks (64 lanes x 16 B) in exactly the order the wave consumes them, across layers: per
-//     32-wide k-group one item of T x (hi chunk, lo chunk).  The kernel keeps a register ring of 16 chunks per wave (8 at four row tiles; 128 KiB
-//     in flight per CU; 8 at four row tiles) and refills a slot right after its MFMAs, so the first weights of layer l+1 are already on their way
-//     while layer l finishes.  Every wave-instruction of the stream is one fully coalesced global_load_dwordx4; all
+//     32-wide k-group one item of T x (hi chunk, lo chunk).  The kernel keeps a register ring of 16 chunks per wave (128 KiB
+//     in flight per CU; 8 chunks at four row tiles) and refills a slot right after its MFMAs, so the first weights of layer l+1 are
+//     already on their way while layer l finishes.  Every wave-instruction of the stream is one fully coalesced global_load_dwordx4; all
 //     workgroups stream the same ~1.4 MB per network from L2 (measured with stamps: 89 GB/s per CU in the first layer);
 //   * biases live in LDS (staged once) and are added by the conversion pass;
 //   * the policy head's noise is drawn in the prologue by the last wave under the latency of the input rows, and a narrow
