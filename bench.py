@@ -225,33 +225,46 @@ def main() -> None:
         prof = lambda: env.step_rows_profiled(act, st.observations[0], st.privileged_observations[0], st.observations[1], st.privileged_observations[1])  # noqa: E731
     else:
         prof = lambda: env.step_profiled(act)  # noqa: E731
-    for _ in range(20):
-        prof()
-    ms = [prof() for _ in range(200)]
-    if args.obs_dtype == "bf16":
-        env.set_row_format(torch.float32)
+    try:
+        for _ in range(20):
+            prof()
+        ms = [prof() for _ in range(200)]
+    finally:  # (lt_env_step* without row pointers refuses to run while the bf16 row format is selected, include/lt_env.h)
+        if args.obs_dtype == "bf16":
+            env.set_row_format(torch.float32)
     k_ms = sum(ms) / len(ms)
     algo_bytes = (ALGO_BYTES_PER_ENV_STEP_BF16_ROWS if args.obs_dtype == "bf16" else ALGO_BYTES_PER_ENV_STEP)[args.task] * n
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
     key = f"{args.task}_{n}" + ("_bf16rows" if args.obs_dtype == "bf16" else "")
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    # The PMC numbers (HBM traffic, VALU instruction count) come from committed rocprofv3 --pmc summaries of this same command
+    # (profiles/traffic.json, profiles/sq_counters.json; tools/profile_round.sh).  Each entry carries the stamp of the kernel
+    # sources it was measured on: an entry whose stamp differs from this tree's is NOT reported (`traffic` null, `stale_profile`).
+    from locotouch_amd.build import step_kernel_source_hash
+
+    tree_hash = step_kernel_source_hash()
+
+    def committed(fname: str) -> tuple[dict, bool]:
+        """(entry, stale) of this configuration's record in profiles/<fname>."""
         try:
-            traffic = json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
+            entry = json.load(open(os.path.join(REPO, "profiles", fname))).get(key, {})
         except Exception:
-            traffic = None
+            return {}, False
+        if entry and entry.get("source_hash") != tree_hash:
+            return {}, True
+        return entry, False
+
+    tentry, tstale = committed("traffic.json")
+    traffic = tentry.get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "lt_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes,
-                "env_only_steps_per_s": n / (k_ms * 1e-3)}
+                "env_only_steps_per_s": n / (k_ms * 1e-3), "kernel_source_hash": tree_hash}
     # what actually bounds the step kernel: VALU issue.  Wave-instructions per launch from the SQ counters of the same command
     # (profiles/sq_counters.json, tools/pmc_sq.py) against what 1024 SIMDs can issue in the measured kernel time.
-    spath = os.path.join(REPO, "profiles", "sq_counters.json")
-    if os.path.exists(spath):
-        try:
-            valu = json.load(open(spath)).get(key, {}).get("valu_wave_insts_per_launch")
-        except Exception:
-            valu = None
+    sentry, sstale = committed("sq_counters.json")
+    if tstale or sstale:
+        roofline["stale_profile"] = True  # profiles/*.json were measured on other kernel sources: re-run tools/profile_round.sh
+    if True:
+        valu = sentry.get("valu_wave_insts_per_launch")
         if valu:
             rate = valu / (k_ms * 1e6)  # G wave-instructions / s
             roofline["valu"] = {"bound": "valu-issue", "kernel": "lt_step_kernel", "achieved": rate, "peak": VALU_PEAK_GINST,
@@ -317,11 +330,13 @@ def main() -> None:
     if dist.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.task, n)
 
+    env.check()  # a chained step launch that lost its population-pass hand-off (LT_F_COUNTERS[1]) fails the run loudly
     if dist.rank == 0:
         task_name = "TransportTeacher" if args.task == "teacher" else "Locomotion"
         out = {"metric": f"env-steps/sec (whole node), {task_name} {n} envs/GPU", "value": value, "unit": "env-steps/s",
                "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if args.obs_dtype == "f32" else "f32 state and arithmetic / bf16 observation rows", "data": "synthetic",
                "config": {"workload": f"{TASKS[args.task]} rollout (policy act + env step + storage), {n} envs/GPU, "
                                       f"random-init ActorCritic [512,256,128], seed 42, env RNG keyed by global env index"
                                       + ("; observation rows, their 6-deep history and the rollout-storage observations in bf16, all state "

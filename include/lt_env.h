@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 10
+#define LT_ABI_VERSION 11
 
 /* error codes */
 #define LT_OK 0
@@ -80,9 +80,14 @@ enum lt_term_bit {
  * term into `terminated` [DEP]; reference cfg: locomotion_base_env_cfg.py:296-313): the caller evaluates the term on the state a step
  * left (lt_env_get_view) and sets LT_TERM_REQUEST_BIT in LT_F_TERM_BITS of the envs it fires for; the NEXT lt_env_step* reads the
  * bit before it rewrites the word, reports LT_T_USER among that step's bits and terminates the env (dones, the `alive` term and the
- * reset like any other termination) - one env step later than a fused term would.  LT_T_USER has no `term_enabled` entry. */
+ * reset like any other termination) - one env step later than a fused term would.  LT_T_USER has no `term_enabled` entry.
+ * A user term with `time_out = True` (TerminationTermCfg.time_out: the TerminationManager ORs it into `time_outs` instead [DEP])
+ * sets LT_TIMEOUT_REQUEST_BIT: the next step reports LT_T_USER_TIME_OUT and ends the env by TIME-OUT (LT_F_TIME_OUT, no `alive`
+ * penalty, value bootstrap in lt_env_step_rollout as for the stock time_out term, loco_rl/loco_rl/algorithms/ppo.py:162-165). */
 #define LT_T_USER 7
+#define LT_T_USER_TIME_OUT 8
 #define LT_TERM_REQUEST_BIT 30
+#define LT_TIMEOUT_REQUEST_BIT 29
 
 /*
  * Environment configuration.  Every member after `seed` is a 4-byte int32_t or float (arrays of them), so
@@ -360,7 +365,8 @@ int lt_env_step_rollout(lt_env* env, const float* actions, const float* prev_pol
  * config 5: bf16 observation rows, history and rollout-storage observations; the arena's own rows and all state stay f32).
  * LT_ROWS_BF16: rows are uint16 [n][obs_dim] (bf16 bit patterns); the newest frame is rounded to nearest-even as it enters a row,
  * older frames are carried bit for bit, so a frame is rounded exactly once.  All four row pointers must then be given (LT_EHIP /
- * invalid value otherwise); lt_env_step is unaffected.  Not available for the tactile tasks.  The reference keeps f32 everywhere
+ * invalid value for some but not all); entry points that take no row pointers (lt_env_step, lt_env_step_profiled) keep stepping
+ * the arena's f32 rows.  Not available for the tactile tasks.  The reference keeps f32 everywhere
  * (loco_rl/loco_rl/storage/rollout_storage.py:36-44). */
 enum lt_row_format { LT_ROWS_F32 = 0, LT_ROWS_BF16 = 1 };
 int lt_env_set_row_format(lt_env* env, int format);
@@ -477,7 +483,14 @@ int lt_rollout_record(int64_t n, float gamma, const float* reward, const int64_t
 /* ---- fused fp32 MLP inference (actor / critic evaluation inside the rollout loop; reference
  * loco_rl/loco_rl/modules/actor_critic.py:113-131: self.actor(obs), self.critic(critic_obs) - Linear layers with one activation between).
  * One launch per network (or both) on the f16 MFMA with error-compensated operand splitting - three MFMAs per f32-equivalent MAC, csrc/lt_mlp.hip;
- * weights are re-packed from the torch.nn.Linear layout once per policy update. ---- */
+ * weights are re-packed from the torch.nn.Linear layout once per policy update.
+ * DOMAIN (applies to lt_mlp_forward, lt_mlp_forward_pair, lt_rollout_policy, lt_rollout_policy_value): every value that enters a
+ * layer - the input rows x / obs and every hidden activation - is SATURATED to [-LT_MLP_INPUT_CLAMP, +LT_MLP_INPUT_CLAMP] before
+ * the operand split (64 x must stay a finite f16 number).  Inside that range the results are f32-equivalent (error below an f32
+ * GEMM's own rounding); outside it the kernel computes MLP(clamp(x)) per layer, which the reference's fp32 ActorCritic does not.
+ * Weights and the outputs of the last layer are not bounded.  The trainer checks the bound on the device once per PPO update
+ * (locotouch_amd/rl/mlp.py: PackedPair.domain_max) and warns when it is reached. ---- */
+#define LT_MLP_INPUT_CLAMP 1000
 #define LT_MLP_MAX_LAYERS 6
 #define LT_MLP_MAX_WIDTH 1008
 enum lt_activation { LT_ACT_NONE = 0, LT_ACT_ELU = 1, LT_ACT_RELU = 2, LT_ACT_TANH = 3 };

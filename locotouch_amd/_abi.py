@@ -67,8 +67,11 @@ class LtCfg(ctypes.Structure):
     def copy(self) -> "LtCfg":
         new = LtCfg()
         ctypes.memmove(ctypes.byref(new), ctypes.byref(self), ctypes.sizeof(self))
-        if hasattr(self, "extra_reward_terms"):  # (compat/cfg_translate.py: user reward terms for the slow torch path)
-            new.extra_reward_terms = list(self.extra_reward_terms)
+        # (compat/cfg_translate.py: user terms for the slow torch path - Python attributes beside the C struct)
+        for attr in ("extra_reward_terms", "extra_termination_terms", "reward_term_params"):
+            if hasattr(self, attr):
+                v = getattr(self, attr)
+                setattr(new, attr, dict(v) if isinstance(v, dict) else list(v))
         return new
 
     def to_dict(self) -> dict:

@@ -34,6 +34,22 @@ def deps() -> list[str]:
                               + glob.glob(os.path.join(REPO, "include", "*.h")))
 
 
+STEP_KERNEL_SOURCES = ("lt_env.hip", "lt_physics_crba.h", "lt_post.h", "lt_device_math.h", "lt_device_prims.h")
+
+
+def step_kernel_source_hash() -> str:
+    """Stamp of the sources lt_step_kernel is compiled from: sha1 over their `git hash-object` ids.  The PMC summaries under
+    profiles/ (traffic.json, sq_counters.json) carry the stamp of the tree they were measured on; bench.py reports their numbers
+    only while the stamp still matches (a kernel change without a re-profile must not print stale counters)."""
+    import hashlib
+
+    ids = []
+    for name in STEP_KERNEL_SOURCES:
+        blob = open(os.path.join(CSRC, name), "rb").read()
+        ids.append(hashlib.sha1(b"blob %d\0" % len(blob) + blob).hexdigest())  # == `git hash-object <file>`
+    return hashlib.sha1("".join(ids).encode()).hexdigest()[:16]
+
+
 def up_to_date() -> bool:
     if not os.path.exists(LIB):
         return False

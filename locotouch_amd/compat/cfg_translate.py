@@ -103,8 +103,8 @@ TACTILE_FORMATS = {"BinaryTactileSignals": "LT_TACTILE_BINARY", "NormalizedTacti
 
 def translate(env_cfg, seed: int | None = None, omit_groups: tuple = (), collect_unknown_rewards: bool = False) -> "_abi.LtCfg":
     """`collect_unknown_rewards`: a reward term the fused kernels do not know is not an error - it is returned in
-    `cfg.extra_reward_terms` [(name, func, weight, params)], an unknown termination term (time_out = False) in
-    `cfg.extra_termination_terms` [(name, func, params)], for the slow torch path (compat/scene_views.py: evaluated on
+    `cfg.extra_reward_terms` [(name, func, weight, params)], an unknown termination term in
+    `cfg.extra_termination_terms` [(name, func, params, time_out)], for the slow torch path (compat/scene_views.py: evaluated on
     IsaacLab-layout views after every step and added to the kernel's reward)."""
     kind = task_kind(env_cfg)
     has_obj = kind != C["LT_TASK_LOCOMOTION"]
@@ -172,6 +172,15 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = (), collect
     rt = _terms(env_cfg.rewards)
     sigma = {}
     extra_terms = []
+    def to_slow_path(name, term, why):
+        """A term under a fused NAME that the fused implementation cannot honour (another function, a parameter value the kernel
+        does not implement): with `collect_unknown_rewards` it is evaluated by the slow path with the cfg's own function -
+        locotouch/mdp/rewards.py:469-481,503-522,545-594 run as they are on the views of compat/scene_views.py - and its fused
+        weight stays 0; strict translation refuses."""
+        _need(collect_unknown_rewards, f"reward {name!r}: {why}")
+        if float(term.weight) != 0.0:
+            extra_terms.append((name, term.func, float(term.weight), dict(term.params or {})))
+
     for name, term in rt.items():
         if name not in _REWARDS and collect_unknown_rewards:
             if float(term.weight) != 0.0:
@@ -182,10 +191,22 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = (), collect
         w = float(term.weight)
         fn = _name(term.func)
         if fn not in funcs:
-            _need(w == 0.0, f"reward {name!r}: func {fn} is not the implemented {sorted(funcs)}")
+            if w != 0.0:
+                to_slow_path(name, term, f"func {fn} is not the implemented {sorted(funcs)}")
             continue
-        cfg.reward_weight[C[enum]] = w
         p = term.params
+        if name in ("object_xy_position", "object_yaw_alignment") and int(p.get("work_only_when_cmd", 0)) != 1 and w != 0.0:
+            to_slow_path(name, term, "work_only_when_cmd must be 1")  # (the function's default is 0, rewards.py:473,549)
+            continue
+        if name == "object_dangerous_state":
+            # x_max / y_max are also read by the gait-with-object class (rewards.py:380-381), whichever path evaluates the term
+            cfg.danger_x_max, cfg.danger_y_max = float(p["x_max"]), float(p["y_max"])
+            if p.get("roll_pitch_max") is not None or any(p.get(k) is None for k in ("z_min", "vel_xy_max")):
+                if w != 0.0:
+                    to_slow_path(name, term, "roll_pitch_max / a disabled limit is not implemented by the fused term")
+                continue
+            cfg.danger_z_min, cfg.danger_vel_xy_max = float(p["z_min"]), float(p["vel_xy_max"])
+        cfg.reward_weight[C[enum]] = w
         if name in ("track_lin_vel_xy", "track_ang_vel_z"):
             sigma[name] = float(p["sigma"])
         elif name == "foot_slip":
@@ -198,12 +219,6 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = (), collect
             cfg.joint_pos_stand_scale, cfg.joint_pos_vel_threshold = float(p["stand_still_scale"]), float(p["velocity_threshold"])
         elif name == "thigh_calf_collision":
             cfg.thigh_calf_threshold = float(p["threshold"])
-        elif name in ("object_xy_position", "object_yaw_alignment"):
-            _need(int(p.get("work_only_when_cmd", 1)) == 1, f"{name}: work_only_when_cmd must be 1")
-        elif name == "object_dangerous_state":
-            _need(p.get("roll_pitch_max") is None, "object_dangerous_state: roll_pitch_max is not implemented")
-            cfg.danger_x_max, cfg.danger_y_max = float(p["x_max"]), float(p["y_max"])
-            cfg.danger_z_min, cfg.danger_vel_xy_max = float(p["z_min"]), float(p["vel_xy_max"])
         elif name == "gait":
             cfg.gait_with_object = 1 if fn.endswith("withObject") else 0
             _need(tuple(map(tuple, p["synced_feet_pair_names"])) == (("a_FR_foot", "d_RL_foot"), ("b_FL_foot", "c_RR_foot")), "gait: foot pairs differ from the trot pairs")
@@ -227,8 +242,9 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = (), collect
     # ---- terminations (locomotion_base_env_cfg.py:296-313, mdp/terminations.py) ----
     extra_terminations = []
     for name, term in _terms(env_cfg.terminations).items():
-        if name not in _TERMINATIONS and collect_unknown_rewards and not bool(term.time_out):
-            extra_terminations.append((name, term.func, dict(term.params or {})))  # slow path: compat/scene_views.py (LT_T_USER)
+        if name not in _TERMINATIONS and collect_unknown_rewards:
+            # slow path (compat/scene_views.py): LT_T_USER, or LT_T_USER_TIME_OUT for a term flagged time_out = True
+            extra_terminations.append((name, term.func, dict(term.params or {}), bool(term.time_out)))
             continue
         _need(name in _TERMINATIONS, f"termination term {name!r} has no fused implementation")
         enum, fn = _TERMINATIONS[name]

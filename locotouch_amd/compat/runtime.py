@@ -98,8 +98,8 @@ class ManagedEnv:
             self.extra = ExtraTerms(vec_env)
             for name, func, weight, params in extra_rewards:
                 self.extra.add_reward(name, func, weight, params)
-        for name, func, params in extra_terminations:
-            self.add_termination_term(name, func, params)
+        for name, func, params, *flag in extra_terminations:
+            self.add_termination_term(name, func, params, time_out=bool(flag and flag[0]))
 
     def add_reward_term(self, name: str, func, weight: float, params: dict | None = None) -> None:
         """Attach a user reward term `func(env, **params) -> (N,)` (reference term signature, mdp/rewards.py:15-20)."""
@@ -109,14 +109,14 @@ class ManagedEnv:
             self.extra = ExtraTerms(self.vec)
         self.extra.add_reward(name, func, weight, params)
 
-    def add_termination_term(self, name: str, func, params: dict | None = None) -> None:
+    def add_termination_term(self, name: str, func, params: dict | None = None, time_out: bool = False) -> None:
         """Attach a user termination term `func(env, **params) -> bool (N,)` (mdp/terminations.py:10-23); it takes effect one env
-        step after it fires (include/lt_env.h, LT_T_USER)."""
+        step after it fires (include/lt_env.h, LT_T_USER; `time_out`: LT_T_USER_TIME_OUT - the env ends by time-out)."""
         if self.extra is None:
             from .scene_views import ExtraTerms
 
             self.extra = ExtraTerms(self.vec)
-        self.extra.add_termination(name, func, params)
+        self.extra.add_termination(name, func, params, time_out=time_out)
 
     @property
     def scene(self):
@@ -127,12 +127,15 @@ class ManagedEnv:
         return self.extra.env.scene
 
     def step(self, actions):
+        if self.extra:
+            self.extra.pre_step()
         obs, rew, dones, extras = self.vec.step(actions)
         if self.extra:
             if self.extra.terms:
                 rew = self.extra.apply(rew, dones)
             if self.extra.terminations:
                 self.extra.request_terminations(dones)
+            self.extra.post_step()
         return obs, rew, dones, extras
 
     @property

@@ -1153,8 +1153,10 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       }
       // a termination the caller requested on the state the previous step left (include/lt_env.h, LT_T_USER)
       if ((req_bits >> LT_TERM_REQUEST_BIT) & 1) bits |= 1 << LT_T_USER;
-      time_out = bits & 1;
-      terminated = (bits & ~1) != 0;
+      if ((req_bits >> LT_TIMEOUT_REQUEST_BIT) & 1) bits |= 1 << LT_T_USER_TIME_OUT;
+      constexpr int k_time_out_bits = (1 << LT_T_TIME_OUT) | (1 << LT_T_USER_TIME_OUT);
+      time_out = (bits & k_time_out_bits) != 0;
+      terminated = (bits & ~k_time_out_bits) != 0;
     }
     const bool alive_in = MODE == MODE_TERMS ? ((const unsigned char*)(arena + L.off_terminated))[env] != 0 : terminated;
     // ---- 5. rewards (reference locotouch/mdp/rewards.py; weights/dt by the RewardManager [DEP])
@@ -1723,7 +1725,9 @@ int launch_step(const lt_env* env, const float* actions, hipStream_t s, const fl
   }
   // bf16 rows (lt_env_set_row_format): only where the caller hands over both row pointers of both groups (rollout-storage slots)
   const bool rb = MODE == MODE_STEP && env->rows_bf16 && prev && next && prev[0] && prev[1] && next[0] && next[1];
-  if (MODE == MODE_STEP && env->rows_bf16 && !rb) return (int)hipErrorInvalidValue;
+  // (no row pointer at all - lt_env_step, lt_env_step_profiled - means the arena's own f32 rows, whatever the format of caller rows)
+  const bool any_rows = (prev && (prev[0] || prev[1])) || (next && (next[0] || next[1]));
+  if (MODE == MODE_STEP && env->rows_bf16 && any_rows && !rb) return (int)hipErrorInvalidValue;
   if (rb && env->cfg.task == LT_TASK_LOCOMOTION) {
     if (helpers) hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE_STEP, true, true>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((lt_step_kernel<LT_TASK_LOCOMOTION, MODE_STEP, false, true>), grid, dim3(64), 0, s, k);

@@ -83,7 +83,7 @@ constexpr int MODE_FORWARD = 0, MODE_POLICY = 1;
 // accumulator (module header, "Arithmetic")
 constexpr float LO_SCALE = 64.f, LO_INV = 1.f / LO_SCALE;
 // |x| beyond this saturates (64 x must stay an f16 number, and inf - inf must not appear)
-constexpr float F16_CLAMP = 1000.f;
+constexpr float F16_CLAMP = (float)LT_MLP_INPUT_CLAMP;  // include/lt_env.h states the contract
 
 __host__ __device__ inline int pad16(int x) { return (x + 15) & ~15; }
 __host__ __device__ inline int pad32(int x) { return (x + 31) & ~31; }

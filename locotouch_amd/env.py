@@ -236,11 +236,12 @@ class LocoTouchVecEnv:
                                                        p(next_critic), self._stream(), ctypes.byref(ms)), "lt_env_step_rows_profiled")
         return float(ms.value)
 
-    def request_termination(self, mask: torch.Tensor) -> None:
-        """Terminate the envs of `mask` (bool [N]) in the NEXT step: sets LT_TERM_REQUEST_BIT in their LT_F_TERM_BITS word
-        (include/lt_env.h, LT_T_USER - the hook of termination terms outside the fused set, compat/scene_views.py)."""
+    def request_termination(self, mask: torch.Tensor, time_out: bool = False) -> None:
+        """End the envs of `mask` (bool [N]) in the NEXT step: sets LT_TERM_REQUEST_BIT (or, `time_out`, LT_TIMEOUT_REQUEST_BIT) in
+        their LT_F_TERM_BITS word (include/lt_env.h, LT_T_USER / LT_T_USER_TIME_OUT - the hook of termination terms outside the
+        fused set, compat/scene_views.py)."""
         bits = self.view(C["LT_F_TERM_BITS"])
-        bits.bitwise_or_(mask.to(device=self.device, dtype=torch.int32) << C["LT_TERM_REQUEST_BIT"])
+        bits.bitwise_or_(mask.to(device=self.device, dtype=torch.int32) << C["LT_TIMEOUT_REQUEST_BIT" if time_out else "LT_TERM_REQUEST_BIT"])
 
     def eval_terms(self) -> None:
         _abi.check(self._lib.lt_env_eval_terms(self._handle, self._stream()), "lt_env_eval_terms")
@@ -273,6 +274,9 @@ class LocoTouchVecEnv:
     def episode_log(self) -> dict:
         """`extras["log"]`-style means over the episodes finished since the last call
         (Episode_Reward/<term> = mean(sum)/max_episode_length_s, RewardManager.reset [DEP])."""
+        # the log is read once per training iteration and waits for the stream anyway: the place to turn a lost chained hand-off
+        # (LT_F_COUNTERS[1], lt_env_defer_gate mode 2) into an error instead of training on a stale command block
+        self.check()
         info = self.field("LT_F_LAST_EPISODE_INFO")[:, 0, :]
         finished = info[:, 0].clone()
         prev = self._log_finished if self._log_finished is not None else torch.zeros_like(finished)

@@ -126,6 +126,11 @@ class _PairForward(torch.autograd.Function):
         _abi.check(lib.lt_mlp_forward_pair(ctypes.byref(nets[0].desc), vp(nets[0].packed.data_ptr()), vp(x0.data_ptr()),
                                            ctypes.byref(nets[1].desc), vp(nets[1].packed.data_ptr()), vp(x1.data_ptr()), m,
                                            vp(ys[0].data_ptr()), vp(ys[1].data_ptr()), arr[0], arr[1], PackedMLP._stream()), "lt_mlp_forward_pair")
+        if pair.check_domain:  # once per PPO update (PackedPair.arm_domain_check): largest |value| that entered any layer
+            pair.check_domain = False
+            with torch.no_grad():
+                m_ = torch.stack([t.abs().max() for t in (x0, x1, *acts[0], *acts[1])]).max()
+                pair.domain_max = m_ if pair.domain_max is None else torch.maximum(pair.domain_max, m_)
         ctx.nl = (len(nets[0].linears), len(nets[1].linears))
         ctx.save_for_backward(x0, x1, *acts[0], *acts[1], *[p for p in params[0::2]])
         ctx.alpha = 1.0
@@ -181,10 +186,26 @@ class PackedPair:
 
     def __init__(self, actor: nn.Sequential, critic: nn.Sequential):
         self.a, self.b = PackedMLP(actor), PackedMLP(critic)
+        # domain monitor of the MLP kernel (include/lt_env.h, LT_MLP_INPUT_CLAMP): layer inputs beyond +-1000 are saturated by the
+        # kernel; the next forward after arm_domain_check() records the largest |input row / hidden activation| on the device
+        self.check_domain = False
+        self.domain_max: torch.Tensor | None = None
         for net in (self.a, self.b):
             dims = [net.desc.dims[i] for i in range(net.desc.num_layers + 1)]
             if any(d % 4 for d in dims[1:-1]) or net.desc.activation != _abi.CONSTS["LT_ACT_ELU"]:
                 raise ValueError("PackedPair: ELU stacks with hidden widths that are multiples of 4")
+
+    def arm_domain_check(self) -> None:
+        self.check_domain = True
+
+    def domain_violated(self) -> bool:
+        """True if a checked forward saw a layer input at or beyond the kernel's saturation bound (host read: call where the
+        trainer reads its statistics anyway).  Resets the record."""
+        if self.domain_max is None:
+            return False
+        v = float(self.domain_max)
+        self.domain_max = None
+        return v >= float(_abi.CONSTS["LT_MLP_INPUT_CLAMP"])
 
     def __call__(self, x0: torch.Tensor, x1: torch.Tensor):
         self.a.pack()

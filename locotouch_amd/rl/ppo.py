@@ -146,6 +146,8 @@ class PPO:
         stats = torch.zeros(3, device=obs.device)
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         pair = self._packed_pair()
+        if pair is not None:
+            pair.arm_domain_check()  # the first minibatch of the update reports the largest layer input (LT_MLP_INPUT_CLAMP)
         for idx in st.mini_batch_indices(self.num_mini_batches, self.num_learning_epochs):
             # both networks' forward in one launch of the MFMA MLP kernel where their shape allows (rl/mlp.py PackedPair)
             o, co = obs[idx], cobs[idx]
@@ -167,6 +169,13 @@ class PPO:
             stats = stats + torch.stack((value_loss, surrogate_loss, ent.detach()))
         n = self.num_learning_epochs * self.num_mini_batches
         sv, ss, se = (stats / n).tolist()
+        if pair is not None and pair.domain_violated():
+            import warnings
+
+            self.mlp_domain_violations = getattr(self, "mlp_domain_violations", 0) + 1
+            warnings.warn("an observation or hidden activation reached the MLP kernel's saturation bound (|x| >= LT_MLP_INPUT_CLAMP, "
+                          "include/lt_env.h): the fused forward computes MLP(clamp(x)) there, unlike the fp32 reference; "
+                          "construct PPO(..., packed_forward=False) and FusedRollout(..., use_packed_mlp=False) to run the fp32 GEMM path")
         st.clear()
         return sv, ss, se, None, None
 

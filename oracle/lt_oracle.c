@@ -1655,8 +1655,9 @@ static void step_one(const lt_cfg* cfg, void* arena, const lt_layout* L, const f
     bits = lt_oracle_terminations(cfg, &in, E.ep_len, max_len);
     /* a termination the caller requested on the state the previous step left (include/lt_env.h, LT_T_USER) */
     if (mode == LT_ORACLE_MODE_STEP && ((((const int32_t*)((char*)arena + L->off_term_bits))[e] >> LT_TERM_REQUEST_BIT) & 1)) bits |= 1 << LT_T_USER;
-    time_out = bits & 1;
-    terminated = (bits & ~1) != 0;
+    if (mode == LT_ORACLE_MODE_STEP && ((((const int32_t*)((char*)arena + L->off_term_bits))[e] >> LT_TIMEOUT_REQUEST_BIT) & 1)) bits |= 1 << LT_T_USER_TIME_OUT;
+    time_out = (bits & ((1 << LT_T_TIME_OUT) | (1 << LT_T_USER_TIME_OUT))) != 0;
+    terminated = (bits & ~((1 << LT_T_TIME_OUT) | (1 << LT_T_USER_TIME_OUT))) != 0;
     ((int32_t*)((char*)arena + L->off_term_bits))[e] = bits;
     /* the terms-only hook takes `terminated` (for the alive term) from the arena */
     in.terminated = mode == LT_ORACLE_MODE_TERMS ? ((uint8_t*)arena + L->off_terminated)[e] : terminated;

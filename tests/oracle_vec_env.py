@@ -38,6 +38,9 @@ class OracleVecEnv:
 
     def field(self, name: str) -> torch.Tensor:
         """Quad field as [N, Q, 4] (component c = q*4 + lane), like LocoTouchVecEnv.field (a copy: the host arena is quad-major)."""
+        if name in self.layout.plain:  # plain [N] / fixed-size fields: views of the host arena
+            a = self.layout.arr(self.o.arena, name)
+            return torch.from_numpy(a[: self.num_envs] if a.shape[0] >= self.num_envs and name not in ("LT_F_CMD_PARAMS", "LT_F_COUNTERS", "LT_F_GATE_RING") else a)
         v = self.layout.vec(self.o.arena, name)
         return torch.from_numpy(v).reshape(self.num_envs, -1, 4)
 
@@ -83,12 +86,16 @@ class OracleVecEnv:
         extras["log"] = {}
         return obs, torch.from_numpy(self._arr("LT_F_REWARD")), torch.from_numpy(self._arr("LT_F_DONES")), extras
 
-    def request_termination(self, mask: torch.Tensor) -> None:
+    def request_termination(self, mask: torch.Tensor, time_out: bool = False) -> None:
         """LocoTouchVecEnv.request_termination on the host arena."""
         from locotouch_amd import _abi
 
         bits = self._arr("LT_F_TERM_BITS")
-        bits |= (mask.cpu().numpy().astype(np.int32) << _abi.CONSTS["LT_TERM_REQUEST_BIT"])
+        bits |= (mask.cpu().numpy().astype(np.int32) << _abi.CONSTS["LT_TIMEOUT_REQUEST_BIT" if time_out else "LT_TERM_REQUEST_BIT"])
+
+    @property
+    def cmd_params(self) -> torch.Tensor:
+        return torch.from_numpy(self.layout.arr(self.o.arena, "LT_F_CMD_PARAMS"))
 
     def close(self):
         pass

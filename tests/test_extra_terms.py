@@ -56,7 +56,7 @@ def test_reference_cfg_with_a_user_term_translates_steps_and_trains(rt, tmp_path
     cfg = rt.load_cfg_from_registry(TASK, "env_cfg_entry_point")
     cfg.scene.num_envs = 48
     cfg.rewards.user_joint_vel = RewTerm(func=joint_vel_l2_user, weight=-2.0e-3, params={"asset_cfg": SceneEntityCfg("robot", joint_names=".*_calf_joint")})
-    cfg.rewards.user_feet = RewTerm(func=feet_force_user, weight=0.25, params={"sensor_cfg": SceneEntityCfg("contact_forces", body_names=".*foot"), "threshold": 1.0})
+    cfg.rewards.user_feet = RewTerm(func=feet_force_user, weight=0.25, params={"sensor_cfg": SceneEntityCfg("robot_contact_senosr", body_names=".*foot"), "threshold": 1.0})
     with pytest.raises(T.UnsupportedCfg):
         T.translate(cfg)  # the strict form still refuses
     lt, sizes = rt.translate_env_cfg(TASK, cfg)
@@ -105,7 +105,7 @@ def test_views_follow_the_isaaclab_layouts():
     assert JOINT_NAMES[4] == "a_FR_thigh_joint" and BODY_NAMES[13:] == ["a_FR_foot", "b_FL_foot", "c_RR_foot", "d_RL_foot"]
     np.testing.assert_allclose(d.projected_gravity_b.norm(dim=1).numpy(), 1.0, atol=1e-5)
     assert torch.allclose(d.default_joint_pos[0, :4], torch.tensor([-0.1, 0.1, -0.1, 0.1]))
-    c = te.scene.sensors["contact_forces"].data
+    c = te.scene.sensors["robot_contact_senosr"].data
     assert c.net_forces_w_history.shape == (16, 3, 17, 3) and c.current_air_time.shape == (16, 17)
     fh = vec.field("LT_F_FORCE_HIST").reshape(16, 3, 4, 4)
     assert torch.equal(torch.norm(c.net_forces_w_history[:, :, 13:17], dim=-1), fh[:, :, 3, :])
@@ -137,11 +137,7 @@ def test_reference_cfg_with_a_user_termination_term_terminates_one_step_later(rt
     cfg.terminations.base_too_fast = DoneTerm(func=base_too_fast_user, params={"limit": 0.35, "asset_cfg": SceneEntityCfg("robot")})
     with pytest.raises(T.UnsupportedCfg):
         T.translate(cfg)  # the strict form still refuses
-    cfg.terminations.user_time_out = DoneTerm(func=base_too_fast_user, time_out=True, params={"limit": 9.0, "asset_cfg": SceneEntityCfg("robot")})
-    with pytest.raises(T.UnsupportedCfg):
-        rt.translate_env_cfg(TASK, cfg)  # a user TIME-OUT term is still outside what the kernels can honour
-    del cfg.terminations.user_time_out
-    lt, sizes = rt.translate_env_cfg(TASK, cfg)
+    lt, sizes = rt.translate_env_cfg(TASK, cfg)  # (user TIME-OUT terms: tests/test_reference_terms_slow_path.py)
     assert [t[0] for t in lt.extra_termination_terms] == ["base_too_fast"] and not lt.extra_reward_terms
     vec = OracleVecEnv(TASK, cfg=lt, object_sizes=sizes)
     env = ManagedEnv(TASK, cfg, vec, extra_terminations=lt.extra_termination_terms)

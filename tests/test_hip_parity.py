@@ -725,6 +725,55 @@ def test_fused_mlp_matches_torch(dims, act, m):
         torch.testing.assert_close(net(x), seq(x), rtol=2e-5, atol=2e-5 * scale)
 
 
+def test_fused_mlp_saturates_layer_inputs_at_the_documented_bound():
+    """include/lt_env.h, LT_MLP_INPUT_CLAMP: every value entering a layer (input rows, hidden activations) is saturated to +-1000 before
+    the f16 operand split; the kernel then equals the fp32 stack evaluated on clamped layer inputs - pinned here just above the
+    bound and far above it - and the trainer-side monitor (PackedPair.domain_violated) sees it."""
+    import torch
+    from locotouch_amd import _abi
+    from locotouch_amd.rl.mlp import PackedMLP, PackedPair
+    from locotouch_amd.rl.modules import build_mlp
+
+    B = float(_abi.CONSTS["LT_MLP_INPUT_CLAMP"])
+    assert B == 1000.0
+    torch.manual_seed(9)
+    seq = build_mlp(64, [128, 64], 12, "elu").to("cuda:0")
+    with torch.no_grad():
+        seq[0].weight.mul_(6.0)  # hidden activations beyond the bound for the large inputs below
+    lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
+
+    def clamped_stack(x):
+        h = x
+        for i, l in enumerate(lin):
+            h = l(h.clamp(-B, B))
+            if i < len(lin) - 1:
+                h = torch.nn.functional.elu(h)
+        return h
+
+    net = PackedMLP(seq)
+    x = torch.randn(256, 64, device="cuda:0")
+    x[:64] *= 1.0          # inside the domain: equal to the plain stack
+    x[64:128] = x[64:128].sign() * (B + 0.5 + 3.0 * torch.rand(64, 64, device="cuda:0"))  # just above the bound
+    x[128:192] *= 20000.0  # far above (still finite in f16 before the clamp would matter: up to ~6e4)
+    x[192:] *= 300.0       # inputs inside, first hidden layer beyond the bound
+    with torch.inference_mode():
+        y, want, plain = net(x), clamped_stack(x), seq(x)
+    scale = float(want.abs().max()) + 1.0
+    torch.testing.assert_close(y, want, rtol=3e-5, atol=3e-5 * scale)
+    torch.testing.assert_close(y[:64], plain[:64], rtol=3e-5, atol=3e-5 * scale)
+    assert float((plain[64:] - want[64:]).abs().max()) > 1e-2 * scale, "the case must actually leave the domain"
+    assert bool(torch.isfinite(y).all())
+    # the monitor: armed once, it records the largest layer input of the next training forward
+    critic = build_mlp(64, [128, 64], 1, "elu").to("cuda:0")
+    pair = PackedPair(seq, critic)
+    pair.arm_domain_check()
+    pair(x[:64].contiguous(), x[:64].contiguous())
+    assert not pair.domain_violated()
+    pair.arm_domain_check()
+    pair(x[64:128].contiguous(), x[:64].contiguous())
+    assert pair.domain_violated() and not pair.domain_violated()  # (reading resets the record)
+
+
 def test_fused_policy_kernel_matches_act_kernel():
     """lt_rollout_policy (actor MLP + sampling in one launch) against actor GEMMs + lt_rollout_act on a twin env."""
     import torch

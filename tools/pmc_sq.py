@@ -17,7 +17,10 @@ for path in sys.argv[3:]:
             continue
         acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in acc.items()}
-d = {"round": rnd, "kernel": "lt_step_kernel (MODE_STEP)", "dispatches": {k: len(v) for k, v in acc.items()}, "mean_per_dispatch": m}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from locotouch_amd.build import step_kernel_source_hash  # noqa: E402  (the stamp bench.py checks before it reports these numbers)
+
+d = {"round": rnd, "source_hash": step_kernel_source_hash(), "kernel": "lt_step_kernel (MODE_STEP)", "dispatches": {k: len(v) for k, v in acc.items()}, "mean_per_dispatch": m}
 g = m.get
 der = {}
 if g("SQ_WAVES") and g("SQ_INSTS_VALU"):

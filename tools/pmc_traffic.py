@@ -19,9 +19,12 @@ def mean_counter(path, name):
 
 f, nf = mean_counter(fetch_csv, "FETCH_SIZE")
 w, nw = mean_counter(write_csv, "WRITE_SIZE")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from locotouch_amd.build import step_kernel_source_hash  # noqa: E402  (the stamp bench.py checks before it reports these numbers)
+
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
 data = json.load(open(path)) if os.path.exists(path) else {}
-data[key] = {"hbm_bytes_per_launch": (2 * f + w) * 1024, "round": rnd, "kernel": "lt_step_kernel (MODE_STEP)", "FETCH_SIZE_KB_mean": f,
+data[key] = {"hbm_bytes_per_launch": (2 * f + w) * 1024, "round": rnd, "source_hash": step_kernel_source_hash(), "kernel": "lt_step_kernel (MODE_STEP)", "FETCH_SIZE_KB_mean": f,
              "WRITE_SIZE_KB_mean": w, "dispatches": [nf, nw],
              "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024  (gfx950: FETCH_SIZE reads 1/2 of the fetched bytes - MI355X_MICROARCH.md HBM "
                         "section; re-calibrated with tools/calib_copy.hip: 1 GiB dword and float4 copies give FETCH 0.5000x, WRITE 1.0000x)",
