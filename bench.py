@@ -81,11 +81,12 @@ def cpu_baseline(task: str, num_envs: int, budget_s: float = 12.0) -> dict:
             "sample": f"{steps} steps x {num_envs} envs of the same task, 0.5*N(0,1) actions, OpenMP over envs, {el:.1f} s"}
 
 
-def _spawn_ranks(args) -> int:
+def _spawn_ranks(args, script: str | None = None, argv: list | None = None) -> int:
     """`python bench.py --gpus N` typed plainly (no torchrun): this parent starts N rank processes of the same script -
     one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment - BEFORE touching torch or the GPU itself
     (a process that has initialised HIP must never exec or fork into another GPU program on this pool), forwards
-    rank 0's single JSON line, and exits with the worst child code."""
+    rank 0's single JSON line, and exits with the worst child code.  (`script` / `argv`: the child to start instead of this
+    file - tests/test_bench_spawn.py checks the rank plumbing with a stub child.)"""
     import socket
     import subprocess
 
@@ -98,7 +99,7 @@ def _spawn_ranks(args) -> int:
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out, _ = procs[0].communicate()
     rc = procs[0].returncode

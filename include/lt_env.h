@@ -432,6 +432,27 @@ int64_t lt_head_wgrad_ws_floats(int64_t M, int n, int k);
  * ws: lt_adam_clip_step_ws_floats(n) floats of scratch. */
 int lt_adam_clip_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float max_norm, float lr, float beta1,
                       float beta2, float eps, float weight_decay, int64_t step, float* ws, float* grad_norm, void* stream);
+/* The same with the learning rate read from device memory (*lr_dev, as lt_ppo_lr_rule leaves it): a PPO update then needs no host
+ * read between its minibatch steps. */
+int lt_adam_clip_step_dev(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float max_norm, const float* lr_dev,
+                          float beta1, float beta2, float eps, float weight_decay, int64_t step, float* ws, float* grad_norm, void* stream);
+/* The adaptive learning-rate rule of PPO.update on the device (loco_rl/loco_rl/algorithms/ppo.py:273-281): with kl = *kl_mean (the
+ * minibatch's mean KL - lt_ppo_loss's out[4]; all-reduced over the ranks by the caller first),
+ *   kl > 2 desired_kl -> *lr = max(lr_min, *lr / factor);   0 < kl < desired_kl / 2 -> *lr = min(lr_max, *lr * factor)
+ * (the reference: 1e-5, 1e-2, 1.5).  kl_mean == NULL or desired_kl <= 0: fixed schedule, *lr untouched.  `stats` (optional, float[3]):
+ * += (value loss, surrogate loss, entropy) taken from `scalars` = lt_ppo_loss's `out` - the statistics the runner logs, read once
+ * per update instead of once per step (ppo.py:361-363).  `dstd_out` (optional, float[num_actions]): receives d loss / d sigma
+ * (scalars[8 ..]) - the std parameter's slot of a flat gradient bucket.  One launch, one wave. */
+int lt_ppo_lr_rule(const float* kl_mean, float desired_kl, float lr_min, float lr_max, float factor, float* lr, float* stats,
+                   const float* scalars, float* dstd_out, int num_actions, void* stream);
+/* njobs (<= 24) ordered partial sums in ONE launch: out0[j][e] = sum over b < nblk[j] of ws[j][b * stride[j] + e] for e < split[j], and
+ * out1[j][e - split[j]] for split[j] <= e < count[j] (out1[j] may be NULL).  All arrays are HOST arrays of device pointers / ints.
+ * lt_elu_backward_bias with db == NULL and lt_head_wgrad with dw == NULL leave their per-block partials in `ws` for this call
+ * (lt_elu_backward_bias_nblk(M) blocks of N floats; lt_head_wgrad_nblk(M) blocks of n * k + 16 floats, weight part first). */
+int lt_partial_sums(int njobs, const float* const* ws, const int* nblk, const int64_t* stride, const int* count, const int* split,
+                    float* const* out0, float* const* out1, void* stream);
+int lt_elu_backward_bias_nblk(int64_t M);
+int lt_head_wgrad_nblk(int64_t M);
 int64_t lt_adam_clip_step_ws_floats(int64_t n);
 /* GRU recurrence of the student's tactile encoder over a padded batch of whole trajectories (reference
  * loco_rl/loco_rl/models/memory_module.py:10-14 -> nn.GRU, single layer; locotouch/distill/student.py:119-123 trains it on

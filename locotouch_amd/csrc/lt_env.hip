@@ -1625,8 +1625,24 @@ __global__ __launch_bounds__(64) void lt_curriculum_kernel(const KArgs a, const 
   curriculum_publish(L, a.arena, (const float*)(a.arena + L.off_cmd_params), gid, leg, in, 0);
 }
 // the global half of the pass (lt_post.h): one wave behind the step kernel / the curriculum hook
-__global__ __launch_bounds__(64) void lt_gate_decide_kernel(const KArgs a, int bump_counter) {
-  curriculum_decide(a.d->cfg, a.d->layout, a.arena, bump_counter, 0, bump_counter > 0 ? -1 : 0);  // (the records hook publishes into set 0)
+// Four waves reduce the tiles' slots (lane-strided, all loads of a trip in flight together; lt_post.h slot_sums), meet in LDS in a
+// fixed order, wave 0 decides.
+__global__ __launch_bounds__(256) void lt_gate_decide_kernel(const KArgs a, int bump_counter) {
+  __shared__ float s_part[4][LT_PARTIAL_FLOATS][64];
+  const lt_layout& L = a.d->layout;
+  const long long* const cnt = (const long long*)(a.arena + L.off_counters);
+  const int set = bump_counter > 0 ? (int)((cnt[0] + bump_counter - 1) & 1) : 0;  // (the records hook publishes into set 0)
+  const float* const slots = (const float*)(a.arena + L.off_partials) + (long long)set * (L.npad / 16) * LT_PARTIAL_FLOATS;
+  float r[LT_PARTIAL_FLOATS];
+  slot_sums<8>(slots, (unsigned)(L.npad / 16), threadIdx.x, 256u, r);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) s_part[wave][i][lane] = r[i];
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] = ((s_part[0][i][lane] + s_part[1][i][lane]) + s_part[2][i][lane]) + s_part[3][i][lane];
+  curriculum_decide(a.d->cfg, L, a.arena, bump_counter, 0, set, r);
 }
 // multi-rank curriculum gate on cross-rank sums (lt_post.h curriculum_apply_global); one wave
 __global__ __launch_bounds__(64) void lt_gate_apply_kernel(const KArgs a, const float* __restrict__ ring_sums, int nsteps, float inv_n_total) {
@@ -1719,7 +1735,7 @@ int launch_step(const lt_env* env, const float* actions, hipStream_t s, const fl
     k.decide_first = (helpers && env->gate_pending) ? (env->test_chain_skew ? 3 : 1) : 0;
     if (k.decide_first == 3) env->test_chain_skew = 0;  // once
     if (env->gate_pending && !k.decide_first) {  // an outstanding pass this launch cannot absorb: run it now
-      hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(64), 0, s, k, env->pending_steps);
+      hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(256), 0, s, k, env->pending_steps);
       env->pending_steps = 0; env->gate_pending = 0; k.step_offset = 0;
     }
   }
@@ -1751,7 +1767,7 @@ int launch_step(const lt_env* env, const float* actions, hipStream_t s, const fl
   if (MODE == MODE_STEP) {
     const int outstanding = env->pending_steps + 1;  // this step's bump joins the ones before it
     if (gate_mode == 0) {
-      hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(64), 0, s, k, outstanding);
+      hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(256), 0, s, k, outstanding);
       env->pending_steps = 0; env->gate_pending = 0;
     } else {  // modes 1, 2 (and the profiled launch, whose caller launches the pass behind its stop event)
       env->pending_steps = outstanding; env->gate_pending = 1;
@@ -1827,7 +1843,7 @@ int lt_launch_eval_terms(const lt_env* env, void* stream) {
 int lt_launch_curriculum(const lt_env* env, const float* records, void* stream) {
   const KArgs k = make_args(env, nullptr);
   hipLaunchKernelGGL(lt_curriculum_kernel, dim3((unsigned)(env->layout.npad / 16)), dim3(64), 0, (hipStream_t)stream, k, records);
-  hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, 0);
+  hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, k, 0);
   return (int)hipGetLastError();
 }
 
@@ -1835,7 +1851,7 @@ int lt_launch_curriculum(const lt_env* env, const float* records, void* stream) 
 int lt_launch_gate_decide(const lt_env* env, int bump_counter, void* stream) {
   const KArgs k = make_args(env, nullptr);
   const int bump = bump_counter < 0 ? env->pending_steps : bump_counter;
-  hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, bump);
+  hipLaunchKernelGGL(lt_gate_decide_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, k, bump);
   env->pending_steps = 0; env->gate_pending = 0;
   return (int)hipGetLastError();
 }

@@ -177,7 +177,40 @@ __device__ __forceinline__ void curriculum_apply_global(const lt_cfg& c, const l
 // is then stored write-through and drained, and counters[2] = chain_flag (the launch's step id) tells the other workgroups of that
 // launch that it is final (MI355X_MICROARCH.md, "Valid forms": sc1 payload -> vmcnt(0) -> flag; consumers poll and load with sc1).
 // `set` < 0: the slot set of the last step launched, (common_step_counter + bump_counter - 1) & 1.
-__device__ __forceinline__ void curriculum_decide(const lt_cfg& c, const lt_layout& L, char* const arena, int bump_counter, long long chain_flag = 0, int set = -1) {
+// Lane-strided partial sums of the tiles' slots (8 floats = two float4 each): thread `t` of `nt` takes slots t, t + nt, ...
+// EIGHT slots (16 loads of 16 B) are requested per trip before anything is added - at 32768 envs (2048 slots) one wave walked its
+// 32 slots as 32 x 8 dependent dword round trips: 12.8 us per step behind every step launch (profiles/r03_kernel_stats_32768_f32.csv).
+// Out-of-range slots re-read the last one and are masked by a select, never by a branch (a branch between a load and its wait makes
+// the compiler wait for every outstanding load).  The order of the additions is fixed by (nt, nwaves): run-to-run identical.
+// Both forms of the pass add in the SAME order - thread t of 256 walks slots t, t + 256, ... in increasing order, the four partials of a
+// lane column are added ((p0 + p1) + p2) + p3, then the 64-lane butterfly - so the chained pass (one wave standing in for the four)
+// and the pass behind every step leave bit-identical sums (tests/test_hip_parity.py::test_chained_population_pass_...).
+template <int U>
+__device__ __forceinline__ void slot_sums(const float* slots, unsigned nwaves, unsigned t, unsigned nt, float (&r)[LT_PARTIAL_FLOATS]) {
+#pragma unroll
+  for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] = 0.f;
+  const float4* const s4 = (const float4*)slots;
+  for (unsigned base = t; base < nwaves; base += U * nt) {
+    float4 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned w = base + u * nt, wc = w < nwaves ? w : nwaves - 1u;
+      a[u] = s4[2ull * wc];
+      b[u] = s4[2ull * wc + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = base + u * nt < nwaves;
+      r[0] += ok ? a[u].x : 0.f; r[1] += ok ? a[u].y : 0.f; r[2] += ok ? a[u].z : 0.f; r[3] += ok ? a[u].w : 0.f;
+      r[4] += ok ? b[u].x : 0.f; r[5] += ok ? b[u].y : 0.f; r[6] += ok ? b[u].z : 0.f; r[7] += ok ? b[u].w : 0.f;
+    }
+  }
+}
+
+// `pre`: this lane's column sum ((p0 + p1) + p2) + p3 made by the caller's four waves (lt_gate_decide_kernel), or nullptr = this wave
+// stands in for the four itself.
+__device__ __forceinline__ void curriculum_decide(const lt_cfg& c, const lt_layout& L, char* const arena, int bump_counter, long long chain_flag = 0, int set = -1,
+                                                  const float* pre = nullptr) {
   float* const P = (float*)(arena + L.off_cmd_params);
   const int lane = threadIdx.x & 63;
   const unsigned nwaves = (unsigned)(L.npad / 16);
@@ -190,11 +223,15 @@ __device__ __forceinline__ void curriculum_decide(const lt_cfg& c, const lt_layo
   for (int i = 0; i < 31; ++i) Pl[i] = P[i];
   const long long cnt0 = cnt[0], cnt3 = cnt[3];
   float r[LT_PARTIAL_FLOATS];
+  if (pre) {
 #pragma unroll
-  for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] = 0.f;
-  for (unsigned w = (unsigned)lane; w < nwaves; w += 64) {
+    for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] = pre[i];
+  } else {
+    float p[4][LT_PARTIAL_FLOATS];
 #pragma unroll
-    for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] += slots[(long long)w * LT_PARTIAL_FLOATS + i];
+    for (int w = 0; w < 4; ++w) slot_sums<1>(slots, nwaves, (unsigned)lane + 64u * w, 256u, p[w]);
+#pragma unroll
+    for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] = ((p[0][i] + p[1][i]) + p[2][i]) + p[3][i];
   }
 #pragma unroll
   for (int i = 0; i < LT_PARTIAL_FLOATS; ++i) r[i] = wave_sum(r[i]);

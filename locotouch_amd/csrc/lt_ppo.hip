@@ -187,6 +187,48 @@ __global__ __launch_bounds__(256) void lt_partial_sum_kernel(const float* __rest
   }
 }
 
+// Several such sums in ONE launch (the backward pass of both stacks leaves ~14 partial buffers - per-block bias sums of
+// lt_elu_bwd_bias_kernel / lt_head_wgrad_kernel and the split-K slabs of the weight-gradient GEMMs - whose sums were 14 launches of
+// ~5 us): job j owns blocks [first[j], first[j + 1]); same per-element order of additions as lt_partial_sum_kernel.
+constexpr int SUM_MAX_JOBS = 24;
+struct SumJobs {
+  const float* ws[SUM_MAX_JOBS];
+  float* out0[SUM_MAX_JOBS];
+  float* out1[SUM_MAX_JOBS];
+  long long stride[SUM_MAX_JOBS];
+  int nblk[SUM_MAX_JOBS], count[SUM_MAX_JOBS], split[SUM_MAX_JOBS], first[SUM_MAX_JOBS + 1];
+  int njobs;
+};
+__global__ __launch_bounds__(256) void lt_partial_sums_kernel(const SumJobs J) {
+  int j = 0;
+  while (j + 1 < J.njobs && (int)blockIdx.x >= J.first[j + 1]) ++j;
+  const float* __restrict__ ws = J.ws[j];
+  const int nblk = J.nblk[j], count = J.count[j], split = J.split[j];
+  const long long stride = J.stride[j];
+  const int e = ((int)blockIdx.x - J.first[j]) * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < count) {
+    int b = lane;
+    for (; b + 48 < nblk; b += 64) {
+      s0 += ws[(long long)b * stride + e];
+      s1 += ws[(long long)(b + 16) * stride + e];
+      s2 += ws[(long long)(b + 32) * stride + e];
+      s3 += ws[(long long)(b + 48) * stride + e];
+    }
+    for (; b < nblk; b += 16) s0 += ws[(long long)b * stride + e];
+  }
+  __shared__ float red[16][16];
+  red[lane][threadIdx.x & 15] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (lane == 0 && e < count) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += red[l][threadIdx.x];
+    if (e < split) J.out0[j][e] = t;
+    else if (J.out1[j]) J.out1[j][e - split] = t;
+  }
+}
+
 // ---- weight + bias gradient of a narrow head layer -----------------------------------------------------------------------------------
 // dW[n][k] = sum_m dy[m][n] x[m][k], db[n] = sum_m dy[m][n] for n <= 16 outputs (the action-mean and value heads: 12 x 128 and
 // 1 x 128 over 24 576 rows).  As GEMMs these are all reduction and no tile: hipBLASLt takes 35-52 us for 75 MFLOP, plus a
@@ -300,8 +342,10 @@ __global__ __launch_bounds__(256) void lt_sumsq_kernel(const float* __restrict__
 
 __global__ __launch_bounds__(256) void lt_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                       long long n, const float* __restrict__ ws, int nblk, float max_norm, float b1,
-                                                      float b2, float eps, float wd, float step_size, float bc2_sqrt, float* __restrict__ norm_out) {
+                                                      float b2, float eps, float wd, float step_size, float bc2_sqrt, float* __restrict__ norm_out,
+                                                      const float* __restrict__ lr_dev, float inv_bc1) {
   __shared__ float s_coef;
+  if (lr_dev) step_size = *lr_dev * inv_bc1;  // the learning rate lives on the device (lt_ppo_lr_rule): no host round trip per step
   if (threadIdx.x < 64) {
     float s = 0.f;
     for (int b = threadIdx.x; b < nblk; b += 64) s += ws[b];
@@ -331,16 +375,46 @@ __global__ __launch_bounds__(256) void lt_adam_kernel(float* __restrict__ p, flo
   }
 }
 
+// The adaptive learning-rate rule of the reference on the device (loco_rl/loco_rl/algorithms/ppo.py:273-281): one lane.
+//   kl > 2 desired -> lr = max(lr_min, lr / factor);   0 < kl < desired / 2 -> lr = min(lr_max, lr * factor)
+// `kl_mean`: the minibatch's mean KL (lt_ppo_loss's out[4]; all-reduced by the caller in a multi-rank job).  The host read of the KL
+// per minibatch step that the rule cost (20 per PPO iteration) becomes one read of *lr per iteration.
+// `stats` (optional): running sums of (value loss, surrogate, entropy) = scalars[2], scalars[1], scalars[3] of lt_ppo_loss's `out`.
+__global__ __launch_bounds__(64) void lt_ppo_lr_rule_kernel(const float* __restrict__ kl_mean, float desired, float lr_min, float lr_max, float factor,
+                                                            float* __restrict__ lr, float* __restrict__ stats, const float* __restrict__ scalars,
+                                                            float* __restrict__ dstd_out, int A) {
+  if (dstd_out && scalars && (int)threadIdx.x < A) dstd_out[threadIdx.x] = scalars[8 + threadIdx.x];  // d loss / d sigma_a -> the gradient bucket
+  if (threadIdx.x != 0) return;
+  if (kl_mean && desired > 0.f) {
+    const float kl = *kl_mean;
+    float v = *lr;
+    if (kl > desired * 2.f) v = fmaxf(lr_min, v / factor);
+    else if (kl < desired * 0.5f && kl > 0.f) v = fminf(lr_max, v * factor);
+    *lr = v;
+  }
+  if (stats && scalars) { stats[0] += scalars[2]; stats[1] += scalars[1]; stats[2] += scalars[3]; }
+}
+
 }  // namespace
 
+extern "C" int lt_ppo_lr_rule(const float* kl_mean, float desired_kl, float lr_min, float lr_max, float factor, float* lr, float* stats,
+                              const float* scalars, float* dstd_out, int num_actions, void* stream) {
+  if (!lr || factor <= 1.f || num_actions < 0 || num_actions > MAX_A) { lt_set_error("lt_ppo_lr_rule: invalid argument"); return LT_EINVAL; }
+  hipLaunchKernelGGL(lt_ppo_lr_rule_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kl_mean, desired_kl, lr_min, lr_max, factor, lr, stats, scalars,
+                     dstd_out, num_actions);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
+  return LT_OK;
+}
+
 extern "C" int lt_elu_backward_bias(const float* da, const float* a, int64_t M, int N, float alpha, float* dz, float* db, float* ws, void* stream) {
-  if (!da || !a || !dz || !db || !ws || M < 1 || N < 4 || (N & 3) || N > 1024) {
+  if (!da || !a || !dz || !ws || M < 1 || N < 4 || (N & 3) || N > 1024) {
     lt_set_error("lt_elu_backward_bias: invalid argument (N a multiple of 4, 4 <= N <= 1024)");
     return LT_EINVAL;
   }
   const int nblk = (int)((M + EB_ROWS - 1) / EB_ROWS);
   hipLaunchKernelGGL(lt_elu_bwd_bias_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, da, a, (long long)M, N, alpha, dz, ws);
-  hipLaunchKernelGGL(lt_partial_sum_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, ws, nblk, (long long)N, N, N, db, (float*)nullptr);
+  if (db) hipLaunchKernelGGL(lt_partial_sum_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, ws, nblk, (long long)N, N, N, db, (float*)nullptr);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;
@@ -349,7 +423,7 @@ extern "C" int lt_elu_backward_bias(const float* da, const float* a, int64_t M, 
 extern "C" int64_t lt_head_wgrad_ws_floats(int64_t M, int n, int k) { return ((M + HW_ROWS - 1) / HW_ROWS) * ((int64_t)n * k + HW_MAX_N); }
 
 extern "C" int lt_head_wgrad(const float* dy, const float* x, int64_t M, int n, int k, float* dw, float* db, float* ws, void* stream) {
-  if (!dy || !x || !dw || !ws || M < 1 || n < 1 || n > HW_MAX_N || k < 4 || (k & 3) || k > 1024) {
+  if (!dy || !x || !ws || M < 1 || n < 1 || n > HW_MAX_N || k < 4 || (k & 3) || k > 1024) {
     lt_set_error("lt_head_wgrad: invalid argument (1 <= n <= 16, k a multiple of 4, 4 <= k <= 1024)");
     return LT_EINVAL;
   }
@@ -369,11 +443,39 @@ extern "C" int lt_head_wgrad(const float* dy, const float* x, int64_t M, int n, 
     case 12: hipLaunchKernelGGL(lt_head_wgrad_kernel<12>, g, b, lds, st, dy, x, (long long)M, n, k, ws); break;
     default: hipLaunchKernelGGL(lt_head_wgrad_kernel<16>, g, b, lds, st, dy, x, (long long)M, n, k, ws); break;
   }
-  hipLaunchKernelGGL(lt_partial_sum_kernel, dim3((unsigned)((n * k + n + 15) / 16)), b, 0, st, ws, nblk, (long long)n * k + HW_MAX_N, n * k + n, n * k, dw, db);
+  if (dw) hipLaunchKernelGGL(lt_partial_sum_kernel, dim3((unsigned)((n * k + n + 15) / 16)), b, 0, st, ws, nblk, (long long)n * k + HW_MAX_N, n * k + n, n * k, dw, db);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;
 }
+
+// Partial-sum jobs in one launch: out0[j][e] = sum_b ws[j][b * stride[j] + e] for e < split[j], out1[j][e - split[j]] for split[j] <= e <
+// count[j] (out1 optional).  The deferred sums of lt_elu_backward_bias (db == NULL: ws holds lt_elu_backward_bias_nblk(M) blocks of N),
+// lt_head_wgrad (dw == NULL: lt_head_wgrad_nblk(M) blocks of n * k + 16, split n * k) and of split-K GEMM slabs.
+extern "C" int lt_partial_sums(int njobs, const float* const* ws, const int* nblk, const int64_t* stride, const int* count, const int* split,
+                               float* const* out0, float* const* out1, void* stream) {
+  if (njobs < 1 || njobs > SUM_MAX_JOBS || !ws || !nblk || !stride || !count || !split || !out0 || !out1) {
+    lt_set_error("lt_partial_sums: invalid argument (1 <= njobs <= 24)");
+    return LT_EINVAL;
+  }
+  SumJobs J = {};
+  J.njobs = njobs;
+  int blocks = 0;
+  for (int j = 0; j < njobs; ++j) {
+    if (!ws[j] || !out0[j] || nblk[j] < 1 || count[j] < 1) { lt_set_error("lt_partial_sums: invalid job"); return LT_EINVAL; }
+    J.ws[j] = ws[j]; J.out0[j] = out0[j]; J.out1[j] = out1[j]; J.stride[j] = stride[j];
+    J.nblk[j] = nblk[j]; J.count[j] = count[j]; J.split[j] = split[j];
+    J.first[j] = blocks;
+    blocks += (count[j] + 15) / 16;
+  }
+  J.first[njobs] = blocks;
+  hipLaunchKernelGGL(lt_partial_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
+  return LT_OK;
+}
+extern "C" int lt_elu_backward_bias_nblk(int64_t M) { return (int)((M + EB_ROWS - 1) / EB_ROWS); }
+extern "C" int lt_head_wgrad_nblk(int64_t M) { return (int)((M + HW_ROWS - 1) / HW_ROWS); }
 
 extern "C" int lt_gae(const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float gamma, float lam, int T,
                       int64_t N, float* returns, float* advantages, void* stream) {
@@ -390,8 +492,22 @@ extern "C" int lt_gae(const float* rewards, const uint8_t* dones, const float* v
 
 extern "C" int64_t lt_elu_backward_bias_ws_floats(int64_t M, int N) { return ((M + EB_ROWS - 1) / EB_ROWS) * (int64_t)N; }
 
+static int adam_clip_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float max_norm, float lr, const float* lr_dev,
+                          float beta1, float beta2, float eps, float weight_decay, int64_t step, float* ws, float* grad_norm, void* stream);
+
 extern "C" int lt_adam_clip_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float max_norm, float lr, float beta1,
                                  float beta2, float eps, float weight_decay, int64_t step, float* ws, float* grad_norm, void* stream) {
+  return adam_clip_step(params, grads, exp_avg, exp_avg_sq, n, max_norm, lr, nullptr, beta1, beta2, eps, weight_decay, step, ws, grad_norm, stream);
+}
+
+extern "C" int lt_adam_clip_step_dev(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float max_norm, const float* lr_dev,
+                                     float beta1, float beta2, float eps, float weight_decay, int64_t step, float* ws, float* grad_norm, void* stream) {
+  if (!lr_dev) { lt_set_error("lt_adam_clip_step_dev: null learning-rate pointer"); return LT_EINVAL; }
+  return adam_clip_step(params, grads, exp_avg, exp_avg_sq, n, max_norm, 0.f, lr_dev, beta1, beta2, eps, weight_decay, step, ws, grad_norm, stream);
+}
+
+static int adam_clip_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float max_norm, float lr, const float* lr_dev,
+                          float beta1, float beta2, float eps, float weight_decay, int64_t step, float* ws, float* grad_norm, void* stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !ws || n < 1 || step < 1) {
     lt_set_error("lt_adam_clip_step: invalid argument");
     return LT_EINVAL;
@@ -400,7 +516,7 @@ extern "C" int lt_adam_clip_step(float* params, float* grads, float* exp_avg, fl
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(lt_sumsq_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, grads, (long long)n, ws);
   hipLaunchKernelGGL(lt_adam_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (long long)n, ws, nblk,
-                     max_norm, beta1, beta2, eps, weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_norm);
+                     max_norm, beta1, beta2, eps, weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_norm, lr_dev, (float)(1.0 / bc1));
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;

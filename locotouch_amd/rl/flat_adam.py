@@ -97,6 +97,29 @@ class FlatAdam:
             p.grad = v
         return self.flat_g
 
+    def grad_views(self) -> dict:
+        """param -> its gradient's view in the flat bucket, `.grad` re-pointed at it: for a backward pass that writes the gradients
+        in place (rl/ppo.py `_direct_update`), with no gather afterwards."""
+        if not self._bound():
+            self._adopt()
+        for p, v in zip(self.params, self._gviews):
+            p.grad = v
+        return {p: v for p, v in zip(self.params, self._gviews)}
+
+    def step_dev(self, max_norm: float, lr_dev: torch.Tensor) -> None:
+        """`step(gathered=True)` with the learning rate read from the device scalar `lr_dev` (lt_ppo_lr_rule keeps it)."""
+        if not self._bound():
+            self._adopt()
+        g = self.optimizer.param_groups[0]
+        self.step_count += 1
+        b1, b2 = g["betas"]
+        vp = ctypes.c_void_p
+        _abi.check(self._lib.lt_adam_clip_step_dev(vp(self.flat_p.data_ptr()), vp(self.flat_g.data_ptr()), vp(self.flat_m.data_ptr()), vp(self.flat_v.data_ptr()),
+                                                   self.n, float(max_norm or 0.0), vp(lr_dev.data_ptr()), float(b1), float(b2), float(g["eps"]),
+                                                   float(g["weight_decay"]), self.step_count, vp(self._ws.data_ptr()), vp(self.grad_norm.data_ptr()),
+                                                   vp(torch.cuda.current_stream(self.flat_p.device).cuda_stream)), "lt_adam_clip_step_dev")
+        self._step_t.fill_(float(self.step_count))
+
     def step(self, max_norm: float, gathered: bool = False) -> None:
         if not self._bound():
             self._adopt()

@@ -179,6 +179,92 @@ class _PairForward(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+def _alloc_outputs(nets, m, device):
+    ys, acts = [], []
+    for net in nets:
+        dims = [net.desc.dims[i] for i in range(net.desc.num_layers + 1)]
+        ys.append(torch.empty(m, dims[-1], device=device, dtype=torch.float32))
+        acts.append([torch.empty(m, d, device=device, dtype=torch.float32) for d in dims[1:-1]])
+    return ys, acts
+
+
+class SumJobs:
+    """Ordered partial sums collected over a backward pass and added by ONE launch (`lt_partial_sums`): the per-block bias sums of
+    lt_elu_backward_bias / lt_head_wgrad and the split-K slabs of the weight-gradient GEMMs were 14 launches of ~5 us per
+    minibatch step."""
+
+    MAX = 24
+
+    def __init__(self):
+        self.jobs: list = []   # (ws tensor, nblk, stride, count, split, out0, out1 | None)
+
+    def add(self, ws, nblk, stride, count, split, out0, out1=None) -> None:
+        self.jobs.append((ws, int(nblk), int(stride), int(count), int(split), out0, out1))
+
+    def launch(self) -> None:
+        lib = _abi.load()
+        vp = ctypes.c_void_p
+        while self.jobs:
+            batch, self.jobs = self.jobs[:self.MAX], self.jobs[self.MAX:]
+            n = len(batch)
+            arr_p = lambda vals: (vp * n)(*vals)  # noqa: E731
+            ws = arr_p([j[0].data_ptr() for j in batch])
+            out0 = arr_p([j[5].data_ptr() for j in batch])
+            out1 = arr_p([None if j[6] is None else j[6].data_ptr() for j in batch])
+            nblk = (ctypes.c_int * n)(*[j[1] for j in batch])
+            stride = (ctypes.c_int64 * n)(*[j[2] for j in batch])
+            count = (ctypes.c_int * n)(*[j[3] for j in batch])
+            split = (ctypes.c_int * n)(*[j[4] for j in batch])
+            _abi.check(lib.lt_partial_sums(n, ws, nblk, stride, count, split, out0, out1, PackedMLP._stream()), "lt_partial_sums")
+            self._keep = batch  # the launch reads the buffers asynchronously
+
+
+def backward_chain(weights, biases_out, weights_out, x, acts, dy, sums: SumJobs):
+    """The backward pass of one Linear/ELU stack by hand, gradients written IN PLACE into the given tensors (views of the flat
+    gradient bucket): `weights[l]` the layer's weight, `weights_out[l]` / `biases_out[l]` where dW_l / db_l go, `x` the stack's
+    input rows, `acts[l]` the activations behind hidden layer l, `dy` the gradient w.r.t. the stack's output.  ELU' + per-block
+    bias sums in one kernel (lt_elu_backward_bias), narrow-head gradients in one (lt_head_wgrad), split-K batched GEMMs for the
+    weight gradients, plain GEMMs for the input gradients; every ordered sum of partials is queued on `sums` (one launch later)."""
+    from .linear import _head_wgrad_ok, pick_splits
+
+    lib = _abi.load()
+    vp = ctypes.c_void_p
+    stream = PackedMLP._stream()
+    L = len(weights)
+    g = dy if dy.is_contiguous() else dy.contiguous()
+    for l in range(L - 1, -1, -1):
+        inp = acts[l - 1] if l > 0 else x
+        w = weights[l]
+        m, n = g.shape
+        k = inp.shape[1]
+        if l < L - 1:  # g is the gradient w.r.t. the activation output: through ELU', with the bias sums in the same pass
+            a = acts[l]
+            dz = torch.empty_like(a)
+            nblk = int(lib.lt_elu_backward_bias_nblk(m))
+            scratch = torch.empty(nblk * n, device=a.device, dtype=torch.float32)
+            _abi.check(lib.lt_elu_backward_bias(vp(g.data_ptr()), vp(a.data_ptr()), m, n, 1.0, vp(dz.data_ptr()), vp(None),
+                                                vp(scratch.data_ptr()), stream), "lt_elu_backward_bias")
+            sums.add(scratch, nblk, n, n, n, biases_out[l])
+        else:
+            dz = g
+        if l == L - 1 and _head_wgrad_ok(dz, inp):
+            nblk = int(lib.lt_head_wgrad_nblk(m))
+            ws = torch.empty(int(lib.lt_head_wgrad_ws_floats(m, n, k)), device=inp.device, dtype=torch.float32)
+            _abi.check(lib.lt_head_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), m, n, k, vp(None), vp(None), vp(ws.data_ptr()), stream), "lt_head_wgrad")
+            sums.add(ws, nblk, n * k + 16, n * k + n, n * k, weights_out[l], biases_out[l])
+        else:
+            sp = pick_splits(m, n, k)
+            if sp > 1:
+                slabs = torch.bmm(dz.view(sp, m // sp, n).transpose(1, 2), inp.view(sp, m // sp, k))
+                sums.add(slabs, sp, n * k, n * k, n * k, weights_out[l])
+            else:
+                torch.mm(dz.t(), inp, out=weights_out[l])
+            if l == L - 1:
+                torch.sum(dz, dim=0, out=biases_out[l])
+        if l > 0:
+            g = dz @ w
+
+
 class PackedPair:
     """The actor and critic stacks of an ActorCritic as one training forward (see `_PairForward`).  `__call__(obs, critic_obs)`
     re-packs the live parameters (they change at every optimizer step), runs the launch and returns (mean, value) with autograd
@@ -206,6 +292,33 @@ class PackedPair:
         v = float(self.domain_max)
         self.domain_max = None
         return v >= float(_abi.CONSTS["LT_MLP_INPUT_CLAMP"])
+
+    def forward_raw(self, x0: torch.Tensor, x1: torch.Tensor):
+        """The launch without autograd: ((mean, value), (activations of the actor, of the critic)); re-packs the live parameters."""
+        self.a.pack()
+        self.b.pack()
+        lib = _abi.load()
+        vp = ctypes.c_void_p
+        nets = (self.a, self.b)
+        m = x0.shape[0]
+        ys, acts = _alloc_outputs(nets, m, x0.device)
+        arr = [(vp * max(1, len(a)))(*[t.data_ptr() for t in a]) for a in acts]
+        _abi.check(lib.lt_mlp_forward_pair(ctypes.byref(nets[0].desc), vp(nets[0].packed.data_ptr()), vp(x0.data_ptr()),
+                                           ctypes.byref(nets[1].desc), vp(nets[1].packed.data_ptr()), vp(x1.data_ptr()), m,
+                                           vp(ys[0].data_ptr()), vp(ys[1].data_ptr()), arr[0], arr[1], PackedMLP._stream()), "lt_mlp_forward_pair")
+        if self.check_domain:
+            self.check_domain = False
+            m_ = torch.stack([t.abs().max() for t in (x0, x1, *acts[0], *acts[1])]).max()
+            self.domain_max = m_ if self.domain_max is None else torch.maximum(self.domain_max, m_)
+        return ys, acts
+
+    def backward_raw(self, x0, x1, acts, dy0, dy1, grad_of) -> None:
+        """Both stacks' backward passes, every parameter gradient written into `grad_of[param]` (the flat bucket's views)."""
+        sums = SumJobs()
+        for net, x, a, dy in ((self.a, x0, acts[0], dy0), (self.b, x1, acts[1], dy1)):
+            ws = [lin.weight for lin in net.linears]
+            backward_chain(ws, [grad_of[lin.bias] for lin in net.linears], [grad_of[lin.weight] for lin in net.linears], x, a, dy, sums)
+        sums.launch()  # every ordered sum of partials of both stacks: one launch
 
     def __call__(self, x0: torch.Tensor, x1: torch.Tensor):
         self.a.pack()

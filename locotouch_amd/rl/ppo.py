@@ -29,7 +29,12 @@ class PPO:
         on_gpu = torch.device(device).type == "cuda"
         self.fused_loss = on_gpu and bool(unused.get("fused_loss", True))  # csrc/lt_ppo.hip: the loss chain and its backward in one launch
         self.packed_forward = on_gpu and bool(unused.get("packed_forward", True))  # csrc/lt_mlp.hip: both networks' training forward in one launch
+        self.direct_update = on_gpu and bool(unused.get("direct_update", True))  # no autograd graph, no host read between minibatch steps (_direct_update)
         self._pair = None
+        if on_gpu and bool(unused.get("tuned_gemms", True)):
+            from . import tuned_gemms
+
+            tuned_gemms.enable()  # library-GEMM algorithm selection recorded for this stack (rl/tuned_gemms.py); no run-time tuning
         self.optimizer = torch.optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
         self.storage: RolloutStorage | None = None
         self.learning_rate = learning_rate
@@ -146,6 +151,8 @@ class PPO:
         stats = torch.zeros(3, device=obs.device)
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         pair = self._packed_pair()
+        if pair is not None and self._flat_adam is not None and self.direct_update and ac.std.requires_grad:
+            return self._direct_update(pair)
         if pair is not None:
             pair.arm_domain_check()  # the first minibatch of the update reports the largest layer input (LT_MLP_INPUT_CLAMP)
         for idx in st.mini_batch_indices(self.num_mini_batches, self.num_learning_epochs):
@@ -170,14 +177,83 @@ class PPO:
         n = self.num_learning_epochs * self.num_mini_batches
         sv, ss, se = (stats / n).tolist()
         if pair is not None and pair.domain_violated():
-            import warnings
-
-            self.mlp_domain_violations = getattr(self, "mlp_domain_violations", 0) + 1
-            warnings.warn("an observation or hidden activation reached the MLP kernel's saturation bound (|x| >= LT_MLP_INPUT_CLAMP, "
-                          "include/lt_env.h): the fused forward computes MLP(clamp(x)) there, unlike the fp32 reference; "
-                          "construct PPO(..., packed_forward=False) and FusedRollout(..., use_packed_mlp=False) to run the fp32 GEMM path")
+            self._warn_mlp_domain()
         st.clear()
         return sv, ss, se, None, None
+
+    def _direct_update(self, pair):
+        """The update of the plain ActorCritic on the GPU with NO host read between its minibatch steps and no autograd graph: per step
+        two row gathers, the packed forward (rl/mlp.py), ONE loss launch that also writes d loss / d (mu, value, std) (csrc/lt_ppo.hip),
+        the adaptive-KL learning-rate rule as a one-lane launch on a device scalar (`lt_ppo_lr_rule`, ppo.py:273-281), the two
+        stacks' backward chains writing their gradients straight into the flat bucket (rl/mlp.py `backward_chain`), [gradient
+        all-reduce], clip + Adam with the learning rate read from the device (`lt_adam_clip_step_dev`).  Statistics and the learning
+        rate come back in ONE read at the end.  Arithmetic equal to `_fused_update` (tests/test_hip_ppo_graph.py); the host used to
+        wait for the KL of every step - 20 stalls per iteration, ~350 us of idle GPU each."""
+        import ctypes
+
+        from .. import _abi
+
+        lib = _abi.load()
+        vp = ctypes.c_void_p
+        ac, st, fa = self.actor_critic, self.storage, self._flat_adam
+        f = lambda t: t.flatten(0, 1)  # noqa: E731
+        obs, cobs = f(st.observations), f(st.privileged_observations)
+        small = [f(t).contiguous() for t in (st.actions, st.actions_log_prob, st.advantages, st.returns, st.values, st.mu, st.sigma)]
+        small = [t.view(-1) if t.shape[-1] == 1 else t for t in small]
+        dev = obs.device
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        a_dim = small[0].shape[1]
+        state = torch.zeros(4, device=dev)  # [0] learning rate, [1..3] sums of (value loss, surrogate, entropy)
+        state[0] = self.learning_rate
+        lr_dev, stats = state[:1], state[1:]
+        grad_of = fa.grad_views()
+        std_c = ac.std.detach()
+        pair.arm_domain_check()
+        n_steps = 0
+        for idx in st.mini_batch_indices(self.num_mini_batches, self.num_learning_epochs):
+            o, co = obs[idx], cobs[idx]
+            if o.dtype != torch.float32:  # bf16 observation storage (BASELINE config 5): the update computes in f32
+                o, co = o.float(), co.float()
+            m = o.shape[0]
+            (mu, value), acts = pair.forward_raw(o, co)
+            dmu = torch.empty_like(mu)
+            dvalue = torch.empty(m, 1, device=dev, dtype=torch.float32)
+            acc = torch.empty(20, device=dev, dtype=torch.float32)
+            out = torch.empty(24, device=dev, dtype=torch.float32)
+            stream = vp(torch.cuda.current_stream(dev).cuda_stream)
+            _abi.check(lib.lt_ppo_loss(vp(mu.data_ptr()), vp(std_c.data_ptr()), vp(value.data_ptr()), *[vp(t.data_ptr()) for t in small],
+                                       vp(idx.data_ptr()), m, a_dim, float(self.clip_param), float(self.value_loss_coef), float(self.entropy_coef),
+                                       int(bool(self.use_clipped_value_loss)), vp(dmu.data_ptr()), vp(dvalue.data_ptr()), vp(acc.data_ptr()),
+                                       vp(out.data_ptr()), stream), "lt_ppo_loss")
+            kl = None
+            if adaptive:
+                kl = out[4:5]
+                if self.dist.world_size > 1:  # every rank must take the same decision (SURVEY.md 8(e).2); the collective is stream-ordered
+                    kl = self.dist.all_reduce_mean_(kl.clone())
+            _abi.check(lib.lt_ppo_lr_rule(vp(kl.data_ptr()) if kl is not None else vp(None), float(self.desired_kl or 0.0), 1e-5, 1e-2, 1.5,
+                                          vp(lr_dev.data_ptr()), vp(stats.data_ptr()), vp(out.data_ptr()), vp(grad_of[ac.std].data_ptr()), a_dim, stream),
+                       "lt_ppo_lr_rule")
+            pair.backward_raw(o, co, acts, dmu, dvalue, grad_of)
+            if self.dist.world_size > 1:
+                self.dist.all_reduce_mean_(self._flat_grad)  # RCCL all-reduce of the policy gradients over xGMI
+            fa.step_dev(self.max_grad_norm, lr_dev)
+            n_steps += 1
+        lr, sv, ss, se = state.tolist()  # the update's only host read
+        self.learning_rate = lr
+        for group in self.optimizer.param_groups:
+            group["lr"] = lr
+        if pair.domain_violated():
+            self._warn_mlp_domain()
+        st.clear()
+        return sv / n_steps, ss / n_steps, se / n_steps, None, None
+
+    def _warn_mlp_domain(self) -> None:
+        import warnings
+
+        self.mlp_domain_violations = getattr(self, "mlp_domain_violations", 0) + 1
+        warnings.warn("an observation or hidden activation reached the MLP kernel's saturation bound (|x| >= LT_MLP_INPUT_CLAMP, "
+                      "include/lt_env.h): the fused forward computes MLP(clamp(x)) there, unlike the fp32 reference; "
+                      "construct PPO(..., packed_forward=False) and FusedRollout(..., use_packed_mlp=False) to run the fp32 GEMM path")
 
     def _adapt_learning_rate(self, mu, sigma, old_mu, old_sigma) -> None:
         with torch.inference_mode():

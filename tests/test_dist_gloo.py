@@ -5,6 +5,7 @@ import socket
 import tempfile
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -67,18 +68,24 @@ def _worker(rank, world, port, outdir):
     dist.shutdown()
 
 
-def test_two_rank_update_equals_single_process():
+@pytest.mark.parametrize("world", [2, 8])
+def test_multi_rank_update_equals_single_process(world):
+    """2 ranks, and the node's 8 (4 envs each): index offsets, advantage moments, KL rule and the gradient mean at the real rank count."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ref, ref_adv, ref_out = _single()
     ref_flat = torch.cat([p.detach().flatten() for p in ref.actor_critic.parameters()]).numpy()
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, port, d), nprocs=2, join=True)
-        r0, r1 = np.load(os.path.join(d, "rank0.npz")), np.load(os.path.join(d, "rank1.npz"))
-    np.testing.assert_array_equal(r0["params"], r1["params"])  # replicas stay bit-identical
-    n = N_TOTAL // 2
-    np.testing.assert_allclose(r0["adv"], ref_adv[:, :n].numpy(), rtol=1e-4, atol=1e-5)  # global advantage normalisation
-    np.testing.assert_allclose(r1["adv"], ref_adv[:, n:].numpy(), rtol=1e-4, atol=1e-5)
-    assert float(r0["lr"]) == float(r1["lr"]) == ref.learning_rate  # same adaptive-LR decisions on every rank
-    np.testing.assert_allclose(r0["params"], ref_flat, rtol=2e-4, atol=2e-5)
+        mp.spawn(_worker, args=(world, port, d), nprocs=world, join=True)
+        rs = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(world)]
+    n = N_TOTAL // world
+    for r, rec in enumerate(rs):
+        np.testing.assert_array_equal(rec["params"], rs[0]["params"])  # replicas stay bit-identical
+        np.testing.assert_allclose(rec["adv"], ref_adv[:, r * n:(r + 1) * n].numpy(), rtol=1e-4, atol=1e-5)  # global advantage normalisation
+        assert float(rec["lr"]) == ref.learning_rate  # same adaptive-LR decisions on every rank
+    # Adam divides by sqrt(v): where a gradient is ~0 a differently ordered 8-way sum moves the step by a visible fraction of lr, so
+    # the tight band may be left by a handful of the 687 513 parameters (counted), never the loose one (2 steps x lr 1e-3)
+    tight = np.isclose(rs[0]["params"], ref_flat, rtol=2e-4, atol=2e-5)
+    assert (~tight).sum() <= 1e-5 * ref_flat.size, int((~tight).sum())
+    np.testing.assert_allclose(rs[0]["params"], ref_flat, rtol=2e-4, atol=4e-4)

@@ -118,6 +118,54 @@ def test_update_with_fused_loss_equals_update_with_torch_ops():
         assert float((pa - pb).abs().mean()) < 3e-4
 
 
+def test_direct_update_without_host_reads_equals_the_autograd_form():
+    """PPO._direct_update (no autograd graph, the KL -> learning-rate rule and the statistics on the device, gradients written into
+    the flat bucket in place, ONE host read per update) against PPO._fused_update (same kernels behind autograd nodes, the host
+    deciding the learning rate from the KL of every minibatch step, loco_rl/loco_rl/algorithms/ppo.py:273-281): same kernels in the
+    same order, so the parameters agree to the rounding of the learning rate itself (f32 on the device, a Python float on the host)."""
+    import torch
+
+    from locotouch_amd.rl import PPO, ActorCritic
+    from tests.rl_synth import N_ACT, N_OBS, POLICY_CFG, PPO_CFG
+
+    from locotouch_amd.rl import tuned_gemms
+
+    tuned_gemms.disable()  # both forms on the library's default GEMM algorithms (TunableOp's state does not reach the autograd thread)
+    n, T = 1024, 24
+    cfg = dict(PPO_CFG, num_learning_epochs=3, num_mini_batches=4, tuned_gemms=False)
+    algs = []
+    for direct in (True, False):
+        torch.manual_seed(0)
+        alg = PPO(ActorCritic(N_OBS, N_OBS, N_ACT, **POLICY_CFG), device="cuda:0", direct_update=direct, **cfg)
+        alg.init_storage(n, T, [N_OBS], [N_OBS], [N_ACT])
+        algs.append(alg)
+    a, b = algs
+    assert a.direct_update and not b.direct_update and a._flat_adam is not None and b._flat_adam is not None
+    lrs = set()
+    for it in range(4):
+        outs = []
+        for alg in (a, b):
+            _fill(alg, 200 + it, n, T)
+            torch.manual_seed(11 + it)
+            outs.append(alg.update())
+        for x, y in zip(outs[0][:3], outs[1][:3]):
+            assert abs(x - y) <= 1e-5 * max(1.0, abs(y)), (it, outs)
+        assert abs(a.learning_rate - b.learning_rate) <= 1e-5 * b.learning_rate  # (repeated x / 1.5 in f32 against the host's f64)
+        assert a.optimizer.param_groups[0]["lr"] == a.learning_rate
+        lrs.add(round(a.learning_rate, 9))
+        for pa, pb in zip(a.actor_critic.parameters(), b.actor_critic.parameters()):
+            torch.testing.assert_close(pa, pb, rtol=1e-4, atol=1e-5)  # (a 1e-6 relative difference of the rate through Adam's normalised steps)
+            assert pa.grad is not None and pa.grad.data_ptr() >= a._flat_adam.flat_g.data_ptr()
+    assert len(lrs) > 1, "the adaptive rule must have moved the learning rate"
+    # fixed schedule: the rule kernel leaves the rate alone
+    torch.manual_seed(0)
+    c = PPO(ActorCritic(N_OBS, N_OBS, N_ACT, **POLICY_CFG), device="cuda:0", **dict(cfg, schedule="fixed"))
+    c.init_storage(n, T, [N_OBS], [N_OBS], [N_ACT])
+    _fill(c, 300, n, T)
+    c.update()
+    assert c.learning_rate == pytest.approx(cfg["learning_rate"], rel=1e-7)
+
+
 @pytest.mark.parametrize("m,n", [(24576, 512), (4100, 256), (5000, 128), (4096, 400), (4097, 4)])
 def test_linear_elu_node_matches_torch(m, n):
     """`MLPSequential`'s fused Linear -> ELU node (csrc/lt_ppo.hip lt_elu_backward_bias) against nn.Linear + nn.ELU."""

@@ -8,6 +8,7 @@ import socket
 import tempfile
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -133,29 +134,32 @@ def _worker(rank, world, port, outdir):
     dist.shutdown()
 
 
-def test_two_ranks_widen_on_the_same_step_as_one_population():
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_widen_on_the_same_step_as_one_population(world):
+    """2 ranks, and the node's 8: 8 x 16 envs with env_index_offset r * 16 == one 128-env population (curriculum ring, RNG keys)."""
     from locotouch_amd.rl import Dist
     from tests.oracle_vec_env import OracleVecEnv
 
     outdir = tempfile.mkdtemp()
     rng = np.random.default_rng(2)
-    actions = (0.3 * rng.standard_normal((ITERS * ROLLOUT, 2 * N_RANK, 12))).astype(np.float32)
+    actions = (0.3 * rng.standard_normal((ITERS * ROLLOUT, world * N_RANK, 12))).astype(np.float32)
     np.save(os.path.join(outdir, "actions.npy"), actions)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, outdir), nprocs=2, join=True)
-    P0, P1 = np.load(os.path.join(outdir, "P_rank0.npy")), np.load(os.path.join(outdir, "P_rank1.npy"))
-    np.testing.assert_array_equal(P0, P1)  # identical command block on both ranks after every rollout
+    mp.spawn(_worker, args=(world, port, outdir), nprocs=world, join=True)
+    P0 = np.load(os.path.join(outdir, "P_rank0.npy"))
+    for r in range(1, world):
+        np.testing.assert_array_equal(P0, np.load(os.path.join(outdir, f"P_rank{r}.npy")))  # identical command block on every rank after every rollout
     bins = P0[:, 17] + P0[:, 18]
     assert bins[-1] >= 3 and (np.diff(bins) >= 0).all(), bins  # the ranges did widen, several times
     # one process holding the whole 32-env population, same lagged gate: the same widenings at the same rollouts
-    env = OracleVecEnv(TASK, cfg=_gate_cfg(2 * N_RANK, 0, 1))
+    env = OracleVecEnv(TASK, cfg=_gate_cfg(world * N_RANK, 0, 1))
     log = []
     _run_rank(env, Dist(), actions, log)
     np.testing.assert_allclose(np.stack(log), P0, rtol=0, atol=0)
     # and the lag against the reference's own per-step gate (cur_gate_external = 0) is bounded by one rollout per widening
-    env = OracleVecEnv(TASK, cfg=_gate_cfg(2 * N_RANK, 0, 0))
+    env = OracleVecEnv(TASK, cfg=_gate_cfg(world * N_RANK, 0, 0))
     log1 = []
     _run_rank(env, Dist(), actions, log1)
     b1 = np.stack(log1)[:, 17] + np.stack(log1)[:, 18]
