@@ -207,6 +207,14 @@ typedef struct lt_cfg {
   float plate_ct;
   float contact_ramp;             /* damping ramp-in depth */
   float gravity;
+  /* joint limits (URDF lower / upper, include/lt_go1_model.h): a unilateral spring-damper on the joint coordinate, integrated
+   * implicitly INSIDE the dynamics solve like the ground contacts: with d the excursion beyond a limit (negative inside) the limit
+   * torque is k d - (k h + c) qd_new along the inward direction, active when the joint would end the step beyond the limit at its
+   * present velocity - it enters the joint's diagonal as h (k h + c) and its right-hand side, acts
+   * between parent and child link (momentum-consistent) and never pulls.  PhysX solves limits as hard constraints
+   * (reference assets/go1.py:18-29); engine parameters, no counterpart in the reference's cfg. */
+  float joint_limit_kp;           /* N m / rad */
+  float joint_limit_kd;           /* N m s / rad */
   int32_t enable_corruption;      /* policy-group noise on/off */
   int32_t debug_terms;            /* 1: write unweighted reward terms to LT_F_REWARD_TERMS every step */
   int32_t max_episode_length;     /* ceil(episode_length_s / step_dt) = 1000 (kept integral: bit-exact time_out) */

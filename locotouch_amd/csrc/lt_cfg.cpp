@@ -153,6 +153,8 @@ void base_locomotion(lt_cfg* c) {
   c->plate_ct = 1.0e3f;
   c->contact_ramp = 1.0e-3f;
   c->gravity = 9.81f;
+  c->joint_limit_kp = 4.0e4f;  // 23.5 N m of motor torque rests 0.6 mrad beyond a limit; a leg (0.08 kg m^2 about its hip) arriving at 20 rad/s overshoots ~10 mrad
+  c->joint_limit_kd = 120.f;   // ~critical for that leg; h (k h + c) = 1.6 kg m^2 against joint inertias of 0.003 .. 0.08: no rebound
 }
 
 void transport_teacher(lt_cfg* c) {

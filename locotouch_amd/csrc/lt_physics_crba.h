@@ -903,6 +903,25 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
     S.rhs[1] = G.tau[1] - f[1].y.x - cr.tb[1];
     S.rhs[2] = G.tau[2] - f[2].y.x - cr.tb[2];
   }
+  // ---- joint limits: unilateral implicit spring-dampers on the joint coordinates (lt_cfg.joint_limit_*; oracle: joint_limit()).
+  //      Beyond a limit by d the torque along the inward direction s is  k d - B s qd_new,  B = k h + c:  s f0 on the right-hand
+  //      side, h B on the joint's diagonal - an internal torque between parent and child, solved with everything else.
+  {
+    const float Bl = c.joint_limit_kp * h + c.joint_limit_kd, hB = h * Bl;
+    float add[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float dlo = k_joint_lo[k] - G.q[k], dhi = G.q[k] - k_joint_hi[k];
+      const float sg = dlo > dhi ? 1.f : -1.f, d = dlo > dhi ? dlo : dhi;  // the nearer limit: its inward direction, the excursion beyond it (< 0 inside)
+      const float f0 = c.joint_limit_kp * d - Bl * sg * G.qd[k];
+      // active when the joint WOULD be beyond the limit at the end of this step at its present velocity (d may still be negative:
+      // at 30 rad/s a joint travels 0.15 rad per step - a penalty that waits for d > 0 lets it through that far), and only pushes
+      const bool on = d - h * sg * G.qd[k] > 0.f && f0 > 0.f;
+      S.rhs[k] += on ? sg * f0 : 0.f;
+      add[k] = on ? hB : 0.f;
+    }
+    S.h00 += add[0]; S.h11 += add[1]; S.h22 += add[2];
+  }
 
   ext.mark(3);
   // ---- eliminate this leg's joints: H = L L^T (3x3), Y = L^-1 H_lb (rows (moment | force)), z = L^-1 rhs ----
@@ -977,11 +996,8 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
   // ---- semi-implicit Euler ----
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    float qd = G.qd[k] + h * qdd[k];
-    float q = G.q[k] + h * qd;
-    if (q < k_joint_lo[k]) { q = k_joint_lo[k]; if (qd < 0.f) qd = 0.f; }
-    if (q > k_joint_hi[k]) { q = k_joint_hi[k]; if (qd > 0.f) qd = 0.f; }
-    G.q[k] = q; G.qd[k] = qd;
+    const float qd = G.qd[k] + h * qdd[k];
+    G.q[k] += h * qd; G.qd[k] = qd;  // (joint limits act inside the solve above: no clamp)
   }
   {
     const V3 acl = a0l + cross(wb, vb);

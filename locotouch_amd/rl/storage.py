@@ -132,11 +132,16 @@ class RolloutStorage:
     def mini_batch_indices(self, num_mini_batches: int, num_epochs: int) -> Iterator[torch.Tensor]:
         """The row indices `mini_batches` gathers with (same single `randperm`, same order), for consumers that gather themselves
         (the fused PPO loss reads the small per-row tensors through the index, csrc/lt_ppo.hip)."""
-        mb = (self.num_envs * self.num_steps) // num_mini_batches
-        perm = torch.randperm(num_mini_batches * mb, requires_grad=False, device=self.device)
+        perm, mb = self.mini_batch_permutation(num_mini_batches)
         for _ in range(num_epochs):
             for i in range(num_mini_batches):
                 yield perm[i * mb:(i + 1) * mb]
+
+    def mini_batch_permutation(self, num_mini_batches: int):
+        """(perm, rows per minibatch): the ONE permutation an update draws and reuses in every epoch (rollout_storage.py:189-190);
+        minibatch i is perm[i * mb:(i + 1) * mb]."""
+        mb = (self.num_envs * self.num_steps) // num_mini_batches
+        return torch.randperm(num_mini_batches * mb, requires_grad=False, device=self.device), mb
 
     def recurrent_mini_batches(self, num_mini_batches: int, num_epochs: int = 8, hidden_states_a="saved", hidden_states_c="saved"):
         """Minibatches of whole trajectories for recurrent policies (reference rollout_storage.py:246-318): envs are dealt to

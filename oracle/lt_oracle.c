@@ -633,6 +633,15 @@ static void physics_substep(const lt_cfg* cfg, env_t* E, real h, int has_object,
     for (int i = 0; i < 6; ++i) U[b][i] = IA[b][i * 6 + ax];
     D[b] = U[b][ax];
     uu[b] = E->tau[l][k] - pA[b][ax];
+    { /* joint limit: unilateral implicit spring-damper on the joint coordinate (lt_cfg.joint_limit_*): beyond a limit by d the
+       * torque along the inward direction s is  k d - B s qd_new,  B = k h + c  ->  (D + h B) qdd = u + s f0 - U^T a_p */
+      real Bl = cfg->joint_limit_kp * h + cfg->joint_limit_kd;
+      real dlo = k_joint_lo[k] - E->q[l][k], dhi = E->q[l][k] - k_joint_hi[k];
+      real sg = dlo > dhi ? (real)1 : (real)-1, d = dlo > dhi ? dlo : dhi; /* the nearer limit */
+      real f0 = cfg->joint_limit_kp * d - Bl * sg * E->qd[l][k];
+      /* active when the joint would be beyond the limit at the end of the step at its present velocity; only pushes */
+      if (d - h * sg * E->qd[l][k] > 0 && f0 > 0) { D[b] += h * Bl; uu[b] += sg * f0; }
+    }
     mat6 Ia;
     vec6 pa, Iac;
     for (int i = 0; i < 6; ++i)
@@ -694,10 +703,7 @@ static void physics_substep(const lt_cfg* cfg, env_t* E, real h, int has_object,
   for (int l = 0; l < 4; ++l)
     for (int k = 0; k < 3; ++k) {
       real qd = E->qd[l][k] + h * E->qdd[l][k];
-      real q = E->q[l][k] + h * qd;
-      if (q < k_joint_lo[k]) { q = k_joint_lo[k]; if (qd < 0) qd = 0; }
-      if (q > k_joint_hi[k]) { q = k_joint_hi[k]; if (qd > 0) qd = 0; }
-      E->q[l][k] = q; E->qd[l][k] = qd;
+      E->q[l][k] += h * qd; E->qd[l][k] = qd; /* (joint limits act inside the solve: no clamp) */
     }
   {
     real wxv[3], acl[3], aw[3], alw[3];

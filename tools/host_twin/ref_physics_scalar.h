@@ -644,6 +644,17 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
   {
     const CrbaOut& cr = pe.crba;
     S.h00 += cr.h00; S.h01 += cr.h01; S.h02 += cr.h02; S.h11 += cr.h11; S.h12 += cr.h12; S.h22 += cr.h22;
+    // (r04: the model's joint limits became implicit spring-dampers inside the solve, lt_cfg.joint_limit_*; this frozen formulation follows the model)
+    for (int k = 0; k < 3; ++k) {
+      const float Bl = c.joint_limit_kp * h + c.joint_limit_kd;
+      const float dlo = k_joint_lo[k] - G.q[k], dhi = G.q[k] - k_joint_hi[k];
+      const float sg = dlo > dhi ? 1.f : -1.f, d = dlo > dhi ? dlo : dhi;
+      const float f0 = c.joint_limit_kp * d - Bl * sg * G.qd[k];
+      if (d - h * sg * G.qd[k] > 0.f && f0 > 0.f) {
+        S.rhs[k] += sg * f0;
+        if (k == 0) S.h00 += h * Bl; else if (k == 1) S.h11 += h * Bl; else S.h22 += h * Bl;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) { S.bn[j] += cr.bn[j]; S.bl[j] += cr.bl[j]; }
     Mbb.A.m[0] += cr.Io.xx; Mbb.A.m[1] += cr.Io.xy; Mbb.A.m[2] += cr.Io.xz;
@@ -728,11 +739,8 @@ __device__ __forceinline__ void physics_substep(const lt_cfg& c, float h, int le
   // ---- semi-implicit Euler ----
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    float qd = G.qd[k] + h * qdd[k];
-    float q = G.q[k] + h * qd;
-    if (q < k_joint_lo[k]) { q = k_joint_lo[k]; if (qd < 0.f) qd = 0.f; }
-    if (q > k_joint_hi[k]) { q = k_joint_hi[k]; if (qd > 0.f) qd = 0.f; }
-    G.q[k] = q; G.qd[k] = qd;
+    const float qd = G.qd[k] + h * qdd[k];
+    G.q[k] += h * qd; G.qd[k] = qd;
   }
   {
     const V3 acl = a0l + cross(wb, vb);

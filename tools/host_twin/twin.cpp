@@ -93,10 +93,10 @@ int main(int argc, char** argv) {
       for (int k = 0; k < 3; ++k) { s.bu[k] = U(-0.6f, 0.6f); s.bw[k] = U(-1.5f, 1.5f); }
       for (int l = 0; l < 4; ++l) {
         const float sy = (l & 1) ? 1.f : -1.f;
-        const float spread = mode == 1 ? 0.9f : 0.35f;
-        s.q[l][0] = clampf(sy * kdef[0] + U(-0.3f, 0.3f), -0.8f, 0.8f);
-        s.q[l][1] = clampf(kdef[1] + U(-spread, spread), -0.6f, 4.4f);
-        s.q[l][2] = clampf(kdef[2] + U(-spread, spread), -2.8f, -0.9f);
+        const float spread = i % 7 == 0 ? 1.15f : (mode == 1 ? 0.9f : 0.35f);  // (every seventh state: calves beyond their limits)
+        s.q[l][0] = clampf(sy * kdef[0] + U(-0.3f, 0.3f) * (i % 5 == 0 ? 3.2f : 1.f), -0.92f, 0.92f);  // (every fifth state may sit beyond a joint limit: the implicit limit torques)
+        s.q[l][1] = clampf(kdef[1] + U(-spread, spread), -0.75f, 4.56f);
+        s.q[l][2] = clampf(kdef[2] + U(-spread, spread), -2.87f, -0.84f);
         for (int k = 0; k < 3; ++k) { s.qd[l][k] = U(-4.f, 4.f); s.tau[l][k] = U(-20.f, 20.f); }
         s.mu[l] = U(0.3f, 1.0f);
       }
