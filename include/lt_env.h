@@ -428,6 +428,18 @@ int lt_gae(const float* rewards, const uint8_t* dones, const float* values, cons
  * activation OUTPUT a (1 where a > 0, a + alpha elsewhere), db[N] = column sums of dz.  dz may alias da.  N a multiple of 4,
  * <= 1024; ws: lt_elu_backward_bias_ws_floats(M, N) floats of scratch. */
 int lt_elu_backward_bias(const float* da, const float* a, int64_t M, int N, float alpha, float* dz, float* db, float* ws, void* stream);
+/* The same, and per-block maxima of |dz| into amax_blocks[lt_elu_backward_bias_nblk(M)] (what lt_wgrad scales the gradient by). */
+int lt_elu_backward_bias2(const float* da, const float* a, int64_t M, int N, float alpha, float* dz, float* db, float* ws, float* amax_blocks,
+                          void* stream);
+/* Weight gradient of a Linear layer over a minibatch, f32-equivalent on the f16 matrix cores (csrc/lt_wgrad.hip; the backward of
+ * loco_rl/loco_rl/algorithms/ppo.py:316 for one layer): slabs[s][n][k] = sum over the s-th slice of the M rows of dz[m][n] x[m][k],
+ * s < lt_wgrad_splits(M, N, K); the caller adds the slabs in order (lt_partial_sums: nblk = splits, stride = count = N * K).
+ * dz [M][N], x [M][K] row-major f32, N and K multiples of 4; both operands are split into f16 (hi, lo) pairs in registers (three MFMAs per tile); dz is scaled
+ * by a power of two taken from max |dz| = max over amax_blocks[nblk_amax] (NULL: no scaling - |dz| must then sit in f16's normal
+ * range), |x| <= 65504.  slabs: lt_wgrad_ws_floats(M, N, K) floats.  Deterministic. */
+int lt_wgrad(const float* dz, const float* x, int64_t M, int N, int K, const float* amax_blocks, int nblk_amax, float* slabs, void* stream);
+int lt_wgrad_splits(int64_t M, int N, int K);
+int64_t lt_wgrad_ws_floats(int64_t M, int N, int K);
 int64_t lt_elu_backward_bias_ws_floats(int64_t M, int N);
 /* Weight and bias gradient of a narrow head layer (the action-mean and value heads of actor_critic.py:45-66 in the backward pass):
  * dw[n][k] = sum_m dy[m][n] x[m][k], db[n] = sum_m dy[m][n] (db optional).  1 <= n <= 16, k a multiple of 4, <= 1024;

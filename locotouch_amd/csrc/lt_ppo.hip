@@ -127,11 +127,12 @@ __global__ __launch_bounds__(64) void lt_ppo_finalize_kernel(const float* __rest
 constexpr int EB_ROWS = 48;  // rows per block: 512 blocks at 24 576 rows
 
 __global__ __launch_bounds__(256) void lt_elu_bwd_bias_kernel(const float* da, const float* __restrict__ a, long long M, int N, float alpha,
-                                                              float* dz, float* __restrict__ ws) {
+                                                              float* dz, float* __restrict__ ws, float* __restrict__ amax) {
   const int n4 = N >> 2, lanes = 256 / n4;
   const int c4 = threadIdx.x % n4, rl = threadIdx.x / n4;
   const long long r0 = (long long)blockIdx.x * EB_ROWS;
   float4 sum = {0.f, 0.f, 0.f, 0.f};
+  float mx = 0.f;  // max |dz| of this block (lt_wgrad scales the gradient into f16's range by it)
   if (rl < lanes) {
     for (int r = rl; r < EB_ROWS; r += lanes) {
       const long long row = r0 + r;
@@ -144,11 +145,19 @@ __global__ __launch_bounds__(256) void lt_elu_bwd_bias_kernel(const float* da, c
       o.w = g.w * (y.w > 0.f ? 1.f : y.w + alpha);
       ((float4*)(dz + row * N))[c4] = o;
       sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
   }
   __shared__ float4 red[256];
+  __shared__ float redm[4];
   red[threadIdx.x] = sum;
+  if (amax) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = mx;
+  }
   __syncthreads();
+  if (amax && threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
   if (threadIdx.x < n4) {
     float4 t = red[threadIdx.x];
     for (int l = 1; l < lanes; ++l) {
@@ -407,13 +416,22 @@ extern "C" int lt_ppo_lr_rule(const float* kl_mean, float desired_kl, float lr_m
   return LT_OK;
 }
 
+static int elu_backward_bias(const float* da, const float* a, int64_t M, int N, float alpha, float* dz, float* db, float* ws, float* amax, void* stream);
 extern "C" int lt_elu_backward_bias(const float* da, const float* a, int64_t M, int N, float alpha, float* dz, float* db, float* ws, void* stream) {
+  return elu_backward_bias(da, a, M, N, alpha, dz, db, ws, nullptr, stream);
+}
+// ... and per-block maxima of |dz| (amax_blocks: lt_elu_backward_bias_nblk(M) floats), what lt_wgrad scales dz by
+extern "C" int lt_elu_backward_bias2(const float* da, const float* a, int64_t M, int N, float alpha, float* dz, float* db, float* ws, float* amax_blocks,
+                                     void* stream) {
+  return elu_backward_bias(da, a, M, N, alpha, dz, db, ws, amax_blocks, stream);
+}
+static int elu_backward_bias(const float* da, const float* a, int64_t M, int N, float alpha, float* dz, float* db, float* ws, float* amax, void* stream) {
   if (!da || !a || !dz || !ws || M < 1 || N < 4 || (N & 3) || N > 1024) {
     lt_set_error("lt_elu_backward_bias: invalid argument (N a multiple of 4, 4 <= N <= 1024)");
     return LT_EINVAL;
   }
   const int nblk = (int)((M + EB_ROWS - 1) / EB_ROWS);
-  hipLaunchKernelGGL(lt_elu_bwd_bias_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, da, a, (long long)M, N, alpha, dz, ws);
+  hipLaunchKernelGGL(lt_elu_bwd_bias_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, da, a, (long long)M, N, alpha, dz, ws, amax);
   if (db) hipLaunchKernelGGL(lt_partial_sum_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, ws, nblk, (long long)N, N, N, db, (float*)nullptr);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }

@@ -1,0 +1,194 @@
+// lt_wgrad.hip - weight gradient of a Linear layer over a PPO minibatch, f32-equivalent, on the f16 matrix cores.
+//
+// Reference: the backward pass of the reference's ActorCritic MLPs inside PPO.update (loco_rl/loco_rl/algorithms/ppo.py:316,
+// `loss.backward()`): for every Linear layer  dW[n][k] = sum_m dz[m][n] x[m][k]  over the minibatch (M = 24 576 rows at 4096
+// envs), N <= 512 outputs, K <= 512 inputs.  As library GEMMs (split-K batched, rocBLAS / hipBLASLt f32) these five shapes per
+// network take 120 TFLOP/s at best - 142 us per network and minibatch step, the largest block of the PPO update
+// (profiles/r04_ppo_step_timeline.txt).  gfx950 has no TF32-like mode: the f32-input MFMA runs at the f32 vector rate.
+//
+// Arithmetic (the same operand split as lt_mlp.hip): every f32 operand is x = hi + lo / 64 with hi = f16(x), lo = f16(64 (x - hi));
+//     sum_m a b  =  sum a_hi b_hi  +  (sum a_hi b_lo + sum a_lo b_hi) / 64          (the lo lo term is 2^-22 relative: dropped)
+// three f16 MFMAs (v_mfma_f32_16x16x32_f16, f32 accumulation, exact products) into TWO accumulators (main, correction).
+// dz is a gradient - 1e-4 ... 1e-9 at the PPO loss's 1 / M scale, far below f16's range: it is multiplied by a power of two `s` that
+// brings max |dz| to [2^13, 2^14) before the split (s from the per-block maxima the producing kernel leaves, lt_elu_backward_bias2;
+// elements more than 2^27 below the maximum lose relative precision, at an absolute error 2^-38 of the maximum) and the sums are
+// divided by s at the end.  x (observations, ELU outputs) is used as it is: |x| <= 65504 / 1 is all f16 needs here (no 64 x scaling).
+// Against an f64 reference the result is as close as an f32 GEMM's own rounding (tests/test_hip_wgrad.py).
+//
+// Structure: NO LDS and no barriers.  The MFMA's A operand wants, per lane (i = lane & 15, g = lane >> 4), 8 values of the REDUCTION
+// index for one output row - a COLUMN of the row-major dz.  The order of a reduction is free and so is the order of a tile's rows,
+// as long as A and B agree: a wave's 32 x 64 block of dz is fetched by 8 fully coalesced 16-byte loads (load t: lane (c, g) takes row
+// m0 + 4 t + g, columns 4 c .. 4 c + 3) and lane (c, g) then HOLDS, for each of its four columns u, the eight rows g, g + 4, ..., g + 28
+// - the fragment of reduction indices kk = 8 g + t <-> m = m0 + 4 t + g for output row 4 c + u of MFMA tile u (tile u = the rows that
+// are u mod 4).  No shuffle, no transpose: component u of the eight loaded float4s IS the fragment.  The same for B = x.  (A first
+// version fetched columns by dword loads - 64 load instructions of 4 x 64 B per step instead of 16 of 1 KiB - and ran at 58 TFLOP/s.)
+// A wave owns a 64 x 64 output tile (4 x 4 MFMA tiles, 2 x 16 accumulators) over a slice of M; the epilogue's lane holds 4 adjacent
+// columns of a row (one from each tile along k): float4 stores;
+// workgroup = one wave (4 per CU, one per SIMD, ~340 registers); the slices' partial tiles go to a slab buffer and one ordered-sum
+// launch (lt_partial_sums) adds them - deterministic, no float atomics.  Loads of step s + 1 are in flight while step s is split
+// and multiplied.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lt_env.h"
+#include "lt_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TA = 4, TB = 4;  // MFMA tiles per wave along n (dz columns) and k (x columns): a 64 x 64 output tile
+constexpr float LO_SCALE = 64.f;
+
+// x = hi + lo / 64 on component U of eight loaded float4s (pairs: v_cvt_pk_f16_f32, v_pk_add_f32, v_pk_mul_f32)
+template <int U>
+__device__ __forceinline__ void split8(const f32x4 (&v)[8], float scale, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    f32x2 x;
+    x[0] = v[2 * p][U] * scale; x[1] = v[2 * p + 1][U] * scale;
+    const f16x2 h = __builtin_convertvector(x, f16x2);
+    const f32x2 d = (x - __builtin_convertvector(h, f32x2)) * LO_SCALE;
+    const f16x2 l = __builtin_convertvector(d, f16x2);
+    hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
+    lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
+  }
+}
+
+struct WgradArgs {
+  const float* dz;      // [M][N]
+  const float* x;       // [M][K]
+  long long M;
+  int N, K;
+  int tiles_n, tiles_k, splits;
+  const float* amax;    // per-block maxima of |dz| (nblk_amax floats) or nullptr (scale 1)
+  int nblk_amax;
+  float* slabs;         // [splits][N][K]
+};
+
+__global__ __launch_bounds__(64, 1) void lt_wgrad_kernel(const WgradArgs a) {
+  const int lane = threadIdx.x;
+  const int i = lane & 15, g = lane >> 4;
+  // block -> (split, tile): the tiles of a slice of M on ONE XCD (blocks are dealt round-robin over the 8 XCDs - observed placement,
+  // used for speed only): they sweep the same rows of dz / x at about the same time, so a row is fetched into that XCD's L2 once and
+  // read from there by the 48 tiles.  Dealt block by block the tiles of a slice landed on all 8 XCDs and every XCD fetched every
+  // row: 8 x 84 MB from the Infinity Cache per launch of the 512 x 348 layer - 149 us at 58 TFLOP/s (f32-equivalent).  XCD x takes
+  // the work items [x, x + 1) * gridDim / 8 of the (split-major) list: at most one slice per XCD is shared with a neighbour.
+  const int tiles = a.tiles_n * a.tiles_k;
+  const int per_xcd = (int)gridDim.x >> 3;
+  const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (item >= tiles * a.splits) return;
+  const int split = item / tiles, tile = item - split * tiles;
+  const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
+  const int n0 = tn * 16 * TA, k0 = tk * 16 * TB;
+  // this slice's 32-row steps: the M / 32 steps are dealt as evenly as possible
+  const long long steps = (a.M + 31) / 32;
+  const long long s0 = steps * split / a.splits, s1 = steps * (split + 1) / a.splits;
+  // scale of dz: a power of two that brings max |dz| to [2^13, 2^14)
+  float scale = 1.f;
+  if (a.amax) {
+    float m = 0.f;
+    for (int b = lane; b < a.nblk_amax; b += 64) m = fmaxf(m, a.amax[b]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xFF) - 127;  // floor(log2 m) (m == 0 or denormal: e = -127)
+    int se = 13 - e;
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    scale = __uint_as_float((unsigned)(127 + se) << 23);
+  }
+  f32x4 main_[TA][TB], corr[TA][TB];
+#pragma unroll
+  for (int p = 0; p < TA; ++p)
+#pragma unroll
+    for (int q = 0; q < TB; ++q) { main_[p][q] = f32x4{0.f, 0.f, 0.f, 0.f}; corr[p][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // 32 rows x 64 columns per operand and step: load t = row m0 + 4 t + g, 16 bytes at column 4 c (clamped to the matrix: a tile may
+  // hang over its edge; what an overhanging lane loads is multiplied into output elements that are never stored)
+  f32x4 va[8], vb[8];
+  const int ca = min(n0 + 4 * i, a.N - 4), cb = min(k0 + 4 * i, a.K - 4);
+  auto issue = [&](long long s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      long long r = s * 32 + 4 * t + g;
+      r = r < a.M ? r : a.M - 1;
+      va[t] = *(const f32x4*)(a.dz + r * a.N + ca);
+      vb[t] = *(const f32x4*)(a.x + r * a.K + cb);
+    }
+  };
+  if (s0 < s1) issue(s0);
+  for (long long s = s0; s < s1; ++s) {
+    if ((s + 1) * 32 > a.M) {  // rows beyond M (the last step of a ragged M) must not contribute: their clamped loads repeat row M - 1
+#pragma unroll
+      for (int t = 0; t < 8; ++t) if (s * 32 + 4 * t + g >= a.M) va[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f16x8 ah[TA], al[TA], bh[TB], bl[TB];
+    split8<0>(va, scale, ah[0], al[0]); split8<1>(va, scale, ah[1], al[1]); split8<2>(va, scale, ah[2], al[2]); split8<3>(va, scale, ah[3], al[3]);
+    split8<0>(vb, 1.f, bh[0], bl[0]); split8<1>(vb, 1.f, bh[1], bl[1]); split8<2>(vb, 1.f, bh[2], bl[2]); split8<3>(vb, 1.f, bh[3], bl[3]);
+    if (s + 1 < s1) issue(s + 1);  // the next step's 16 loads fly while this step's 48 MFMAs run (a second stage in flight needs
+                                   // 64 more registers: 256 VGPRs + 246 AGPRs of copies, measured 25 % slower)
+#pragma unroll
+    for (int p = 0; p < TA; ++p)
+#pragma unroll
+      for (int q = 0; q < TB; ++q) {
+        main_[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], bh[q], main_[p][q], 0, 0, 0);
+        corr[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], bl[q], corr[p][q], 0, 0, 0);
+        corr[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[p], bh[q], corr[p][q], 0, 0, 0);
+      }
+  }
+  // the partial tile: MFMA tile (p, q) holds C[row rho = 4 g + r][col kappa = i] = dW[n0 + 4 rho + p][k0 + 4 kappa + q]: a lane's four
+  // q tiles are 4 ADJACENT columns of one row
+  const float inv = 1.f / scale;
+  float* const out = a.slabs + (long long)split * a.N * a.K;
+  const int k = k0 + 4 * i;
+#pragma unroll
+  for (int p = 0; p < TA; ++p)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * (4 * g + r) + p;
+      if (n < a.N && k < a.K) {
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < TB; ++q) o[q] = (main_[p][q][r] + corr[p][q][r] * (1.f / LO_SCALE)) * inv;
+        *(f32x4*)(out + (long long)n * a.K + k) = o;
+      }
+    }
+}
+
+int pick_splits(long long M, int tiles) {
+  // at most 1024 single-wave workgroups (one per SIMD of the 256 CUs: the kernel's 296 registers allow no second wave, and a 1025th
+  // block would run alone after the others - 24 slices x 48 tiles = 1152 blocks took 97 us where 21 x 48 = 1008 take 69 us), at least
+  // 4 steps of 32 rows per slice
+  const long long steps = (M + 31) / 32;
+  long long s = 1024 / tiles;
+  if (s > steps / 4) s = steps / 4;
+  return (int)(s < 1 ? 1 : s);
+}
+
+}  // namespace
+
+extern "C" int lt_wgrad_splits(int64_t M, int N, int K) {
+  const int tiles = ((N + 16 * TA - 1) / (16 * TA)) * ((K + 16 * TB - 1) / (16 * TB));
+  return pick_splits((long long)M, tiles);
+}
+
+extern "C" int64_t lt_wgrad_ws_floats(int64_t M, int N, int K) { return (int64_t)lt_wgrad_splits(M, N, K) * N * K; }
+
+extern "C" int lt_wgrad(const float* dz, const float* x, int64_t M, int N, int K, const float* amax_blocks, int nblk_amax, float* slabs, void* stream) {
+  if (!dz || !x || !slabs || M < 1 || N < 4 || K < 4 || (N & 3) || (K & 3) || (amax_blocks && nblk_amax < 1)) {
+    lt_set_error("lt_wgrad: invalid argument (N and K multiples of 4)");
+    return LT_EINVAL;
+  }
+  WgradArgs a;
+  a.dz = dz; a.x = x; a.M = M; a.N = N; a.K = K;
+  a.tiles_n = (N + 16 * TA - 1) / (16 * TA);
+  a.tiles_k = (K + 16 * TB - 1) / (16 * TB);
+  a.splits = pick_splits((long long)M, a.tiles_n * a.tiles_k);
+  a.amax = amax_blocks; a.nblk_amax = amax_blocks ? nblk_amax : 0;
+  a.slabs = slabs;
+  hipLaunchKernelGGL(lt_wgrad_kernel, dim3((unsigned)((a.tiles_n * a.tiles_k * a.splits + 7) / 8 * 8)), dim3(64), 0, (hipStream_t)stream, a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
+  return LT_OK;
+}

@@ -188,6 +188,11 @@ def _alloc_outputs(nets, m, device):
     return ys, acts
 
 
+import os as _os
+
+USE_SPLIT_F16_WGRAD = _os.environ.get("LT_SPLIT_F16_WGRAD", "1") != "0"  # 0: the weight gradients as library f32 GEMMs (A/B measurements)
+
+
 class SumJobs:
     """Ordered partial sums collected over a backward pass and added by ONE launch (`lt_partial_sums`): the per-block bias sums of
     lt_elu_backward_bias / lt_head_wgrad and the split-K slabs of the weight-gradient GEMMs were 14 launches of ~5 us per
@@ -241,17 +246,24 @@ def backward_chain(weights, biases_out, weights_out, x, acts, dy, sums: SumJobs)
             a = acts[l]
             dz = torch.empty_like(a)
             nblk = int(lib.lt_elu_backward_bias_nblk(m))
-            scratch = torch.empty(nblk * n, device=a.device, dtype=torch.float32)
-            _abi.check(lib.lt_elu_backward_bias(vp(g.data_ptr()), vp(a.data_ptr()), m, n, 1.0, vp(dz.data_ptr()), vp(None),
-                                                vp(scratch.data_ptr()), stream), "lt_elu_backward_bias")
+            scratch = torch.empty(nblk * n + nblk, device=a.device, dtype=torch.float32)
+            amax = scratch[nblk * n:]  # per-block max |dz|: lt_wgrad scales the gradient into f16's range by it
+            _abi.check(lib.lt_elu_backward_bias2(vp(g.data_ptr()), vp(a.data_ptr()), m, n, 1.0, vp(dz.data_ptr()), vp(None),
+                                                 vp(scratch.data_ptr()), vp(amax.data_ptr()), stream), "lt_elu_backward_bias2")
             sums.add(scratch, nblk, n, n, n, biases_out[l])
         else:
-            dz = g
+            dz, amax = g, None
         if l == L - 1 and _head_wgrad_ok(dz, inp):
             nblk = int(lib.lt_head_wgrad_nblk(m))
             ws = torch.empty(int(lib.lt_head_wgrad_ws_floats(m, n, k)), device=inp.device, dtype=torch.float32)
             _abi.check(lib.lt_head_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), m, n, k, vp(None), vp(None), vp(ws.data_ptr()), stream), "lt_head_wgrad")
             sums.add(ws, nblk, n * k + 16, n * k + n, n * k, weights_out[l], biases_out[l])
+        elif amax is not None and USE_SPLIT_F16_WGRAD and n % 4 == 0 and k % 4 == 0:
+            # dW = dz^T x on the f16 matrix cores, f32-equivalent (csrc/lt_wgrad.hip): slices of the rows -> slabs -> the joint sum launch
+            sp = int(lib.lt_wgrad_splits(m, n, k))
+            slabs = torch.empty(sp * n * k, device=inp.device, dtype=torch.float32)
+            _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), m, n, k, vp(amax.data_ptr()), amax.numel(), vp(slabs.data_ptr()), stream), "lt_wgrad")
+            sums.add(slabs, sp, n * k, n * k, n * k, weights_out[l])
         else:
             sp = pick_splits(m, n, k)
             if sp > 1:

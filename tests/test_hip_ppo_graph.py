@@ -120,27 +120,50 @@ def test_update_with_fused_loss_equals_update_with_torch_ops():
 
 def test_direct_update_without_host_reads_equals_the_autograd_form():
     """PPO._direct_update (no autograd graph, the KL -> learning-rate rule and the statistics on the device, gradients written into
-    the flat bucket in place, ONE host read per update) against PPO._fused_update (same kernels behind autograd nodes, the host
-    deciding the learning rate from the KL of every minibatch step, loco_rl/loco_rl/algorithms/ppo.py:273-281): same kernels in the
-    same order, so the parameters agree to the rounding of the learning rate itself (f32 on the device, a Python float on the host)."""
+    the flat bucket in place, ONE host read per update) against PPO._fused_update (same forward / loss kernels behind autograd nodes,
+    the host deciding the learning rate from the KL of every minibatch step, loco_rl/loco_rl/algorithms/ppo.py:273-281).
+
+    What can be pinned tightly is ONE optimizer step from identical parameters: the two forms differ only in who adds the partial
+    sums and in the weight-gradient kernel (csrc/lt_wgrad.hip there, ~1e-8 of max |dW| from f64; the library's f32 GEMM here, ~2e-7).
+    Over several steps PPO itself is a discontinuous map of its parameters (the ratio clip and the value clip pick a branch per
+    sample, and a heavy-tailed sample that changes its branch moves the minibatch gradient by percents), so there the check is
+    statistical: same learning-rate decisions, same losses, parameters within a few learning rates."""
     import torch
 
-    from locotouch_amd.rl import PPO, ActorCritic
+    from locotouch_amd.rl import PPO, ActorCritic, tuned_gemms
     from tests.rl_synth import N_ACT, N_OBS, POLICY_CFG, PPO_CFG
-
-    from locotouch_amd.rl import tuned_gemms
 
     tuned_gemms.disable()  # both forms on the library's default GEMM algorithms (TunableOp's state does not reach the autograd thread)
     n, T = 1024, 24
-    cfg = dict(PPO_CFG, num_learning_epochs=1, num_mini_batches=4, tuned_gemms=False)
-    algs = []
-    for direct in (True, False):
-        torch.manual_seed(0)
-        alg = PPO(ActorCritic(N_OBS, N_OBS, N_ACT, **POLICY_CFG), device="cuda:0", direct_update=direct, **cfg)
-        alg.init_storage(n, T, [N_OBS], [N_OBS], [N_ACT])
-        algs.append(alg)
-    a, b = algs
-    assert a.direct_update and not b.direct_update and a._flat_adam is not None and b._flat_adam is not None
+
+    def pair_of(cfg):
+        out = []
+        for direct in (True, False):
+            torch.manual_seed(0)
+            alg = PPO(ActorCritic(N_OBS, N_OBS, N_ACT, **POLICY_CFG), device="cuda:0", direct_update=direct, **cfg)
+            alg.init_storage(n, T, [N_OBS], [N_OBS], [N_ACT])
+            out.append(alg)
+        assert out[0].direct_update and not out[1].direct_update and out[0]._flat_adam is not None and out[1]._flat_adam is not None
+        return out
+
+    # (1) one step from identical parameters: gradients to the f32 GEMM's own error, parameters to one Adam step of it
+    a, b = pair_of(dict(PPO_CFG, num_learning_epochs=1, num_mini_batches=1, tuned_gemms=False))
+    outs = []
+    for alg in (a, b):
+        _fill(alg, 200, n, T)
+        torch.manual_seed(11)
+        outs.append(alg.update())
+    for x, y in zip(outs[0][:3], outs[1][:3]):
+        assert abs(x - y) <= 1e-6 * max(1.0, abs(y)), outs
+    for (name, pa), pb in zip(a.actor_critic.named_parameters(), b.actor_critic.parameters()):
+        assert float((pa.grad - pb.grad).abs().max()) <= 3e-6 * float(pb.grad.abs().max()), name
+        assert pa.grad.data_ptr() >= a._flat_adam.flat_g.data_ptr()
+        # Adam's first step is lr * g / (|g| + eps): where |g| ~ eps = 1e-8 an error of 1e-9 is a visible fraction of lr
+        torch.testing.assert_close(pa, pb, rtol=0, atol=2 * a.learning_rate)
+        assert float((pa - pb).abs().mean()) < 1e-6, name
+
+    # (2) four iterations of four minibatch steps
+    a, b = pair_of(dict(PPO_CFG, num_learning_epochs=1, num_mini_batches=4, tuned_gemms=False))
     lrs = set()
     for it in range(4):
         outs = []
@@ -149,20 +172,16 @@ def test_direct_update_without_host_reads_equals_the_autograd_form():
             torch.manual_seed(11 + it)
             outs.append(alg.update())
         for x, y in zip(outs[0][:3], outs[1][:3]):
-            assert abs(x - y) <= 1e-5 * max(1.0, abs(y)), (it, outs)
+            assert abs(x - y) <= 2e-3 * max(1.0, abs(y)), (it, outs)
         assert abs(a.learning_rate - b.learning_rate) <= 1e-5 * b.learning_rate  # (repeated x / 1.5 in f32 against the host's f64)
         assert a.optimizer.param_groups[0]["lr"] == a.learning_rate
         lrs.add(round(a.learning_rate, 9))
-        # Same kernels, but the split-K slabs and per-block bias sums are added by lt_partial_sums here and by torch's sum there:
-        # gradients agree to f32 summation order (~4e-8), and Adam turns a sign flip of a ~0 gradient component into up to 2 lr, so
-        # a handful of parameters sit ~1e-5 apart after 4 steps (measured: max 8.8e-6) - the bound grows with the number of steps
         for pa, pb in zip(a.actor_critic.parameters(), b.actor_critic.parameters()):
-            torch.testing.assert_close(pa.grad, pb.grad, rtol=1e-4, atol=5e-7)
-            torch.testing.assert_close(pa, pb, rtol=1e-4, atol=1e-4 * (it + 1))
-            assert float((pa - pb).abs().mean()) < 2e-6 * (it + 1)
-            assert pa.grad.data_ptr() >= a._flat_adam.flat_g.data_ptr()
+            torch.testing.assert_close(pa, pb, rtol=0, atol=4e-3)
+            assert float((pa - pb).abs().mean()) < 1e-4 * (it + 1)
     assert len(lrs) > 1, "the adaptive rule must have moved the learning rate"
     # fixed schedule: the rule kernel leaves the rate alone
+    cfg = dict(PPO_CFG, num_learning_epochs=1, num_mini_batches=4, tuned_gemms=False)
     torch.manual_seed(0)
     c = PPO(ActorCritic(N_OBS, N_OBS, N_ACT, **POLICY_CFG), device="cuda:0", **dict(cfg, schedule="fixed"))
     c.init_storage(n, T, [N_OBS], [N_OBS], [N_ACT])
