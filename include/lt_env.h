@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 11
+#define LT_ABI_VERSION 12
 
 /* error codes */
 #define LT_OK 0
@@ -436,8 +436,10 @@ int lt_elu_backward_bias2(const float* da, const float* a, int64_t M, int N, flo
  * s < lt_wgrad_splits(M, N, K); the caller adds the slabs in order (lt_partial_sums: nblk = splits, stride = count = N * K).
  * dz [M][N], x [M][K] row-major f32, N and K multiples of 4; both operands are split into f16 (hi, lo) pairs in registers (three MFMAs per tile); dz is scaled
  * by a power of two taken from max |dz| = max over amax_blocks[nblk_amax] (NULL: no scaling - |dz| must then sit in f16's normal
- * range), |x| <= 65504.  slabs: lt_wgrad_ws_floats(M, N, K) floats.  Deterministic. */
-int lt_wgrad(const float* dz, const float* x, int64_t M, int N, int K, const float* amax_blocks, int nblk_amax, float* slabs, void* stream);
+ * range), |x| <= 65504.  slabs: lt_wgrad_ws_floats(M, N, K) floats.  db_slabs (optional, splits x N floats): the slices' column
+ * sums of dz, i.e. the partials of the bias gradient (lt_partial_sums: nblk = splits, stride = count = N).  Deterministic. */
+int lt_wgrad(const float* dz, const float* x, int64_t M, int N, int K, const float* amax_blocks, int nblk_amax, float* slabs, float* db_slabs,
+             void* stream);
 int lt_wgrad_splits(int64_t M, int N, int K);
 int64_t lt_wgrad_ws_floats(int64_t M, int N, int K);
 int64_t lt_elu_backward_bias_ws_floats(int64_t M, int N);
@@ -553,6 +555,22 @@ int lt_mlp_forward(const lt_mlp_desc* desc, const float* packed, const float* x,
  * the backward pass needs.  Same kernel and arithmetic as lt_mlp_forward. */
 int lt_mlp_forward_pair(const lt_mlp_desc* d0, const float* packed0, const float* x0, const lt_mlp_desc* d1, const float* packed1, const float* x1,
                         int64_t m, float* y0, float* y1, float* const* acts0, float* const* acts1, void* stream);
+/* The backward DATA path of that pair in one launch (loss.backward() of loco_rl/loco_rl/algorithms/ppo.py:316, the part autograd runs
+ * as three `dz @ W` GEMMs and three ELU-backward kernels per network): for every hidden layer l, from the last to the first,
+ *     dz_l = (dz_{l+1} W_{l+1}) * ELU'(a_l),     dz_{L-1} = dy,
+ * through the forward kernel with the TRANSPOSED weights (packed by lt_mlp_pack_backward into lt_mlp_backward_packed_floats floats;
+ * `fwd` is the FORWARD descriptor: ELU, >= 2 layers, hidden widths multiples of 8, <= 64 outputs).  The gradients stay in LDS between
+ * layers; each dz_l is written once, for lt_wgrad, with the per-workgroup max |dz_l| it scales by.
+ * dy* [m][out]; acts*[l]: the forward activations (lt_mlp_forward_pair); OUT dz*[l] [m][dims[l + 1]]; OUT amax*[l]:
+ * lt_mlp_backward_blocks(fwd0, fwd1, m) floats.  Every workgroup scales its own rows by a power of two (max |dy| -> [1, 2)) and
+ * unscales what it writes; sat_count (optional, device float): += 1 per workgroup and layer whose scaled gradients reached
+ * LT_MLP_INPUT_CLAMP (growth by > 500x through the chain) - those rows are saturated, not exact. */
+int lt_mlp_backward_packed_floats(const lt_mlp_desc* fwd, size_t* floats);
+int lt_mlp_pack_backward(const lt_mlp_desc* fwd, const float* const* weights, float* packed, void* stream);
+int64_t lt_mlp_backward_blocks(const lt_mlp_desc* fwd0, const lt_mlp_desc* fwd1, int64_t m);
+int lt_mlp_backward_pair(const lt_mlp_desc* fwd0, const float* bpacked0, const float* dy0, const float* const* acts0, float* const* dz0,
+                         float* const* amax0, const lt_mlp_desc* fwd1, const float* bpacked1, const float* dy1, const float* const* acts1,
+                         float* const* dz1, float* const* amax1, int64_t m, float* sat_count, void* stream);
 /* Actor forward + the sampling / log-prob / storage-slot writes of lt_rollout_act in one launch (the policy head must have 12 outputs).
  * Philox key step = *step_counter + step_offset. */
 int lt_rollout_policy(const lt_mlp_desc* actor, const float* packed, const float* obs, int64_t n, uint64_t seed, const int64_t* step_counter,

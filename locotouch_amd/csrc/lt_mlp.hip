@@ -78,7 +78,8 @@ constexpr int NW = LT_MLP_WAVES;       // waves per workgroup (two per SIMD)
 #endif
 constexpr int RING = LT_MLP_RING_GRAIN;  // chunk granularity of the packed streams (layers are padded to multiples of it) = the largest ring
 constexpr unsigned RS_POLICY = 0x400;  // same Philox stream id as lt_rollout_act
-constexpr int MODE_FORWARD = 0, MODE_POLICY = 1;
+constexpr int MODE_FORWARD = 0, MODE_POLICY = 1, MODE_BACKWARD = 2;
+constexpr int KIND_GATE = 100;  // the backward chain's "activation": multiply by ELU'(a) of the forward activation a (lt_mlp_backward_pair)
 // scale of the low parts - and of the main product's activation operand, so that all three MFMAs of the split sum into ONE
 // accumulator (module header, "Arithmetic")
 constexpr float LO_SCALE = 64.f, LO_INV = 1.f / LO_SCALE;
@@ -165,6 +166,11 @@ struct MlpArgs {
   long long step_offset;
   const float* std12;
   float* st_actions; float* st_mu; float* st_sigma; float* st_logp; float* actions_out;
+  // MODE_BACKWARD (the chain of input gradients, module footer): per chain layer the forward activations that gate its output,
+  // the per-workgroup maxima of |output| (for lt_wgrad's scale) and a counter of saturated workgroups
+  const float* gate_in[LT_MLP_MAX_LAYERS];
+  float* amax_out[LT_MLP_MAX_LAYERS];
+  float* sat_count;
 };
 struct DualArgs {
   MlpArgs net[2];
@@ -408,6 +414,92 @@ __device__ __forceinline__ void convert_pass(const MlpArgs& a, int l, float* s_a
       }
     }
   }
+}
+
+// The backward chain's layer epilogue (KIND_GATE): raw sums -> x = sum / 64 -> x * ELU'(a) with a = the forward activation of the
+// same unit, read from HBM (ELU'(z) = 1 for z > 0, else exp(z) = a + 1) -> the (hi, lo) image for the next chain layer, the f32
+// copy dz (unscaled: x / scale) for the weight-gradient kernel, and the workgroup's max |x|.
+// Consecutive lanes take consecutive GROUPS OF A ROW (unlike convert_pass, whose lanes walk down the rows for conflict-free LDS
+// access): a wave's gate loads and dz stores are then whole 2-KiB stretches of a row - lane-per-row, both moved 32 bytes per
+// 128-byte line and request (measured on the 24 576-row update: loads +73 us, stores +43 us on a 75 us launch) - and the LDS side
+// pays a 2-way bank conflict on its b128 accesses instead.  ALL gate loads of the layer leave before the first is used (at most 8
+// groups per thread at 64 rows x 512 features; the accumulators are dead here, the registers are free): one HBM round trip per
+// layer.
+template <int ROWS>
+__device__ __forceinline__ float gate_pass(const MlpArgs& a, int l, float* s_act, int tid, long long row0, float inv_scale, bool to_lds) {
+  constexpr int NT = 64 * NW, U = ROWS >= 64 ? 8 : (ROWS >= 32 ? 4 : 2);  // ROWS * 64 groups (N = 512) / NT threads
+  const int S = a.stride;
+  const int N = a.dims[l + 1];  // a multiple of 8 (lt_mlp_backward_pair)
+  const unsigned gpr = (unsigned)N >> 3;  // groups per row (<= 64)
+  const unsigned magic = 0xFFFFFFFFu / gpr + 1u;  // idx / gpr == umulhi(idx, magic) for idx < 2^16
+  const int total = ROWS * (int)gpr;
+  const bool ksplit = a.l_ks[l] > 1;
+  const int koff = pad32(N);
+  const float* const gate = a.gate_in[l];
+  float* const dst = a.act_out[l];
+  const long long left = a.m - row0;
+  const int rmax = left < ROWS ? (int)left - 1 : ROWS - 1;
+  float mx = 0.f;
+  f32x4 gt[U][2];
+  int at[U];      // float offset of the group inside the image: row * S + 8 j
+  int row[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int idx = tid + u * NT;
+    row[u] = -1;
+    if (idx < total) {  // (wave-uniform: total and NT are multiples of 64)
+      const unsigned r = __umulhi((unsigned)idx, magic), j = (unsigned)idx - r * gpr;
+      row[u] = (int)r;
+      at[u] = (int)r * S + 8 * (int)j;
+#ifdef LT_GATE_NO_LOAD  // probe builds (tools/mlp_backward_probe.py)
+      gt[u][0] = gt[u][1] = f32x4{1.f, 1.f, 1.f, 1.f};
+#else
+      const float* const gp = gate + (row0 + min((int)r, rmax)) * N + 8 * j;
+      gt[u][0] = __builtin_nontemporal_load((const f32x4*)gp);
+      gt[u][1] = __builtin_nontemporal_load((const f32x4*)(gp + 4));
+#endif
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (row[u] < 0) continue;
+    float* const g = s_act + at[u];
+    f32x4 x[2];
+    x[0] = *(const f32x4*)g;
+    x[1] = *(const f32x4*)(g + 4);
+    if (ksplit) { x[0] += *(const f32x4*)(g + koff); x[1] += *(const f32x4*)(g + koff + 4); }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a_ = gt[u][h][i];
+        x[h][i] = x[h][i] * LO_INV * (a_ > 0.f ? 1.f : a_ + 1.f);
+      }
+    const bool live = row[u] <= rmax;
+    if (live) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x[h][0]), fabsf(x[h][1]))), fmaxf(fabsf(x[h][2]), fabsf(x[h][3])));
+    }
+    if (to_lds) {
+      f16x4 hi[2], lo[2];
+      split4(x[0], hi[0], lo[0]);
+      split4(x[1], hi[1], lo[1]);
+      *(f16x4*)g = hi[0]; *((f16x4*)g + 1) = hi[1];
+      *((f16x4*)g + 2) = lo[0]; *((f16x4*)g + 3) = lo[1];
+    }
+#ifdef LT_GATE_NO_STORE
+    if (live && x[0][0] == 123.456f) {
+#else
+    if (live) {
+#endif
+      float* const o = dst + (row0 + row[u]) * N + (at[u] - row[u] * S);
+      *(f32x4*)o = x[0] * inv_scale;
+      *(f32x4*)(o + 4) = x[1] * inv_scale;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  return mx;
 }
 
 // Policy head, first half: the standard-normal draws of this workgroup's rows and the log-density of the sample
@@ -692,6 +784,34 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
   float* const s_noise = s_img + a.noise_off;
   // The policy head's noise: by the last wave (idle in the narrow layers), under the latency of the input rows.
   if (a.mode == MODE_POLICY && wave == NW - 1) policy_noise<RT>(a, row0, lane, s_noise);
+  // Backward chain: the workgroup's input rows (gradients: 1e-3 .. 1e-9) are scaled by a power of two that brings their largest
+  // magnitude to [1, 2) - the (hi, lo) f16 image resolves 2^-30 absolutely, and saturates at F16_CLAMP: three layers of growth by
+  // less than 500 each time are covered; a workgroup that saturates all the same is counted (sat_count).  Rows are independent in
+  // the chain, so every workgroup has its own scale and takes it out again where it writes dz.
+  float scale = 1.f, inv_scale = 1.f;
+  if constexpr (KIND == KIND_GATE) {
+    float mx = 0.f;
+    if (vec_in || vec2_in) {
+#pragma unroll
+      for (int u = 0; u < B; ++u) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(vin[u][0]), fabsf(vin[u][1]))), fmaxf(fabsf(vin[u][2]), fabsf(vin[u][3])));
+    } else {
+      for (int idx = tid; idx < ROWS * K0; idx += NT) {
+        const unsigned rr = idx / K0;
+        mx = fmaxf(mx, fabsf(a.x[(row0 + min(rr, rmax)) * K0 + (idx - rr * K0)]));
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) s_noise[wave] = mx;
+    lds_barrier();
+    float m_ = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) m_ = fmaxf(m_, s_noise[w]);
+    int se = 127 - (int)((__float_as_uint(m_) >> 23) & 0xFF);  // -floor(log2 max); zero / denormal rows: 127 -> clamped
+    se = m_ > 0.f ? (se > 100 ? 100 : (se < -100 ? -100 : se)) : 0;
+    scale = __uint_as_float((unsigned)(127 + se) << 23);
+    inv_scale = __uint_as_float((unsigned)(127 - se) << 23);
+  }
   {
 #pragma unroll
     for (int u = 0; u < BB; ++u) s_bias[min(tid + u * NT, a.bias_total - 1)] = bv[u];
@@ -705,9 +825,9 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
         }
       } else {
 #pragma unroll
-        for (int u = 0; u < B; ++u) store_split4(s_act, lds_at[u], vin[u]);
+        for (int u = 0; u < B; ++u) store_split4(s_act, lds_at[u], KIND == KIND_GATE ? vin[u] * scale : vin[u]);
       }
-      for (unsigned idx = tid + B * NT; idx < tv; idx += NT) {  // inputs wider than one batch
+      for (unsigned idx = tid + B * NT; idx < tv; idx += NT) {  // inputs wider than one batch (not in the backward chain: its inputs are <= 64 wide)
         const unsigned rr = idx / k4, cc = idx - rr * k4;
         store_split4(s_act, half_group_at(rr, cc, S), load_in4(a, (row0 + min(rr, rmax)) * K0 + 4 * cc));
       }
@@ -719,8 +839,9 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
     } else if (vec2_in) {
 #pragma unroll
       for (int u = 0; u < B; ++u) {
-        store_split2(s_act, lds_at[u], f32x2{vin[u][0], vin[u][1]});
-        store_split2(s_act, lds_at2[u], f32x2{vin[u][2], vin[u][3]});
+        const f32x4 v = KIND == KIND_GATE ? vin[u] * scale : vin[u];
+        store_split2(s_act, lds_at[u], f32x2{v[0], v[1]});
+        store_split2(s_act, lds_at2[u], f32x2{v[2], v[3]});
       }
       for (unsigned idx = tid + 2 * B * NT; idx < tv2; idx += NT) {  // inputs wider than one batch
         const unsigned rr = idx / p2, c2 = idx - rr * p2;
@@ -735,7 +856,8 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
       for (int idx = tid; idx < ROWS * K0p; idx += NT) {
         const int rr = idx / K0p, cc = idx - rr * K0p;
         const long long e = row0 + rr;
-        store_split1(s_act, rr, cc, S, (cc < K0 && e < a.m) ? (a.x_bf16 ? __uint_as_float((unsigned)((const unsigned short*)a.x)[e * K0 + cc] << 16) : a.x[e * K0 + cc]) : 0.f);
+        const float v = (cc < K0 && e < a.m) ? (a.x_bf16 ? __uint_as_float((unsigned)((const unsigned short*)a.x)[e * K0 + cc] << 16) : a.x[e * K0 + cc]) : 0.f;
+        store_split1(s_act, rr, cc, S, KIND == KIND_GATE ? v * scale : v);
       }
     }
   }
@@ -746,7 +868,7 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
 #pragma unroll 1
   for (int l = 0; l < a.L; ++l) {
     const int T = tiles_per_wave(pad16(a.dims[l + 1]) / 16);
-    const bool last = l == a.L - 1;
+    const bool last = KIND != KIND_GATE && l == a.L - 1;  // (the chain's last layer is gated and written like the others)
     const float* const bias_l = s_bias + boff;
     if (NW <= 4 && T == 8) mlp_layer<(NW <= 4 ? 8 : 4), RT, RG, KIND>(a, l, last, s_act, bias_l, s_noise, wave, lane, row_block, ring, stream, c0);  // (eight waves: at most 4 tiles each)
     else if (T == 4) mlp_layer<4, RT, RG, KIND>(a, l, last, s_act, bias_l, s_noise, wave, lane, row_block, ring, stream, c0);
@@ -755,16 +877,30 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
     MLP_STAMP(2 + l);
     if (last) break;
     lds_barrier();  // the raw sums of the whole layer are in the image
-    convert_pass<KIND, ROWS>(a, l, s_act, bias_l, tid, row0);
-    boff += pad16(a.dims[l + 1]);
-    lds_barrier();
+    if constexpr (KIND == KIND_GATE) {
+      const float mx = gate_pass<ROWS>(a, l, s_act, tid, row0, inv_scale, l + 1 < a.L);
+      if (lane == 0) s_noise[wave] = mx;
+      lds_barrier();
+      if (tid == 0) {
+        float m_ = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) m_ = fmaxf(m_, s_noise[w]);
+        a.amax_out[l][row_block] = m_ * inv_scale;
+        if (m_ >= F16_CLAMP && a.sat_count) atomicAdd(a.sat_count, 1.f);
+      }
+    } else {
+      convert_pass<KIND, ROWS>(a, l, s_act, bias_l, tid, row0);
+      boff += pad16(a.dims[l + 1]);
+      lds_barrier();
+    }
   }
 }
 
 // One layer of one network: weights [N][K] (torch.nn.Linear layout) -> the per-wave chunk streams, bias [N] -> the bias block.
 struct PackArgs {
-  const float* w; const float* b;
+  const float* w; const float* b;  // b == nullptr: zero biases
   int K, N;
+  int transposed;           // element (n, k) is w[k * N + n] (the backward chain multiplies by W^T of a torch.nn.Linear weight [K][N])
   long long chunk_off[NW];  // first chunk of this layer in each wave's stream (absolute, in chunks)
   Plan plan;                // how the layer is dealt to the waves
   long long bias_float_off; // first float of this layer's (pad16(N)) bias slice
@@ -778,7 +914,7 @@ __global__ void lt_mlp_pack_kernel(const PackAll all) {
   const int T = pl.T, G = pl.Gl, C = 2 * T;
   const int chunks = layer_chunks(pl), nact = pl.waves;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (wave, chunk, lane)
-  if (idx < pad16(p.N)) p.packed[p.bias_float_off + idx] = idx < p.N ? p.b[idx] : 0.f;
+  if (idx < pad16(p.N)) p.packed[p.bias_float_off + idx] = (idx < p.N && p.b) ? p.b[idx] : 0.f;
   if (idx >= (long long)nact * chunks * 64) return;
   const int lane = (int)(idx & 63);
   const int c = (int)((idx >> 6) % chunks), wv = (int)((idx >> 6) / chunks);
@@ -792,7 +928,7 @@ __global__ void lt_mlp_pack_kernel(const PackAll all) {
     f16x8 h;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float x = (n < p.N && k0 + j < p.K) ? p.w[(long long)n * p.K + k0 + j] : 0.f;
+      float x = (n < p.N && k0 + j < p.K) ? (p.transposed ? p.w[(long long)(k0 + j) * p.N + n] : p.w[(long long)n * p.K + k0 + j]) : 0.f;
       x = fminf(fmaxf(x, -F16_CLAMP), F16_CLAMP);
       const _Float16 hi = (_Float16)x;
       h[j] = comp == 0 ? hi : (_Float16)((x - (float)hi) * LO_SCALE);
@@ -877,7 +1013,7 @@ int input_kind(const MlpArgs& a) {
   return a.in_magic2 ? IN_F32X2 : IN_ANY;
 }
 template <int RT>
-void launch_rt(const DualArgs& d, bool elu, int in, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+void launch_rt(const DualArgs& d, bool elu, bool gate, int in, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {  // more than the default 64 KB of dynamic LDS
     attr_set = true;
@@ -886,15 +1022,18 @@ void launch_rt(const DualArgs& d, bool elu, int in, dim3 grid, dim3 block, size_
     (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<RT, LT_ACT_ELU, IN_F32X4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<RT, LT_ACT_ELU, IN_BF16X4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<RT, LT_ACT_ELU, IN_F32X2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lt_mlp_kernel<RT, KIND_GATE, IN_ANY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  if (!elu) hipLaunchKernelGGL((lt_mlp_kernel<RT, -1, IN_ANY>), grid, block, lds, s, d);
+  if (gate) hipLaunchKernelGGL((lt_mlp_kernel<RT, KIND_GATE, IN_ANY>), grid, block, lds, s, d);
+  else if (!elu) hipLaunchKernelGGL((lt_mlp_kernel<RT, -1, IN_ANY>), grid, block, lds, s, d);
   else if (in == IN_F32X4) hipLaunchKernelGGL((lt_mlp_kernel<RT, LT_ACT_ELU, IN_F32X4>), grid, block, lds, s, d);
   else if (in == IN_BF16X4) hipLaunchKernelGGL((lt_mlp_kernel<RT, LT_ACT_ELU, IN_BF16X4>), grid, block, lds, s, d);
   else if (in == IN_F32X2) hipLaunchKernelGGL((lt_mlp_kernel<RT, LT_ACT_ELU, IN_F32X2>), grid, block, lds, s, d);
   else hipLaunchKernelGGL((lt_mlp_kernel<RT, LT_ACT_ELU, IN_ANY>), grid, block, lds, s, d);
 }
 
-int launch(DualArgs& d, int nets, hipStream_t s) {
+// row tiles per workgroup and the LDS bytes of a launch of `nets` networks (their shared LDS geometry is written back into d)
+int launch_shape(DualArgs& d, int nets, size_t* lds_out) {
   int stride = d.net[0].stride, bias = d.net[0].bias_total;
   if (nets == 2 && d.net[1].stride > stride) stride = d.net[1].stride;
   if (nets == 2 && d.net[1].bias_total > bias) bias = d.net[1].bias_total;
@@ -907,8 +1046,15 @@ int launch(DualArgs& d, int nets, hipStream_t s) {
   if (const char* o = getenv("LT_MLP_ROW_TILES")) rt = atoi(o) == 4 ? 4 : (atoi(o) == 2 ? 2 : 1);  // diagnostic override
   // one workgroup's activations (+ the policy head's [rows][12 draws + 3 log-density partials + pad] block) must fit the LDS
   while (rt > 1 && (size_t)16 * rt * row_bytes + bias_bytes + (size_t)16 * rt * 64 > 160 * 1024) rt /= 2;
-  const size_t lds = (size_t)16 * rt * row_bytes + bias_bytes + (size_t)16 * rt * 64;
+  *lds_out = (size_t)16 * rt * row_bytes + bias_bytes + (size_t)16 * rt * 64;
   for (int n = 0; n < nets; ++n) d.net[n].noise_off = 16 * rt * stride + bias;
+  return rt;
+}
+
+int launch(DualArgs& d, int nets, hipStream_t s) {
+  size_t lds;
+  const int rt = launch_shape(d, nets, &lds);
+  const long long t0 = (d.net[0].m + 15) / 16, t1 = nets == 2 ? (d.net[1].m + 15) / 16 : 0;
   const long long b0 = (t0 + rt - 1) / rt, b1 = (t1 + rt - 1) / rt;
   d.split = (int)b0;
   // Two networks of equal row count: split them by XCD instead of by block range.  Each XCD's 4 MiB L2 then holds ONE
@@ -919,17 +1065,44 @@ int launch(DualArgs& d, int nets, hipStream_t s) {
   d.blocks_per_net = (int)b0;
   const long long nblocks = d.xcd_split ? (b0 + 3) / 4 * 8 : b0 + b1;
   const dim3 grid((unsigned)nblocks), block(64 * NW);
+  const bool gate = d.net[0].mode == MODE_BACKWARD;
   const bool elu = d.net[0].activation == LT_ACT_ELU && (nets == 1 || d.net[1].activation == LT_ACT_ELU);
   // the input-staging form as a compile-time constant when both networks of the launch take the same one
   int in = input_kind(d.net[0]);
   if (nets == 2 && input_kind(d.net[1]) != in) in = IN_ANY;
   if (rt == 4) {
-    launch_rt<4>(d, elu, in, grid, block, lds, s);
-  } else if (rt == 2) launch_rt<2>(d, elu, in, grid, block, lds, s);
-  else launch_rt<1>(d, elu, in, grid, block, lds, s);
+    launch_rt<4>(d, elu, gate, in, grid, block, lds, s);
+  } else if (rt == 2) launch_rt<2>(d, elu, gate, in, grid, block, lds, s);
+  else launch_rt<1>(d, elu, gate, in, grid, block, lds, s);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;
+}
+
+// The chain of input gradients of a forward network `fwd` (L layers) as a network of its own: L - 1 layers, widths
+// [out, h_{L-2}, ..., h_0], layer j multiplies by W_{L-1-j}^T (no bias) and its output is gated by ELU'(a_{L-2-j}).
+bool backward_desc(const lt_mlp_desc* fwd, lt_mlp_desc* bd) {
+  if (!desc_ok(fwd) || fwd->num_layers < 2 || fwd->activation != LT_ACT_ELU || fwd->dims[fwd->num_layers] > 64) return false;
+  const int L = fwd->num_layers;
+  *bd = *fwd;
+  bd->num_layers = L - 1;
+  bd->input_format = LT_ROWS_F32;
+  for (int j = 0; j <= L - 1; ++j) bd->dims[j] = fwd->dims[L - j];
+  for (int j = 1; j <= L - 1; ++j)
+    if (bd->dims[j] & 7) return false;  // gate_pass works on groups of 8 features
+  return desc_ok(bd);
+}
+
+void fill_backward(const lt_mlp_desc* bd, int Lf, const float* packed, const float* dy, int64_t m, const float* const* acts, float* const* dz,
+                   float* const* amax, float* sat_count, MlpArgs& a) {
+  fill_args(bd, a);
+  a.mode = MODE_BACKWARD;
+  a.packed = packed; a.x = dy; a.m = m; a.y = nullptr; a.sat_count = sat_count;
+  for (int j = 0; j < bd->num_layers; ++j) {
+    a.gate_in[j] = acts[Lf - 2 - j];
+    a.act_out[j] = dz[Lf - 2 - j];
+    a.amax_out[j] = amax[Lf - 2 - j];
+  }
 }
 
 bool policy_args_ok(const lt_mlp_desc* actor, const float* packed, const float* obs, int64_t n, const int64_t* step_counter, const float* std12,
@@ -1049,6 +1222,85 @@ int lt_rollout_policy_value(const lt_mlp_desc* actor, const float* actor_packed,
   fill_args(critic, d.net[1]);
   d.net[1].mode = MODE_FORWARD;
   d.net[1].packed = critic_packed; d.net[1].x = critic_obs; d.net[1].m = n; d.net[1].y = values;
+  return launch(d, 2, (hipStream_t)stream);
+}
+
+
+// ---- the backward data path of the PPO update: dz_l = (dz_{l+1} W_{l+1}) * ELU'(a_l) for every hidden layer, one launch -------------
+// loco_rl/loco_rl/algorithms/ppo.py:283-289 (loss.backward()): autograd runs, per network, three GEMMs dz @ W and three ELU-backward
+// kernels over [24576][512 / 256 / 128] - 150 us of f32 library GEMMs and 95 us of HBM-bound elementwise passes per optimizer step.
+// The chain is a forward pass of a network with the transposed weights (backward_desc), so it runs through the same kernel:
+// gradients stay in LDS between layers, the gate is applied where the sums leave the accumulators, each dz_l is written once (the
+// weight-gradient kernel lt_wgrad reads it) together with the per-workgroup max |dz_l| lt_wgrad scales by.
+int lt_mlp_backward_packed_floats(const lt_mlp_desc* fwd, size_t* floats) {
+  lt_mlp_desc bd;
+  if (!fwd || !floats || !backward_desc(fwd, &bd)) { lt_set_error("lt_mlp_backward_packed_floats: needs an ELU network of >= 2 layers, hidden widths multiples of 8, <= 64 outputs"); return LT_EINVAL; }
+  *floats = (size_t)geometry(&bd).total_chunks * 256;
+  return LT_OK;
+}
+
+int lt_mlp_pack_backward(const lt_mlp_desc* fwd, const float* const* weights, float* packed, void* stream) {
+  lt_mlp_desc bd;
+  if (!fwd || !weights || !packed || !backward_desc(fwd, &bd)) { lt_set_error("lt_mlp_pack_backward: invalid argument"); return LT_EINVAL; }
+  const Geometry g = geometry(&bd);
+  const int L = fwd->num_layers;
+  long long bias_off = 0, most = 0;
+  PackAll all = {};
+  for (int j = 0; j < bd.num_layers; ++j) {
+    if (!weights[L - 1 - j]) { lt_set_error("lt_mlp_pack_backward: null layer pointer"); return LT_EINVAL; }
+    PackArgs& p = all.layer[j];
+    p.w = weights[L - 1 - j]; p.b = nullptr; p.K = bd.dims[j]; p.N = bd.dims[j + 1]; p.transposed = 1; p.packed = packed;
+    for (int w = 0; w < NW; ++w) p.chunk_off[w] = g.layer_off[j][w];
+    p.plan = plan_of(bd.dims, bd.num_layers, j);
+    p.bias_float_off = g.bias_chunk * 256 + bias_off;
+    bias_off += pad16(p.N);
+    long long total = (long long)p.plan.waves * layer_chunks(p.plan) * 64;
+    total = total < pad16(p.N) ? pad16(p.N) : total;
+    most = total > most ? total : most;
+  }
+  hipLaunchKernelGGL(lt_mlp_pack_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)bd.num_layers), dim3(256), 0, (hipStream_t)stream, all);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
+  return LT_OK;
+}
+
+// workgroups per network of lt_mlp_backward_pair over m rows = entries of every amax array it writes
+int64_t lt_mlp_backward_blocks(const lt_mlp_desc* fwd0, const lt_mlp_desc* fwd1, int64_t m) {
+  lt_mlp_desc b0, b1;
+  if (!fwd0 || !fwd1 || m <= 0 || !backward_desc(fwd0, &b0) || !backward_desc(fwd1, &b1)) return 0;
+  DualArgs d = {};
+  fill_args(&b0, d.net[0]);
+  fill_args(&b1, d.net[1]);
+  d.net[0].m = d.net[1].m = m;
+  size_t lds;
+  const int rt = launch_shape(d, 2, &lds);
+  return ((m + 15) / 16 + rt - 1) / rt;
+}
+
+// dy0 [m][out0], dy1 [m][out1]: gradients w.r.t. the two networks' outputs.  acts*[l]: the forward activations behind hidden layer
+// l (lt_mlp_forward_pair); dz*[l]: OUT, the gradient w.r.t. hidden layer l's pre-activation, [m][dims[l + 1]]; amax*[l]: OUT,
+// lt_mlp_backward_blocks() floats, the per-workgroup max |dz_l|.  sat_count (optional): += 1 per workgroup and layer whose scaled
+// gradients reached the f16 image's bound (LT_MLP_INPUT_CLAMP) - the result is then saturated, not exact.
+int lt_mlp_backward_pair(const lt_mlp_desc* fwd0, const float* bpacked0, const float* dy0, const float* const* acts0, float* const* dz0, float* const* amax0,
+                         const lt_mlp_desc* fwd1, const float* bpacked1, const float* dy1, const float* const* acts1, float* const* dz1, float* const* amax1,
+                         int64_t m, float* sat_count, void* stream) {
+  lt_mlp_desc bd[2];
+  const lt_mlp_desc* fw[2] = {fwd0, fwd1};
+  const float* pk[2] = {bpacked0, bpacked1};
+  const float* dy[2] = {dy0, dy1};
+  const float* const* ac[2] = {acts0, acts1};
+  float* const* dz[2] = {dz0, dz1};
+  float* const* am[2] = {amax0, amax1};
+  DualArgs d = {};
+  for (int k = 0; k < 2; ++k) {
+    if (!fw[k] || !pk[k] || !dy[k] || !ac[k] || !dz[k] || !am[k] || m <= 0 || !backward_desc(fw[k], &bd[k])) {
+      lt_set_error("lt_mlp_backward_pair: invalid argument");
+      return LT_EINVAL;
+    }
+    for (int l = 0; l + 1 < fw[k]->num_layers; ++l)
+      if (!ac[k][l] || !dz[k][l] || !am[k][l]) { lt_set_error("lt_mlp_backward_pair: null layer buffer"); return LT_EINVAL; }
+    fill_backward(&bd[k], fw[k]->num_layers, pk[k], dy[k], m, ac[k], dz[k], am[k], sat_count, d.net[k]);
+  }
   return launch(d, 2, (hipStream_t)stream);
 }
 

@@ -67,6 +67,7 @@ struct WgradArgs {
   const float* amax;    // per-block maxima of |dz| (nblk_amax floats) or nullptr (scale 1)
   int nblk_amax;
   float* slabs;         // [splits][N][K]
+  float* db;            // optional [splits][N]: the slices' column sums of dz (the bias gradient's partials), by the tiles of the first k column
 };
 
 __global__ __launch_bounds__(64, 1) void lt_wgrad_kernel(const WgradArgs a) {
@@ -117,11 +118,17 @@ __global__ __launch_bounds__(64, 1) void lt_wgrad_kernel(const WgradArgs a) {
       vb[t] = *(const f32x4*)(a.x + r * a.K + cb);
     }
   };
+  const bool colsum = a.db != nullptr && tk == 0;  // (uniform)
+  f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
   if (s0 < s1) issue(s0);
   for (long long s = s0; s < s1; ++s) {
     if ((s + 1) * 32 > a.M) {  // rows beyond M (the last step of a ragged M) must not contribute: their clamped loads repeat row M - 1
 #pragma unroll
       for (int t = 0; t < 8; ++t) if (s * 32 + 4 * t + g >= a.M) va[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (colsum) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) cs += va[t];
     }
     f16x8 ah[TA], al[TA], bh[TB], bl[TB];
     split8<0>(va, scale, ah[0], al[0]); split8<1>(va, scale, ah[1], al[1]); split8<2>(va, scale, ah[2], al[2]); split8<3>(va, scale, ah[3], al[3]);
@@ -136,6 +143,14 @@ __global__ __launch_bounds__(64, 1) void lt_wgrad_kernel(const WgradArgs a) {
         corr[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], bl[q], corr[p][q], 0, 0, 0);
         corr[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[p], bh[q], corr[p][q], 0, 0, 0);
       }
+  }
+  if (colsum) {  // lane (c, g) holds the sums of rows g mod 4 of columns n0 + 4 c .. + 3
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      cs[u] += __shfl_xor(cs[u], 16, 64);
+      cs[u] += __shfl_xor(cs[u], 32, 64);
+    }
+    if (g == 0 && n0 + 4 * i < a.N) *(f32x4*)(a.db + (long long)split * a.N + n0 + 4 * i) = cs;
   }
   // the partial tile: MFMA tile (p, q) holds C[row rho = 4 g + r][col kappa = i] = dW[n0 + 4 rho + p][k0 + 4 kappa + q]: a lane's four
   // q tiles are 4 ADJACENT columns of one row
@@ -175,7 +190,7 @@ extern "C" int lt_wgrad_splits(int64_t M, int N, int K) {
 
 extern "C" int64_t lt_wgrad_ws_floats(int64_t M, int N, int K) { return (int64_t)lt_wgrad_splits(M, N, K) * N * K; }
 
-extern "C" int lt_wgrad(const float* dz, const float* x, int64_t M, int N, int K, const float* amax_blocks, int nblk_amax, float* slabs, void* stream) {
+extern "C" int lt_wgrad(const float* dz, const float* x, int64_t M, int N, int K, const float* amax_blocks, int nblk_amax, float* slabs, float* db_slabs, void* stream) {
   if (!dz || !x || !slabs || M < 1 || N < 4 || K < 4 || (N & 3) || (K & 3) || (amax_blocks && nblk_amax < 1)) {
     lt_set_error("lt_wgrad: invalid argument (N and K multiples of 4)");
     return LT_EINVAL;
@@ -186,7 +201,7 @@ extern "C" int lt_wgrad(const float* dz, const float* x, int64_t M, int N, int K
   a.tiles_k = (K + 16 * TB - 1) / (16 * TB);
   a.splits = pick_splits((long long)M, a.tiles_n * a.tiles_k);
   a.amax = amax_blocks; a.nblk_amax = amax_blocks ? nblk_amax : 0;
-  a.slabs = slabs;
+  a.slabs = slabs; a.db = db_slabs;
   hipLaunchKernelGGL(lt_wgrad_kernel, dim3((unsigned)((a.tiles_n * a.tiles_k * a.splits + 7) / 8 * 8)), dim3(64), 0, (hipStream_t)stream, a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }

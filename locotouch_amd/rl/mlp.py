@@ -83,6 +83,21 @@ class PackedMLP:
                 raise ValueError("Linear.weight must be contiguous")
         _abi.check(self.lib.lt_mlp_pack(ctypes.byref(self.desc), w, b, ctypes.c_void_p(self.packed.data_ptr()), self._stream()), "lt_mlp_pack")
 
+    def backward_ok(self) -> bool:
+        """The chain of input gradients can run through the MLP kernel (lt_mlp_backward_pair): ELU, hidden widths % 8, <= 64 outputs."""
+        n = ctypes.c_size_t()
+        return self.lib.lt_mlp_backward_packed_floats(ctypes.byref(self.desc), ctypes.byref(n)) == 0
+
+    def pack_backward(self) -> None:
+        """The transposed weights in the kernel's stream layout (the backward chain multiplies by W^T); re-packed at every optimizer step."""
+        if getattr(self, "bpacked", None) is None:
+            n = ctypes.c_size_t()
+            _abi.check(self.lib.lt_mlp_backward_packed_floats(ctypes.byref(self.desc), ctypes.byref(n)), "lt_mlp_backward_packed_floats")
+            self.bpacked = torch.zeros(int(n.value), device=self.packed.device, dtype=torch.float32)
+        L = len(self.linears)
+        w = (ctypes.c_void_p * L)(*[l.weight.data_ptr() for l in self.linears])
+        _abi.check(self.lib.lt_mlp_pack_backward(ctypes.byref(self.desc), w, ctypes.c_void_p(self.bpacked.data_ptr()), self._stream()), "lt_mlp_pack_backward")
+
     def set_input_format(self, dtype: torch.dtype) -> None:
         """float32 rows (default) or bfloat16 rows (BASELINE config 5: widened exactly to f32 inside the kernel)."""
         if dtype not in (torch.float32, torch.bfloat16):
@@ -191,6 +206,7 @@ def _alloc_outputs(nets, m, device):
 import os as _os
 
 USE_SPLIT_F16_WGRAD = _os.environ.get("LT_SPLIT_F16_WGRAD", "1") != "0"  # 0: the weight gradients as library f32 GEMMs (A/B measurements)
+USE_FUSED_BACKWARD = _os.environ.get("LT_FUSED_BACKWARD", "1") != "0"  # 0: dz @ W as library GEMMs + lt_elu_backward_bias per layer
 
 
 class SumJobs:
@@ -262,7 +278,7 @@ def backward_chain(weights, biases_out, weights_out, x, acts, dy, sums: SumJobs)
             # dW = dz^T x on the f16 matrix cores, f32-equivalent (csrc/lt_wgrad.hip): slices of the rows -> slabs -> the joint sum launch
             sp = int(lib.lt_wgrad_splits(m, n, k))
             slabs = torch.empty(sp * n * k, device=inp.device, dtype=torch.float32)
-            _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), m, n, k, vp(amax.data_ptr()), amax.numel(), vp(slabs.data_ptr()), stream), "lt_wgrad")
+            _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), m, n, k, vp(amax.data_ptr()), amax.numel(), vp(slabs.data_ptr()), vp(None), stream), "lt_wgrad")
             sums.add(slabs, sp, n * k, n * k, n * k, weights_out[l])
         else:
             sp = pick_splits(m, n, k)
@@ -324,9 +340,75 @@ class PackedPair:
             self.domain_max = m_ if self.domain_max is None else torch.maximum(self.domain_max, m_)
         return ys, acts
 
+    def _fused_backward_ok(self, x0, x1, dy0, dy1) -> bool:
+        from .linear import _head_wgrad_ok
+
+        if not (USE_FUSED_BACKWARD and USE_SPLIT_F16_WGRAD and self.a.backward_ok() and self.b.backward_ok()):
+            return False
+        for net, x, dy in ((self.a, x0, dy0), (self.b, x1, dy1)):
+            dims = [net.desc.dims[i] for i in range(net.desc.num_layers + 1)]
+            if dims[0] % 4 or x.dtype != torch.float32 or not x.is_contiguous():
+                return False
+            if not _head_wgrad_ok(dy, torch.empty(0, dims[-2], device=x.device)):
+                return False
+        return True
+
+    def _backward_fused(self, x0, x1, acts, dy0, dy1, grad_of, sums) -> None:
+        """The backward pass as: two head launches (lt_head_wgrad), ONE launch for both stacks' chains of input gradients
+        (lt_mlp_backward_pair: dz of every hidden layer, ELU' applied in the layer epilogue, per-workgroup max |dz|), six weight
+        gradients on the matrix cores that also leave the bias gradients' partials (lt_wgrad), one launch of ordered sums."""
+        lib = _abi.load()
+        vp = ctypes.c_void_p
+        stream = PackedMLP._stream()
+        m = x0.shape[0]
+        nets, xs = (self.a, self.b), (x0, x1)
+        dys = [d if d.is_contiguous() else d.contiguous() for d in (dy0, dy1)]
+        dev = x0.device
+        if getattr(self, "sat", None) is None:
+            self.sat = torch.zeros(1, device=dev, dtype=torch.float32)  # workgroups x layers of the chain that saturated (domain check)
+        nblk = int(lib.lt_mlp_backward_blocks(ctypes.byref(nets[0].desc), ctypes.byref(nets[1].desc), m))
+        dzs, amaxs, arrs = [], [], []
+        for k, net in enumerate(nets):
+            net.pack_backward()
+            L = len(net.linears)
+            n, kk = dys[k].shape[1], acts[k][L - 2].shape[1]
+            ws = torch.empty(int(lib.lt_head_wgrad_ws_floats(m, n, kk)), device=dev, dtype=torch.float32)
+            _abi.check(lib.lt_head_wgrad(vp(dys[k].data_ptr()), vp(acts[k][L - 2].data_ptr()), m, n, kk, vp(None), vp(None), vp(ws.data_ptr()), stream), "lt_head_wgrad")
+            sums.add(ws, int(lib.lt_head_wgrad_nblk(m)), n * kk + 16, n * kk + n, n * kk, grad_of[net.linears[L - 1].weight], grad_of[net.linears[L - 1].bias])
+            dz = [torch.empty_like(a) for a in acts[k]]
+            am = torch.empty(L - 1, nblk, device=dev, dtype=torch.float32)
+            dzs.append(dz)
+            amaxs.append(am)
+            arr = ctypes.c_void_p * (L - 1)
+            arrs.append((arr(*[a.data_ptr() for a in acts[k]]), arr(*[t.data_ptr() for t in dz]), arr(*[am[l].data_ptr() for l in range(L - 1)])))
+        _abi.check(lib.lt_mlp_backward_pair(ctypes.byref(nets[0].desc), vp(nets[0].bpacked.data_ptr()), vp(dys[0].data_ptr()), *arrs[0],
+                                            ctypes.byref(nets[1].desc), vp(nets[1].bpacked.data_ptr()), vp(dys[1].data_ptr()), *arrs[1],
+                                            m, vp(self.sat.data_ptr()), stream), "lt_mlp_backward_pair")
+        for k, net in enumerate(nets):
+            for l in range(len(net.linears) - 2, -1, -1):
+                inp = acts[k][l - 1] if l > 0 else xs[k]
+                dz = dzs[k][l]
+                n, kk = dz.shape[1], inp.shape[1]
+                sp = int(lib.lt_wgrad_splits(m, n, kk))
+                slabs = torch.empty(sp * n * kk + sp * n, device=dev, dtype=torch.float32)
+                dbs = slabs[sp * n * kk:]
+                _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), m, n, kk, vp(amaxs[k][l].data_ptr()), nblk, vp(slabs.data_ptr()),
+                                        vp(dbs.data_ptr()), stream), "lt_wgrad")
+                sums.add(slabs, sp, n * kk, n * kk, n * kk, grad_of[net.linears[l].weight])
+                sums.add(dbs, sp, n, n, n, grad_of[net.linears[l].bias])
+        self._keep_bwd = (dzs, amaxs, dys)
+
+    def saturated(self) -> torch.Tensor | None:
+        """Device counter of saturated workgroups of the fused backward chain (None: that path has not run)."""
+        return getattr(self, "sat", None)
+
     def backward_raw(self, x0, x1, acts, dy0, dy1, grad_of) -> None:
         """Both stacks' backward passes, every parameter gradient written into `grad_of[param]` (the flat bucket's views)."""
         sums = SumJobs()
+        if self._fused_backward_ok(x0, x1, dy0, dy1):
+            self._backward_fused(x0, x1, acts, dy0, dy1, grad_of, sums)
+            sums.launch()
+            return
         for net, x, a, dy in ((self.a, x0, acts[0], dy0), (self.b, x1, acts[1], dy1)):
             ws = [lin.weight for lin in net.linears]
             backward_chain(ws, [grad_of[lin.bias] for lin in net.linears], [grad_of[lin.weight] for lin in net.linears], x, a, dy, sums)

@@ -245,7 +245,15 @@ class PPO:
                 self.dist.all_reduce_mean_(self._flat_grad)  # RCCL all-reduce of the policy gradients over xGMI
             fa.step_dev(self.max_grad_norm, lr_dev)
             n_steps += 1
-        lr, sv, ss, se = state.tolist()  # the update's only host read
+        sat = pair.saturated()
+        lr, sv, ss, se, nsat = torch.cat((state, sat if sat is not None else state[:0].new_zeros(1))).tolist()  # the update's only host read
+        if nsat > 0:
+            import warnings
+
+            sat.zero_()
+            warnings.warn(f"lt_mlp_backward_pair: {int(nsat)} workgroup-layers of the gradient chain reached the f16 image's bound "
+                          "(a gradient grew by more than 500x through the layers): those rows were saturated; set LT_FUSED_BACKWARD=0 "
+                          "to run the chain as f32 library GEMMs")
         self.learning_rate = lr
         for group in self.optimizer.param_groups:
             group["lr"] = lr

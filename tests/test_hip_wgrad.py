@@ -23,7 +23,7 @@ def _wgrad(dz, x, amax=None):
     assert slabs.numel() == sp * n * k
     st = vp(torch.cuda.current_stream().cuda_stream)
     _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(x.data_ptr()), m, n, k, vp(amax.data_ptr()) if amax is not None else vp(None),
-                            0 if amax is None else amax.numel(), vp(slabs.data_ptr()), st), "lt_wgrad")
+                            0 if amax is None else amax.numel(), vp(slabs.data_ptr()), vp(None), st), "lt_wgrad")
     return slabs.view(sp, n, k).sum(0), sp
 
 
