@@ -8,11 +8,14 @@
 //
 // Arithmetic (the same operand split as lt_mlp.hip): every f32 operand is x = hi + lo / 64 with hi = f16(x), lo = f16(64 (x - hi));
 //     sum_m a b  =  sum a_hi b_hi  +  (sum a_hi b_lo + sum a_lo b_hi) / 64          (the lo lo term is 2^-22 relative: dropped)
-// three f16 MFMAs (v_mfma_f32_16x16x32_f16, f32 accumulation, exact products) into TWO accumulators (main, correction).
+// three f16 MFMAs (v_mfma_f32_16x16x32_f16, f32 accumulation, exact products) into ONE accumulator that holds 64 x the sum:
+//     acc += (64 a_hi) b_hi + a_hi b_lo + a_lo b_hi                                (64 a_hi is exact: see the scale of dz)
+// (two accumulator sets - main and correction - were 128 registers: one wave per SIMD and nobody to hide a fetch behind; with one
+// set a wave needs < 256 and two share a SIMD).
 // dz is a gradient - 1e-4 ... 1e-9 at the PPO loss's 1 / M scale, far below f16's range: it is multiplied by a power of two `s` that
-// brings max |dz| to [2^13, 2^14) before the split (s from the per-block maxima the producing kernel leaves, lt_elu_backward_bias2;
-// elements more than 2^27 below the maximum lose relative precision, at an absolute error 2^-38 of the maximum) and the sums are
-// divided by s at the end.  x (observations, ELU outputs) is used as it is: |x| <= 65504 / 1 is all f16 needs here (no 64 x scaling).
+// brings max |dz| to [2^7, 2^8) before the split (s from the per-block maxima the producing kernel leaves - lt_mlp_backward_pair,
+// lt_elu_backward_bias2; elements more than 2^21 below the maximum lose relative precision, at an absolute error 2^-37 of the
+// maximum) and the sums are divided by 64 s at the end.  x (observations, ELU outputs) is used as it is: |x| <= 65504.
 // Against an f64 reference the result is as close as an f32 GEMM's own rounding (tests/test_hip_wgrad.py).
 //
 // Structure: NO LDS and no barriers.  The MFMA's A operand wants, per lane (i = lane & 15, g = lane >> 4), 8 values of the REDUCTION
@@ -22,11 +25,12 @@
 // - the fragment of reduction indices kk = 8 g + t <-> m = m0 + 4 t + g for output row 4 c + u of MFMA tile u (tile u = the rows that
 // are u mod 4).  No shuffle, no transpose: component u of the eight loaded float4s IS the fragment.  The same for B = x.  (A first
 // version fetched columns by dword loads - 64 load instructions of 4 x 64 B per step instead of 16 of 1 KiB - and ran at 58 TFLOP/s.)
-// A wave owns a 64 x 64 output tile (4 x 4 MFMA tiles, 2 x 16 accumulators) over a slice of M; the epilogue's lane holds 4 adjacent
-// columns of a row (one from each tile along k): float4 stores;
-// workgroup = one wave (4 per CU, one per SIMD, ~340 registers); the slices' partial tiles go to a slab buffer and one ordered-sum
-// launch (lt_partial_sums) adds them - deterministic, no float atomics.  Loads of step s + 1 are in flight while step s is split
-// and multiplied.
+// A wave owns a 64 x 64 output tile (4 x 4 MFMA tiles, 16 accumulators) over a slice of M; the epilogue's lane holds 4 adjacent
+// columns of a row (one from each tile along k): float4 stores.  A workgroup is TWO waves on the two halves of a slice (8 waves
+// per CU, two per SIMD: one wave's fetch hides behind the other's MFMAs); the second wave hands its tile over through 16 KiB of
+// LDS and the first adds and stores - a fixed order.  The slices' partial tiles go to a slab buffer and one ordered-sum launch
+// (lt_partial_sums) adds them - deterministic, no float atomics.  Loads of step s + 1 are in flight while step s is split and
+// multiplied.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -70,8 +74,10 @@ struct WgradArgs {
   float* db;            // optional [splits][N]: the slices' column sums of dz (the bias gradient's partials), by the tiles of the first k column
 };
 
-__global__ __launch_bounds__(64, 1) void lt_wgrad_kernel(const WgradArgs a) {
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(128, 2) void lt_wgrad_kernel(const WgradArgs a) {
+  __shared__ f32x4 s_tile[TA * TB + 1][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
   // block -> (split, tile): the tiles of a slice of M on ONE XCD (blocks are dealt round-robin over the 8 XCDs - observed placement,
   // used for speed only): they sweep the same rows of dz / x at about the same time, so a row is fetched into that XCD's L2 once and
@@ -85,10 +91,11 @@ __global__ __launch_bounds__(64, 1) void lt_wgrad_kernel(const WgradArgs a) {
   const int split = item / tiles, tile = item - split * tiles;
   const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
   const int n0 = tn * 16 * TA, k0 = tk * 16 * TB;
-  // this slice's 32-row steps: the M / 32 steps are dealt as evenly as possible
+  // this slice's 32-row steps (the M / 32 steps are dealt as evenly as possible), first half to wave 0, second to wave 1
   const long long steps = (a.M + 31) / 32;
-  const long long s0 = steps * split / a.splits, s1 = steps * (split + 1) / a.splits;
-  // scale of dz: a power of two that brings max |dz| to [2^13, 2^14)
+  const long long b0 = steps * split / a.splits, b1 = steps * (split + 1) / a.splits, mid = b0 + (b1 - b0 + 1) / 2;
+  const long long s0 = wave ? mid : b0, s1 = wave ? b1 : mid;
+  // scale of dz: a power of two that brings max |dz| to [2^7, 2^8) - 64 x its hi half is still an f16 number
   float scale = 1.f;
   if (a.amax) {
     float m = 0.f;
@@ -96,15 +103,15 @@ __global__ __launch_bounds__(64, 1) void lt_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     const int e = (int)((__float_as_uint(m) >> 23) & 0xFF) - 127;  // floor(log2 m) (m == 0 or denormal: e = -127)
-    int se = 13 - e;
+    int se = 7 - e;
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
     scale = __uint_as_float((unsigned)(127 + se) << 23);
   }
-  f32x4 main_[TA][TB], corr[TA][TB];
+  f32x4 acc[TA][TB];
 #pragma unroll
   for (int p = 0; p < TA; ++p)
 #pragma unroll
-    for (int q = 0; q < TB; ++q) { main_[p][q] = f32x4{0.f, 0.f, 0.f, 0.f}; corr[p][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int q = 0; q < TB; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
   // 32 rows x 64 columns per operand and step: load t = row m0 + 4 t + g, 16 bytes at column 4 c (clamped to the matrix: a tile may
   // hang over its edge; what an overhanging lane loads is multiplied into output elements that are never stored)
   f32x4 va[8], vb[8];
@@ -133,17 +140,33 @@ __global__ __launch_bounds__(64, 1) void lt_wgrad_kernel(const WgradArgs a) {
     f16x8 ah[TA], al[TA], bh[TB], bl[TB];
     split8<0>(va, scale, ah[0], al[0]); split8<1>(va, scale, ah[1], al[1]); split8<2>(va, scale, ah[2], al[2]); split8<3>(va, scale, ah[3], al[3]);
     split8<0>(vb, 1.f, bh[0], bl[0]); split8<1>(vb, 1.f, bh[1], bl[1]); split8<2>(vb, 1.f, bh[2], bl[2]); split8<3>(vb, 1.f, bh[3], bl[3]);
-    if (s + 1 < s1) issue(s + 1);  // the next step's 16 loads fly while this step's 48 MFMAs run (a second stage in flight needs
-                                   // 64 more registers: 256 VGPRs + 246 AGPRs of copies, measured 25 % slower)
+    if (s + 1 < s1) issue(s + 1);  // the next step's 16 loads fly while this step's 48 MFMAs run
+#pragma unroll
+    for (int p = 0; p < TA; ++p) {
+      const f16x8 a64 = ah[p] * (_Float16)LO_SCALE;  // exact: |scaled dz| < 2^8
+#pragma unroll
+      for (int q = 0; q < TB; ++q) {
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a64, bh[q], acc[p][q], 0, 0, 0);
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], bl[q], acc[p][q], 0, 0, 0);
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[p], bh[q], acc[p][q], 0, 0, 0);
+      }
+    }
+  }
+  // wave 1 hands its tile and column sums to wave 0
+  if (wave == 1) {
 #pragma unroll
     for (int p = 0; p < TA; ++p)
 #pragma unroll
-      for (int q = 0; q < TB; ++q) {
-        main_[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], bh[q], main_[p][q], 0, 0, 0);
-        corr[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], bl[q], corr[p][q], 0, 0, 0);
-        corr[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[p], bh[q], corr[p][q], 0, 0, 0);
-      }
+      for (int q = 0; q < TB; ++q) s_tile[p * TB + q][lane] = acc[p][q];
+    s_tile[TA * TB][lane] = cs;
   }
+  __syncthreads();
+  if (wave == 1) return;
+#pragma unroll
+  for (int p = 0; p < TA; ++p)
+#pragma unroll
+    for (int q = 0; q < TB; ++q) acc[p][q] += s_tile[p * TB + q][lane];
+  cs += s_tile[TA * TB][lane];
   if (colsum) {  // lane (c, g) holds the sums of rows g mod 4 of columns n0 + 4 c .. + 3
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -154,7 +177,7 @@ __global__ __launch_bounds__(64, 1) void lt_wgrad_kernel(const WgradArgs a) {
   }
   // the partial tile: MFMA tile (p, q) holds C[row rho = 4 g + r][col kappa = i] = dW[n0 + 4 rho + p][k0 + 4 kappa + q]: a lane's four
   // q tiles are 4 ADJACENT columns of one row
-  const float inv = 1.f / scale;
+  const float inv = 1.f / (scale * LO_SCALE);
   float* const out = a.slabs + (long long)split * a.N * a.K;
   const int k = k0 + 4 * i;
 #pragma unroll
@@ -165,16 +188,15 @@ __global__ __launch_bounds__(64, 1) void lt_wgrad_kernel(const WgradArgs a) {
       if (n < a.N && k < a.K) {
         f32x4 o;
 #pragma unroll
-        for (int q = 0; q < TB; ++q) o[q] = (main_[p][q][r] + corr[p][q][r] * (1.f / LO_SCALE)) * inv;
+        for (int q = 0; q < TB; ++q) o[q] = acc[p][q][r] * inv;
         *(f32x4*)(out + (long long)n * a.K + k) = o;
       }
     }
 }
 
 int pick_splits(long long M, int tiles) {
-  // at most 1024 single-wave workgroups (one per SIMD of the 256 CUs: the kernel's 296 registers allow no second wave, and a 1025th
-  // block would run alone after the others - 24 slices x 48 tiles = 1152 blocks took 97 us where 21 x 48 = 1008 take 69 us), at least
-  // 4 steps of 32 rows per slice
+  // at most 1024 two-wave workgroups (four per CU, two waves per SIMD: a 1025th block would run alone after the others - 24 slices x
+  // 48 tiles = 1152 single-wave blocks took 97 us where 21 x 48 = 1008 took 69 us), at least 4 steps of 32 rows per slice
   const long long steps = (M + 31) / 32;
   long long s = 1024 / tiles;
   if (s > steps / 4) s = steps / 4;
@@ -202,7 +224,7 @@ extern "C" int lt_wgrad(const float* dz, const float* x, int64_t M, int N, int K
   a.splits = pick_splits((long long)M, a.tiles_n * a.tiles_k);
   a.amax = amax_blocks; a.nblk_amax = amax_blocks ? nblk_amax : 0;
   a.slabs = slabs; a.db = db_slabs;
-  hipLaunchKernelGGL(lt_wgrad_kernel, dim3((unsigned)((a.tiles_n * a.tiles_k * a.splits + 7) / 8 * 8)), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(lt_wgrad_kernel, dim3((unsigned)((a.tiles_n * a.tiles_k * a.splits + 7) / 8 * 8)), dim3(128), 0, (hipStream_t)stream, a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;

@@ -89,3 +89,33 @@ def test_backward_chain_with_the_split_f16_weight_gradients_matches_autograd():
         for p, q in zip(net.parameters(), ref.parameters()):
             s = float(q.grad.abs().max())
             assert float((grad_of[p].double() - q.grad).abs().max()) < 3e-6 * s + 1e-12, (tuple(p.shape), s)
+
+
+def test_partial_sums_launch_adds_every_job_in_a_fixed_order():
+    """lt_partial_sums (csrc/lt_ppo.hip): several ordered sums of partials in one launch - the slabs of lt_wgrad, the per-block bias
+    sums, the head kernels' [dW | db] blocks (count not a multiple of 4, outputs split over two tensors)."""
+    import torch
+
+    from locotouch_amd.rl.mlp import SumJobs
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    jobs, refs = SumJobs(), []
+    for nblk, stride, count, split in ((21, 512 * 348, 512 * 348, 512 * 348), (256, 128 + 16, 129, 128), (1, 40, 37, 37), (513, 12 * 128 + 16, 12 * 128 + 12, 12 * 128),
+                                       (7, 5, 5, 5), (128, 256, 256, 256)):
+        ws = torch.randn(nblk * stride + 3, device="cuda", generator=g)[: nblk * stride]
+        out0 = torch.full((split,), float("nan"), device="cuda")
+        out1 = torch.full((count - split,), float("nan"), device="cuda") if count > split else None
+        jobs.add(ws, nblk, stride, count, split, out0, out1)
+        refs.append((ws.view(nblk, stride)[:, :count].double().sum(0), out0, out1, split, nblk))
+    keep = list(jobs.jobs)
+    jobs.launch()
+    torch.cuda.synchronize()
+    first = [(o0.clone(), None if o1 is None else o1.clone()) for _, o0, o1, _, _ in refs]
+    for ref, o0, o1, split, nblk in refs:
+        got = o0 if o1 is None else torch.cat((o0, o1))
+        assert float((got.double() - ref).abs().max()) <= 2e-6 * max(1.0, nblk ** 0.5), nblk
+    jobs.jobs = keep
+    jobs.launch()
+    torch.cuda.synchronize()
+    for (a0, a1), (_, o0, o1, _, _) in zip(first, refs):
+        assert torch.equal(a0, o0) and (a1 is None or torch.equal(a1, o1))
