@@ -300,6 +300,7 @@ __device__ __forceinline__ void convert_pass(const MlpArgs& a, int l, float* s_a
   // in instruction fetch than it hides.
   if (ROWS >= 64 && (N & 31) == 0 && (KIND == LT_ACT_ELU || KIND == LT_ACT_NONE)) {
     constexpr int NT = 64 * NW;
+    const unsigned gpr = (unsigned)N >> 3, row_magic = 0xFFFFFFFFu / gpr + 1u;  // groups per row; idx / gpr == umulhi(idx, magic) below 2^16
 #pragma unroll 1
     for (int base = tid; base < total; base += 2 * NT) {
       float* g[2];
@@ -311,8 +312,14 @@ __device__ __forceinline__ void convert_pass(const MlpArgs& a, int l, float* s_a
         const int idx = base + u * NT;
         ok[u] = idx < total;
         const int id = ok[u] ? idx : base;  // (a surplus slot re-reads the first group and stores nothing)
-        row[u] = id & (ROWS - 1);
-        n0[u] = 8 * (id / ROWS);
+        if (dst) {  // training forward: lanes walk along a ROW, so that a wave's act_out stores are whole KiB stretches (gate_pass)
+          const unsigned r_ = __umulhi((unsigned)id, row_magic);
+          row[u] = (int)r_;
+          n0[u] = 8 * (int)((unsigned)id - r_ * gpr);
+        } else {    // rollout: lanes walk down the rows - conflict-free LDS access
+          row[u] = id & (ROWS - 1);
+          n0[u] = 8 * (id / ROWS);
+        }
         g[u] = s_act + row[u] * S + n0[u];
         x[u][0] = *(const f32x4*)g[u];
         x[u][1] = *(const f32x4*)(g[u] + 4);
