@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 12
+#define LT_ABI_VERSION 13
 
 /* error codes */
 #define LT_OK 0
@@ -260,7 +260,7 @@ enum lt_field {
   LT_F_JOINT_POS, LT_F_JOINT_VEL, LT_F_JOINT_ACC, LT_F_APPLIED_TORQUE,
   LT_F_ACT_RAW, LT_F_ACT_PREV_RAW, LT_F_ACT_PREV_PREV_RAW,
   LT_F_FORCE_HIST,      /* |F| history: [slot 3][type 4: hip,thigh,calf,foot] quad arrays (per leg) */
-  LT_F_TRUNK_FORCE_HIST,/* (h0,h1,h2,_) */
+  LT_F_TRUNK_FORCE_HIST,/* (h0,h1,h2, foot_air_time_variance of the command term's metrics - see LT_F_EVENT_TIMERS) */
   LT_F_FOOT_CUR_AIR, LT_F_FOOT_CUR_CONTACT, LT_F_FOOT_LAST_AIR, LT_F_FOOT_LAST_CONTACT,
   LT_F_FOOT_POS_W,      /* 3 quad arrays: x,y,z per leg (derived, written each step) */
   LT_F_FOOT_VEL_W,      /* 3 quad arrays */
@@ -273,7 +273,9 @@ enum lt_field {
   LT_F_GAIT_CMD,        /* (last_cmd xyz, step_from_changing_cmd) */
   LT_F_CMD,             /* (vx, vy, wz, time_left) */
   LT_F_CMD_BUF,         /* (vx, vy, wz, is_standing) */
-  LT_F_EVENT_TIMERS,    /* (push_robot_left, push_obj_left, _, _) */
+  LT_F_EVENT_TIMERS,    /* (push_robot_left, push_obj_left, error_vel_xy, error_vel_yaw): lanes 2, 3 and LT_F_TRUNK_FORCE_HIST lane 3 hold the
+                         * command term's per-env metrics as CommandTerm.compute left them at the end of the last step
+                         * (locotouch/mdp/commands.py:392-396: assigned, not accumulated; zero after lt_env_reset_all) */
   LT_F_EPISODE_SUMS,    /* 7 quad arrays: per reward term, weighted*dt accumulated */
   LT_F_LAST_EPISODE_SUMS,/* 7 quad arrays: snapshot at the last reset (logging) */
   LT_F_LAST_EPISODE_INFO,/* (episodes_finished, last_ep_len, last_term_bits, _) */
@@ -281,8 +283,13 @@ enum lt_field {
                          * (reset_lin, len_lin, sum_lin, reset_ang); (len_ang, sum_ang, _, _).  The trackers lag the
                          * reference's by one pass: LT_F_CMD_PARAMS[27..30] holds the operations still to be applied */
   LT_F_REWARD_TERMS,    /* 7 quad arrays: unweighted term values of the last step (diagnostics / parity) */
+  LT_F_LAST_CMD_METRICS,/* (error_vel_xy, error_vel_yaw, foot_air_time_variance, step id & 0xFFFFFF): the metrics of the env at its last
+                         * reset, i.e. the values CommandTerm.reset averaged over that step's reset batch into `extras["log"]`
+                         * (IsaacLab CommandTerm.reset [DEP]; the reference's own metrics: commands.py:392-417), and the
+                         * common_step_counter of that step, so that the host can form the per-batch means */
   LT_F_PLATE_SAMPLES,   /* 3 quad arrays (lane = plate sample): contact point x, y in the trunk frame and normal force of the
-                         * cylinder-on-plate contact at the last tactile refresh (zero after a reset); tactile tasks only */
+                         * cylinder-on-plate contact at the last tactile refresh (zero after a reset); tactile tasks only.
+                         * MUST stay the last quad field: it takes no space without cfg.tactile_enabled */
   LT_NUM_QUAD_FIELDS,
   /* plain (non-quad) arrays */
   LT_F_EP_LEN = 64,     /* int64 [N] */

@@ -956,7 +956,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     t = hot.obj_timers; O.cur_air = qbcast<0>(t); O.cur_con = qbcast<1>(t); O.last_air = qbcast<2>(t); O.last_con = qbcast<3>(t);
     t = hot.obj_params; O.rad = qbcast<0>(t); O.len = qbcast<1>(t); O.mass = qbcast<2>(t); O.mu = qbcast<3>(t);
     t = hot.env_params; X.trunk_mass_add = qbcast<0>(t); X.trunk_mu = qbcast<1>(t); X.trunk_rest = qbcast<2>(t); X.obj_rest = qbcast<3>(t);
-    t = hot.trunk_fh; X.trunk_fh[0] = qbcast<0>(t); X.trunk_fh[1] = qbcast<1>(t); X.trunk_fh[2] = qbcast<2>(t);
+    t = hot.trunk_fh; X.trunk_fh[0] = qbcast<0>(t); X.trunk_fh[1] = qbcast<1>(t); X.trunk_fh[2] = qbcast<2>(t); X.m_airvar = qbcast<3>(t);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       G.q[k] = hot.q[k]; G.qd[k] = hot.qd[k];
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     float t;
     t = *F(LT_F_CMD, 0); X.cmd = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.cmd_time_left = qbcast<3>(t);
     t = *F(LT_F_CMD_BUF, 0); X.cmd_buf = v3(qbcast<0>(t), qbcast<1>(t), qbcast<2>(t)); X.cmd_standing = qbcast<3>(t);
-    t = *F(LT_F_EVENT_TIMERS, 0); X.push_robot_left = qbcast<0>(t); X.push_obj_left = qbcast<1>(t);
+    t = *F(LT_F_EVENT_TIMERS, 0); X.push_robot_left = qbcast<0>(t); X.push_obj_left = qbcast<1>(t); X.m_exy = qbcast<2>(t); X.m_eyaw = qbcast<3>(t);
     X.ep_len = ((const long long*)(arena + L.off_ep_len))[env];
     if (MODE == MODE_STEP) req_bits = ((const int*)(arena + L.off_term_bits))[env];  // last step's word: carries the caller's termination request (LT_T_USER)
     if (!(HELPERS && MODE == MODE_STEP)) {  // (helper form: wave 1 holds the gait class state and hands it back with the gait term)
@@ -1277,6 +1277,8 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       for (int q = 0; q < LT_REWARD_SLOTS / 4; ++q) *F(LT_F_LAST_EPISODE_SUMS, q) = sums[q];
       const float fin = *F(LT_F_LAST_EPISODE_INFO, 0);  // lane 0 holds episodes_finished
       *F(LT_F_LAST_EPISODE_INFO, 0) = sel4(leg, fin + 1.f, (float)X.ep_len, (float)bits, 0.f);
+      // CommandTerm.reset [DEP]: the metrics this env contributes to its step's reset batch are the ones the last compute() left
+      *F(LT_F_LAST_CMD_METRICS, 0) = sel4(leg, X.m_exy, X.m_eyaw, X.m_airvar, (float)(step & 0xFFFFFFull));
     }
   }
   // the step's event draws: from wave 3's bank (helper form: computed beside the physics) or inline Philox - the same uniforms
@@ -1352,8 +1354,18 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
     foot_kinematics(sgn, B, G);
     if (MODE == MODE_RESET_ALL && c.cmd_multi_sampling && 0 < (int)P[15]) X.cmd = v3(0, 0, 0);                 // commands.py:559
   }
+  if (MODE == MODE_RESET_ALL) X.m_exy = X.m_eyaw = X.m_airvar = 0.f;  // CommandTerm.reset zeroes them; env.reset() runs no compute()
   if (MODE == MODE_STEP) {
-    // 7. CommandTerm.compute [DEP] + MultiSampling._update_command (commands.py:561-576)
+    // 7. CommandTerm.compute [DEP]: _update_metrics first (commands.py:392-396, on the state the resets left and the command as it
+    //    stands before this call's resample), then the timers, + MultiSampling._update_command (commands.py:561-576)
+    {
+      const V3 vb = qapply_inv(B.q, B.u), wb = qapply_inv(B.q, B.w);
+      const float ex = X.cmd.x - vb.x, ey = X.cmd.y - vb.y;
+      X.m_exy = sqrtf(ex * ex + ey * ey);
+      X.m_eyaw = fabsf(X.cmd.z - wb.z);
+      const float mean = 0.25f * qsum(G.last_air), d = G.last_air - mean;
+      X.m_airvar = qsum(d * d) * (1.f / 3.f);  // torch.var: unbiased
+    }
     X.cmd_time_left -= step_dt;
     if (X.cmd_time_left <= 0.f) command_resample(c, P, draw(RS_CMD_TIMER, 4, 2), draw(RS_CMD_TIMER + 1, 4, 3), X);
     if (c.cmd_multi_sampling) {
@@ -1487,10 +1499,10 @@ __global__ __launch_bounds__(HELPERS ? 256 : 64, HELPERS ? 1 : LT_STEP_MIN_WAVES
       ST_STATE(F(LT_F_OBJ_PARAMS, 0), sel4(leg, O.rad, O.len, O.mass, O.mu));
     }
     ST_STATE(F(LT_F_ENV_PARAMS, 0), sel4(leg, X.trunk_mass_add, X.trunk_mu, X.trunk_rest, X.obj_rest));
-    ST_STATE(F(LT_F_TRUNK_FORCE_HIST, 0), sel4(leg, X.trunk_fh[0], X.trunk_fh[1], X.trunk_fh[2], 0.f));
+    ST_STATE(F(LT_F_TRUNK_FORCE_HIST, 0), sel4(leg, X.trunk_fh[0], X.trunk_fh[1], X.trunk_fh[2], X.m_airvar));
     ST_STATE(F(LT_F_CMD, 0), sel4(leg, X.cmd.x, X.cmd.y, X.cmd.z, X.cmd_time_left));
     ST_STATE(F(LT_F_CMD_BUF, 0), sel4(leg, X.cmd_buf.x, X.cmd_buf.y, X.cmd_buf.z, X.cmd_standing));
-    ST_STATE(F(LT_F_EVENT_TIMERS, 0), sel4(leg, X.push_robot_left, X.push_obj_left, 0.f, 0.f));
+    ST_STATE(F(LT_F_EVENT_TIMERS, 0), sel4(leg, X.push_robot_left, X.push_obj_left, X.m_exy, X.m_eyaw));
     ST_STATE(F(LT_F_GAIT_CMD, 0), sel4(leg, X.gait_cmd.x, X.gait_cmd.y, X.gait_cmd.z, X.gait_step));
     if (leg == 0) ((long long*)(arena + L.off_ep_len))[env] = X.ep_len;
     if (TAC && tac_new) { ST_STATE(F(LT_F_PLATE_SAMPLES, 0), tac.x); ST_STATE(F(LT_F_PLATE_SAMPLES, 1), tac.y); ST_STATE(F(LT_F_PLATE_SAMPLES, 2), tac.z); }

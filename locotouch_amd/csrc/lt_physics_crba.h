@@ -82,6 +82,7 @@ struct Misc {
   float trunk_fh[3];
   V3 cmd; float cmd_time_left; V3 cmd_buf; float cmd_standing;
   float push_robot_left, push_obj_left;
+  float m_exy, m_eyaw, m_airvar;  // the command term's per-env metrics as of the end of the last step (commands.py:392-396)
   V3 gait_cmd; float gait_step;
   long long ep_len;
 };

@@ -294,7 +294,7 @@ class LocoTouchVecEnv:
                     log[f"Episode_Termination/{name}"] = float(((bits >> b) & 1).float().sum())
             log["Episode/length"] = float(info[mask, 1].mean())
             log["Episode/reward"] = float(sums[:, : len(REWARD_TERM_NAMES)].sum(1).mean())
-        log.update(self.command_metrics())
+        log.update(self.command_metrics(mask))
         p = self.cmd_params
         log["Metrics/base_velocity/lin_vel_x"] = float(p[1])
         log["Metrics/base_velocity/lin_vel_y"] = float(p[3])
@@ -303,24 +303,27 @@ class LocoTouchVecEnv:
         log["Metrics/base_velocity/rel_standing_envs"] = float(p[16])
         return log
 
-    def command_metrics(self) -> dict:
-        """The command term's `Metrics/base_velocity/*` (reference mdp/commands.py:392-417 + the stock base-class errors):
-        instantaneous quantities of the current state.  The reference logs their mean over the envs that reset in a step;
-        here they are sampled over ALL envs when the log is read (once per training iteration) - logging, not control."""
+    def command_metrics(self, mask: torch.Tensor | None = None) -> dict:
+        """The command term's `Metrics/base_velocity/*` (reference mdp/commands.py:392-417; IsaacLab CommandTerm.reset [DEP] logs the
+        MEAN OVER THE ENVS THAT RESET IN A STEP of the values the last `compute()` left, and the runner averages those per-step
+        entries over the iteration, loco_rl/loco_rl/runners/on_policy_runner.py log()).
+
+        error_vel_xy, error_vel_yaw, foot_air_time_variance: the step kernel keeps each env's values as of the end of the last step
+        and snapshots them, with the step id, in the env's reset path (LT_F_LAST_CMD_METRICS); here the envs in `mask` (those that
+        finished an episode since the last log read; None: every env that has finished one) are grouped by step id -> one mean per
+        reset batch -> the mean of the batches, the runner's number.  An env that reset twice since the last read counts with its
+        later reset only.
+        The six gait statistics (foot_step_frequency ...) are POPULATION means in the reference (broadcast to every env by
+        `metrics[...][:] = average`, commands.py:404-417): they are formed here from the current state of all envs - the reference
+        logs the same quantity as of the step before each reset batch."""
         f = self.field
-        q = f("LT_F_ROOT_QUAT")[:, 0, :]
-        w, v = q[:, :1], q[:, 1:]
-
-        def to_body(u):  # quat_apply_inverse
-            t = 2.0 * torch.cross(v, u, dim=1)
-            return u - w * t + torch.cross(v, t, dim=1)
-
-        lin_b = to_body(f("LT_F_ROOT_LIN_VEL_W")[:, 0, :3])
-        ang_b = to_body(f("LT_F_ROOT_ANG_VEL_W")[:, 0, :3])
-        cmd = f("LT_F_CMD")[:, 0, :3]
-        out = {"Metrics/base_velocity/error_vel_xy": float((cmd[:, :2] - lin_b[:, :2]).norm(dim=1).mean()),
-               "Metrics/base_velocity/error_vel_yaw": float((cmd[:, 2] - ang_b[:, 2]).abs().mean()),
-               "Metrics/base_velocity/foot_air_time_variance": float(f("LT_F_FOOT_LAST_AIR")[:, 0, :].var(dim=1).mean())}
+        out = {}
+        last = f("LT_F_LAST_CMD_METRICS")[:, 0, :]
+        if mask is None:
+            mask = self.field("LT_F_LAST_EPISODE_INFO")[:, 0, 0] > 0
+        if bool(mask.any()):
+            for name, v in zip(("error_vel_xy", "error_vel_yaw", "foot_air_time_variance"), reset_batch_means(last[mask])):
+                out[f"Metrics/base_velocity/{name}"] = v
         valid = f("LT_F_GAIT_VALID_LAST_AIR")[:, 0, :][:, [0, 3, 1, 2]]  # gait-class column order [FR, RL, FL, RR]
         ok = (valid > 1.0e-6).all(dim=1)
         stats = {"foot_step_frequency": 0.0, "pair_1_step_frequency": 0.0, "pair_2_step_frequency": 0.0,
@@ -334,6 +337,11 @@ class LocoTouchVecEnv:
         out.update({f"Metrics/base_velocity/{k}": v_ for k, v_ in stats.items()})
         return out
 
+    def current_command_metrics(self) -> dict:
+        """The per-env metric tensors as `command_manager.get_term("base_velocity").metrics` holds them between two steps."""
+        t = self.field("LT_F_EVENT_TIMERS")[:, 0, :]
+        return {"error_vel_xy": t[:, 2], "error_vel_yaw": t[:, 3], "foot_air_time_variance": self.field("LT_F_TRUNK_FORCE_HIST")[:, 0, 3]}
+
     def close(self) -> None:
         if getattr(self, "_handle", None):
             self._lib.lt_env_destroy(self._handle)
@@ -346,10 +354,19 @@ class LocoTouchVecEnv:
             pass
 
 
+def reset_batch_means(rows: torch.Tensor) -> list[float]:
+    """rows [k][4] = LT_F_LAST_CMD_METRICS of k envs (three metric values + the step id of the env's last reset): the mean over the
+    reset batches (one per distinct step id) of each batch's mean - what the reference's runner reports for a window of steps
+    (CommandTerm.reset logs a batch mean per step, the runner averages the steps)."""
+    ids, inv = torch.unique(rows[:, 3], return_inverse=True)
+    cnt = torch.zeros(ids.numel(), device=rows.device, dtype=rows.dtype).index_add_(0, inv, torch.ones_like(rows[:, 0]))
+    return [float((torch.zeros_like(cnt).index_add_(0, inv, rows[:, i]) / cnt).mean()) for i in range(3)]
+
+
 def make(task: str, num_envs: int | None = None, device: str = "cuda:0", seed: int = 42, **kw) -> LocoTouchVecEnv:
     """`gym.make(task, cfg=...)` + `RslRlVecEnvWrapper(env)` equivalent (reference locotouch/scripts/train.py:98,116)."""
     return LocoTouchVecEnv(task, num_envs=num_envs, device=device, seed=seed, **kw)
 
 
-__all__ = ["LocoTouchVecEnv", "make", "task_ids", "REWARD_TERM_NAMES", "TERMINATION_NAMES"]
+__all__ = ["LocoTouchVecEnv", "make", "task_ids", "reset_batch_means", "REWARD_TERM_NAMES", "TERMINATION_NAMES"]
 _ = math

@@ -86,6 +86,7 @@ typedef struct {
   real gait_cmd[3], gait_step_from_change;
   real cmd[3], cmd_time_left, cmd_buf[3], cmd_standing;
   real push_robot_left, push_obj_left;
+  real m_exy, m_eyaw, m_airvar, last_m[4]; /* command-term metrics (commands.py:392-396) now / at the last reset + its step id */
   real sums[LT_REWARD_SLOTS], last_sums[LT_REWARD_SLOTS];
   real episodes_finished, last_ep_len, last_term_bits;
   real cur_step[4], cur_track[8];
@@ -119,6 +120,8 @@ static void gather(env_t* E, void* arena, const lt_layout* L, int64_t e) {
   E->gait_step_from_change = Q(LT_F_GAIT_CMD, 0, 3);
   E->cmd_time_left = Q(LT_F_CMD, 0, 3);
   E->cmd_standing = Q(LT_F_CMD_BUF, 0, 3);
+  E->m_exy = Q(LT_F_EVENT_TIMERS, 0, 2); E->m_eyaw = Q(LT_F_EVENT_TIMERS, 0, 3); E->m_airvar = Q(LT_F_TRUNK_FORCE_HIST, 0, 3);
+  for (int c = 0; c < 4; ++c) E->last_m[c] = Q(LT_F_LAST_CMD_METRICS, 0, c);
   E->push_robot_left = Q(LT_F_EVENT_TIMERS, 0, 0);
   E->push_obj_left = Q(LT_F_EVENT_TIMERS, 0, 1);
   E->obj_radius = Q(LT_F_OBJ_PARAMS, 0, 0); E->obj_length = Q(LT_F_OBJ_PARAMS, 0, 1);
@@ -179,6 +182,8 @@ static void scatter(const env_t* E, void* arena, const lt_layout* L, int64_t e) 
   Q(LT_F_GAIT_CMD, 0, 3) = E->gait_step_from_change;
   Q(LT_F_CMD, 0, 3) = E->cmd_time_left;
   Q(LT_F_CMD_BUF, 0, 3) = E->cmd_standing;
+  Q(LT_F_EVENT_TIMERS, 0, 2) = E->m_exy; Q(LT_F_EVENT_TIMERS, 0, 3) = E->m_eyaw; Q(LT_F_TRUNK_FORCE_HIST, 0, 3) = E->m_airvar;
+  for (int c = 0; c < 4; ++c) Q(LT_F_LAST_CMD_METRICS, 0, c) = E->last_m[c];
   Q(LT_F_EVENT_TIMERS, 0, 0) = E->push_robot_left;
   Q(LT_F_EVENT_TIMERS, 0, 1) = E->push_obj_left;
   Q(LT_F_OBJ_PARAMS, 0, 0) = E->obj_radius; Q(LT_F_OBJ_PARAMS, 0, 1) = E->obj_length;
@@ -1696,10 +1701,25 @@ static void step_one(const lt_cfg* cfg, void* arena, const lt_layout* L, const f
     if (reset) {
       for (int i = 0; i < LT_REWARD_SLOTS; ++i) E.last_sums[i] = E.sums[i];
       E.episodes_finished += 1; E.last_ep_len = (real)E.ep_len; E.last_term_bits = (real)bits;
+      /* CommandTerm.reset [DEP]: what this env contributes to its step's reset batch is what the last compute() left */
+      E.last_m[0] = E.m_exy; E.last_m[1] = E.m_eyaw; E.last_m[2] = E.m_airvar; E.last_m[3] = (real)(step & 0xFFFFFFull);
       reset_env(cfg, P, &E, EKEY(cfg, e), step, has_object);
       memset(E.plate, 0, sizeof(E.plate)); /* ContactSensor.reset [DEP]: the reset envs' net forces are zeroed */
     }
-    /* 7. command term compute */
+    /* 7. command term compute: _update_metrics first (commands.py:392-396), on the state the resets left and the command as it
+     *    stands before this call's resample */
+    {
+      real vb[3], wb[3];
+      quat_apply_inv(vb, E.root_quat, E.root_lin);
+      quat_apply_inv(wb, E.root_quat, E.root_ang);
+      const real ex = E.cmd[0] - vb[0], ey = E.cmd[1] - vb[1];
+      E.m_exy = (real)sqrtf((float)(ex * ex + ey * ey));
+      E.m_eyaw = (real)fabsf((float)(E.cmd[2] - wb[2]));
+      const real mean = (real)0.25 * (((E.foot_last_air[0] + E.foot_last_air[1]) + E.foot_last_air[2]) + E.foot_last_air[3]);
+      real v = 0;
+      for (int l = 0; l < 4; ++l) v += (E.foot_last_air[l] - mean) * (E.foot_last_air[l] - mean);
+      E.m_airvar = v * (real)(1.0 / 3.0); /* torch.var: unbiased */
+    }
     E.cmd_time_left -= step_dt;
     if (E.cmd_time_left <= 0)
       command_resample(cfg, P, cfg->seed, EKEY(cfg, e), step, RS_CMD_TIMER, E.cmd, E.cmd_buf, &E.cmd_standing, &E.cmd_time_left);
