@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 13
+#define LT_ABI_VERSION 14
 
 /* error codes */
 #define LT_OK 0
@@ -444,16 +444,21 @@ int lt_elu_backward_bias2(const float* da, const float* a, int64_t M, int N, flo
  * dz [M][N], x [M][K] row-major f32, N and K multiples of 4; both operands are split into f16 (hi, lo) pairs in registers (three MFMAs per tile); dz is scaled
  * by a power of two taken from max |dz| = max over amax_blocks[nblk_amax] (NULL: no scaling - |dz| must then sit in f16's normal
  * range), |x| <= 65504.  slabs: lt_wgrad_ws_floats(M, N, K) floats.  db_slabs (optional, splits x N floats): the slices' column
- * sums of dz, i.e. the partials of the bias gradient (lt_partial_sums: nblk = splits, stride = count = N).  Deterministic. */
-int lt_wgrad(const float* dz, const float* x, int64_t M, int N, int K, const float* amax_blocks, int nblk_amax, float* slabs, float* db_slabs,
-             void* stream);
+ * sums of dz, i.e. the partials of the bias gradient (lt_partial_sums: nblk = splits, stride = count = N).  x_split: x is in the
+ * SPLIT FORMAT (lt_mlp_forward_pair, lt_split_rows) - its halves go to the matrix cores as they are.  Deterministic. */
+int lt_wgrad(const float* dz, const float* x, int x_split, int64_t M, int N, int K, const float* amax_blocks, int nblk_amax, float* slabs,
+             float* db_slabs, void* stream);
+/* out[i] = clamp(x[i], +-LT_MLP_INPUT_CLAMP) in the SPLIT FORMAT (lt_mlp_forward_pair), i < count (a multiple of 4): the observation rows
+ * of a PPO update, converted once per update for the first layer's weight gradient (lt_wgrad, x_split = 1). */
+int lt_split_rows(const float* x, void* out, int64_t count, void* stream);
 int lt_wgrad_splits(int64_t M, int N, int K);
 int64_t lt_wgrad_ws_floats(int64_t M, int N, int K);
 int64_t lt_elu_backward_bias_ws_floats(int64_t M, int N);
 /* Weight and bias gradient of a narrow head layer (the action-mean and value heads of actor_critic.py:45-66 in the backward pass):
  * dw[n][k] = sum_m dy[m][n] x[m][k], db[n] = sum_m dy[m][n] (db optional).  1 <= n <= 16, k a multiple of 4, <= 1024;
- * ws: lt_head_wgrad_ws_floats(M, n, k) floats of scratch.  Deterministic (no float atomics). */
-int lt_head_wgrad(const float* dy, const float* x, int64_t M, int n, int k, float* dw, float* db, float* ws, void* stream);
+ * ws: lt_head_wgrad_ws_floats(M, n, k) floats of scratch.  x_split: x is in the SPLIT FORMAT (lt_mlp_forward_pair).  Deterministic
+ * (no float atomics). */
+int lt_head_wgrad(const float* dy, const float* x, int x_split, int64_t M, int n, int k, float* dw, float* db, float* ws, void* stream);
 int64_t lt_head_wgrad_ws_floats(int64_t M, int n, int k);
 /* clip_grad_norm_(max_norm) + Adam.step() on FLAT f32 buffers of n elements in two launches (ppo.py:318-319; torch's arithmetic
  * order, `step` = the 1-based count of this update).  grads are left scaled by the clip coefficient, as clip_grad_norm_ leaves
@@ -561,7 +566,10 @@ int lt_mlp_forward(const lt_mlp_desc* desc, const float* packed, const float* x,
  * minibatch): y0 / y1 [m][out] and the activations behind every hidden layer, acts0[l] / acts1[l] [m][dims[l + 1]] (l < L - 1), which
  * the backward pass needs.  Same kernel and arithmetic as lt_mlp_forward. */
 int lt_mlp_forward_pair(const lt_mlp_desc* d0, const float* packed0, const float* x0, const lt_mlp_desc* d1, const float* packed1, const float* x1,
-                        int64_t m, float* y0, float* y1, float* const* acts0, float* const* acts1, void* stream);
+                        int64_t m, float* y0, float* y1, float* const* acts0, float* const* acts1, int acts_split, void* stream);
+/* acts_split != 0: the activations are written in the SPLIT FORMAT - one dword per element, low half = f16 hi, high half = f16 lo,
+ * value = hi + lo / 64 (the pair the kernel forms for its own matrix-core operands; 2^-22 relative, |value| <= LT_MLP_INPUT_CLAMP) -
+ * which lt_mlp_backward_pair, lt_wgrad and lt_head_wgrad read without converting (acts_split / x_split = 1). */
 /* The backward DATA path of that pair in one launch (loss.backward() of loco_rl/loco_rl/algorithms/ppo.py:316, the part autograd runs
  * as three `dz @ W` GEMMs and three ELU-backward kernels per network): for every hidden layer l, from the last to the first,
  *     dz_l = (dz_{l+1} W_{l+1}) * ELU'(a_l),     dz_{L-1} = dy,
@@ -577,7 +585,7 @@ int lt_mlp_pack_backward(const lt_mlp_desc* fwd, const float* const* weights, fl
 int64_t lt_mlp_backward_blocks(const lt_mlp_desc* fwd0, const lt_mlp_desc* fwd1, int64_t m);
 int lt_mlp_backward_pair(const lt_mlp_desc* fwd0, const float* bpacked0, const float* dy0, const float* const* acts0, float* const* dz0,
                          float* const* amax0, const lt_mlp_desc* fwd1, const float* bpacked1, const float* dy1, const float* const* acts1,
-                         float* const* dz1, float* const* amax1, int64_t m, float* sat_count, void* stream);
+                         float* const* dz1, float* const* amax1, int64_t m, int acts_split, float* sat_count, void* stream);
 /* Actor forward + the sampling / log-prob / storage-slot writes of lt_rollout_act in one launch (the policy head must have 12 outputs).
  * Philox key step = *step_counter + step_offset. */
 int lt_rollout_policy(const lt_mlp_desc* actor, const float* packed, const float* obs, int64_t n, uint64_t seed, const int64_t* step_counter,

@@ -132,13 +132,14 @@ def load() -> ctypes.CDLL:
     lib.lt_ppo_loss.argtypes = [_vp] * 11 + [ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int] + [_vp] * 5
     lib.lt_elu_backward_bias.argtypes = [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp, _vp]
     lib.lt_elu_backward_bias2.argtypes = [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]
-    lib.lt_wgrad.argtypes = [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp]
+    lib.lt_wgrad.argtypes = [_vp, _vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp]
+    lib.lt_split_rows.argtypes = [_vp, _vp, ctypes.c_int64, _vp]
     lib.lt_wgrad_splits.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
     lib.lt_wgrad_ws_floats.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
     lib.lt_wgrad_ws_floats.restype = ctypes.c_int64
     lib.lt_elu_backward_bias_ws_floats.argtypes = [ctypes.c_int64, ctypes.c_int]
     lib.lt_elu_backward_bias_ws_floats.restype = ctypes.c_int64
-    lib.lt_head_wgrad.argtypes = [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]
+    lib.lt_head_wgrad.argtypes = [_vp, _vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]
     lib.lt_head_wgrad_ws_floats.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
     lib.lt_head_wgrad_ws_floats.restype = ctypes.c_int64
     lib.lt_gae.argtypes = [_vp] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp]
@@ -163,13 +164,13 @@ def load() -> ctypes.CDLL:
     lib.lt_mlp_packed_floats.argtypes = [dp, ctypes.POINTER(ctypes.c_size_t)]
     lib.lt_mlp_pack.argtypes = [dp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]
     lib.lt_mlp_forward.argtypes = [dp, vp, vp, ctypes.c_int64, vp, vp]
-    lib.lt_mlp_forward_pair.argtypes = [dp, vp, vp, dp, vp, vp, ctypes.c_int64, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
+    lib.lt_mlp_forward_pair.argtypes = [dp, vp, vp, dp, vp, vp, ctypes.c_int64, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_int, vp]
     pvp = ctypes.POINTER(vp)
     lib.lt_mlp_backward_packed_floats.argtypes = [dp, ctypes.POINTER(ctypes.c_size_t)]
     lib.lt_mlp_pack_backward.argtypes = [dp, pvp, vp, vp]
     lib.lt_mlp_backward_blocks.argtypes = [dp, dp, ctypes.c_int64]
     lib.lt_mlp_backward_blocks.restype = ctypes.c_int64
-    lib.lt_mlp_backward_pair.argtypes = [dp, vp, vp, pvp, pvp, pvp, dp, vp, vp, pvp, pvp, pvp, ctypes.c_int64, vp, vp]
+    lib.lt_mlp_backward_pair.argtypes = [dp, vp, vp, pvp, pvp, pvp, dp, vp, vp, pvp, pvp, pvp, ctypes.c_int64, ctypes.c_int, vp, vp]
     lib.lt_rollout_policy.argtypes = [dp, vp, vp, ctypes.c_int64, ctypes.c_uint64, vp, ctypes.c_int64] + [vp] * 7
     lib.lt_rollout_policy_value.argtypes = [dp, vp, vp, dp, vp, vp, vp, ctypes.c_int64, ctypes.c_uint64, vp, ctypes.c_int64] + [vp] * 7
     lib.lt_env_step_rollout.argtypes = [ctypes.c_void_p] + [vp] * 6 + [ctypes.c_float, vp, vp, vp]
@@ -183,7 +184,7 @@ def load() -> ctypes.CDLL:
     return lib
 
 
-EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_preset", "lt_cfg_num_presets", "lt_cfg_preset_id", "lt_cfg_obs_dim", "lt_cfg_tactile_dim", "lt_env_create", "lt_env_tactile_update", "lt_env_defer_gate", "lt_env_gate_update", "lt_env_check", "lt_env_set_row_format", "lt_env_step_rows_profiled", "lt_mlp_forward_pair", "lt_mlp_backward_packed_floats", "lt_mlp_pack_backward", "lt_mlp_backward_blocks", "lt_mlp_backward_pair", "lt_env_curriculum_apply_global", "lt_gru_forward", "lt_gru_backward", "lt_ppo_loss", "lt_elu_backward_bias", "lt_elu_backward_bias_ws_floats", "lt_elu_backward_bias2", "lt_wgrad", "lt_wgrad_splits", "lt_wgrad_ws_floats", "lt_adam_clip_step", "lt_adam_clip_step_dev", "lt_ppo_lr_rule", "lt_partial_sums", "lt_elu_backward_bias_nblk", "lt_head_wgrad_nblk", "lt_adam_clip_step_ws_floats", "lt_gae", "lt_head_wgrad", "lt_head_wgrad_ws_floats",
+EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_preset", "lt_cfg_num_presets", "lt_cfg_preset_id", "lt_cfg_obs_dim", "lt_cfg_tactile_dim", "lt_env_create", "lt_env_tactile_update", "lt_env_defer_gate", "lt_env_gate_update", "lt_env_check", "lt_env_set_row_format", "lt_env_step_rows_profiled", "lt_mlp_forward_pair", "lt_mlp_backward_packed_floats", "lt_mlp_pack_backward", "lt_mlp_backward_blocks", "lt_mlp_backward_pair", "lt_env_curriculum_apply_global", "lt_gru_forward", "lt_gru_backward", "lt_ppo_loss", "lt_elu_backward_bias", "lt_elu_backward_bias_ws_floats", "lt_elu_backward_bias2", "lt_wgrad", "lt_split_rows", "lt_wgrad_splits", "lt_wgrad_ws_floats", "lt_adam_clip_step", "lt_adam_clip_step_dev", "lt_ppo_lr_rule", "lt_partial_sums", "lt_elu_backward_bias_nblk", "lt_head_wgrad_nblk", "lt_adam_clip_step_ws_floats", "lt_gae", "lt_head_wgrad", "lt_head_wgrad_ws_floats",
            "lt_env_destroy", "lt_env_state_bytes", "lt_env_bind", "lt_env_reset_all", "lt_env_step", "lt_env_step_profiled", "lt_env_eval_terms",
            "lt_env_curriculum_update", "lt_env_step_rows", "lt_env_step_rollout", "lt_env_get_view", "lt_env_set_command_ranges", "lt_rollout_act", "lt_rollout_record", "lt_mlp_packed_floats", "lt_mlp_pack", "lt_mlp_forward", "lt_rollout_policy", "lt_rollout_policy_value",
            "lt_env_kernel_name"]

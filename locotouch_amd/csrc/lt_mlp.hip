@@ -168,6 +168,7 @@ struct MlpArgs {
   float* st_actions; float* st_mu; float* st_sigma; float* st_logp; float* actions_out;
   // MODE_BACKWARD (the chain of input gradients, module footer): per chain layer the forward activations that gate its output,
   // the per-workgroup maxima of |output| (for lt_wgrad's scale) and a counter of saturated workgroups
+  int acts_split;  // act_out (forward) / gate_in (backward chain) are in the split format: per element one dword, f16 hi | f16 lo << 16 (lt_env.h)
   const float* gate_in[LT_MLP_MAX_LAYERS];
   float* amax_out[LT_MLP_MAX_LAYERS];
   float* sat_count;
@@ -235,6 +236,25 @@ __device__ __forceinline__ void store_split1(float* s_act, int rr, int col, int 
   _Float16* const g = (_Float16*)(s_act + rr * S + (col >> 3) * 8);
   g[col & 7] = h;
   g[8 + (col & 7)] = (_Float16)((x - (float)h) * LO_SCALE);
+}
+
+
+// The SPLIT FORMAT of an activation matrix in HBM (training forward -> backward chain, weight gradients): one dword per element,
+// low half = f16 hi, high half = f16 lo with x = hi + lo / 64 (|x| <= F16_CLAMP) - the pair this kernel forms anyway for its LDS
+// image.  Consumers that multiply on the f16 matrix cores (lt_wgrad) take the halves as they are: no conversion on their side.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 interleave4(const f16x4& hi, const f16x4& lo) {
+  const u32x2 h = __builtin_bit_cast(u32x2, hi), l = __builtin_bit_cast(u32x2, lo);
+  return u32x4{__builtin_amdgcn_perm(l[0], h[0], 0x05040100u), __builtin_amdgcn_perm(l[0], h[0], 0x07060302u),
+               __builtin_amdgcn_perm(l[1], h[1], 0x05040100u), __builtin_amdgcn_perm(l[1], h[1], 0x07060302u)};
+}
+__device__ __forceinline__ f32x4 unsplit4(const u32x4& w) {
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    r[i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[i] & 0xFFFFu)) + (float)__builtin_bit_cast(_Float16, (unsigned short)(w[i] >> 16)) * LO_INV;
+  return r;
 }
 
 // four consecutive input elements starting at element `off` of the input rows: f32, or bf16 widened exactly (read-once: nontemporal)
@@ -360,8 +380,13 @@ __device__ __forceinline__ void convert_pass(const MlpArgs& a, int l, float* s_a
         if (dst) {
           const long long e = row0 + row[u];
           if (e < a.m) {
-            *(f32x4*)(dst + e * N + n0[u]) = x[u][0];
-            *(f32x4*)(dst + e * N + n0[u] + 4) = x[u][1];
+            if (a.acts_split) {
+              *(u32x4*)(dst + e * N + n0[u]) = interleave4(hi[u][0], lo[u][0]);
+              *(u32x4*)(dst + e * N + n0[u] + 4) = interleave4(hi[u][1], lo[u][1]);
+            } else {
+              *(f32x4*)(dst + e * N + n0[u]) = x[u][0];
+              *(f32x4*)(dst + e * N + n0[u] + 4) = x[u][1];
+            }
           }
         }
       }
@@ -416,8 +441,13 @@ __device__ __forceinline__ void convert_pass(const MlpArgs& a, int l, float* s_a
     if (dst) {  // (hidden widths of such networks are multiples of 4: lt_mlp_forward_pair)
       const long long e = row0 + rr;
       if (e < a.m) {
-        if (n0 < N) *(f32x4*)(dst + e * N + n0) = x[0];
-        if (n0 + 4 < N) *(f32x4*)(dst + e * N + n0 + 4) = x[1];
+        if (a.acts_split) {
+          if (n0 < N) *(u32x4*)(dst + e * N + n0) = interleave4(hi[0], lo[0]);
+          if (n0 + 4 < N) *(u32x4*)(dst + e * N + n0 + 4) = interleave4(hi[1], lo[1]);
+        } else {
+          if (n0 < N) *(f32x4*)(dst + e * N + n0) = x[0];
+          if (n0 + 4 < N) *(f32x4*)(dst + e * N + n0 + 4) = x[1];
+        }
       }
     }
   }
@@ -475,6 +505,10 @@ __device__ __forceinline__ float gate_pass(const MlpArgs& a, int l, float* s_act
     x[0] = *(const f32x4*)g;
     x[1] = *(const f32x4*)(g + 4);
     if (ksplit) { x[0] += *(const f32x4*)(g + koff); x[1] += *(const f32x4*)(g + koff + 4); }
+    if (a.acts_split) {  // (uniform) the forward left (hi, lo) pairs: a = hi + lo / 64
+      gt[u][0] = unsplit4(__builtin_bit_cast(u32x4, gt[u][0]));
+      gt[u][1] = unsplit4(__builtin_bit_cast(u32x4, gt[u][1]));
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1180,7 +1214,7 @@ int lt_mlp_forward(const lt_mlp_desc* desc, const float* packed, const float* x,
 // outputs y0 [m][dims0[L0]], y1 [m][dims1[L1]] and, for the backward pass, the activations behind every hidden layer
 // (acts0[l], acts1[l]: [m][dims[l + 1]], l < L - 1; hidden widths must be multiples of 4).
 int lt_mlp_forward_pair(const lt_mlp_desc* d0, const float* packed0, const float* x0, const lt_mlp_desc* d1, const float* packed1, const float* x1,
-                        int64_t m, float* y0, float* y1, float* const* acts0, float* const* acts1, void* stream) {
+                        int64_t m, float* y0, float* y1, float* const* acts0, float* const* acts1, int acts_split, void* stream) {
   if (!desc_ok(d0) || !desc_ok(d1) || !packed0 || !packed1 || !x0 || !x1 || !y0 || !y1 || !acts0 || !acts1 || m <= 0) {
     lt_set_error("lt_mlp_forward_pair: invalid argument");
     return LT_EINVAL;
@@ -1194,7 +1228,7 @@ int lt_mlp_forward_pair(const lt_mlp_desc* d0, const float* packed0, const float
   for (int k = 0; k < 2; ++k) {
     fill_args(ds[k], d.net[k]);
     d.net[k].mode = MODE_FORWARD;
-    d.net[k].packed = pk[k]; d.net[k].x = xs[k]; d.net[k].m = m; d.net[k].y = ys[k];
+    d.net[k].packed = pk[k]; d.net[k].x = xs[k]; d.net[k].m = m; d.net[k].y = ys[k]; d.net[k].acts_split = acts_split != 0;
     for (int l = 0; l + 1 < ds[k]->num_layers; ++l) {
       if (!as[k][l] || (ds[k]->dims[l + 1] & 3)) { lt_set_error("lt_mlp_forward_pair: hidden widths must be multiples of 4 and every activation buffer given"); return LT_EINVAL; }
       d.net[k].act_out[l] = as[k][l];
@@ -1290,7 +1324,7 @@ int64_t lt_mlp_backward_blocks(const lt_mlp_desc* fwd0, const lt_mlp_desc* fwd1,
 // gradients reached the f16 image's bound (LT_MLP_INPUT_CLAMP) - the result is then saturated, not exact.
 int lt_mlp_backward_pair(const lt_mlp_desc* fwd0, const float* bpacked0, const float* dy0, const float* const* acts0, float* const* dz0, float* const* amax0,
                          const lt_mlp_desc* fwd1, const float* bpacked1, const float* dy1, const float* const* acts1, float* const* dz1, float* const* amax1,
-                         int64_t m, float* sat_count, void* stream) {
+                         int64_t m, int acts_split, float* sat_count, void* stream) {
   lt_mlp_desc bd[2];
   const lt_mlp_desc* fw[2] = {fwd0, fwd1};
   const float* pk[2] = {bpacked0, bpacked1};
@@ -1307,6 +1341,7 @@ int lt_mlp_backward_pair(const lt_mlp_desc* fwd0, const float* bpacked0, const f
     for (int l = 0; l + 1 < fw[k]->num_layers; ++l)
       if (!ac[k][l] || !dz[k][l] || !am[k][l]) { lt_set_error("lt_mlp_backward_pair: null layer buffer"); return LT_EINVAL; }
     fill_backward(&bd[k], fw[k]->num_layers, pk[k], dy[k], m, ac[k], dz[k], am[k], sat_count, d.net[k]);
+    d.net[k].acts_split = acts_split != 0;
   }
   return launch(d, 2, (hipStream_t)stream);
 }

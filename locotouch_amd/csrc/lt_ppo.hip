@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void lt_partial_sums_kernel(const SumJobs J) {
 constexpr int HW_ROWS = 96, HW_MAX_N = 16;
 
 template <int NN>
-__global__ __launch_bounds__(256) void lt_head_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, long long M, int n, int k,
+__global__ __launch_bounds__(256) void lt_head_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int x_split, long long M, int n, int k,
                                                             float* __restrict__ ws) {
   const int k4 = k >> 2, lanes = 256 / k4;
   const int c4 = threadIdx.x % k4, rl = threadIdx.x / k4;
@@ -287,6 +287,14 @@ __global__ __launch_bounds__(256) void lt_head_wgrad_kernel(const float* __restr
         const long long row = r0 + r + u * lanes;
         const bool ok = (r + u * lanes) < HW_ROWS && row < M;
         xv[u] = ok ? ((const float4*)(x + row * k))[c4] : float4{0.f, 0.f, 0.f, 0.f};
+        if (x_split) {  // (uniform) split format of the training forward (lt_mlp.hip): dword = f16 hi | f16 lo << 16, x = hi + lo / 64
+          const unsigned w[4] = {__float_as_uint(xv[u].x), __float_as_uint(xv[u].y), __float_as_uint(xv[u].z), __float_as_uint(xv[u].w)};
+          float f[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            f[i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[i] & 0xFFFFu)) + (float)__builtin_bit_cast(_Float16, (unsigned short)(w[i] >> 16)) * (1.f / 64.f);
+          xv[u] = float4{f[0], f[1], f[2], f[3]};
+        }
 #pragma unroll
         for (int j = 0; j < NN; ++j) d[u][j] = (ok && j < n) ? dy[row * n + j] : 0.f;
       }
@@ -463,7 +471,7 @@ static int elu_backward_bias(const float* da, const float* a, int64_t M, int N, 
 
 extern "C" int64_t lt_head_wgrad_ws_floats(int64_t M, int n, int k) { return ((M + HW_ROWS - 1) / HW_ROWS) * ((int64_t)n * k + HW_MAX_N); }
 
-extern "C" int lt_head_wgrad(const float* dy, const float* x, int64_t M, int n, int k, float* dw, float* db, float* ws, void* stream) {
+extern "C" int lt_head_wgrad(const float* dy, const float* x, int x_split, int64_t M, int n, int k, float* dw, float* db, float* ws, void* stream) {
   if (!dy || !x || !ws || M < 1 || n < 1 || n > HW_MAX_N || k < 4 || (k & 3) || k > 1024) {
     lt_set_error("lt_head_wgrad: invalid argument (1 <= n <= 16, k a multiple of 4, 4 <= k <= 1024)");
     return LT_EINVAL;
@@ -478,11 +486,11 @@ extern "C" int lt_head_wgrad(const float* dy, const float* x, int64_t M, int n, 
   const dim3 g((unsigned)nblk), b(256);
   hipStream_t st = (hipStream_t)stream;
   switch (nn) {
-    case 1: hipLaunchKernelGGL(lt_head_wgrad_kernel<1>, g, b, lds, st, dy, x, (long long)M, n, k, ws); break;
-    case 4: hipLaunchKernelGGL(lt_head_wgrad_kernel<4>, g, b, lds, st, dy, x, (long long)M, n, k, ws); break;
-    case 8: hipLaunchKernelGGL(lt_head_wgrad_kernel<8>, g, b, lds, st, dy, x, (long long)M, n, k, ws); break;
-    case 12: hipLaunchKernelGGL(lt_head_wgrad_kernel<12>, g, b, lds, st, dy, x, (long long)M, n, k, ws); break;
-    default: hipLaunchKernelGGL(lt_head_wgrad_kernel<16>, g, b, lds, st, dy, x, (long long)M, n, k, ws); break;
+    case 1: hipLaunchKernelGGL(lt_head_wgrad_kernel<1>, g, b, lds, st, dy, x, x_split, (long long)M, n, k, ws); break;
+    case 4: hipLaunchKernelGGL(lt_head_wgrad_kernel<4>, g, b, lds, st, dy, x, x_split, (long long)M, n, k, ws); break;
+    case 8: hipLaunchKernelGGL(lt_head_wgrad_kernel<8>, g, b, lds, st, dy, x, x_split, (long long)M, n, k, ws); break;
+    case 12: hipLaunchKernelGGL(lt_head_wgrad_kernel<12>, g, b, lds, st, dy, x, x_split, (long long)M, n, k, ws); break;
+    default: hipLaunchKernelGGL(lt_head_wgrad_kernel<16>, g, b, lds, st, dy, x, x_split, (long long)M, n, k, ws); break;
   }
   if (dw) hipLaunchKernelGGL(lt_partial_sum_kernel, dim3((unsigned)((n * k + n + 15) / 16)), b, 0, st, ws, nblk, (long long)n * k + HW_MAX_N, n * k + n, n * k, dw, db);
   const hipError_t e = hipGetLastError();

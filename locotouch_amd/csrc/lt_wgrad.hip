@@ -62,6 +62,22 @@ __device__ __forceinline__ void split8(const f32x4 (&v)[8], float scale, f16x8& 
   }
 }
 
+// the same fragments from operands stored in the SPLIT FORMAT (dword = f16 hi | f16 lo << 16; written by the training forward and
+// by lt_split_rows): two byte permutes per pair of rows instead of ~7 conversion instructions
+template <int U>
+__device__ __forceinline__ void unpack8(const f32x4 (&v)[8], f16x8& hi, f16x8& lo) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 h, l;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const unsigned w0 = __float_as_uint(v[2 * p][U]), w1 = __float_as_uint(v[2 * p + 1][U]);
+    h[p] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+    l[p] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+  }
+  hi = __builtin_bit_cast(f16x8, h);
+  lo = __builtin_bit_cast(f16x8, l);
+}
+
 struct WgradArgs {
   const float* dz;      // [M][N]
   const float* x;       // [M][K]
@@ -71,6 +87,7 @@ struct WgradArgs {
   const float* amax;    // per-block maxima of |dz| (nblk_amax floats) or nullptr (scale 1)
   int nblk_amax;
   float* slabs;         // [splits][N][K]
+  int x_split;          // x is in the split format (one dword per element: f16 hi | f16 lo << 16, lt_mlp.hip): no conversion here
   float* db;            // optional [splits][N]: the slices' column sums of dz (the bias gradient's partials), by the tiles of the first k column
 };
 
@@ -139,7 +156,11 @@ __global__ __launch_bounds__(128, 2) void lt_wgrad_kernel(const WgradArgs a) {
     }
     f16x8 ah[TA], al[TA], bh[TB], bl[TB];
     split8<0>(va, scale, ah[0], al[0]); split8<1>(va, scale, ah[1], al[1]); split8<2>(va, scale, ah[2], al[2]); split8<3>(va, scale, ah[3], al[3]);
-    split8<0>(vb, 1.f, bh[0], bl[0]); split8<1>(vb, 1.f, bh[1], bl[1]); split8<2>(vb, 1.f, bh[2], bl[2]); split8<3>(vb, 1.f, bh[3], bl[3]);
+    if (a.x_split) {  // (uniform)
+      unpack8<0>(vb, bh[0], bl[0]); unpack8<1>(vb, bh[1], bl[1]); unpack8<2>(vb, bh[2], bl[2]); unpack8<3>(vb, bh[3], bl[3]);
+    } else {
+      split8<0>(vb, 1.f, bh[0], bl[0]); split8<1>(vb, 1.f, bh[1], bl[1]); split8<2>(vb, 1.f, bh[2], bl[2]); split8<3>(vb, 1.f, bh[3], bl[3]);
+    }
     if (s + 1 < s1) issue(s + 1);  // the next step's 16 loads fly while this step's 48 MFMAs run
 #pragma unroll
     for (int p = 0; p < TA; ++p) {
@@ -212,7 +233,8 @@ extern "C" int lt_wgrad_splits(int64_t M, int N, int K) {
 
 extern "C" int64_t lt_wgrad_ws_floats(int64_t M, int N, int K) { return (int64_t)lt_wgrad_splits(M, N, K) * N * K; }
 
-extern "C" int lt_wgrad(const float* dz, const float* x, int64_t M, int N, int K, const float* amax_blocks, int nblk_amax, float* slabs, float* db_slabs, void* stream) {
+extern "C" int lt_wgrad(const float* dz, const float* x, int x_split, int64_t M, int N, int K, const float* amax_blocks, int nblk_amax, float* slabs, float* db_slabs,
+                        void* stream) {
   if (!dz || !x || !slabs || M < 1 || N < 4 || K < 4 || (N & 3) || (K & 3) || (amax_blocks && nblk_amax < 1)) {
     lt_set_error("lt_wgrad: invalid argument (N and K multiples of 4)");
     return LT_EINVAL;
@@ -223,8 +245,37 @@ extern "C" int lt_wgrad(const float* dz, const float* x, int64_t M, int N, int K
   a.tiles_k = (K + 16 * TB - 1) / (16 * TB);
   a.splits = pick_splits((long long)M, a.tiles_n * a.tiles_k);
   a.amax = amax_blocks; a.nblk_amax = amax_blocks ? nblk_amax : 0;
-  a.slabs = slabs; a.db = db_slabs;
+  a.slabs = slabs; a.db = db_slabs; a.x_split = x_split != 0;
   hipLaunchKernelGGL(lt_wgrad_kernel, dim3((unsigned)((a.tiles_n * a.tiles_k * a.splits + 7) / 8 * 8)), dim3(128), 0, (hipStream_t)stream, a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
+  return LT_OK;
+}
+
+// Rows in the split format (see unpack8): out[i] = f16 hi | f16 lo << 16 of clamp(x[i], +-LT_MLP_INPUT_CLAMP) - the observation rows of a
+// PPO update, once per update (the first layer's weight gradient reads them in each of the 20 optimizer steps; the forward pass
+// saturates its input rows at the same bound, so these ARE the values the first layer multiplied).
+namespace {
+__global__ __launch_bounds__(256) void lt_split_rows_kernel(const float* __restrict__ x, unsigned* __restrict__ out, long long n4) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = ((const f32x4*)x)[i];
+  u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float c = __builtin_amdgcn_fmed3f(v[k], -(float)LT_MLP_INPUT_CLAMP, (float)LT_MLP_INPUT_CLAMP);
+    const _Float16 h = (_Float16)c;
+    const _Float16 l = (_Float16)((c - (float)h) * LO_SCALE);
+    o[k] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+  }
+  ((u32x4*)out)[i] = o;
+}
+}  // namespace
+
+extern "C" int lt_split_rows(const float* x, void* out, int64_t count, void* stream) {
+  if (!x || !out || count < 4 || (count & 3)) { lt_set_error("lt_split_rows: invalid argument (count a multiple of 4)"); return LT_EINVAL; }
+  hipLaunchKernelGGL(lt_split_rows_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (unsigned*)out, (long long)(count / 4));
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;

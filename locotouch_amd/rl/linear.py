@@ -110,7 +110,7 @@ def _head_wgrad(dy: torch.Tensor, x: torch.Tensor):
     db = torch.empty(n, device=x.device, dtype=torch.float32)
     ws = torch.empty(int(lib.lt_head_wgrad_ws_floats(m, n, k)), device=x.device, dtype=torch.float32)
     vp = ctypes.c_void_p
-    _abi.check(lib.lt_head_wgrad(vp(dy.data_ptr()), vp(x.data_ptr()), m, n, k, vp(dw.data_ptr()), vp(db.data_ptr()), vp(ws.data_ptr()),
+    _abi.check(lib.lt_head_wgrad(vp(dy.data_ptr()), vp(x.data_ptr()), 0, m, n, k, vp(dw.data_ptr()), vp(db.data_ptr()), vp(ws.data_ptr()),
                                  vp(torch.cuda.current_stream(x.device).cuda_stream)), "lt_head_wgrad")
     return dw, db
 

@@ -140,7 +140,7 @@ class _PairForward(torch.autograd.Function):
         arr = [(vp * max(1, len(a)))(*[t.data_ptr() for t in a]) for a in acts]
         _abi.check(lib.lt_mlp_forward_pair(ctypes.byref(nets[0].desc), vp(nets[0].packed.data_ptr()), vp(x0.data_ptr()),
                                            ctypes.byref(nets[1].desc), vp(nets[1].packed.data_ptr()), vp(x1.data_ptr()), m,
-                                           vp(ys[0].data_ptr()), vp(ys[1].data_ptr()), arr[0], arr[1], PackedMLP._stream()), "lt_mlp_forward_pair")
+                                           vp(ys[0].data_ptr()), vp(ys[1].data_ptr()), arr[0], arr[1], 0, PackedMLP._stream()), "lt_mlp_forward_pair")
         if pair.check_domain:  # once per PPO update (PackedPair.arm_domain_check): largest |value| that entered any layer
             pair.check_domain = False
             with torch.no_grad():
@@ -272,13 +272,13 @@ def backward_chain(weights, biases_out, weights_out, x, acts, dy, sums: SumJobs)
         if l == L - 1 and _head_wgrad_ok(dz, inp):
             nblk = int(lib.lt_head_wgrad_nblk(m))
             ws = torch.empty(int(lib.lt_head_wgrad_ws_floats(m, n, k)), device=inp.device, dtype=torch.float32)
-            _abi.check(lib.lt_head_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), m, n, k, vp(None), vp(None), vp(ws.data_ptr()), stream), "lt_head_wgrad")
+            _abi.check(lib.lt_head_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), 0, m, n, k, vp(None), vp(None), vp(ws.data_ptr()), stream), "lt_head_wgrad")
             sums.add(ws, nblk, n * k + 16, n * k + n, n * k, weights_out[l], biases_out[l])
         elif amax is not None and USE_SPLIT_F16_WGRAD and n % 4 == 0 and k % 4 == 0:
             # dW = dz^T x on the f16 matrix cores, f32-equivalent (csrc/lt_wgrad.hip): slices of the rows -> slabs -> the joint sum launch
             sp = int(lib.lt_wgrad_splits(m, n, k))
             slabs = torch.empty(sp * n * k, device=inp.device, dtype=torch.float32)
-            _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), m, n, k, vp(amax.data_ptr()), amax.numel(), vp(slabs.data_ptr()), vp(None), stream), "lt_wgrad")
+            _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), 0, m, n, k, vp(amax.data_ptr()), amax.numel(), vp(slabs.data_ptr()), vp(None), stream), "lt_wgrad")
             sums.add(slabs, sp, n * k, n * k, n * k, weights_out[l])
         else:
             sp = pick_splits(m, n, k)
@@ -321,39 +321,56 @@ class PackedPair:
         self.domain_max = None
         return v >= float(_abi.CONSTS["LT_MLP_INPUT_CLAMP"])
 
-    def forward_raw(self, x0: torch.Tensor, x1: torch.Tensor):
-        """The launch without autograd: ((mean, value), (activations of the actor, of the critic)); re-packs the live parameters."""
+    def forward_raw(self, x0: torch.Tensor, x1: torch.Tensor, split: bool | None = None):
+        """The launch without autograd: ((mean, value), (activations of the actor, of the critic)); re-packs the live parameters.
+        `split` (default: whenever the fused backward pass will consume them): the activations are written in the kernel's split
+        format - one dword per element, f16 hi | f16 lo << 16, value = hi + lo / 64 (include/lt_env.h, lt_mlp_forward_pair) - which
+        the backward chain and the weight-gradient kernel read without converting; the tensors keep dtype float32 as a container."""
         self.a.pack()
         self.b.pack()
         lib = _abi.load()
         vp = ctypes.c_void_p
         nets = (self.a, self.b)
         m = x0.shape[0]
+        if split is None:
+            split = self._fused_backward_possible(x0, x1)
+        self.acts_split = bool(split)
         ys, acts = _alloc_outputs(nets, m, x0.device)
         arr = [(vp * max(1, len(a)))(*[t.data_ptr() for t in a]) for a in acts]
         _abi.check(lib.lt_mlp_forward_pair(ctypes.byref(nets[0].desc), vp(nets[0].packed.data_ptr()), vp(x0.data_ptr()),
                                            ctypes.byref(nets[1].desc), vp(nets[1].packed.data_ptr()), vp(x1.data_ptr()), m,
-                                           vp(ys[0].data_ptr()), vp(ys[1].data_ptr()), arr[0], arr[1], PackedMLP._stream()), "lt_mlp_forward_pair")
+                                           vp(ys[0].data_ptr()), vp(ys[1].data_ptr()), arr[0], arr[1], int(self.acts_split), PackedMLP._stream()), "lt_mlp_forward_pair")
         if self.check_domain:
             self.check_domain = False
-            m_ = torch.stack([t.abs().max() for t in (x0, x1, *acts[0], *acts[1])]).max()
+            hidden = [t.view(torch.float16)[:, 0::2] if self.acts_split else t for t in (*acts[0], *acts[1])]  # (the hi halves carry the magnitude)
+            m_ = torch.stack([t.abs().max().float() for t in (x0, x1, *hidden)]).max()
             self.domain_max = m_ if self.domain_max is None else torch.maximum(self.domain_max, m_)
         return ys, acts
 
-    def _fused_backward_ok(self, x0, x1, dy0, dy1) -> bool:
+    def split_rows(self, x: torch.Tensor) -> torch.Tensor:
+        """Observation rows in the split format (lt_split_rows): converted once per PPO update for the first layer's weight gradient."""
+        lib = _abi.load()
+        out = torch.empty_like(x, dtype=torch.float32)
+        _abi.check(lib.lt_split_rows(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), x.numel(), PackedMLP._stream()), "lt_split_rows")
+        return out
+
+    def _fused_backward_possible(self, x0, x1) -> bool:
         from .linear import _head_wgrad_ok
 
         if not (USE_FUSED_BACKWARD and USE_SPLIT_F16_WGRAD and self.a.backward_ok() and self.b.backward_ok()):
             return False
-        for net, x, dy in ((self.a, x0, dy0), (self.b, x1, dy1)):
+        for net, x in ((self.a, x0), (self.b, x1)):
             dims = [net.desc.dims[i] for i in range(net.desc.num_layers + 1)]
             if dims[0] % 4 or x.dtype != torch.float32 or not x.is_contiguous():
                 return False
-            if not _head_wgrad_ok(dy, torch.empty(0, dims[-2], device=x.device)):
+            if not _head_wgrad_ok(torch.empty(0, dims[-1], device=x.device), torch.empty(0, dims[-2], device=x.device)):
                 return False
         return True
 
-    def _backward_fused(self, x0, x1, acts, dy0, dy1, grad_of, sums) -> None:
+    def _fused_backward_ok(self, x0, x1, dy0, dy1) -> bool:
+        return self._fused_backward_possible(x0, x1) and dy0.dtype == torch.float32 and dy1.dtype == torch.float32
+
+    def _backward_fused(self, x0, x1, acts, dy0, dy1, grad_of, sums, x_split_rows=None) -> None:
         """The backward pass as: two head launches (lt_head_wgrad), ONE launch for both stacks' chains of input gradients
         (lt_mlp_backward_pair: dz of every hidden layer, ELU' applied in the layer epilogue, per-workgroup max |dz|), six weight
         gradients on the matrix cores that also leave the bias gradients' partials (lt_wgrad), one launch of ordered sums."""
@@ -362,6 +379,10 @@ class PackedPair:
         stream = PackedMLP._stream()
         m = x0.shape[0]
         nets, xs = (self.a, self.b), (x0, x1)
+        asp = int(getattr(self, "acts_split", False))   # format of `acts` (forward_raw)
+        xsp = int(x_split_rows is not None)             # the observation rows in the split format, from the caller (once per update)
+        if xsp:
+            xs = x_split_rows
         dys = [d if d.is_contiguous() else d.contiguous() for d in (dy0, dy1)]
         dev = x0.device
         if getattr(self, "sat", None) is None:
@@ -373,7 +394,7 @@ class PackedPair:
             L = len(net.linears)
             n, kk = dys[k].shape[1], acts[k][L - 2].shape[1]
             ws = torch.empty(int(lib.lt_head_wgrad_ws_floats(m, n, kk)), device=dev, dtype=torch.float32)
-            _abi.check(lib.lt_head_wgrad(vp(dys[k].data_ptr()), vp(acts[k][L - 2].data_ptr()), m, n, kk, vp(None), vp(None), vp(ws.data_ptr()), stream), "lt_head_wgrad")
+            _abi.check(lib.lt_head_wgrad(vp(dys[k].data_ptr()), vp(acts[k][L - 2].data_ptr()), asp, m, n, kk, vp(None), vp(None), vp(ws.data_ptr()), stream), "lt_head_wgrad")
             sums.add(ws, int(lib.lt_head_wgrad_nblk(m)), n * kk + 16, n * kk + n, n * kk, grad_of[net.linears[L - 1].weight], grad_of[net.linears[L - 1].bias])
             dz = [torch.empty_like(a) for a in acts[k]]
             am = torch.empty(L - 1, nblk, device=dev, dtype=torch.float32)
@@ -383,7 +404,7 @@ class PackedPair:
             arrs.append((arr(*[a.data_ptr() for a in acts[k]]), arr(*[t.data_ptr() for t in dz]), arr(*[am[l].data_ptr() for l in range(L - 1)])))
         _abi.check(lib.lt_mlp_backward_pair(ctypes.byref(nets[0].desc), vp(nets[0].bpacked.data_ptr()), vp(dys[0].data_ptr()), *arrs[0],
                                             ctypes.byref(nets[1].desc), vp(nets[1].bpacked.data_ptr()), vp(dys[1].data_ptr()), *arrs[1],
-                                            m, vp(self.sat.data_ptr()), stream), "lt_mlp_backward_pair")
+                                            m, asp, vp(self.sat.data_ptr()), stream), "lt_mlp_backward_pair")
         for k, net in enumerate(nets):
             for l in range(len(net.linears) - 2, -1, -1):
                 inp = acts[k][l - 1] if l > 0 else xs[k]
@@ -392,8 +413,8 @@ class PackedPair:
                 sp = int(lib.lt_wgrad_splits(m, n, kk))
                 slabs = torch.empty(sp * n * kk + sp * n, device=dev, dtype=torch.float32)
                 dbs = slabs[sp * n * kk:]
-                _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), m, n, kk, vp(amaxs[k][l].data_ptr()), nblk, vp(slabs.data_ptr()),
-                                        vp(dbs.data_ptr()), stream), "lt_wgrad")
+                _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), asp if l > 0 else xsp, m, n, kk, vp(amaxs[k][l].data_ptr()), nblk,
+                                        vp(slabs.data_ptr()), vp(dbs.data_ptr()), stream), "lt_wgrad")
                 sums.add(slabs, sp, n * kk, n * kk, n * kk, grad_of[net.linears[l].weight])
                 sums.add(dbs, sp, n, n, n, grad_of[net.linears[l].bias])
         self._keep_bwd = (dzs, amaxs, dys)
@@ -402,13 +423,17 @@ class PackedPair:
         """Device counter of saturated workgroups of the fused backward chain (None: that path has not run)."""
         return getattr(self, "sat", None)
 
-    def backward_raw(self, x0, x1, acts, dy0, dy1, grad_of) -> None:
-        """Both stacks' backward passes, every parameter gradient written into `grad_of[param]` (the flat bucket's views)."""
+    def backward_raw(self, x0, x1, acts, dy0, dy1, grad_of, x_split_rows=None) -> None:
+        """Both stacks' backward passes, every parameter gradient written into `grad_of[param]` (the flat bucket's views).
+        `x_split_rows`: (x0, x1) in the split format (`split_rows`), if the caller has them."""
         sums = SumJobs()
         if self._fused_backward_ok(x0, x1, dy0, dy1):
-            self._backward_fused(x0, x1, acts, dy0, dy1, grad_of, sums)
+            self._backward_fused(x0, x1, acts, dy0, dy1, grad_of, sums, x_split_rows)
             sums.launch()
             return
+        if getattr(self, "acts_split", False):
+            raise RuntimeError("PackedPair.backward_raw: the activations are in the split format, which only the fused backward pass reads "
+                               "(forward_raw(..., split=False) for the library path)")
         for net, x, a, dy in ((self.a, x0, acts[0], dy0), (self.b, x1, acts[1], dy1)):
             ws = [lin.weight for lin in net.linears]
             backward_chain(ws, [grad_of[lin.bias] for lin in net.linears], [grad_of[lin.weight] for lin in net.linears], x, a, dy, sums)

@@ -218,10 +218,13 @@ class PPO:
         perm_o, perm_co = obs[perm], cobs[perm]
         if perm_o.dtype != torch.float32:  # bf16 observation storage (BASELINE config 5): the update computes in f32
             perm_o, perm_co = perm_o.float(), perm_co.float()
+        # the same rows in the MLP kernels' split format (f16 hi | f16 lo): what the first layer's weight gradient multiplies, 20 times
+        split_o = (pair.split_rows(perm_o), pair.split_rows(perm_co)) if pair._fused_backward_possible(perm_o[:m], perm_co[:m]) else None
         for step_i in range(self.num_learning_epochs * self.num_mini_batches):
             i = step_i % self.num_mini_batches
             idx = perm[i * m:(i + 1) * m]
             o, co = perm_o[i * m:(i + 1) * m], perm_co[i * m:(i + 1) * m]
+            xs = (split_o[0][i * m:(i + 1) * m], split_o[1][i * m:(i + 1) * m]) if split_o is not None else None
             (mu, value), acts = pair.forward_raw(o, co)
             dmu = torch.empty_like(mu)
             dvalue = torch.empty(m, 1, device=dev, dtype=torch.float32)
@@ -240,7 +243,7 @@ class PPO:
             _abi.check(lib.lt_ppo_lr_rule(vp(kl.data_ptr()) if kl is not None else vp(None), float(self.desired_kl or 0.0), 1e-5, 1e-2, 1.5,
                                           vp(lr_dev.data_ptr()), vp(stats.data_ptr()), vp(out.data_ptr()), vp(grad_of[ac.std].data_ptr()), a_dim, stream),
                        "lt_ppo_lr_rule")
-            pair.backward_raw(o, co, acts, dmu, dvalue, grad_of)
+            pair.backward_raw(o, co, acts, dmu, dvalue, grad_of, xs)
             if self.dist.world_size > 1:
                 self.dist.all_reduce_mean_(self._flat_grad)  # RCCL all-reduce of the policy gradients over xGMI
             fa.step_dev(self.max_grad_norm, lr_dev)

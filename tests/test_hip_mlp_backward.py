@@ -73,7 +73,13 @@ def test_fused_backward_matches_float64(m, scale):
             res[fused] = grads
             if fused:
                 dzs, amaxs, _ = pair._keep_bwd
-                assert float(pair.saturated()) == 0.0
+                assert float(pair.saturated()) == 0.0 and pair.acts_split
+                # the observation rows handed over in the split format (as PPO._direct_update does, once per update): same gradients
+                again = {p: torch.full_like(p, float("nan")) for p in grads}
+                pair.backward_raw(x0, x1, acts, dy0, dy1, again, (pair.split_rows(x0), pair.split_rows(x1)))
+                torch.cuda.synchronize()
+                for p in grads:
+                    assert torch.equal(again[p], grads[p])
         finally:
             M.USE_FUSED_BACKWARD = True
     for k, (net, x, dy) in enumerate(((actor, x0, dy0), (critic, x1, dy1))):

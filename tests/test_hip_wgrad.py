@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _wgrad(dz, x, amax=None):
+def _wgrad(dz, x, amax=None, x_split=False):
     import torch
 
     from locotouch_amd import _abi
@@ -22,7 +22,7 @@ def _wgrad(dz, x, amax=None):
     slabs = torch.empty(int(lib.lt_wgrad_ws_floats(m, n, k)), device=dz.device)
     assert slabs.numel() == sp * n * k
     st = vp(torch.cuda.current_stream().cuda_stream)
-    _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(x.data_ptr()), m, n, k, vp(amax.data_ptr()) if amax is not None else vp(None),
+    _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(x.data_ptr()), int(x_split), m, n, k, vp(amax.data_ptr()) if amax is not None else vp(None),
                             0 if amax is None else amax.numel(), vp(slabs.data_ptr()), vp(None), st), "lt_wgrad")
     return slabs.view(sp, n, k).sum(0), sp
 
@@ -119,3 +119,29 @@ def test_partial_sums_launch_adds_every_job_in_a_fixed_order():
     torch.cuda.synchronize()
     for (a0, a1), (_, o0, o1, _, _) in zip(first, refs):
         assert torch.equal(a0, o0) and (a1 is None or torch.equal(a1, o1))
+
+
+def test_operand_in_the_split_format_gives_the_same_gradient_as_the_clamped_rows():
+    """lt_split_rows + lt_wgrad(x_split = 1): x handed over as (f16 hi | f16 lo << 16) dwords - what the training forward writes for
+    its activations - equals the on-the-fly split of clamp(x, +-1000) bit for bit (same halves, same MFMAs)."""
+    import torch
+
+    from locotouch_amd import _abi
+
+    lib, vp = _abi.load(), ctypes.c_void_p
+    m, n, k = 6144, 256, 348
+    g = torch.Generator(device="cuda").manual_seed(1)
+    dz = torch.randn(m, n, device="cuda", generator=g) * 1e-4
+    x = torch.randn(m, k, device="cuda", generator=g)
+    x[::7, ::5] *= 900.0  # beyond the bound: saturated by the split format, as by the forward kernel
+    am = dz.abs().max().reshape(1)
+    xs = torch.empty(m, k, device="cuda", dtype=torch.int32)
+    _abi.check(lib.lt_split_rows(vp(x.data_ptr()), vp(xs.data_ptr()), x.numel(), vp(torch.cuda.current_stream().cuda_stream)), "lt_split_rows")
+    halves = xs.view(torch.float16).view(m, k, 2).float()
+    rebuilt = halves[..., 0] + halves[..., 1] / 64.0
+    xc = x.clamp(-1000.0, 1000.0)
+    assert float((rebuilt - xc).abs().max()) <= 2.0 ** -21 * 1000.0 and float(((rebuilt - xc).abs() / xc.abs().clamp_min(1e-3)).max()) < 5e-7  # 2^-21
+    a, _ = _wgrad(dz, xs.view(torch.float32), am, x_split=True)
+    b, _ = _wgrad(dz, xc, am)
+    assert torch.equal(a, b)
+    assert lib.lt_split_rows(vp(x.data_ptr()), vp(xs.data_ptr()), 6, None) != 0
