@@ -34,6 +34,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "lt_env.h"
 #include "lt_internal.h"
 
@@ -87,6 +89,7 @@ struct WgradArgs {
   const float* amax;    // per-block maxima of |dz| (nblk_amax floats) or nullptr (scale 1)
   int nblk_amax;
   float* slabs;         // [splits][N][K]
+  int probe;            // measurements only (LT_WGRAD_PROBE): 1 = fetch the first step's panels only, 2 = no MFMAs, 3 = no LDS staging after the first
   int x_split;          // x is in the split format (one dword per element: f16 hi | f16 lo << 16, lt_mlp.hip): no conversion here
   float* db;            // optional [splits][N]: the slices' column sums of dz (the bias gradient's partials), by the tiles of the first k column
 };
@@ -215,6 +218,176 @@ __global__ __launch_bounds__(128, 2) void lt_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ---- the same product on 128 x 128 tiles shared through LDS ---------------------------------------------------------------------------
+// The one-wave-per-tile kernel above moves 16 KiB from L2 per wave and step for 48 MFMAs - 8 waves of a CU ask the L2 port for
+// 128 KiB per 1536 matrix-pipe cycles, 83 B/clk of a port that delivers ~37 (89 GB/s per CU measured in lt_mlp.hip): 54 us for the
+// 512 x 348 layer whose MFMA time is 10 us.  Here a workgroup of four waves (2 x 2) owns a 128 x 128 tile: a step's 32 x 128 panels
+// of dz and x enter the CU once (32 KiB per 4 x 48 MFMAs: half the traffic), go through LDS as (hi, lo) dwords - dz split by the
+// thread that fetched it (a quarter of the conversions per wave), x copied as it is when it arrives in the split format - and every
+// wave reads its two 32 x 64 halves as the same 16-byte (row 4 t + g, columns 4 c ..) pieces the register kernel loads from HBM.
+// Two panel stages in LDS (64 KiB per workgroup, two workgroups per CU), one barrier per step.
+constexpr int PT = 128;  // panel / tile width
+struct Panels { unsigned a[2][32][PT]; unsigned b[2][32][PT]; };
+
+__global__ __launch_bounds__(256, 2) void lt_wgrad128_kernel(const WgradArgs a) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  Panels& S = *reinterpret_cast<Panels*>(s_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 1, wj = wave & 1;  // this wave's 64 x 64 quarter of the tile
+  const int i = lane & 15, g = lane >> 4;
+  const int tiles = a.tiles_n * a.tiles_k;
+  const int per_xcd = (int)gridDim.x >> 3;
+  const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);  // (see lt_wgrad_kernel: a slice's tiles on one XCD)
+  if (item >= tiles * a.splits) return;
+  const int split = item / tiles, tile = item - split * tiles;
+  const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
+  const int n0 = tn * PT, k0 = tk * PT;
+  const long long steps = (a.M + 31) / 32;
+  const long long s0 = steps * split / a.splits, s1 = steps * (split + 1) / a.splits;
+  float scale = 1.f;
+  if (a.amax) {
+    float m = 0.f;
+    for (int b = lane; b < a.nblk_amax; b += 64) m = fmaxf(m, a.amax[b]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xFF) - 127;
+    int se = 7 - e;
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    scale = __uint_as_float((unsigned)(127 + se) << 23);
+  }
+  f32x4 acc[TA][TB];
+#pragma unroll
+  for (int p = 0; p < TA; ++p)
+#pragma unroll
+    for (int q = 0; q < TB; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // panel fetch: thread -> rows (tid >> 5) + 8 j, j < 4, columns 4 (tid & 31) .. + 3 of both panels (a wave: two whole 512-byte rows)
+  const int prow = tid >> 5, pcol = 4 * (tid & 31);
+  const int ca = min(n0 + pcol, a.N - 4), cb = min(k0 + pcol, a.K - 4);  // (overhanging columns re-read the edge: their products are never stored)
+  f32x4 ga[4], gb[4];
+  auto fetch = [&](long long s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      long long r = s * 32 + prow + 8 * j;
+      r = r < a.M ? r : a.M - 1;
+      ga[j] = *(const f32x4*)(a.dz + r * a.N + ca);
+      gb[j] = *(const f32x4*)(a.x + r * a.K + cb);
+    }
+  };
+  const bool colsum = a.db != nullptr && tk == 0;  // (uniform)
+  f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto to_pair = [&](const f32x4& v, float sc) __attribute__((always_inline)) {  // four values -> four (hi | lo << 16) dwords
+    u32x4 o;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      f32x2 x;
+      x[0] = v[2 * p] * sc; x[1] = v[2 * p + 1] * sc;
+      const f16x2 h = __builtin_convertvector(x, f16x2);
+      const f32x2 d = (x - __builtin_convertvector(h, f32x2)) * LO_SCALE;
+      const f16x2 l = __builtin_convertvector(d, f16x2);
+      const unsigned hw = __builtin_bit_cast(unsigned, h), lw = __builtin_bit_cast(unsigned, l);
+      o[2 * p] = __builtin_amdgcn_perm(lw, hw, 0x05040100u);
+      o[2 * p + 1] = __builtin_amdgcn_perm(lw, hw, 0x07060302u);
+    }
+    return o;
+  };
+  auto stage = [&](int st, long long s) __attribute__((always_inline)) {  // the fetched registers -> panels of stage st
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool live = s * 32 + prow + 8 * j < a.M;  // rows beyond M contribute nothing
+      const f32x4 va = live ? ga[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (colsum) cs += va;
+      *(u32x4*)&S.a[st][prow + 8 * j][pcol] = to_pair(va, scale);
+      *(u32x4*)&S.b[st][prow + 8 * j][pcol] = a.x_split ? __builtin_bit_cast(u32x4, gb[j]) : to_pair(gb[j], 1.f);
+    }
+  };
+  if (s0 < s1) {
+    fetch(s0);
+    stage(0, s0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (long long s = s0; s < s1; ++s) {
+    if (s + 1 < s1 && a.probe != 1) fetch(s + 1);  // in flight under this step's LDS reads and MFMAs
+    f32x4 va[8], vb[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      va[t] = __builtin_bit_cast(f32x4, *(const u32x4*)&S.a[cur][4 * t + g][64 * wi + 4 * i]);
+      vb[t] = __builtin_bit_cast(f32x4, *(const u32x4*)&S.b[cur][4 * t + g][64 * wj + 4 * i]);
+    }
+    f16x8 bh[TB], bl[TB];
+    unpack8<0>(vb, bh[0], bl[0]); unpack8<1>(vb, bh[1], bl[1]); unpack8<2>(vb, bh[2], bl[2]); unpack8<3>(vb, bh[3], bl[3]);
+    f16x8 ah[TA], al[TA];
+    unpack8<0>(va, ah[0], al[0]); unpack8<1>(va, ah[1], al[1]); unpack8<2>(va, ah[2], al[2]); unpack8<3>(va, ah[3], al[3]);
+    if (a.probe == 2) {
+#pragma unroll
+      for (int p = 0; p < TA; ++p)
+#pragma unroll
+        for (int q = 0; q < TB; ++q) acc[p][q][0] += (float)ah[p][0] * (float)bh[q][0] + (float)al[p][1] * (float)bl[q][1];
+    } else {
+#pragma unroll
+    for (int p = 0; p < TA; ++p) {
+      const f16x8 a64 = ah[p] * (_Float16)LO_SCALE;  // exact: |scaled dz| < 2^8
+#pragma unroll
+      for (int q = 0; q < TB; ++q) {
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a64, bh[q], acc[p][q], 0, 0, 0);
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], bl[q], acc[p][q], 0, 0, 0);
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[p], bh[q], acc[p][q], 0, 0, 0);
+      }
+    }
+    }
+    if (s + 1 < s1 && a.probe != 3) stage(cur ^ 1, s + 1);  // (issued in front of the MFMAs instead: 53.9 -> 57.7 us)
+    __syncthreads();  // stage cur^1 is complete; everybody is done reading stage cur
+    cur ^= 1;
+  }
+  // column sums of dz (bias-gradient partials): a thread holds columns pcol .. + 3 over its rows; the 8 row groups meet in LDS
+  if (colsum) {
+    f32x4* const red = reinterpret_cast<f32x4*>(s_raw);  // [8][32] (the panels are dead: the loop ended with a barrier)
+    red[(tid >> 5) * 32 + (tid & 31)] = cs;
+    __syncthreads();
+    if (tid < 32) {
+      f32x4 t = red[tid];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) t += red[r * 32 + tid];
+      if (n0 + 4 * tid < a.N) *(f32x4*)(a.db + (long long)split * a.N + n0 + 4 * tid) = t;
+    }
+  }
+  const float inv = 1.f / (scale * LO_SCALE);
+  float* const out = a.slabs + (long long)split * a.N * a.K;
+  const int k = k0 + 64 * wj + 4 * i;
+#pragma unroll
+  for (int p = 0; p < TA; ++p)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 64 * wi + 4 * (4 * g + r) + p;
+      if (n < a.N && k < a.K) {
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < TB; ++q) o[q] = acc[p][q][r] * inv;
+        *(f32x4*)(out + (long long)n * a.K + k) = o;
+      }
+    }
+}
+
+// Which form runs a shape.  MEASURED (tools/wgrad_bench.py, 24 576 rows, x in the split format; us for 512 x 348 / 256 x 512 / 128 x 256):
+// one wave per 64 x 64 tile 52.7 / 35.6 / 14.8, tiled 50.9 / 35.2 / 16.6 with twice the slices (42 / 64 / 192: twice the slab bytes
+// for lt_partial_sums) - no gain worth the slabs, so the tiled form is OFF unless LT_WGRAD_TILED=1.  Its probes (LT_WGRAD_PROBE) say
+// why: without the panel fetches 49.5 us of 53.9, without the MFMAs 44.8, without the LDS staging 40.0 - no single phase bounds it;
+// LDS reads + unpacking, MFMAs and staging of a wave run one after the other between two barriers, and two workgroups per CU do not
+// hide that.  The floor of either form is the 84 MB of operands from HBM (~17 us) and 10.5 us of MFMA time.
+bool use_tiled(int N, int K) {
+  static const int force = [] { const char* e = getenv("LT_WGRAD_TILED"); return e ? atoi(e) : 0; }();
+  return force != 0 && N >= 96 && K >= 96;
+}
+int pick_splits_tiled(long long M, int tiles) {
+  static const int target = [] { const char* e = getenv("LT_WGRAD_TILED_BLOCKS"); return e ? atoi(e) : 512; }();
+  const long long steps = (M + 31) / 32;
+  long long s = target / tiles;
+  if (s > steps / 4) s = steps / 4;
+  return (int)(s < 1 ? 1 : s);
+}
+
 int pick_splits(long long M, int tiles) {
   // at most 1024 two-wave workgroups (four per CU, two waves per SIMD: a 1025th block would run alone after the others - 24 slices x
   // 48 tiles = 1152 single-wave blocks took 97 us where 21 x 48 = 1008 took 69 us), at least 4 steps of 32 rows per slice
@@ -227,6 +400,7 @@ int pick_splits(long long M, int tiles) {
 }  // namespace
 
 extern "C" int lt_wgrad_splits(int64_t M, int N, int K) {
+  if (use_tiled(N, K)) return pick_splits_tiled((long long)M, ((N + PT - 1) / PT) * ((K + PT - 1) / PT));
   const int tiles = ((N + 16 * TA - 1) / (16 * TA)) * ((K + 16 * TB - 1) / (16 * TB));
   return pick_splits((long long)M, tiles);
 }
@@ -241,12 +415,23 @@ extern "C" int lt_wgrad(const float* dz, const float* x, int x_split, int64_t M,
   }
   WgradArgs a;
   a.dz = dz; a.x = x; a.M = M; a.N = N; a.K = K;
-  a.tiles_n = (N + 16 * TA - 1) / (16 * TA);
-  a.tiles_k = (K + 16 * TB - 1) / (16 * TB);
-  a.splits = pick_splits((long long)M, a.tiles_n * a.tiles_k);
   a.amax = amax_blocks; a.nblk_amax = amax_blocks ? nblk_amax : 0;
   a.slabs = slabs; a.db = db_slabs; a.x_split = x_split != 0;
-  hipLaunchKernelGGL(lt_wgrad_kernel, dim3((unsigned)((a.tiles_n * a.tiles_k * a.splits + 7) / 8 * 8)), dim3(128), 0, (hipStream_t)stream, a);
+  static const int probe = [] { const char* e = getenv("LT_WGRAD_PROBE"); return e ? atoi(e) : 0; }();
+  a.probe = probe;
+  if (use_tiled(N, K)) {
+    a.tiles_n = (N + PT - 1) / PT;
+    a.tiles_k = (K + PT - 1) / PT;
+    a.splits = pick_splits_tiled((long long)M, a.tiles_n * a.tiles_k);
+    static bool attr_set = false;
+    if (!attr_set) { attr_set = true; (void)hipFuncSetAttribute((const void*)lt_wgrad128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Panels)); }
+    hipLaunchKernelGGL(lt_wgrad128_kernel, dim3((unsigned)((a.tiles_n * a.tiles_k * a.splits + 7) / 8 * 8)), dim3(256), sizeof(Panels), (hipStream_t)stream, a);
+  } else {
+    a.tiles_n = (N + 16 * TA - 1) / (16 * TA);
+    a.tiles_k = (K + 16 * TB - 1) / (16 * TB);
+    a.splits = pick_splits((long long)M, a.tiles_n * a.tiles_k);
+    hipLaunchKernelGGL(lt_wgrad_kernel, dim3((unsigned)((a.tiles_n * a.tiles_k * a.splits + 7) / 8 * 8)), dim3(128), 0, (hipStream_t)stream, a);
+  }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;

@@ -145,3 +145,33 @@ def test_operand_in_the_split_format_gives_the_same_gradient_as_the_clamped_rows
     b, _ = _wgrad(dz, xc, am)
     assert torch.equal(a, b)
     assert lib.lt_split_rows(vp(x.data_ptr()), vp(xs.data_ptr()), 6, None) != 0
+
+
+def test_tiled_form_gives_the_same_gradients(monkeypatch):
+    """lt_wgrad128_kernel (128 x 128 tiles through LDS, LT_WGRAD_TILED=1; off by default - csrc/lt_wgrad.hip says why): same product,
+    bias partials included, checked in a child process because the switch is read once per process."""
+    import subprocess, sys, os
+
+    code = r'''
+import ctypes, torch
+from locotouch_amd import _abi
+lib, vp = _abi.load(), ctypes.c_void_p
+for (m, n, k) in ((6144, 512, 348), (4100, 128, 256), (1000, 200, 100)):
+    g = torch.Generator(device="cuda").manual_seed(m)
+    dz = torch.randn(m, n, device="cuda", generator=g) * 1e-5
+    x = torch.randn(m, k, device="cuda", generator=g)
+    am = dz.abs().max().reshape(1)
+    sp = int(lib.lt_wgrad_splits(m, n, k))
+    slabs = torch.empty(sp * n * k + sp * n, device="cuda")
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(x.data_ptr()), 0, m, n, k, vp(am.data_ptr()), 1, vp(slabs.data_ptr()), vp(slabs[sp * n * k:].data_ptr()), st), "lt_wgrad")
+    ref = dz.double().t() @ x.double()
+    got = slabs[:sp * n * k].view(sp, n, k).double().sum(0)
+    db = slabs[sp * n * k:].view(sp, n).double().sum(0)
+    assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max()), (m, n, k)
+    assert float((db - dz.double().sum(0)).abs().max()) <= 2e-6 * float(dz.double().sum(0).abs().max()), (m, n, k)
+print("ok")
+'''
+    env = dict(os.environ, LT_WGRAD_TILED="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
