@@ -106,6 +106,13 @@ class FlatAdam:
             p.grad = v
         return {p: v for p, v in zip(self.params, self._gviews)}
 
+    def offset_of(self, param) -> int:
+        """Element offset of `param`'s gradient inside the flat bucket (rl/ppo.py splits the bucket into per-network all-reduces)."""
+        for p, off in zip(self.params, self.offsets):
+            if p is param:
+                return off
+        raise KeyError("parameter not in the flat bucket")
+
     def step_dev(self, max_norm: float, lr_dev: torch.Tensor) -> None:
         """`step(gathered=True)` with the learning rate read from the device scalar `lr_dev` (lt_ppo_lr_rule keeps it)."""
         if not self._bound():

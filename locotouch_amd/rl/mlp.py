@@ -370,7 +370,7 @@ class PackedPair:
     def _fused_backward_ok(self, x0, x1, dy0, dy1) -> bool:
         return self._fused_backward_possible(x0, x1) and dy0.dtype == torch.float32 and dy1.dtype == torch.float32
 
-    def _backward_fused(self, x0, x1, acts, dy0, dy1, grad_of, sums, x_split_rows=None) -> None:
+    def _backward_fused(self, x0, x1, acts, dy0, dy1, grad_of, sums, x_split_rows=None, after_first=None) -> None:
         """The backward pass as: two head launches (lt_head_wgrad), ONE launch for both stacks' chains of input gradients
         (lt_mlp_backward_pair: dz of every hidden layer, ELU' applied in the layer epilogue, per-workgroup max |dz|), six weight
         gradients on the matrix cores that also leave the bias gradients' partials (lt_wgrad), one launch of ordered sums."""
@@ -389,13 +389,16 @@ class PackedPair:
             self.sat = torch.zeros(1, device=dev, dtype=torch.float32)  # workgroups x layers of the chain that saturated (domain check)
         nblk = int(lib.lt_mlp_backward_blocks(ctypes.byref(nets[0].desc), ctypes.byref(nets[1].desc), m))
         dzs, amaxs, arrs = [], [], []
+        # one list of ordered sums per network when the caller wants the first network's gradients early (`after_first`: the trainer
+        # starts the all-reduce of the actor's half of the bucket under the critic's weight gradients), else one list for both
+        per_net = (SumJobs(), SumJobs()) if after_first is not None else (sums, sums)
         for k, net in enumerate(nets):
             net.pack_backward()
             L = len(net.linears)
             n, kk = dys[k].shape[1], acts[k][L - 2].shape[1]
             ws = torch.empty(int(lib.lt_head_wgrad_ws_floats(m, n, kk)), device=dev, dtype=torch.float32)
             _abi.check(lib.lt_head_wgrad(vp(dys[k].data_ptr()), vp(acts[k][L - 2].data_ptr()), asp, m, n, kk, vp(None), vp(None), vp(ws.data_ptr()), stream), "lt_head_wgrad")
-            sums.add(ws, int(lib.lt_head_wgrad_nblk(m)), n * kk + 16, n * kk + n, n * kk, grad_of[net.linears[L - 1].weight], grad_of[net.linears[L - 1].bias])
+            per_net[k].add(ws, int(lib.lt_head_wgrad_nblk(m)), n * kk + 16, n * kk + n, n * kk, grad_of[net.linears[L - 1].weight], grad_of[net.linears[L - 1].bias])
             dz = [torch.empty_like(a) for a in acts[k]]
             am = torch.empty(L - 1, nblk, device=dev, dtype=torch.float32)
             dzs.append(dz)
@@ -415,20 +418,25 @@ class PackedPair:
                 dbs = slabs[sp * n * kk:]
                 _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), asp if l > 0 else xsp, m, n, kk, vp(amaxs[k][l].data_ptr()), nblk,
                                         vp(slabs.data_ptr()), vp(dbs.data_ptr()), stream), "lt_wgrad")
-                sums.add(slabs, sp, n * kk, n * kk, n * kk, grad_of[net.linears[l].weight])
-                sums.add(dbs, sp, n, n, n, grad_of[net.linears[l].bias])
-        self._keep_bwd = (dzs, amaxs, dys)
+                per_net[k].add(slabs, sp, n * kk, n * kk, n * kk, grad_of[net.linears[l].weight])
+                per_net[k].add(dbs, sp, n, n, n, grad_of[net.linears[l].bias])
+            if after_first is not None:
+                per_net[k].launch()
+                if k == 0:
+                    after_first()
+        self._keep_bwd = (dzs, amaxs, dys, per_net)
 
     def saturated(self) -> torch.Tensor | None:
         """Device counter of saturated workgroups of the fused backward chain (None: that path has not run)."""
         return getattr(self, "sat", None)
 
-    def backward_raw(self, x0, x1, acts, dy0, dy1, grad_of, x_split_rows=None) -> None:
+    def backward_raw(self, x0, x1, acts, dy0, dy1, grad_of, x_split_rows=None, after_first=None) -> None:
         """Both stacks' backward passes, every parameter gradient written into `grad_of[param]` (the flat bucket's views).
-        `x_split_rows`: (x0, x1) in the split format (`split_rows`), if the caller has them."""
+        `x_split_rows`: (x0, x1) in the split format (`split_rows`), if the caller has them.  `after_first()`: called when every
+        gradient of the FIRST stack (the actor) has been enqueued - before the second stack's weight gradients are."""
         sums = SumJobs()
         if self._fused_backward_ok(x0, x1, dy0, dy1):
-            self._backward_fused(x0, x1, acts, dy0, dy1, grad_of, sums, x_split_rows)
+            self._backward_fused(x0, x1, acts, dy0, dy1, grad_of, sums, x_split_rows, after_first)
             sums.launch()
             return
         if getattr(self, "acts_split", False):

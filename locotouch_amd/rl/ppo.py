@@ -181,7 +181,7 @@ class PPO:
         st.clear()
         return sv, ss, se, None, None
 
-    def _direct_update(self, pair):
+    def _direct_update(self, pair, split_buckets: bool = True):
         """The update of the plain ActorCritic on the GPU with NO host read between its minibatch steps and no autograd graph: per step
         two row gathers, the packed forward (rl/mlp.py), ONE loss launch that also writes d loss / d (mu, value, std) (csrc/lt_ppo.hip),
         the adaptive-KL learning-rate rule as a one-lane launch on a device scalar (`lt_ppo_lr_rule`, ppo.py:273-281), the two
@@ -214,6 +214,8 @@ class PPO:
         # matrices are gathered through it once - minibatch i of every epoch is rows [i mb, (i + 1) mb) of the permuted copies -
         # instead of 2 x 16 us of row gathers in each of the 20 steps.  (The small per-row tensors are read through the index
         # by the loss kernel itself.)
+        critic_at = fa.offset_of(next(iter(ac.critic.parameters())))
+        two_buckets = split_buckets and 0 < critic_at < self._flat_grad.numel()
         perm, m = st.mini_batch_permutation(self.num_mini_batches)
         perm_o, perm_co = obs[perm], cobs[perm]
         if perm_o.dtype != torch.float32:  # bf16 observation storage (BASELINE config 5): the update computes in f32
@@ -243,9 +245,19 @@ class PPO:
             _abi.check(lib.lt_ppo_lr_rule(vp(kl.data_ptr()) if kl is not None else vp(None), float(self.desired_kl or 0.0), 1e-5, 1e-2, 1.5,
                                           vp(lr_dev.data_ptr()), vp(stats.data_ptr()), vp(out.data_ptr()), vp(grad_of[ac.std].data_ptr()), a_dim, stream),
                        "lt_ppo_lr_rule")
-            pair.backward_raw(o, co, acts, dmu, dvalue, grad_of, xs)
-            if self.dist.world_size > 1:
-                self.dist.all_reduce_mean_(self._flat_grad)  # RCCL all-reduce of the policy gradients over xGMI
+            if self.dist.world_size > 1 and two_buckets:
+                # the bucket in two halves (std + actor | critic): the actor's all-reduce runs on RCCL's stream under the critic's
+                # three weight-gradient launches (~105 us at 24 576 rows), only the critic's half stays exposed
+                handles = []
+                pair.backward_raw(o, co, acts, dmu, dvalue, grad_of, xs, after_first=lambda: handles.append(self.dist.all_reduce_mean_begin(self._flat_grad[:critic_at])))
+                # (a backward pass on the library path never calls back: the whole bucket then)
+                handles.append(self.dist.all_reduce_mean_begin(self._flat_grad[critic_at:] if handles else self._flat_grad))
+                for h in handles:
+                    self.dist.all_reduce_mean_end(h)
+            else:
+                pair.backward_raw(o, co, acts, dmu, dvalue, grad_of, xs)
+                if self.dist.world_size > 1:
+                    self.dist.all_reduce_mean_(self._flat_grad)  # RCCL all-reduce of the policy gradients over xGMI
             fa.step_dev(self.max_grad_norm, lr_dev)
             n_steps += 1
         sat = pair.saturated()
