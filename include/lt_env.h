@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 14
+#define LT_ABI_VERSION 15
 
 /* error codes */
 #define LT_OK 0
@@ -583,6 +583,11 @@ int lt_mlp_forward_pair(const lt_mlp_desc* d0, const float* packed0, const float
 int lt_mlp_backward_packed_floats(const lt_mlp_desc* fwd, size_t* floats);
 int lt_mlp_pack_backward(const lt_mlp_desc* fwd, const float* const* weights, float* packed, void* stream);
 int64_t lt_mlp_backward_blocks(const lt_mlp_desc* fwd0, const lt_mlp_desc* fwd1, int64_t m);
+/* lt_mlp_pack of two networks and, where bpacked* is given, their lt_mlp_pack_backward - ONE launch (a training step re-packs all of
+ * them: the optimizer has moved the weights). */
+int lt_mlp_pack_training(const lt_mlp_desc* d0, const float* const* weights0, const float* const* biases0, float* packed0, float* bpacked0,
+                         const lt_mlp_desc* d1, const float* const* weights1, const float* const* biases1, float* packed1, float* bpacked1,
+                         void* stream);
 int lt_mlp_backward_pair(const lt_mlp_desc* fwd0, const float* bpacked0, const float* dy0, const float* const* acts0, float* const* dz0,
                          float* const* amax0, const lt_mlp_desc* fwd1, const float* bpacked1, const float* dy1, const float* const* acts1,
                          float* const* dz1, float* const* amax1, int64_t m, int acts_split, float* sat_count, void* stream);

@@ -168,6 +168,7 @@ def load() -> ctypes.CDLL:
     pvp = ctypes.POINTER(vp)
     lib.lt_mlp_backward_packed_floats.argtypes = [dp, ctypes.POINTER(ctypes.c_size_t)]
     lib.lt_mlp_pack_backward.argtypes = [dp, pvp, vp, vp]
+    lib.lt_mlp_pack_training.argtypes = [dp, pvp, pvp, vp, vp, dp, pvp, pvp, vp, vp, vp]
     lib.lt_mlp_backward_blocks.argtypes = [dp, dp, ctypes.c_int64]
     lib.lt_mlp_backward_blocks.restype = ctypes.c_int64
     lib.lt_mlp_backward_pair.argtypes = [dp, vp, vp, pvp, pvp, pvp, dp, vp, vp, pvp, pvp, pvp, ctypes.c_int64, ctypes.c_int, vp, vp]
@@ -184,7 +185,7 @@ def load() -> ctypes.CDLL:
     return lib
 
 
-EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_preset", "lt_cfg_num_presets", "lt_cfg_preset_id", "lt_cfg_obs_dim", "lt_cfg_tactile_dim", "lt_env_create", "lt_env_tactile_update", "lt_env_defer_gate", "lt_env_gate_update", "lt_env_check", "lt_env_set_row_format", "lt_env_step_rows_profiled", "lt_mlp_forward_pair", "lt_mlp_backward_packed_floats", "lt_mlp_pack_backward", "lt_mlp_backward_blocks", "lt_mlp_backward_pair", "lt_env_curriculum_apply_global", "lt_gru_forward", "lt_gru_backward", "lt_ppo_loss", "lt_elu_backward_bias", "lt_elu_backward_bias_ws_floats", "lt_elu_backward_bias2", "lt_wgrad", "lt_split_rows", "lt_wgrad_splits", "lt_wgrad_ws_floats", "lt_adam_clip_step", "lt_adam_clip_step_dev", "lt_ppo_lr_rule", "lt_partial_sums", "lt_elu_backward_bias_nblk", "lt_head_wgrad_nblk", "lt_adam_clip_step_ws_floats", "lt_gae", "lt_head_wgrad", "lt_head_wgrad_ws_floats",
+EXPORTS = ["lt_abi_version", "lt_cfg_sizeof", "lt_last_error", "lt_cfg_default", "lt_cfg_preset", "lt_cfg_num_presets", "lt_cfg_preset_id", "lt_cfg_obs_dim", "lt_cfg_tactile_dim", "lt_env_create", "lt_env_tactile_update", "lt_env_defer_gate", "lt_env_gate_update", "lt_env_check", "lt_env_set_row_format", "lt_env_step_rows_profiled", "lt_mlp_forward_pair", "lt_mlp_backward_packed_floats", "lt_mlp_pack_backward", "lt_mlp_backward_blocks", "lt_mlp_backward_pair", "lt_mlp_pack_training", "lt_env_curriculum_apply_global", "lt_gru_forward", "lt_gru_backward", "lt_ppo_loss", "lt_elu_backward_bias", "lt_elu_backward_bias_ws_floats", "lt_elu_backward_bias2", "lt_wgrad", "lt_split_rows", "lt_wgrad_splits", "lt_wgrad_ws_floats", "lt_adam_clip_step", "lt_adam_clip_step_dev", "lt_ppo_lr_rule", "lt_partial_sums", "lt_elu_backward_bias_nblk", "lt_head_wgrad_nblk", "lt_adam_clip_step_ws_floats", "lt_gae", "lt_head_wgrad", "lt_head_wgrad_ws_floats",
            "lt_env_destroy", "lt_env_state_bytes", "lt_env_bind", "lt_env_reset_all", "lt_env_step", "lt_env_step_profiled", "lt_env_eval_terms",
            "lt_env_curriculum_update", "lt_env_step_rows", "lt_env_step_rollout", "lt_env_get_view", "lt_env_set_command_ranges", "lt_rollout_act", "lt_rollout_record", "lt_mlp_packed_floats", "lt_mlp_pack", "lt_mlp_forward", "lt_rollout_policy", "lt_rollout_policy_value",
            "lt_env_kernel_name"]

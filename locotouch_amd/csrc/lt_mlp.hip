@@ -949,7 +949,10 @@ struct PackArgs {
 };
 // all layers of a network in one launch: blockIdx.y = layer
 struct PackAll { PackArgs layer[LT_MLP_MAX_LAYERS]; };
-__global__ void lt_mlp_pack_kernel(const PackAll all) {
+// forward + backward streams of two networks (lt_mlp_pack_training): 2 x (L + L - 1) layers in one launch
+struct PackMany { PackArgs layer[4 * LT_MLP_MAX_LAYERS]; };
+template <class ALL>
+__global__ void lt_mlp_pack_kernel(const ALL all) {
   const PackArgs& p = all.layer[blockIdx.y];
   const Plan& pl = p.plan;
   const int T = pl.T, G = pl.Gl, C = 2 * T;
@@ -1162,6 +1165,44 @@ void fill_policy(const lt_mlp_desc* actor, const float* packed, const float* obs
   a.st_actions = st_actions; a.st_mu = st_mu; a.st_sigma = st_sigma; a.st_logp = st_logp; a.actions_out = actions_out;
 }
 
+
+// PackArgs of every layer of a network's forward stream / backward (transposed) stream; returns the largest thread count a layer needs
+long long fill_pack_forward(const lt_mlp_desc* desc, const float* const* weights, const float* const* biases, float* packed, PackArgs* out) {
+  const Geometry g = geometry(desc);
+  long long bias_off = 0, most = 0;
+  for (int l = 0; l < desc->num_layers; ++l) {
+    PackArgs& p = out[l];
+    p = PackArgs{};
+    p.w = weights[l]; p.b = biases[l]; p.K = desc->dims[l]; p.N = desc->dims[l + 1]; p.packed = packed;
+    for (int w = 0; w < NW; ++w) p.chunk_off[w] = g.layer_off[l][w];
+    p.plan = plan_of(desc->dims, desc->num_layers, l);
+    p.bias_float_off = g.bias_chunk * 256 + bias_off;
+    bias_off += pad16(p.N);
+    long long total = (long long)p.plan.waves * layer_chunks(p.plan) * 64;
+    total = total < pad16(p.N) ? pad16(p.N) : total;  // (the bias slice is written by the first pad16(N) threads)
+    most = total > most ? total : most;
+  }
+  return most;
+}
+long long fill_pack_backward(const lt_mlp_desc* fwd, const lt_mlp_desc& bd, const float* const* weights, float* packed, PackArgs* out) {
+  const Geometry g = geometry(&bd);
+  const int L = fwd->num_layers;
+  long long bias_off = 0, most = 0;
+  for (int j = 0; j < bd.num_layers; ++j) {
+    PackArgs& p = out[j];
+    p = PackArgs{};
+    p.w = weights[L - 1 - j]; p.b = nullptr; p.K = bd.dims[j]; p.N = bd.dims[j + 1]; p.transposed = 1; p.packed = packed;
+    for (int w = 0; w < NW; ++w) p.chunk_off[w] = g.layer_off[j][w];
+    p.plan = plan_of(bd.dims, bd.num_layers, j);
+    p.bias_float_off = g.bias_chunk * 256 + bias_off;
+    bias_off += pad16(p.N);
+    long long total = (long long)p.plan.waves * layer_chunks(p.plan) * 64;
+    total = total < pad16(p.N) ? pad16(p.N) : total;
+    most = total > most ? total : most;
+  }
+  return most;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1195,7 +1236,7 @@ int lt_mlp_pack(const lt_mlp_desc* desc, const float* const* weights, const floa
     total = total < pad16(p.N) ? pad16(p.N) : total;  // (the bias slice is written by the first pad16(N) threads)
     most = total > most ? total : most;
   }
-  hipLaunchKernelGGL(lt_mlp_pack_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)desc->num_layers), dim3(256), 0, (hipStream_t)stream, all);
+  hipLaunchKernelGGL(lt_mlp_pack_kernel<PackAll>, dim3((unsigned)((most + 255) / 256), (unsigned)desc->num_layers), dim3(256), 0, (hipStream_t)stream, all);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;
@@ -1299,7 +1340,7 @@ int lt_mlp_pack_backward(const lt_mlp_desc* fwd, const float* const* weights, fl
     total = total < pad16(p.N) ? pad16(p.N) : total;
     most = total > most ? total : most;
   }
-  hipLaunchKernelGGL(lt_mlp_pack_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)bd.num_layers), dim3(256), 0, (hipStream_t)stream, all);
+  hipLaunchKernelGGL(lt_mlp_pack_kernel<PackAll>, dim3((unsigned)((most + 255) / 256), (unsigned)bd.num_layers), dim3(256), 0, (hipStream_t)stream, all);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   return LT_OK;
@@ -1344,6 +1385,41 @@ int lt_mlp_backward_pair(const lt_mlp_desc* fwd0, const float* bpacked0, const f
     d.net[k].acts_split = acts_split != 0;
   }
   return launch(d, 2, (hipStream_t)stream);
+}
+
+
+// Everything a training step needs packed, in ONE launch: the forward streams of both networks (lt_mlp_pack) and, where the network
+// qualifies (lt_mlp_backward_packed_floats), their transposed streams for lt_mlp_backward_pair (bpacked* may be NULL: forward only).
+// The optimizer moves the weights at every step, so this runs 20 times per PPO update: four launches of ~5 us were 3 % of a step.
+int lt_mlp_pack_training(const lt_mlp_desc* d0, const float* const* weights0, const float* const* biases0, float* packed0, float* bpacked0,
+                         const lt_mlp_desc* d1, const float* const* weights1, const float* const* biases1, float* packed1, float* bpacked1, void* stream) {
+  const lt_mlp_desc* ds[2] = {d0, d1};
+  const float* const* ws[2] = {weights0, weights1};
+  const float* const* bs[2] = {biases0, biases1};
+  float* pk[2] = {packed0, packed1};
+  float* bp[2] = {bpacked0, bpacked1};
+  PackMany all = {};
+  int n = 0;
+  long long most = 0;
+  for (int k = 0; k < 2; ++k) {
+    if (!desc_ok(ds[k]) || !ws[k] || !bs[k] || !pk[k]) { lt_set_error("lt_mlp_pack_training: invalid argument"); return LT_EINVAL; }
+    for (int l = 0; l < ds[k]->num_layers; ++l)
+      if (!ws[k][l] || !bs[k][l]) { lt_set_error("lt_mlp_pack_training: null layer pointer"); return LT_EINVAL; }
+    const long long m = fill_pack_forward(ds[k], ws[k], bs[k], pk[k], all.layer + n);
+    most = m > most ? m : most;
+    n += ds[k]->num_layers;
+    if (bp[k]) {
+      lt_mlp_desc bd;
+      if (!backward_desc(ds[k], &bd)) { lt_set_error("lt_mlp_pack_training: the network has no backward stream (lt_mlp_backward_packed_floats)"); return LT_EINVAL; }
+      const long long mb = fill_pack_backward(ds[k], bd, ws[k], bp[k], all.layer + n);
+      most = mb > most ? mb : most;
+      n += bd.num_layers;
+    }
+  }
+  hipLaunchKernelGGL(lt_mlp_pack_kernel<PackMany>, dim3((unsigned)((most + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, all);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
+  return LT_OK;
 }
 
 }  // extern "C"

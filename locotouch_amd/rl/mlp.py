@@ -326,8 +326,6 @@ class PackedPair:
         `split` (default: whenever the fused backward pass will consume them): the activations are written in the kernel's split
         format - one dword per element, f16 hi | f16 lo << 16, value = hi + lo / 64 (include/lt_env.h, lt_mlp_forward_pair) - which
         the backward chain and the weight-gradient kernel read without converting; the tensors keep dtype float32 as a container."""
-        self.a.pack()
-        self.b.pack()
         lib = _abi.load()
         vp = ctypes.c_void_p
         nets = (self.a, self.b)
@@ -335,6 +333,7 @@ class PackedPair:
         if split is None:
             split = self._fused_backward_possible(x0, x1)
         self.acts_split = bool(split)
+        self.pack_training(with_backward=self.acts_split)
         ys, acts = _alloc_outputs(nets, m, x0.device)
         arr = [(vp * max(1, len(a)))(*[t.data_ptr() for t in a]) for a in acts]
         _abi.check(lib.lt_mlp_forward_pair(ctypes.byref(nets[0].desc), vp(nets[0].packed.data_ptr()), vp(x0.data_ptr()),
@@ -346,6 +345,24 @@ class PackedPair:
             m_ = torch.stack([t.abs().max().float() for t in (x0, x1, *hidden)]).max()
             self.domain_max = m_ if self.domain_max is None else torch.maximum(self.domain_max, m_)
         return ys, acts
+
+    def pack_training(self, with_backward: bool) -> None:
+        """The forward streams of both networks and (with_backward) their transposed streams for the fused backward pass, in ONE
+        launch (`lt_mlp_pack_training`): a training step re-packs everything, the optimizer has moved the weights."""
+        lib = _abi.load()
+        vp = ctypes.c_void_p
+        args = []
+        for net in (self.a, self.b):
+            if with_backward and getattr(net, "bpacked", None) is None:
+                n = ctypes.c_size_t()
+                _abi.check(lib.lt_mlp_backward_packed_floats(ctypes.byref(net.desc), ctypes.byref(n)), "lt_mlp_backward_packed_floats")
+                net.bpacked = torch.zeros(int(n.value), device=net.packed.device, dtype=torch.float32)
+            L = len(net.linears)
+            arr = ctypes.c_void_p * L
+            args += [ctypes.byref(net.desc), arr(*[l.weight.data_ptr() for l in net.linears]), arr(*[l.bias.data_ptr() for l in net.linears]),
+                     vp(net.packed.data_ptr()), vp(net.bpacked.data_ptr()) if with_backward else vp(None)]
+        _abi.check(lib.lt_mlp_pack_training(*args, PackedMLP._stream()), "lt_mlp_pack_training")
+        self._bpacked_fresh = bool(with_backward)
 
     def split_rows(self, x: torch.Tensor) -> torch.Tensor:
         """Observation rows in the split format (lt_split_rows): converted once per PPO update for the first layer's weight gradient."""
@@ -393,7 +410,8 @@ class PackedPair:
         # starts the all-reduce of the actor's half of the bucket under the critic's weight gradients), else one list for both
         per_net = (SumJobs(), SumJobs()) if after_first is not None else (sums, sums)
         for k, net in enumerate(nets):
-            net.pack_backward()
+            if not getattr(self, "_bpacked_fresh", False):  # (forward_raw packs the transposed streams with the forward ones)
+                net.pack_backward()
             L = len(net.linears)
             n, kk = dys[k].shape[1], acts[k][L - 2].shape[1]
             ws = torch.empty(int(lib.lt_head_wgrad_ws_floats(m, n, kk)), device=dev, dtype=torch.float32)
@@ -425,6 +443,7 @@ class PackedPair:
                 if k == 0:
                     after_first()
         self._keep_bwd = (dzs, amaxs, dys, per_net)
+        self._bpacked_fresh = False  # the optimizer steps next
 
     def saturated(self) -> torch.Tensor | None:
         """Device counter of saturated workgroups of the fused backward chain (None: that path has not run)."""
