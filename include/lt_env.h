@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 15
+#define LT_ABI_VERSION 16
 
 /* error codes */
 #define LT_OK 0
@@ -251,7 +251,10 @@ typedef struct lt_cfg {
                                    * 245-259) to lt_env_curriculum_apply_global on sums all-reduced over the ranks */
   int32_t env_index_offset;       /* global index of this shard's env 0: the RNG streams are keyed (seed, offset + env, step,
                                    * stream), so R ranks with offsets r * N draw exactly what one R * N-env population draws */
-  int32_t reserved[2];
+  int32_t cmd_binary_maximal;     /* `binary_maximal_command` of the command terms (mdp/commands.py:95-104,189-197,452-461,518-521; off in every
+                                   * registered config): a resample draws one of the 8 sign combinations (+-1, +-1, +-1) uniformly and
+                                   * multiplies it by the current upper range bounds; the standing flag is not redrawn */
+  int32_t reserved[1];
 } lt_cfg;
 
 /* Fields of the state arena (zero-copy views for the manager-term data contract). */

@@ -154,6 +154,7 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = (), collect
     _need(cname in ("UniformVelocityCommandGaitLogging", "UniformVelocityCommandGaitLoggingMultiSampling"), f"command class {cname} unsupported")
     _need(not cc.heading_command, "heading commands are not implemented")
     cfg.cmd_multi_sampling = 1 if cname.endswith("MultiSampling") else 0
+    cfg.cmd_binary_maximal = 1 if getattr(cc, "binary_maximal_command", False) else 0  # (commands.py:95-104, 452-461: both classes)
     for d, key in enumerate(("lin_vel_x", "lin_vel_y", "ang_vel_z")):
         _rng(cfg.cmd_range_init[d], getattr(cc.ranges, key))
         cfg.cmd_range_max[d] = float(getattr(cc.ranges, key)[1])
@@ -162,7 +163,6 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = (), collect
     cfg.cmd_zero_steps = cfg.cmd_zero_steps_final = 0
     cfg.cmd_new_probs = 0.15
     if cfg.cmd_multi_sampling:
-        _need(not cc.binary_maximal_command, "binary_maximal_command is a debug branch of the reference; not implemented")
         cfg.cmd_new_probs = float(cc.new_command_probs)
         cfg.cmd_rel_standing_final = float(cc.final_rel_standing_envs)
         cfg.cmd_zero_steps = int(cc.initial_zero_command_steps)

@@ -383,9 +383,13 @@ __device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P
     }
     cmd[d] = lo + uv[d] * (hi - lo);
   }
+  if (c.cmd_binary_maximal) {  // commands.py:518-521: maximal_command_sampling[randint(8)] * (upper range bounds); index = 4 i + 2 j + k over [-1, 1]
+    const int idx = min((int)(u0.a * 8.f), 7);
+    cmd[0] = (idx & 4) ? P[1] : -P[1]; cmd[1] = (idx & 2) ? P[3] : -P[3]; cmd[2] = (idx & 1) ? P[5] : -P[5];
+  }
   X.cmd = v3(cmd[0], cmd[1], cmd[2]);
   X.cmd_buf = X.cmd;
-  X.cmd_standing = (u1.c <= P[16]) ? 1.f : 0.f;
+  if (!c.cmd_binary_maximal) X.cmd_standing = (u1.c <= P[16]) ? 1.f : 0.f;  // (that branch leaves is_standing_env alone)
   X.cmd_time_left = c.cmd_resample_time[0] + u1.d * (c.cmd_resample_time[1] - c.cmd_resample_time[0]);
 }
 __device__ __forceinline__ void command_resample(const lt_cfg& c, const float* P, uint32_t env, uint64_t step, uint32_t stream, Misc& X) {

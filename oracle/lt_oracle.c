@@ -1124,7 +1124,13 @@ void lt_oracle_command_resample_u(const lt_cfg* cfg, const float* P, const float
     }
     cmd[d] = lo + (real)uv[d] * (hi - lo);
   }
-  *standing = (ustand <= P[16]) ? 1 : 0;                                                        /* :555 */
+  if (cfg->cmd_binary_maximal) {  /* :518-521: one of the 8 sign combinations (index 4 i + 2 j + k over [-1, 1]) times the upper bounds */
+    int idx = (int)(ub[0] * 8.0f);
+    if (idx > 7) idx = 7;
+    cmd[0] = (idx & 4) ? P[1] : -P[1]; cmd[1] = (idx & 2) ? P[3] : -P[3]; cmd[2] = (idx & 1) ? P[5] : -P[5];
+  } else {
+    *standing = (ustand <= P[16]) ? 1 : 0;                                                      /* :555 */
+  }
   *time_left = cfg->cmd_resample_time[0] + (real)utime * (cfg->cmd_resample_time[1] - cfg->cmd_resample_time[0]);
   for (int d = 0; d < 3; ++d) cmd_buf[d] = cmd[d];                                              /* :558 */
 }

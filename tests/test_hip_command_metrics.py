@@ -38,3 +38,36 @@ def test_episode_log_groups_the_reset_snapshots_by_step():
     env2.episode_log()
     env2.step(torch.zeros(64, 12, device="cuda:0"))
     assert "Metrics/base_velocity/error_vel_xy" not in env2.episode_log()
+
+
+def test_binary_maximal_command_matches_the_oracle_step_by_step():
+    """cfg.cmd_binary_maximal (commands.py:518-521) through resets and timer resamples: kernel == oracle from byte-identical arenas,
+    and every command is one of the 8 corner commands."""
+    import numpy as np
+    import torch
+
+    from locotouch_amd.layout import Layout
+    from tests import oracle_lib as O
+    from tests.parity_util import Tally, compare_arenas
+    from tests.test_hip_parity import make_env
+
+    n = 64
+    env = make_env("teacher", n, cmd_binary_maximal=1, max_episode_length=12)
+    ora = O.OracleEnv(env.cfg)
+    ora.reset_all()
+    g = torch.Generator().manual_seed(4)
+    tally = Tally(n)
+    L = Layout(n, env.num_obs, 0)
+    resets = 0
+    for t in range(40):
+        act = torch.randn(n, 12, generator=g)
+        env._arena_aligned.copy_(torch.from_numpy(ora.arena))
+        env.step(act.cuda())
+        ora.step(act.numpy())
+        torch.cuda.synchronize()
+        tally.add(compare_arenas(env, ora, what=f"binary maximal step {t}", max_flip_frac=0.05, max_event_frac=2.0 / n))
+        resets += int(L.arr(ora.arena, "LT_F_DONES")[:n].sum())
+    assert resets > n
+    P = env.cmd_params.cpu().numpy()
+    buf = env.field("LT_F_CMD_BUF")[:, 0, :3].cpu().numpy()
+    assert (np.abs(buf) == np.array([P[1], P[3], P[5]], np.float32)).all()

@@ -63,3 +63,21 @@ def test_metrics_follow_update_metrics_and_the_reset_batch_log():
     want = np.mean([m[d & once].mean(axis=0) for d, m in window if (d & once).any()], axis=0)
     rows = torch.from_numpy(f("LT_F_LAST_CMD_METRICS")[:, 0, :][once].copy())
     np.testing.assert_allclose(reset_batch_means(rows), want, rtol=1e-5)
+
+
+def test_binary_maximal_command_draws_the_eight_corner_commands():
+    """`binary_maximal_command` (commands.py:95-104, 189-197, 518-521; off in every registered config): a resample picks one of the 8
+    sign combinations uniformly and scales it by the current upper range bounds; `is_standing_env` is left alone."""
+    cfg = _abi.preset_cfg("Isaac-RandCylinderTransportTeacher-LocoTouch-v1", num_envs=512, seed=3)
+    cfg.cmd_binary_maximal = 1
+    cfg.cmd_zero_steps = 0
+    env = OracleVecEnv("", cfg=cfg)
+    P = env.cmd_params.numpy()
+    hi = np.array([P[1], P[3], P[5]], np.float32)
+    cmd = env.field("LT_F_CMD_BUF").numpy()[:, 0, :3]
+    assert (np.abs(cmd) == hi).all()
+    combos = {tuple(np.sign(c).astype(int)) for c in cmd}
+    assert len(combos) == 8
+    counts = np.array([sum(1 for c in cmd if tuple(np.sign(c).astype(int)) == k) for k in sorted(combos)])
+    assert counts.min() > 512 / 8 * 0.5 and counts.max() < 512 / 8 * 1.6  # uniform over the 8 corners
+    assert (env.field("LT_F_CMD_BUF").numpy()[:, 0, 3] == 0).all()  # nobody was made a standing env by the resample
