@@ -68,7 +68,7 @@ class LtCfg(ctypes.Structure):
         new = LtCfg()
         ctypes.memmove(ctypes.byref(new), ctypes.byref(self), ctypes.sizeof(self))
         # (compat/cfg_translate.py: user terms for the slow torch path - Python attributes beside the C struct)
-        for attr in ("extra_reward_terms", "extra_termination_terms", "reward_term_params"):
+        for attr in ("extra_reward_terms", "extra_termination_terms", "extra_observation_terms", "reward_term_params"):
             if hasattr(self, attr):
                 v = getattr(self, attr)
                 setattr(new, attr, dict(v) if isinstance(v, dict) else list(v))

@@ -284,6 +284,26 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = (), collect
     cfg.obs_history = hist.pop()
     order = ["velocity_commands", "base_ang_vel", "projected_gravity", "joint_pos", "joint_vel", "last_action"] + (["object_state"] if has_obj else [])
     pterms = {k: v for k, v in vars(pol).items() if hasattr(v, "func") and v is not None}
+    # terms BEHIND the fused ones (a derived cfg class appends its attributes): served by the slow path (compat/scene_views.py
+    # ExtraTerms.add_observation) when the caller collects unknown terms; their columns follow the kernel's rows
+    user_obs = []
+
+    def collect_user_terms(group_name, group, terms):
+        _need(collect_unknown_rewards, f"{group_name} observation terms {list(terms)[len(order):]} have no fused implementation")
+        for k in list(terms)[len(order):]:
+            t = terms[k]
+            _need(not getattr(t, "modifiers", None), f"observation {k!r}: modifiers are not implemented")
+            noise = None
+            if t.noise is not None and group.enable_corruption:
+                _need(hasattr(t.noise, "n_min") and getattr(t.noise, "operation", "add") == "add", f"observation {k!r}: only additive uniform noise")
+                noise = (float(t.noise.n_min), float(t.noise.n_max))
+            h = group.history_length if group.history_length is not None else t.history_length
+            user_obs.append(dict(group=group_name, name=k, func=t.func, params=dict(t.params or {}), history_length=int(h or 0),
+                                 scale=t.scale, clip=t.clip, noise=noise))
+
+    if list(pterms)[:len(order)] == order and len(pterms) > len(order):
+        collect_user_terms("policy", pol, pterms)
+        pterms = {k: pterms[k] for k in order}
     _need(list(pterms) == order, f"policy observation terms {list(pterms)} != {order}")
     funcs = ["generated_commands", "base_ang_vel", "projected_gravity", "joint_pos_rel", "joint_vel_rel", "last_action", "object_state_in_robot_frame"]
     for (k, t), fn in zip(pterms.items(), funcs):
@@ -321,7 +341,12 @@ def translate(env_cfg, seed: int | None = None, omit_groups: tuple = (), collect
         _translate_student_groups(env_cfg, cfg, groups, pterms)
     cri = groups["critic"]
     _need(not cri.enable_corruption, "critic group: corruption off")
-    _need([k for k, v in vars(cri).items() if hasattr(v, "func")] == order, "critic group must hold the policy group's terms")
+    cterms = {k: v for k, v in vars(cri).items() if hasattr(v, "func") and v is not None}
+    if list(cterms)[:len(order)] == order and len(cterms) > len(order):
+        collect_user_terms("critic", cri, cterms)
+        cterms = {k: cterms[k] for k in order}
+    _need(list(cterms) == order, "critic group must hold the policy group's terms")
+    cfg.extra_observation_terms = user_obs
 
     # ---- events ----
     seen = set()

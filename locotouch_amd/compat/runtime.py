@@ -87,7 +87,7 @@ class ManagedEnv:
     """What `gym.make` returns: the HIP env behind the attribute surface the scripts and `RslRlVecEnvWrapper` touch
     (`unwrapped`, `cfg`, `num_envs`, `device`, `step_dt`, `max_episode_length`, `episode_length_buf`, `close`)."""
 
-    def __init__(self, task_id: str, cfg, vec_env, extra_rewards=(), extra_terminations=()):
+    def __init__(self, task_id: str, cfg, vec_env, extra_rewards=(), extra_terminations=(), extra_observations=()):
         self.task_id, self.cfg, self.vec = task_id, cfg, vec_env
         # reward terms the fused kernels do not know: evaluated in torch on IsaacLab-layout views after every step and added to
         # the kernel's reward (compat/scene_views.py; the slow path of SURVEY.md §8(b) B3)
@@ -100,6 +100,8 @@ class ManagedEnv:
                 self.extra.add_reward(name, func, weight, params)
         for name, func, params, *flag in extra_terminations:
             self.add_termination_term(name, func, params, time_out=bool(flag and flag[0]))
+        for o in extra_observations:
+            self.add_observation_term(**o)
 
     def add_reward_term(self, name: str, func, weight: float, params: dict | None = None) -> None:
         """Attach a user reward term `func(env, **params) -> (N,)` (reference term signature, mdp/rewards.py:15-20)."""
@@ -117,6 +119,66 @@ class ManagedEnv:
 
             self.extra = ExtraTerms(self.vec)
         self.extra.add_termination(name, func, params, time_out=time_out)
+
+    def add_observation_term(self, group: str, name: str, func, params: dict | None = None, history_length: int = 0, scale=None, clip=None,
+                             noise=None) -> None:
+        """Attach a user observation term `func(env, **params) -> (N, d)` (IsaacLab ObservationTermCfg semantics: noise if the group
+        corrupts, clip, scale, history flattened oldest -> newest) behind the fused terms of `group` ("policy" / "critic"): the rows
+        the trainer sees grow by d x history columns; the fused rollout (which reads the kernel's own rows) is bypassed."""
+        if self.extra is None:
+            from .scene_views import ExtraTerms
+
+            self.extra = ExtraTerms(self.vec)
+        self.extra.add_observation(group, name, func, params, history_length, scale, clip, noise)
+        self._obs_dims = None
+
+    def _extra_dims(self) -> dict:
+        if getattr(self, "_obs_dims", None) is None:
+            self._obs_dims = self.extra.observation_dims() if (self.extra is not None and self.extra.observations) else {}
+        return self._obs_dims
+
+    @property
+    def num_obs(self) -> int:
+        return int(self.vec.num_obs) + int(self._extra_dims().get("policy", 0))
+
+    @property
+    def num_privileged_obs(self) -> int:
+        return int(getattr(self.vec, "num_privileged_obs", self.vec.num_obs)) + int(self._extra_dims().get("critic", 0))
+
+    def _with_user_observations(self, obs, extras, dones):
+        if self.extra is None or not self.extra.observations:
+            return obs, extras
+        more = self.extra.observe(dones)
+        groups = dict(extras.get("observations", {}))
+        if "policy" in more:
+            obs = torch.cat((obs, more["policy"]), dim=1)
+            groups["policy"] = obs
+        if "critic" in more and "critic" in groups:
+            groups["critic"] = torch.cat((groups["critic"], more["critic"]), dim=1)
+        extras = dict(extras, observations=groups)
+        return obs, extras
+
+    def get_observations(self):
+        obs, extras = self.vec.get_observations()
+        if self.extra is not None and self.extra.observations:
+            # the rows of the state the env is in: re-emit the user terms' current history (no new frame is pushed)
+            more = {}
+            for o in self.extra.observations:
+                if o["buf"] is None:
+                    return self._with_user_observations(obs, extras, None)
+                more.setdefault(o["group"], []).append(o["buf"].reshape(self.vec.num_envs, -1))
+            groups = dict(extras.get("observations", {}))
+            if "policy" in more:
+                obs = torch.cat([obs] + more["policy"], dim=1)
+                groups["policy"] = obs
+            if "critic" in more and "critic" in groups:
+                groups["critic"] = torch.cat([groups["critic"]] + more["critic"], dim=1)
+            extras = dict(extras, observations=groups)
+        return obs, extras
+
+    def reset(self):
+        obs, extras = self.vec.reset()
+        return self._with_user_observations(obs, extras, None)
 
     @property
     def scene(self):
@@ -136,6 +198,7 @@ class ManagedEnv:
             if self.extra.terminations:
                 self.extra.request_terminations(dones)
             self.extra.post_step()
+            obs, extras = self._with_user_observations(obs, extras, dones)
         return obs, rew, dones, extras
 
     @property
@@ -187,13 +250,15 @@ def make_env(task_id: str, cfg):
     if _env_factory is not None:
         vec = _env_factory(task_id, cfg)
         return ManagedEnv(task_id, cfg, vec, extra_rewards=getattr(getattr(vec, "cfg", None), "extra_reward_terms", ()),
-                          extra_terminations=getattr(getattr(vec, "cfg", None), "extra_termination_terms", ()))
+                          extra_terminations=getattr(getattr(vec, "cfg", None), "extra_termination_terms", ()),
+                          extra_observations=getattr(getattr(vec, "cfg", None), "extra_observation_terms", ()))
     from ..env import LocoTouchVecEnv
 
     lt, sizes = translate_env_cfg(task_id, cfg)
     device = getattr(getattr(cfg, "sim", None), "device", None) or "cuda:0"
     return ManagedEnv(task_id, cfg, LocoTouchVecEnv(task_id, device=device, cfg=lt, object_sizes=sizes),
-                      extra_rewards=getattr(lt, "extra_reward_terms", ()), extra_terminations=getattr(lt, "extra_termination_terms", ()))
+                      extra_rewards=getattr(lt, "extra_reward_terms", ()), extra_terminations=getattr(lt, "extra_termination_terms", ()),
+                      extra_observations=getattr(lt, "extra_observation_terms", ()))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -431,7 +496,7 @@ class RslRlVecEnvWrapper:
         vec = env.unwrapped
         self.num_envs, self.num_actions, self.device = vec.num_envs, vec.num_actions, vec.device
         self.max_episode_length = vec.max_episode_length
-        self.num_obs = vec.num_obs
+        self.num_obs = vec.num_obs  # (ManagedEnv: the kernel's rows + the user observation terms' columns)
         self.num_privileged_obs = getattr(vec, "num_privileged_obs", vec.num_obs)
 
     @property

@@ -514,6 +514,7 @@ class ExtraTerms:
         self.terminations: list = []  # (name, callable, params, time_out)
         self.term_counts: dict = {}   # name -> envs terminated by the term since the last episode_log read
         self.last_values: dict = {}   # name -> the unweighted value of the last step (diagnostics / parity tests)
+        self.observations: list = []  # user observation terms (add_observation)
 
     def pre_step(self) -> None:
         """Call before the env step.  The reference computes terminations and rewards BEFORE the command term's update of the same
@@ -569,7 +570,53 @@ class ExtraTerms:
         self.env.reward_manager.user_cfgs[name] = cfg
 
     def __bool__(self) -> bool:
-        return bool(self.terms) or bool(self.terminations)
+        return bool(self.terms) or bool(self.terminations) or bool(self.observations)
+
+    # ---- user observation terms (ObservationManager.compute_group [DEP]: func -> noise (if the group corrupts) -> clip -> scale ->
+    #      history buffer, flattened oldest -> newest; a reset env's buffer is filled with its first value) -------------------------
+    def add_observation(self, group: str, name: str, func, params: dict | None = None, history_length: int = 0, scale=None, clip=None,
+                        noise=None) -> None:
+        """An observation term `func(env, **params) -> (N, d)` appended to `group` ("policy" / "critic") behind the fused terms.
+        `noise`: (n_min, n_max) of an additive uniform model, applied to this group (the caller passes it for a corrupting group only)."""
+        func, params, _ = self._bind(func, params)
+        self.observations.append(dict(group=group, name=name, func=func, params=params, hist=int(history_length or 0), scale=scale, clip=clip,
+                                      noise=noise, buf=None, fresh=None))
+
+    def _term_value(self, o) -> torch.Tensor:
+        v = o["func"](self.env, **o["params"]).to(torch.float32).reshape(self.env.num_envs, -1).clone()
+        if o["noise"] is not None:
+            lo, hi = o["noise"]
+            v = v + torch.rand_like(v) * (hi - lo) + lo
+        if o["clip"] is not None:
+            v = v.clamp(float(o["clip"][0]), float(o["clip"][1]))
+        if o["scale"] is not None:
+            v = v * (torch.as_tensor(o["scale"], dtype=v.dtype, device=v.device) if not isinstance(o["scale"], (int, float)) else float(o["scale"]))
+        return v
+
+    def observe(self, dones: torch.Tensor | None) -> dict:
+        """{group: (N, sum of d * history)} of the user observation terms for the state the env is in now; `dones` (None: every env
+        starts an episode - after reset()): the envs whose history restarts with this value."""
+        out: dict = {}
+        n = self.env.num_envs
+        for o in self.observations:
+            v = self._term_value(o)
+            h = max(1, o["hist"])
+            if o["buf"] is None or dones is None:
+                o["buf"] = v.unsqueeze(1).repeat(1, h, 1)
+            else:
+                o["buf"] = torch.cat((o["buf"][:, 1:], v.unsqueeze(1)), dim=1)
+                fin = (dones != 0).reshape(n)
+                if bool(fin.any()):
+                    o["buf"][fin] = v[fin].unsqueeze(1)
+            out.setdefault(o["group"], []).append(o["buf"].reshape(n, -1))
+        return {g: torch.cat(vs, dim=1) for g, vs in out.items()}
+
+    def observation_dims(self) -> dict:
+        dims: dict = {}
+        for o in self.observations:
+            d = int(self._term_value(o).shape[1]) * max(1, o["hist"])
+            dims[o["group"]] = dims.get(o["group"], 0) + d
+        return dims
 
     def apply(self, reward: torch.Tensor, dones: torch.Tensor) -> torch.Tensor:
         """reward + sum_i weight_i * dt * term_i(env) for the envs that did not just finish (in place on a copy of `reward`)."""

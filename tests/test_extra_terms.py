@@ -156,3 +156,75 @@ def test_reference_cfg_with_a_user_termination_term_terminates_one_step_later(rt
         assert torch.equal(pending, (v.norm(dim=1) > 0.35) & (dones == 0))
         fired_total += int(user.sum())
     assert fired_total > 5 and env.extra.term_counts["base_too_fast"] >= fired_total
+
+
+def base_height_user(env, asset_cfg):
+    """a user observation term in IsaacLab's style (isaaclab.envs.mdp.observations.base_pos_z [DEP]): (N, 1)"""
+    return env.scene[asset_cfg.name].data.root_pos_w[:, 2].unsqueeze(-1)
+
+
+def calf_vel_user(env, asset_cfg):
+    return env.scene[asset_cfg.name].data.joint_vel[:, asset_cfg.joint_ids]
+
+
+def test_user_observation_terms_follow_the_observation_manager(rt):
+    """VERDICT r03 missing #4: observation terms outside the fused set.  A derived cfg appends two ObsTerms to the policy group and one to
+    the critic group; the translated env returns the kernel's rows followed by the user terms' columns with IsaacLab's
+    ObservationManager semantics [DEP]: clip, scale, the group's history (6 frames, oldest -> newest, a reset env's history filled
+    with its first value), additive uniform noise in the corrupting group only."""
+    from isaaclab.managers import ObservationTermCfg as ObsTerm
+    from isaaclab.managers import SceneEntityCfg
+    from isaaclab.utils.noise import AdditiveUniformNoiseCfg as Unoise
+
+    from locotouch_amd.compat import cfg_translate as T
+    from locotouch_amd.compat.runtime import ManagedEnv, RslRlVecEnvWrapper
+    from tests.oracle_vec_env import OracleVecEnv
+
+    cfg = rt.load_cfg_from_registry(TASK, "env_cfg_entry_point")
+    cfg.scene.num_envs = 24
+    cfg.observations.policy.base_height = ObsTerm(func=base_height_user, params={"asset_cfg": SceneEntityCfg("robot")}, scale=2.0, clip=(0.0, 0.3))
+    cfg.observations.policy.calf_vel = ObsTerm(func=calf_vel_user, params={"asset_cfg": SceneEntityCfg("robot", joint_names=".*_calf_joint")},
+                                               noise=Unoise(n_min=-0.5, n_max=0.5))
+    cfg.observations.critic.base_height = ObsTerm(func=base_height_user, params={"asset_cfg": SceneEntityCfg("robot")})
+    with pytest.raises(T.UnsupportedCfg):
+        T.translate(cfg)
+    lt, sizes = rt.translate_env_cfg(TASK, cfg)
+    assert [(o["group"], o["name"], o["history_length"]) for o in lt.extra_observation_terms] == [("policy", "base_height", 6), ("policy", "calf_vel", 6), ("critic", "base_height", 6)]
+    assert lt.extra_observation_terms[1]["noise"] == (-0.5, 0.5) and lt.extra_observation_terms[2]["noise"] is None
+    vec = OracleVecEnv(TASK, cfg=lt, object_sizes=sizes)
+    env = ManagedEnv(TASK, cfg, vec, extra_observations=lt.extra_observation_terms)
+    w = RslRlVecEnvWrapper(env)
+    assert w.num_obs == 348 + 6 * (1 + 4) and w.num_privileged_obs == 348 + 6 and w.fused_target() is None
+    obs0, ex0 = env.reset()
+    assert obs0.shape == (24, 378) and ex0["observations"]["critic"].shape == (24, 354)
+    z0 = vec.field("LT_F_ROOT_POS")[:, 0, 2]
+    torch.testing.assert_close(obs0[:, 348:354], (2.0 * z0.clamp(0.0, 0.3)).unsqueeze(1).expand(24, 6))  # the first value fills the history
+    hist_z = [z0.clone()] * 6
+    g = torch.Generator().manual_seed(1)
+    vec.cfg.max_episode_length = vec.o.cfg.max_episode_length = 9  # resets inside the window
+    for t in range(14):
+        obs, rew, dones, ex = env.step(0.7 * torch.randn(24, 12, generator=g))
+        z = vec.field("LT_F_ROOT_POS")[:, 0, 2].clone()
+        fin = dones != 0
+        hist_z = hist_z[1:] + [z]
+        if bool(fin.any()):
+            hist_z = [torch.where(fin, z, h) for h in hist_z]
+        want = torch.stack(hist_z, dim=1)
+        assert torch.equal(obs[:, :348], torch.from_numpy(vec._arr("LT_F_OBS_POLICY")))
+        torch.testing.assert_close(obs[:, 348:354], 2.0 * want.clamp(0.0, 0.3))
+        torch.testing.assert_close(ex["observations"]["critic"][:, 348:354], want)          # no clip / scale, no noise in the critic group
+        newest_calf = obs[:, 354:378].reshape(24, 6, 4)[:, -1]
+        clean = vec.field("LT_F_JOINT_VEL")[:, 2, :]
+        assert float((newest_calf - clean).abs().max()) <= 0.5 + 1e-6 and float((newest_calf - clean).abs().max()) > 0.05  # noisy, bounded
+        o2, e2 = env.get_observations()
+        assert torch.equal(o2, obs) and torch.equal(e2["observations"]["critic"], ex["observations"]["critic"])  # no frame pushed by a read
+    # and the trainer builds its networks for the wider rows and runs on them
+    from locotouch_amd.agents import train_cfg
+    from locotouch_amd.rl import OnPolicyRunner
+
+    agent = train_cfg(TASK)
+    agent["num_steps_per_env"] = 4
+    runner = OnPolicyRunner(w, agent, log_dir=None, device="cpu")
+    runner.learn(num_learning_iterations=1)
+    assert runner.alg.actor_critic.actor[0].in_features == 378 and runner.alg.actor_critic.critic[0].in_features == 354
+    assert all(torch.isfinite(p).all() for p in runner.alg.actor_critic.parameters())
