@@ -99,3 +99,35 @@ def test_a_requested_termination_matches_the_oracle_and_resets_in_the_next_step(
         total += int(user.sum())
     assert total > 0
     _ = np
+
+
+def test_a_user_observation_term_rides_behind_the_kernels_rows_on_the_gpu():
+    """ManagedEnv.add_observation_term over the HIP env: the kernel's rows untouched in front, the user term's history (3 frames,
+    oldest -> newest, restarted at a reset) behind them; the fused rollout is bypassed."""
+    import torch
+
+    from locotouch_amd.compat.runtime import ManagedEnv, RslRlVecEnvWrapper
+    from locotouch_amd.env import LocoTouchVecEnv
+
+    n = 128
+    vec = LocoTouchVecEnv(TASK, num_envs=n, device="cuda:0", seed=2, max_episode_length=8)
+    env = ManagedEnv(TASK, None, vec)
+    env.add_observation_term("policy", "base_z", lambda e: e.scene["robot"].data.root_pos_w[:, 2:3], history_length=3, scale=10.0)
+    w = RslRlVecEnvWrapper(env)
+    assert w.num_obs == 348 + 3 and w.num_privileged_obs == 348 and w.fused_target() is None
+    obs, _ = env.reset()
+    z = vec.field("LT_F_ROOT_POS")[:, 0, 2].clone()
+    hist = [z, z, z]
+    assert torch.allclose(obs[:, 348:], 10.0 * torch.stack(hist, 1))
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    resets = 0
+    for _ in range(20):
+        obs, rew, dones, ex = env.step(torch.randn(n, 12, device="cuda:0", generator=g))
+        z = vec.field("LT_F_ROOT_POS")[:, 0, 2].clone()
+        fin = dones != 0
+        resets += int(fin.sum())
+        hist = [torch.where(fin, z, h) for h in hist[1:] + [z]]
+        assert obs.shape == (n, 351) and torch.equal(obs[:, :348], vec.obs_policy)
+        assert torch.allclose(obs[:, 348:], 10.0 * torch.stack(hist, 1))
+        assert ex["observations"]["critic"].shape == (n, 348)
+    assert resets > n
