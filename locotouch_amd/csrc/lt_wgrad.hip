@@ -89,7 +89,7 @@ struct WgradArgs {
   const float* amax;    // per-block maxima of |dz| (nblk_amax floats) or nullptr (scale 1)
   int nblk_amax;
   float* slabs;         // [splits][N][K]
-  int probe;            // measurements only (LT_WGRAD_PROBE): 1 = fetch the first step's panels only, 2 = no MFMAs, 3 = no LDS staging after the first
+  int probe;            // measurements only (LT_WGRAD_PROBE): 1 = fetch the first step's panels only, 2 = no MFMAs, 3 = no LDS staging after the first, 4 = 1 + 3
   int x_split;          // x is in the split format (one dword per element: f16 hi | f16 lo << 16, lt_mlp.hip): no conversion here
   float* db;            // optional [splits][N]: the slices' column sums of dz (the bias gradient's partials), by the tiles of the first k column
 };
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void lt_wgrad128_kernel(const WgradArgs a) 
   __syncthreads();
   int cur = 0;
   for (long long s = s0; s < s1; ++s) {
-    if (s + 1 < s1 && a.probe != 1) fetch(s + 1);  // in flight under this step's LDS reads and MFMAs
+    if (s + 1 < s1 && a.probe != 1 && a.probe != 4) fetch(s + 1);  // in flight under this step's LDS reads and MFMAs
     f32x4 va[8], vb[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void lt_wgrad128_kernel(const WgradArgs a) 
       }
     }
     }
-    if (s + 1 < s1 && a.probe != 3) stage(cur ^ 1, s + 1);  // (issued in front of the MFMAs instead: 53.9 -> 57.7 us)
+    if (s + 1 < s1 && a.probe != 3 && a.probe != 4) stage(cur ^ 1, s + 1);  // (issued in front of the MFMAs instead: 53.9 -> 57.7 us)
     __syncthreads();  // stage cur^1 is complete; everybody is done reading stage cur
     cur ^= 1;
   }
@@ -373,7 +373,8 @@ __global__ __launch_bounds__(256, 2) void lt_wgrad128_kernel(const WgradArgs a) 
 // Which form runs a shape.  MEASURED (tools/wgrad_bench.py, 24 576 rows, x in the split format; us for 512 x 348 / 256 x 512 / 128 x 256):
 // one wave per 64 x 64 tile 52.7 / 35.6 / 14.8, tiled 50.9 / 35.2 / 16.6 with twice the slices (42 / 64 / 192: twice the slab bytes
 // for lt_partial_sums) - no gain worth the slabs, so the tiled form is OFF unless LT_WGRAD_TILED=1.  Its probes (LT_WGRAD_PROBE) say
-// why: without the panel fetches 49.5 us of 53.9, without the MFMAs 44.8, without the LDS staging 40.0 - no single phase bounds it;
+// why: without the panel fetches 49.5 us of 53.9, without the MFMAs 44.8, without the LDS staging 40.0, with neither fetches nor staging
+// (fragment reads + unpacking + MFMAs + the barrier alone: what a DMA-fed form of this loop could reach at best) 34.0 - no single phase bounds it;
 // LDS reads + unpacking, MFMAs and staging of a wave run one after the other between two barriers, and two workgroups per CU do not
 // hide that.  The floor of either form is the 84 MB of operands from HBM (~17 us) and 10.5 us of MFMA time.
 bool use_tiled(int N, int K) {
