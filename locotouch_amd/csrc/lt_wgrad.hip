@@ -136,14 +136,20 @@ __global__ __launch_bounds__(128, 2) void lt_wgrad_kernel(const WgradArgs a) {
   // hang over its edge; what an overhanging lane loads is multiplied into output elements that are never stored)
   f32x4 va[8], vb[8];
   const int ca = min(n0 + 4 * i, a.N - 4), cb = min(k0 + 4 * i, a.K - 4);
-  auto issue = [&](long long s) __attribute__((always_inline)) {
+  // addresses as 32-bit byte offsets from the (uniform) matrix bases: one add per load and one per step (as 64-bit pointers rebuilt
+  // from the row index the 16 loads of a step cost 132 VALU instructions - a third of the loop).  Rows beyond M are redirected to the
+  // last valid offset: what they load is multiplied by zeroed dz rows (below).  M x N x 4 bytes < 4 GiB (lt_wgrad checks).
+  const unsigned row_a = (unsigned)a.N * 4u, row_b = (unsigned)a.K * 4u;
+  const unsigned last_a = (unsigned)(a.M - 1) * row_a + (unsigned)ca * 4u, last_b = (unsigned)(a.M - 1) * row_b + (unsigned)cb * 4u;
+  unsigned off_a = ((unsigned)s0 * 32u + (unsigned)g) * row_a + (unsigned)ca * 4u, off_b = ((unsigned)s0 * 32u + (unsigned)g) * row_b + (unsigned)cb * 4u;
+  auto issue = [&](long long) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      long long r = s * 32 + 4 * t + g;
-      r = r < a.M ? r : a.M - 1;
-      va[t] = *(const f32x4*)(a.dz + r * a.N + ca);
-      vb[t] = *(const f32x4*)(a.x + r * a.K + cb);
+      va[t] = *(const f32x4*)((const char*)a.dz + min(off_a + (unsigned)(4 * t) * row_a, last_a));
+      vb[t] = *(const f32x4*)((const char*)a.x + min(off_b + (unsigned)(4 * t) * row_b, last_b));
     }
+    off_a += 32u * row_a;
+    off_b += 32u * row_b;
   };
   const bool colsum = a.db != nullptr && tk == 0;  // (uniform)
   f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -175,6 +181,142 @@ __global__ __launch_bounds__(128, 2) void lt_wgrad_kernel(const WgradArgs a) {
         acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[p], bh[q], acc[p][q], 0, 0, 0);
       }
     }
+  }
+  // wave 1 hands its tile and column sums to wave 0
+  if (wave == 1) {
+#pragma unroll
+    for (int p = 0; p < TA; ++p)
+#pragma unroll
+      for (int q = 0; q < TB; ++q) s_tile[p * TB + q][lane] = acc[p][q];
+    s_tile[TA * TB][lane] = cs;
+  }
+  __syncthreads();
+  if (wave == 1) return;
+#pragma unroll
+  for (int p = 0; p < TA; ++p)
+#pragma unroll
+    for (int q = 0; q < TB; ++q) acc[p][q] += s_tile[p * TB + q][lane];
+  cs += s_tile[TA * TB][lane];
+  if (colsum) {  // lane (c, g) holds the sums of rows g mod 4 of columns n0 + 4 c .. + 3
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      cs[u] += __shfl_xor(cs[u], 16, 64);
+      cs[u] += __shfl_xor(cs[u], 32, 64);
+    }
+    if (g == 0 && n0 + 4 * i < a.N) *(f32x4*)(a.db + (long long)split * a.N + n0 + 4 * i) = cs;
+  }
+  // the partial tile: MFMA tile (p, q) holds C[row rho = 4 g + r][col kappa = i] = dW[n0 + 4 rho + p][k0 + 4 kappa + q]: a lane's four
+  // q tiles are 4 ADJACENT columns of one row
+  const float inv = 1.f / (scale * LO_SCALE);
+  float* const out = a.slabs + (long long)split * a.N * a.K;
+  const int k = k0 + 4 * i;
+#pragma unroll
+  for (int p = 0; p < TA; ++p)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * (4 * g + r) + p;
+      if (n < a.N && k < a.K) {
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < TB; ++q) o[q] = acc[p][q][r] * inv;
+        *(f32x4*)(out + (long long)n * a.K + k) = o;
+      }
+    }
+}
+
+// The same kernel with NST steps of operand loads in flight per wave instead of one, at ONE wave per SIMD (the stages take the
+// registers a second wave would): a wave's step is one HBM / L2 round trip (~2 us) for ~0.7 us of conversions and MFMAs, and what
+// hides it is loads in flight - two waves x one step there, one wave x NST steps here.
+template <int NST>
+__global__ __launch_bounds__(128, 1) void lt_wgrad_deep_kernel(const WgradArgs a) {
+  __shared__ f32x4 s_tile[TA * TB + 1][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  // block -> (split, tile): the tiles of a slice of M on ONE XCD (blocks are dealt round-robin over the 8 XCDs - observed placement,
+  // used for speed only): they sweep the same rows of dz / x at about the same time, so a row is fetched into that XCD's L2 once and
+  // read from there by the 48 tiles.  Dealt block by block the tiles of a slice landed on all 8 XCDs and every XCD fetched every
+  // row: 8 x 84 MB from the Infinity Cache per launch of the 512 x 348 layer - 149 us at 58 TFLOP/s (f32-equivalent).  XCD x takes
+  // the work items [x, x + 1) * gridDim / 8 of the (split-major) list: at most one slice per XCD is shared with a neighbour.
+  const int tiles = a.tiles_n * a.tiles_k;
+  const int per_xcd = (int)gridDim.x >> 3;
+  const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (item >= tiles * a.splits) return;
+  const int split = item / tiles, tile = item - split * tiles;
+  const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
+  const int n0 = tn * 16 * TA, k0 = tk * 16 * TB;
+  // this slice's 32-row steps (the M / 32 steps are dealt as evenly as possible), first half to wave 0, second to wave 1
+  const long long steps = (a.M + 31) / 32;
+  const long long b0 = steps * split / a.splits, b1 = steps * (split + 1) / a.splits, mid = b0 + (b1 - b0 + 1) / 2;
+  const long long s0 = wave ? mid : b0, s1 = wave ? b1 : mid;
+  // scale of dz: a power of two that brings max |dz| to [2^7, 2^8) - 64 x its hi half is still an f16 number
+  float scale = 1.f;
+  if (a.amax) {
+    float m = 0.f;
+    for (int b = lane; b < a.nblk_amax; b += 64) m = fmaxf(m, a.amax[b]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xFF) - 127;  // floor(log2 m) (m == 0 or denormal: e = -127)
+    int se = 7 - e;
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    scale = __uint_as_float((unsigned)(127 + se) << 23);
+  }
+  f32x4 acc[TA][TB];
+#pragma unroll
+  for (int p = 0; p < TA; ++p)
+#pragma unroll
+    for (int q = 0; q < TB; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // 32 rows x 64 columns per operand and step: load t = row m0 + 4 t + g, 16 bytes at column 4 c (clamped to the matrix: a tile may
+  // hang over its edge; what an overhanging lane loads is multiplied into output elements that are never stored)
+  struct Stage { f32x4 a[8], b[8]; };
+  Stage st[NST];
+  const int ca = min(n0 + 4 * i, a.N - 4), cb = min(k0 + 4 * i, a.K - 4);
+  auto issue = [&](Stage& S, long long s) __attribute__((always_inline)) {
+    if (s >= s1) return;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      long long r = s * 32 + 4 * t + g;
+      r = r < a.M ? r : a.M - 1;
+      S.a[t] = *(const f32x4*)(a.dz + r * a.N + ca);
+      S.b[t] = *(const f32x4*)(a.x + r * a.K + cb);
+    }
+  };
+  const bool colsum = a.db != nullptr && tk == 0;  // (uniform)
+  f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto consume = [&](Stage& S, long long s) __attribute__((always_inline)) {
+    if ((s + 1) * 32 > a.M) {  // rows beyond M (the last step of a ragged M) must not contribute: their clamped loads repeat row M - 1
+#pragma unroll
+      for (int t = 0; t < 8; ++t) if (s * 32 + 4 * t + g >= a.M) S.a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (colsum) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) cs += S.a[t];
+    }
+    f16x8 ah[TA], al[TA], bh[TB], bl[TB];
+    split8<0>(S.a, scale, ah[0], al[0]); split8<1>(S.a, scale, ah[1], al[1]); split8<2>(S.a, scale, ah[2], al[2]); split8<3>(S.a, scale, ah[3], al[3]);
+    if (a.x_split) {  // (uniform)
+      unpack8<0>(S.b, bh[0], bl[0]); unpack8<1>(S.b, bh[1], bl[1]); unpack8<2>(S.b, bh[2], bl[2]); unpack8<3>(S.b, bh[3], bl[3]);
+    } else {
+      split8<0>(S.b, 1.f, bh[0], bl[0]); split8<1>(S.b, 1.f, bh[1], bl[1]); split8<2>(S.b, 1.f, bh[2], bl[2]); split8<3>(S.b, 1.f, bh[3], bl[3]);
+    }
+    issue(S, s + NST);  // this stage's registers are free again
+#pragma unroll
+    for (int p = 0; p < TA; ++p) {
+      const f16x8 a64 = ah[p] * (_Float16)LO_SCALE;  // exact: |scaled dz| < 2^8
+#pragma unroll
+      for (int q = 0; q < TB; ++q) {
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a64, bh[q], acc[p][q], 0, 0, 0);
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], bl[q], acc[p][q], 0, 0, 0);
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[p], bh[q], acc[p][q], 0, 0, 0);
+      }
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < NST; ++j) issue(st[j], s0 + j);
+  for (long long s = s0; s < s1; s += NST) {
+#pragma unroll
+    for (int j = 0; j < NST; ++j)
+      if (s + j < s1) consume(st[j], s + j);
   }
   // wave 1 hands its tile and column sums to wave 0
   if (wave == 1) {
@@ -392,8 +534,9 @@ int pick_splits_tiled(long long M, int tiles) {
 int pick_splits(long long M, int tiles) {
   // at most 1024 two-wave workgroups (four per CU, two waves per SIMD: a 1025th block would run alone after the others - 24 slices x
   // 48 tiles = 1152 single-wave blocks took 97 us where 21 x 48 = 1008 took 69 us), at least 4 steps of 32 rows per slice
+  static const int target = [] { const char* e = getenv("LT_WGRAD_BLOCKS"); if (e) return atoi(e); const char* d = getenv("LT_WGRAD_DEEP"); return (d && atoi(d) >= 3) ? 512 : 1024; }();  // (measurements)
   const long long steps = (M + 31) / 32;
-  long long s = 1024 / tiles;
+  long long s = target / tiles;
   if (s > steps / 4) s = steps / 4;
   return (int)(s < 1 ? 1 : s);
 }
@@ -410,8 +553,8 @@ extern "C" int64_t lt_wgrad_ws_floats(int64_t M, int N, int K) { return (int64_t
 
 extern "C" int lt_wgrad(const float* dz, const float* x, int x_split, int64_t M, int N, int K, const float* amax_blocks, int nblk_amax, float* slabs, float* db_slabs,
                         void* stream) {
-  if (!dz || !x || !slabs || M < 1 || N < 4 || K < 4 || (N & 3) || (K & 3) || (amax_blocks && nblk_amax < 1)) {
-    lt_set_error("lt_wgrad: invalid argument (N and K multiples of 4)");
+  if (!dz || !x || !slabs || M < 1 || N < 4 || K < 4 || (N & 3) || (K & 3) || (amax_blocks && nblk_amax < 1) || (long long)M * (N > K ? N : K) * 4 >= (1ll << 32)) {
+    lt_set_error("lt_wgrad: invalid argument (N and K multiples of 4, each operand below 4 GiB)");
     return LT_EINVAL;
   }
   WgradArgs a;
@@ -431,7 +574,12 @@ extern "C" int lt_wgrad(const float* dz, const float* x, int x_split, int64_t M,
     a.tiles_n = (N + 16 * TA - 1) / (16 * TA);
     a.tiles_k = (K + 16 * TB - 1) / (16 * TB);
     a.splits = pick_splits((long long)M, a.tiles_n * a.tiles_k);
-    hipLaunchKernelGGL(lt_wgrad_kernel, dim3((unsigned)((a.tiles_n * a.tiles_k * a.splits + 7) / 8 * 8)), dim3(128), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)((a.tiles_n * a.tiles_k * a.splits + 7) / 8 * 8));
+    static const int deep = [] { const char* e = getenv("LT_WGRAD_DEEP"); return e ? atoi(e) : 0; }();
+    if (deep == 3) hipLaunchKernelGGL(lt_wgrad_deep_kernel<3>, grid, dim3(128), 0, (hipStream_t)stream, a);
+    else if (deep == 4) hipLaunchKernelGGL(lt_wgrad_deep_kernel<4>, grid, dim3(128), 0, (hipStream_t)stream, a);
+    else if (deep == 5) hipLaunchKernelGGL(lt_wgrad_deep_kernel<5>, grid, dim3(128), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(lt_wgrad_kernel, grid, dim3(128), 0, (hipStream_t)stream, a);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
