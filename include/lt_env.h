@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 16
+#define LT_ABI_VERSION 17
 
 /* error codes */
 #define LT_OK 0
@@ -417,7 +417,8 @@ int lt_env_step_rows_profiled(lt_env* env, const float* actions, const float* pr
  * mu, actions, old_mu, old_sigma: [M][A]; std: [A] (the policy's state-independent std); value, old_logp, adv, returns,
  * old_values: [M].  Outputs: dmu [M][A] and dvalue [M] = d loss / d mu, d loss / d value for
  * loss = mean(surrogate) + value_loss_coef * mean(value loss) - entropy_coef * entropy  (the entropy term depends on std only and
- * is the caller's); acc [20]: [0] sum surrogate, [1] sum value loss, [2] sum KL, [4 + a] sum over rows of
+ * is the caller's); acc [24]: [0] sum surrogate, [1] sum value loss, [2] sum KL, [20] max |dmu|, [21] max |dvalue| (what
+ * lt_mlp_backward_pair scales the gradients by), [4 + a] sum over rows of
  * d surrogate-row / d sigma_a scaled by 1 / M.  1 <= A <= 16.  Device pointers, f32.
  * out (optional, 24 floats): the finished scalars - [0] loss = mean surrogate + value_loss_coef * mean value loss - entropy_coef * entropy,
  * [1] mean surrogate, [2] mean value loss, [3] entropy (sum_a 0.5 + 0.5 log 2 pi + log sigma_a), [4] mean KL, [8 + a] d loss / d sigma_a
@@ -448,9 +449,11 @@ int lt_elu_backward_bias2(const float* da, const float* a, int64_t M, int N, flo
  * by a power of two taken from max |dz| = max over amax_blocks[nblk_amax] (NULL: no scaling - |dz| must then sit in f16's normal
  * range), |x| <= 65504.  slabs: lt_wgrad_ws_floats(M, N, K) floats.  db_slabs (optional, splits x N floats): the slices' column
  * sums of dz, i.e. the partials of the bias gradient (lt_partial_sums: nblk = splits, stride = count = N).  x_split: x is in the
- * SPLIT FORMAT (lt_mlp_forward_pair, lt_split_rows) - its halves go to the matrix cores as they are.  Deterministic. */
-int lt_wgrad(const float* dz, const float* x, int x_split, int64_t M, int N, int K, const float* amax_blocks, int nblk_amax, float* slabs,
-             float* db_slabs, void* stream);
+ * SPLIT FORMAT (lt_mlp_forward_pair, lt_split_rows) - its halves go to the matrix cores as they are.  dz_split: so is dz, multiplied by
+ * *dz_scale (a device float: lt_mlp_backward_pair's scales_out; |scaled dz| <= LT_MLP_INPUT_CLAMP) - amax_blocks is then unused.
+ * Deterministic. */
+int lt_wgrad(const float* dz, int dz_split, const float* dz_scale, const float* x, int x_split, int64_t M, int N, int K,
+             const float* amax_blocks, int nblk_amax, float* slabs, float* db_slabs, void* stream);
 /* out[i] = clamp(x[i], +-LT_MLP_INPUT_CLAMP) in the SPLIT FORMAT (lt_mlp_forward_pair), i < count (a multiple of 4): the observation rows
  * of a PPO update, converted once per update for the first layer's weight gradient (lt_wgrad, x_split = 1). */
 int lt_split_rows(const float* x, void* out, int64_t count, void* stream);
@@ -582,7 +585,10 @@ int lt_mlp_forward_pair(const lt_mlp_desc* d0, const float* packed0, const float
  * dy* [m][out]; acts*[l]: the forward activations (lt_mlp_forward_pair); OUT dz*[l] [m][dims[l + 1]]; OUT amax*[l]:
  * lt_mlp_backward_blocks(fwd0, fwd1, m) floats.  Every workgroup scales its own rows by a power of two (max |dy| -> [1, 2)) and
  * unscales what it writes; sat_count (optional, device float): += 1 per workgroup and layer whose scaled gradients reached
- * LT_MLP_INPUT_CLAMP (growth by > 500x through the chain) - those rows are saturated, not exact. */
+ * LT_MLP_INPUT_CLAMP (growth by > 500x through the chain) - those rows are saturated, not exact.
+ * in_amax0 / in_amax1 (optional device scalars: max |dy0|, max |dy1|, e.g. acc[20], acc[21] of lt_ppo_loss): ONE scale per network for
+ * the whole launch instead of one per workgroup; required for dz_split = 1: the dz* are then written in the SPLIT FORMAT, still
+ * multiplied by that scale (scales_out[0 / 1], device floats) - the form lt_wgrad(dz_split = 1) reads without converting. */
 int lt_mlp_backward_packed_floats(const lt_mlp_desc* fwd, size_t* floats);
 int lt_mlp_pack_backward(const lt_mlp_desc* fwd, const float* const* weights, float* packed, void* stream);
 int64_t lt_mlp_backward_blocks(const lt_mlp_desc* fwd0, const lt_mlp_desc* fwd1, int64_t m);
@@ -593,7 +599,8 @@ int lt_mlp_pack_training(const lt_mlp_desc* d0, const float* const* weights0, co
                          void* stream);
 int lt_mlp_backward_pair(const lt_mlp_desc* fwd0, const float* bpacked0, const float* dy0, const float* const* acts0, float* const* dz0,
                          float* const* amax0, const lt_mlp_desc* fwd1, const float* bpacked1, const float* dy1, const float* const* acts1,
-                         float* const* dz1, float* const* amax1, int64_t m, int acts_split, float* sat_count, void* stream);
+                         float* const* dz1, float* const* amax1, int64_t m, int acts_split, const float* in_amax0, const float* in_amax1,
+                         int dz_split, float* scales_out, float* sat_count, void* stream);
 /* Actor forward + the sampling / log-prob / storage-slot writes of lt_rollout_act in one launch (the policy head must have 12 outputs).
  * Philox key step = *step_counter + step_offset. */
 int lt_rollout_policy(const lt_mlp_desc* actor, const float* packed, const float* obs, int64_t n, uint64_t seed, const int64_t* step_counter,

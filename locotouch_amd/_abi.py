@@ -132,7 +132,7 @@ def load() -> ctypes.CDLL:
     lib.lt_ppo_loss.argtypes = [_vp] * 11 + [ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int] + [_vp] * 5
     lib.lt_elu_backward_bias.argtypes = [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp, _vp]
     lib.lt_elu_backward_bias2.argtypes = [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]
-    lib.lt_wgrad.argtypes = [_vp, _vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp]
+    lib.lt_wgrad.argtypes = [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp]
     lib.lt_split_rows.argtypes = [_vp, _vp, ctypes.c_int64, _vp]
     lib.lt_wgrad_splits.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
     lib.lt_wgrad_ws_floats.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
@@ -171,7 +171,7 @@ def load() -> ctypes.CDLL:
     lib.lt_mlp_pack_training.argtypes = [dp, pvp, pvp, vp, vp, dp, pvp, pvp, vp, vp, vp]
     lib.lt_mlp_backward_blocks.argtypes = [dp, dp, ctypes.c_int64]
     lib.lt_mlp_backward_blocks.restype = ctypes.c_int64
-    lib.lt_mlp_backward_pair.argtypes = [dp, vp, vp, pvp, pvp, pvp, dp, vp, vp, pvp, pvp, pvp, ctypes.c_int64, ctypes.c_int, vp, vp]
+    lib.lt_mlp_backward_pair.argtypes = [dp, vp, vp, pvp, pvp, pvp, dp, vp, vp, pvp, pvp, pvp, ctypes.c_int64, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp, vp]
     lib.lt_rollout_policy.argtypes = [dp, vp, vp, ctypes.c_int64, ctypes.c_uint64, vp, ctypes.c_int64] + [vp] * 7
     lib.lt_rollout_policy_value.argtypes = [dp, vp, vp, dp, vp, vp, vp, ctypes.c_int64, ctypes.c_uint64, vp, ctypes.c_int64] + [vp] * 7
     lib.lt_env_step_rollout.argtypes = [ctypes.c_void_p] + [vp] * 6 + [ctypes.c_float, vp, vp, vp]

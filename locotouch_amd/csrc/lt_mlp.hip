@@ -169,6 +169,9 @@ struct MlpArgs {
   // MODE_BACKWARD (the chain of input gradients, module footer): per chain layer the forward activations that gate its output,
   // the per-workgroup maxima of |output| (for lt_wgrad's scale) and a counter of saturated workgroups
   int acts_split;  // act_out (forward) / gate_in (backward chain) are in the split format: per element one dword, f16 hi | f16 lo << 16 (lt_env.h)
+  int dz_split;             // MODE_BACKWARD: act_out (dz) is written in the split format, still SCALED by the launch's scale (scale_out)
+  const float* in_amax;     // MODE_BACKWARD: global max |input| (device scalar) - one scale for the whole launch; nullptr: one per workgroup
+  float* scale_out;         // MODE_BACKWARD: the scale (workgroup 0's), for whoever reads a split dz
   const float* gate_in[LT_MLP_MAX_LAYERS];
   float* amax_out[LT_MLP_MAX_LAYERS];
   float* sat_count;
@@ -521,10 +524,12 @@ __device__ __forceinline__ float gate_pass(const MlpArgs& a, int l, float* s_act
 #pragma unroll
       for (int h = 0; h < 2; ++h) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x[h][0]), fabsf(x[h][1]))), fmaxf(fabsf(x[h][2]), fabsf(x[h][3])));
     }
-    if (to_lds) {
-      f16x4 hi[2], lo[2];
+    f16x4 hi[2], lo[2];
+    if (to_lds || a.dz_split) {
       split4(x[0], hi[0], lo[0]);
       split4(x[1], hi[1], lo[1]);
+    }
+    if (to_lds) {
       *(f16x4*)g = hi[0]; *((f16x4*)g + 1) = hi[1];
       *((f16x4*)g + 2) = lo[0]; *((f16x4*)g + 3) = lo[1];
     }
@@ -534,8 +539,13 @@ __device__ __forceinline__ float gate_pass(const MlpArgs& a, int l, float* s_act
     if (live) {
 #endif
       float* const o = dst + (row0 + row[u]) * N + (at[u] - row[u] * S);
-      *(f32x4*)o = x[0] * inv_scale;
-      *(f32x4*)(o + 4) = x[1] * inv_scale;
+      if (a.dz_split) {  // (uniform) the halves the next chain layer multiplies, as they are - scaled: lt_wgrad divides its sums
+        *(u32x4*)o = interleave4(hi[0], lo[0]);
+        *(u32x4*)(o + 4) = interleave4(hi[1], lo[1]);
+      } else {
+        *(f32x4*)o = x[0] * inv_scale;
+        *(f32x4*)(o + 4) = x[1] * inv_scale;
+      }
     }
   }
 #pragma unroll
@@ -831,27 +841,33 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
   // the chain, so every workgroup has its own scale and takes it out again where it writes dz.
   float scale = 1.f, inv_scale = 1.f;
   if constexpr (KIND == KIND_GATE) {
-    float mx = 0.f;
-    if (vec_in || vec2_in) {
-#pragma unroll
-      for (int u = 0; u < B; ++u) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(vin[u][0]), fabsf(vin[u][1]))), fmaxf(fabsf(vin[u][2]), fabsf(vin[u][3])));
-    } else {
-      for (int idx = tid; idx < ROWS * K0; idx += NT) {
-        const unsigned rr = idx / K0;
-        mx = fmaxf(mx, fabsf(a.x[(row0 + min(rr, rmax)) * K0 + (idx - rr * K0)]));
-      }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    if (lane == 0) s_noise[wave] = mx;
-    lds_barrier();
     float m_ = 0.f;
+    if (a.in_amax) {  // (uniform) ONE scale for the launch, from the maximum the producer of the input left (lt_ppo_loss): a dz
+                      // written in the split format must carry the same scale in every row - lt_wgrad adds rows of all workgroups
+      m_ = *a.in_amax;
+    } else {
+      float mx = 0.f;
+      if (vec_in || vec2_in) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) m_ = fmaxf(m_, s_noise[w]);
+        for (int u = 0; u < B; ++u) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(vin[u][0]), fabsf(vin[u][1]))), fmaxf(fabsf(vin[u][2]), fabsf(vin[u][3])));
+      } else {
+        for (int idx = tid; idx < ROWS * K0; idx += NT) {
+          const unsigned rr = idx / K0;
+          mx = fmaxf(mx, fabsf(a.x[(row0 + min(rr, rmax)) * K0 + (idx - rr * K0)]));
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      if (lane == 0) s_noise[wave] = mx;
+      lds_barrier();
+#pragma unroll
+      for (int w = 0; w < NW; ++w) m_ = fmaxf(m_, s_noise[w]);
+    }
     int se = 127 - (int)((__float_as_uint(m_) >> 23) & 0xFF);  // -floor(log2 max); zero / denormal rows: 127 -> clamped
     se = m_ > 0.f ? (se > 100 ? 100 : (se < -100 ? -100 : se)) : 0;
     scale = __uint_as_float((unsigned)(127 + se) << 23);
     inv_scale = __uint_as_float((unsigned)(127 - se) << 23);
+    if (a.scale_out && row_block == 0 && tid == 0) *a.scale_out = scale;
   }
   {
 #pragma unroll
@@ -1365,8 +1381,11 @@ int64_t lt_mlp_backward_blocks(const lt_mlp_desc* fwd0, const lt_mlp_desc* fwd1,
 // gradients reached the f16 image's bound (LT_MLP_INPUT_CLAMP) - the result is then saturated, not exact.
 int lt_mlp_backward_pair(const lt_mlp_desc* fwd0, const float* bpacked0, const float* dy0, const float* const* acts0, float* const* dz0, float* const* amax0,
                          const lt_mlp_desc* fwd1, const float* bpacked1, const float* dy1, const float* const* acts1, float* const* dz1, float* const* amax1,
-                         int64_t m, int acts_split, float* sat_count, void* stream) {
+                         int64_t m, int acts_split, const float* in_amax0, const float* in_amax1, int dz_split, float* scales_out, float* sat_count,
+                         void* stream) {
   lt_mlp_desc bd[2];
+  const float* ia[2] = {in_amax0, in_amax1};
+  if (dz_split && (!in_amax0 || !in_amax1 || !scales_out)) { lt_set_error("lt_mlp_backward_pair: a split dz needs the global input maxima and scales_out"); return LT_EINVAL; }
   const lt_mlp_desc* fw[2] = {fwd0, fwd1};
   const float* pk[2] = {bpacked0, bpacked1};
   const float* dy[2] = {dy0, dy1};
@@ -1383,6 +1402,7 @@ int lt_mlp_backward_pair(const lt_mlp_desc* fwd0, const float* bpacked0, const f
       if (!ac[k][l] || !dz[k][l] || !am[k][l]) { lt_set_error("lt_mlp_backward_pair: null layer buffer"); return LT_EINVAL; }
     fill_backward(&bd[k], fw[k]->num_layers, pk[k], dy[k], m, ac[k], dz[k], am[k], sat_count, d.net[k]);
     d.net[k].acts_split = acts_split != 0;
+    d.net[k].in_amax = ia[k]; d.net[k].dz_split = dz_split != 0; d.net[k].scale_out = scales_out ? scales_out + k : nullptr;
   }
   return launch(d, 2, (hipStream_t)stream);
 }

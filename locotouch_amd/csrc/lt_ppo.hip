@@ -19,7 +19,9 @@ namespace {
 constexpr int MAX_A = 16;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 
-// acc layout: [0] sum surrogate, [1] sum value loss, [2] sum kl, [3] unused, [4 .. 4 + A) sum over rows of d surrogate / d sigma_a
+// acc layout: [0] sum surrogate, [1] sum value loss, [2] sum kl, [3] unused, [4 .. 4 + A) sum over rows of d surrogate / d sigma_a,
+// [20] max |dmu|, [21] max |dvalue| (bit patterns of non-negative floats, merged with an integer atomicMax: order-independent) - the
+// scales the backward chain brings the two gradients into f16's range with (lt_mlp_backward_pair)
 __global__ __launch_bounds__(256) void lt_ppo_loss_kernel(const float* __restrict__ mu, const float* __restrict__ stdp, const float* __restrict__ value,
                                                           const float* __restrict__ actions, const float* __restrict__ old_logp,
                                                           const float* __restrict__ adv, const float* __restrict__ returns,
@@ -31,6 +33,7 @@ __global__ __launch_bounds__(256) void lt_ppo_loss_kernel(const float* __restric
   const bool ok = row < M;
   const long long src = (ok && idx) ? idx[row] : row;  // row of the rollout storage this minibatch row was drawn from
   float part[4 + MAX_A];
+  float amax_mu = 0.f, amax_v = 0.f;
 #pragma unroll
   for (int i = 0; i < 4 + MAX_A; ++i) part[i] = 0.f;
   if (ok) {
@@ -60,6 +63,7 @@ __global__ __launch_bounds__(256) void lt_ppo_loss_kernel(const float* __restric
     for (int a = 0; a < MAX_A; ++a) {
       if (a < A) {
         dmu[row * A + a] = dlogp * z[a] * isg[a];
+        amax_mu = fmaxf(amax_mu, fabsf(dlogp * z[a] * isg[a]));
         part[4 + a] = dlogp * (z[a] * z[a] - 1.f) * isg[a];  // d logp / d sigma_a = ((x - mu)^2 / sigma^3 - 1 / sigma)
       }
     }
@@ -78,6 +82,7 @@ __global__ __launch_bounds__(256) void lt_ppo_loss_kernel(const float* __restric
       dv = 2.f * (v - R);
     }
     dvalue[row] = vcoef * dv * inv_m;
+    amax_v = fabsf(vcoef * dv * inv_m);
     part[0] = fmaxf(s1, s2);
     part[1] = vl;
     part[2] = kl;
@@ -91,6 +96,15 @@ __global__ __launch_bounds__(256) void lt_ppo_loss_kernel(const float* __restric
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     if (lane == 0) red[wave][i] = v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    amax_mu = fmaxf(amax_mu, __shfl_xor(amax_mu, off, 64));
+    amax_v = fmaxf(amax_v, __shfl_xor(amax_v, off, 64));
+  }
+  if (lane == 0) {
+    atomicMax((unsigned*)acc + 20, __float_as_uint(amax_mu));
+    atomicMax((unsigned*)acc + 21, __float_as_uint(amax_v));
   }
   __syncthreads();
   if (threadIdx.x < 4 + A && threadIdx.x != 3) {
@@ -582,7 +596,7 @@ extern "C" int lt_ppo_loss(const float* mu, const float* stdp, const float* valu
     lt_set_error("lt_ppo_loss: invalid argument (1 <= num_actions <= 16)");
     return LT_EINVAL;
   }
-  hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * (4 + MAX_A), (hipStream_t)stream);
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * (4 + MAX_A + 4), (hipStream_t)stream);
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
   hipLaunchKernelGGL(lt_ppo_loss_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu, stdp, value, actions, old_logp, adv,
                      returns, old_values, old_mu, old_sigma, (const long long*)idx, (long long)M, A, clip, value_loss_coef, use_clipped_value_loss, dmu, dvalue, acc);

@@ -90,6 +90,8 @@ struct WgradArgs {
   int nblk_amax;
   float* slabs;         // [splits][N][K]
   int probe;            // measurements only (LT_WGRAD_PROBE): 1 = fetch the first step's panels only, 2 = no MFMAs, 3 = no LDS staging after the first, 4 = 1 + 3
+  int dz_split;         // dz is in the split format AND multiplied by *dz_scale (lt_mlp_backward_pair, dz_split = 1): no conversion, no amax
+  const float* dz_scale;
   int x_split;          // x is in the split format (one dword per element: f16 hi | f16 lo << 16, lt_mlp.hip): no conversion here
   float* db;            // optional [splits][N]: the slices' column sums of dz (the bias gradient's partials), by the tiles of the first k column
 };
@@ -117,7 +119,9 @@ __global__ __launch_bounds__(128, 2) void lt_wgrad_kernel(const WgradArgs a) {
   const long long s0 = wave ? mid : b0, s1 = wave ? b1 : mid;
   // scale of dz: a power of two that brings max |dz| to [2^7, 2^8) - 64 x its hi half is still an f16 number
   float scale = 1.f;
-  if (a.amax) {
+  if (a.dz_split) {
+    scale = *a.dz_scale;
+  } else if (a.amax) {
     float m = 0.f;
     for (int b = lane; b < a.nblk_amax; b += 64) m = fmaxf(m, a.amax[b]);
 #pragma unroll
@@ -160,11 +164,25 @@ __global__ __launch_bounds__(128, 2) void lt_wgrad_kernel(const WgradArgs a) {
       for (int t = 0; t < 8; ++t) if (s * 32 + 4 * t + g >= a.M) va[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (colsum) {
+      if (a.dz_split) {  // (uniform; the tiles of the first k column only) value = hi + lo / 64, still scaled
 #pragma unroll
-      for (int t = 0; t < 8; ++t) cs += va[t];
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned w = __float_as_uint(va[t][u]);
+            cs[u] += (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)) + (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)) * (1.f / LO_SCALE);
+          }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cs += va[t];
+      }
     }
     f16x8 ah[TA], al[TA], bh[TB], bl[TB];
-    split8<0>(va, scale, ah[0], al[0]); split8<1>(va, scale, ah[1], al[1]); split8<2>(va, scale, ah[2], al[2]); split8<3>(va, scale, ah[3], al[3]);
+    if (a.dz_split) {  // (uniform)
+      unpack8<0>(va, ah[0], al[0]); unpack8<1>(va, ah[1], al[1]); unpack8<2>(va, ah[2], al[2]); unpack8<3>(va, ah[3], al[3]);
+    } else {
+      split8<0>(va, scale, ah[0], al[0]); split8<1>(va, scale, ah[1], al[1]); split8<2>(va, scale, ah[2], al[2]); split8<3>(va, scale, ah[3], al[3]);
+    }
     if (a.x_split) {  // (uniform)
       unpack8<0>(vb, bh[0], bl[0]); unpack8<1>(vb, bh[1], bl[1]); unpack8<2>(vb, bh[2], bl[2]); unpack8<3>(vb, bh[3], bl[3]);
     } else {
@@ -203,6 +221,7 @@ __global__ __launch_bounds__(128, 2) void lt_wgrad_kernel(const WgradArgs a) {
       cs[u] += __shfl_xor(cs[u], 16, 64);
       cs[u] += __shfl_xor(cs[u], 32, 64);
     }
+    if (a.dz_split) cs *= 1.f / scale;
     if (g == 0 && n0 + 4 * i < a.N) *(f32x4*)(a.db + (long long)split * a.N + n0 + 4 * i) = cs;
   }
   // the partial tile: MFMA tile (p, q) holds C[row rho = 4 g + r][col kappa = i] = dW[n0 + 4 rho + p][k0 + 4 kappa + q]: a lane's four
@@ -224,85 +243,73 @@ __global__ __launch_bounds__(128, 2) void lt_wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// The same kernel with NST steps of operand loads in flight per wave instead of one, at ONE wave per SIMD (the stages take the
-// registers a second wave would): a wave's step is one HBM / L2 round trip (~2 us) for ~0.7 us of conversions and MFMAs, and what
-// hides it is loads in flight - two waves x one step there, one wave x NST steps here.
+// Both operands in the split format (the production path of the PPO update), NST steps of loads in flight per wave, ONE wave per SIMD:
+// with nothing left to convert a wave's step is ~0.5 us of byte permutes and MFMAs behind a ~2 us HBM / L2 round trip, and what
+// hides the round trip is loads in flight - two waves x one step in the kernel above, one wave x NST steps here (the stages take the
+// registers a second wave would; those beyond 256 live in AGPRs and cost a copy each).
 template <int NST>
-__global__ __launch_bounds__(128, 1) void lt_wgrad_deep_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(128, 1) void lt_wgrad_split_kernel(const WgradArgs a) {
   __shared__ f32x4 s_tile[TA * TB + 1][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
-  // block -> (split, tile): the tiles of a slice of M on ONE XCD (blocks are dealt round-robin over the 8 XCDs - observed placement,
-  // used for speed only): they sweep the same rows of dz / x at about the same time, so a row is fetched into that XCD's L2 once and
-  // read from there by the 48 tiles.  Dealt block by block the tiles of a slice landed on all 8 XCDs and every XCD fetched every
-  // row: 8 x 84 MB from the Infinity Cache per launch of the 512 x 348 layer - 149 us at 58 TFLOP/s (f32-equivalent).  XCD x takes
-  // the work items [x, x + 1) * gridDim / 8 of the (split-major) list: at most one slice per XCD is shared with a neighbour.
   const int tiles = a.tiles_n * a.tiles_k;
   const int per_xcd = (int)gridDim.x >> 3;
-  const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);  // (lt_wgrad_kernel: a slice's tiles on one XCD)
   if (item >= tiles * a.splits) return;
   const int split = item / tiles, tile = item - split * tiles;
   const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
   const int n0 = tn * 16 * TA, k0 = tk * 16 * TB;
-  // this slice's 32-row steps (the M / 32 steps are dealt as evenly as possible), first half to wave 0, second to wave 1
   const long long steps = (a.M + 31) / 32;
   const long long b0 = steps * split / a.splits, b1 = steps * (split + 1) / a.splits, mid = b0 + (b1 - b0 + 1) / 2;
   const long long s0 = wave ? mid : b0, s1 = wave ? b1 : mid;
-  // scale of dz: a power of two that brings max |dz| to [2^7, 2^8) - 64 x its hi half is still an f16 number
-  float scale = 1.f;
-  if (a.amax) {
-    float m = 0.f;
-    for (int b = lane; b < a.nblk_amax; b += 64) m = fmaxf(m, a.amax[b]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    const int e = (int)((__float_as_uint(m) >> 23) & 0xFF) - 127;  // floor(log2 m) (m == 0 or denormal: e = -127)
-    int se = 7 - e;
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    scale = __uint_as_float((unsigned)(127 + se) << 23);
-  }
+  const float scale = *a.dz_scale;
   f32x4 acc[TA][TB];
 #pragma unroll
   for (int p = 0; p < TA; ++p)
 #pragma unroll
     for (int q = 0; q < TB; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // 32 rows x 64 columns per operand and step: load t = row m0 + 4 t + g, 16 bytes at column 4 c (clamped to the matrix: a tile may
-  // hang over its edge; what an overhanging lane loads is multiplied into output elements that are never stored)
   struct Stage { f32x4 a[8], b[8]; };
   Stage st[NST];
   const int ca = min(n0 + 4 * i, a.N - 4), cb = min(k0 + 4 * i, a.K - 4);
-  auto issue = [&](Stage& S, long long s) __attribute__((always_inline)) {
-    if (s >= s1) return;
+  const unsigned row_a = (unsigned)a.N * 4u, row_b = (unsigned)a.K * 4u;
+  const unsigned last_a = (unsigned)(a.M - 1) * row_a + (unsigned)ca * 4u, last_b = (unsigned)(a.M - 1) * row_b + (unsigned)cb * 4u;
+  unsigned off_a = ((unsigned)s0 * 32u + (unsigned)g) * row_a + (unsigned)ca * 4u, off_b = ((unsigned)s0 * 32u + (unsigned)g) * row_b + (unsigned)cb * 4u;
+  long long issued = s0;
+  auto issue = [&](Stage& S) __attribute__((always_inline)) {  // the next step not yet requested
+    if (issued >= s1) return;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      long long r = s * 32 + 4 * t + g;
-      r = r < a.M ? r : a.M - 1;
-      S.a[t] = *(const f32x4*)(a.dz + r * a.N + ca);
-      S.b[t] = *(const f32x4*)(a.x + r * a.K + cb);
+      S.a[t] = *(const f32x4*)((const char*)a.dz + min(off_a + (unsigned)(4 * t) * row_a, last_a));
+      S.b[t] = *(const f32x4*)((const char*)a.x + min(off_b + (unsigned)(4 * t) * row_b, last_b));
     }
+    off_a += 32u * row_a;
+    off_b += 32u * row_b;
+    ++issued;
   };
   const bool colsum = a.db != nullptr && tk == 0;  // (uniform)
   f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
   auto consume = [&](Stage& S, long long s) __attribute__((always_inline)) {
-    if ((s + 1) * 32 > a.M) {  // rows beyond M (the last step of a ragged M) must not contribute: their clamped loads repeat row M - 1
+    if ((s + 1) * 32 > a.M) {  // rows beyond M (the last step of a ragged M): zero halves contribute nothing
 #pragma unroll
       for (int t = 0; t < 8; ++t) if (s * 32 + 4 * t + g >= a.M) S.a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (colsum) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) cs += S.a[t];
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned w = __float_as_uint(S.a[t][u]);
+          cs[u] += (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)) + (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)) * (1.f / LO_SCALE);
+        }
     }
     f16x8 ah[TA], al[TA], bh[TB], bl[TB];
-    split8<0>(S.a, scale, ah[0], al[0]); split8<1>(S.a, scale, ah[1], al[1]); split8<2>(S.a, scale, ah[2], al[2]); split8<3>(S.a, scale, ah[3], al[3]);
-    if (a.x_split) {  // (uniform)
-      unpack8<0>(S.b, bh[0], bl[0]); unpack8<1>(S.b, bh[1], bl[1]); unpack8<2>(S.b, bh[2], bl[2]); unpack8<3>(S.b, bh[3], bl[3]);
-    } else {
-      split8<0>(S.b, 1.f, bh[0], bl[0]); split8<1>(S.b, 1.f, bh[1], bl[1]); split8<2>(S.b, 1.f, bh[2], bl[2]); split8<3>(S.b, 1.f, bh[3], bl[3]);
-    }
-    issue(S, s + NST);  // this stage's registers are free again
+    unpack8<0>(S.a, ah[0], al[0]); unpack8<1>(S.a, ah[1], al[1]); unpack8<2>(S.a, ah[2], al[2]); unpack8<3>(S.a, ah[3], al[3]);
+    unpack8<0>(S.b, bh[0], bl[0]); unpack8<1>(S.b, bh[1], bl[1]); unpack8<2>(S.b, bh[2], bl[2]); unpack8<3>(S.b, bh[3], bl[3]);
+    issue(S);  // this stage's registers are free again
 #pragma unroll
     for (int p = 0; p < TA; ++p) {
-      const f16x8 a64 = ah[p] * (_Float16)LO_SCALE;  // exact: |scaled dz| < 2^8
+      const f16x8 a64 = ah[p] * (_Float16)LO_SCALE;  // exact: |scaled dz| <= LT_MLP_INPUT_CLAMP
 #pragma unroll
       for (int q = 0; q < TB; ++q) {
         acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a64, bh[q], acc[p][q], 0, 0, 0);
@@ -312,13 +319,12 @@ __global__ __launch_bounds__(128, 1) void lt_wgrad_deep_kernel(const WgradArgs a
     }
   };
 #pragma unroll
-  for (int j = 0; j < NST; ++j) issue(st[j], s0 + j);
+  for (int j = 0; j < NST; ++j) issue(st[j]);
   for (long long s = s0; s < s1; s += NST) {
 #pragma unroll
     for (int j = 0; j < NST; ++j)
       if (s + j < s1) consume(st[j], s + j);
   }
-  // wave 1 hands its tile and column sums to wave 0
   if (wave == 1) {
 #pragma unroll
     for (int p = 0; p < TA; ++p)
@@ -333,16 +339,15 @@ __global__ __launch_bounds__(128, 1) void lt_wgrad_deep_kernel(const WgradArgs a
 #pragma unroll
     for (int q = 0; q < TB; ++q) acc[p][q] += s_tile[p * TB + q][lane];
   cs += s_tile[TA * TB][lane];
-  if (colsum) {  // lane (c, g) holds the sums of rows g mod 4 of columns n0 + 4 c .. + 3
+  if (colsum) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       cs[u] += __shfl_xor(cs[u], 16, 64);
       cs[u] += __shfl_xor(cs[u], 32, 64);
     }
+    cs *= 1.f / scale;
     if (g == 0 && n0 + 4 * i < a.N) *(f32x4*)(a.db + (long long)split * a.N + n0 + 4 * i) = cs;
   }
-  // the partial tile: MFMA tile (p, q) holds C[row rho = 4 g + r][col kappa = i] = dW[n0 + 4 rho + p][k0 + 4 kappa + q]: a lane's four
-  // q tiles are 4 ADJACENT columns of one row
   const float inv = 1.f / (scale * LO_SCALE);
   float* const out = a.slabs + (long long)split * a.N * a.K;
   const int k = k0 + 4 * i;
@@ -551,8 +556,8 @@ extern "C" int lt_wgrad_splits(int64_t M, int N, int K) {
 
 extern "C" int64_t lt_wgrad_ws_floats(int64_t M, int N, int K) { return (int64_t)lt_wgrad_splits(M, N, K) * N * K; }
 
-extern "C" int lt_wgrad(const float* dz, const float* x, int x_split, int64_t M, int N, int K, const float* amax_blocks, int nblk_amax, float* slabs, float* db_slabs,
-                        void* stream) {
+extern "C" int lt_wgrad(const float* dz, int dz_split, const float* dz_scale, const float* x, int x_split, int64_t M, int N, int K, const float* amax_blocks,
+                        int nblk_amax, float* slabs, float* db_slabs, void* stream) {
   if (!dz || !x || !slabs || M < 1 || N < 4 || K < 4 || (N & 3) || (K & 3) || (amax_blocks && nblk_amax < 1) || (long long)M * (N > K ? N : K) * 4 >= (1ll << 32)) {
     lt_set_error("lt_wgrad: invalid argument (N and K multiples of 4, each operand below 4 GiB)");
     return LT_EINVAL;
@@ -560,7 +565,8 @@ extern "C" int lt_wgrad(const float* dz, const float* x, int x_split, int64_t M,
   WgradArgs a;
   a.dz = dz; a.x = x; a.M = M; a.N = N; a.K = K;
   a.amax = amax_blocks; a.nblk_amax = amax_blocks ? nblk_amax : 0;
-  a.slabs = slabs; a.db = db_slabs; a.x_split = x_split != 0;
+  a.slabs = slabs; a.db = db_slabs; a.x_split = x_split != 0; a.dz_split = dz_split != 0; a.dz_scale = dz_scale;
+  if (a.dz_split && (!dz_scale || use_tiled(N, K))) { lt_set_error("lt_wgrad: a split dz needs its scale (and the one-wave form)"); return LT_EINVAL; }
   static const int probe = [] { const char* e = getenv("LT_WGRAD_PROBE"); return e ? atoi(e) : 0; }();
   a.probe = probe;
   if (use_tiled(N, K)) {
@@ -576,9 +582,10 @@ extern "C" int lt_wgrad(const float* dz, const float* x, int x_split, int64_t M,
     a.splits = pick_splits((long long)M, a.tiles_n * a.tiles_k);
     const dim3 grid((unsigned)((a.tiles_n * a.tiles_k * a.splits + 7) / 8 * 8));
     static const int deep = [] { const char* e = getenv("LT_WGRAD_DEEP"); return e ? atoi(e) : 0; }();
-    if (deep == 3) hipLaunchKernelGGL(lt_wgrad_deep_kernel<3>, grid, dim3(128), 0, (hipStream_t)stream, a);
-    else if (deep == 4) hipLaunchKernelGGL(lt_wgrad_deep_kernel<4>, grid, dim3(128), 0, (hipStream_t)stream, a);
-    else if (deep == 5) hipLaunchKernelGGL(lt_wgrad_deep_kernel<5>, grid, dim3(128), 0, (hipStream_t)stream, a);
+    const bool both_split = a.dz_split && a.x_split;
+    if (both_split && deep == 3) hipLaunchKernelGGL(lt_wgrad_split_kernel<3>, grid, dim3(128), 0, (hipStream_t)stream, a);
+    else if (both_split && deep == 4) hipLaunchKernelGGL(lt_wgrad_split_kernel<4>, grid, dim3(128), 0, (hipStream_t)stream, a);
+    else if (both_split && deep == 5) hipLaunchKernelGGL(lt_wgrad_split_kernel<5>, grid, dim3(128), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(lt_wgrad_kernel, grid, dim3(128), 0, (hipStream_t)stream, a);
   }
   const hipError_t e = hipGetLastError();

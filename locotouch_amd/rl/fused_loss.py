@@ -23,7 +23,7 @@ class _FusedPPOLoss(torch.autograd.Function):
         mu_c, std_c, v_c = c(mu), c(std), c(value).view(-1)
         dmu = torch.empty_like(mu_c)
         dvalue = torch.empty(m, device=mu.device, dtype=torch.float32)
-        acc = torch.empty(20, device=mu.device, dtype=torch.float32)
+        acc = torch.empty(24, device=mu.device, dtype=torch.float32)
         vp = ctypes.c_void_p
         args = [c(actions), c(old_logp).view(-1), c(adv).view(-1), c(returns).view(-1), c(old_values).view(-1), c(old_mu), c(old_sigma)]
         rows = args[0].shape[0]

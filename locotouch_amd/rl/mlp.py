@@ -206,6 +206,7 @@ def _alloc_outputs(nets, m, device):
 import os as _os
 
 USE_SPLIT_F16_WGRAD = _os.environ.get("LT_SPLIT_F16_WGRAD", "1") != "0"  # 0: the weight gradients as library f32 GEMMs (A/B measurements)
+USE_SPLIT_DZ = _os.environ.get("LT_SPLIT_DZ", "1") != "0"  # 0: the chain writes f32 dz (one scale per workgroup), lt_wgrad splits it on the fly
 USE_FUSED_BACKWARD = _os.environ.get("LT_FUSED_BACKWARD", "1") != "0"  # 0: dz @ W as library GEMMs + lt_elu_backward_bias per layer
 
 
@@ -278,7 +279,7 @@ def backward_chain(weights, biases_out, weights_out, x, acts, dy, sums: SumJobs)
             # dW = dz^T x on the f16 matrix cores, f32-equivalent (csrc/lt_wgrad.hip): slices of the rows -> slabs -> the joint sum launch
             sp = int(lib.lt_wgrad_splits(m, n, k))
             slabs = torch.empty(sp * n * k, device=inp.device, dtype=torch.float32)
-            _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), 0, m, n, k, vp(amax.data_ptr()), amax.numel(), vp(slabs.data_ptr()), vp(None), stream), "lt_wgrad")
+            _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), 0, vp(None), vp(inp.data_ptr()), 0, m, n, k, vp(amax.data_ptr()), amax.numel(), vp(slabs.data_ptr()), vp(None), stream), "lt_wgrad")
             sums.add(slabs, sp, n * k, n * k, n * k, weights_out[l])
         else:
             sp = pick_splits(m, n, k)
@@ -387,7 +388,7 @@ class PackedPair:
     def _fused_backward_ok(self, x0, x1, dy0, dy1) -> bool:
         return self._fused_backward_possible(x0, x1) and dy0.dtype == torch.float32 and dy1.dtype == torch.float32
 
-    def _backward_fused(self, x0, x1, acts, dy0, dy1, grad_of, sums, x_split_rows=None, after_first=None) -> None:
+    def _backward_fused(self, x0, x1, acts, dy0, dy1, grad_of, sums, x_split_rows=None, after_first=None, dy_amax=None) -> None:
         """The backward pass as: two head launches (lt_head_wgrad), ONE launch for both stacks' chains of input gradients
         (lt_mlp_backward_pair: dz of every hidden layer, ELU' applied in the layer epilogue, per-workgroup max |dz|), six weight
         gradients on the matrix cores that also leave the bias gradients' partials (lt_wgrad), one launch of ordered sums."""
@@ -423,9 +424,14 @@ class PackedPair:
             amaxs.append(am)
             arr = ctypes.c_void_p * (L - 1)
             arrs.append((arr(*[a.data_ptr() for a in acts[k]]), arr(*[t.data_ptr() for t in dz]), arr(*[am[l].data_ptr() for l in range(L - 1)])))
+        # `dy_amax`: (max |dy0|, max |dy1|) as device scalars (lt_ppo_loss leaves them): the chain then runs on ONE scale per network
+        # and writes every dz in the split format, scaled - what lt_wgrad reads without converting
+        dzsp = int(dy_amax is not None and USE_SPLIT_DZ)
+        scales = torch.empty(2, device=dev, dtype=torch.float32)
         _abi.check(lib.lt_mlp_backward_pair(ctypes.byref(nets[0].desc), vp(nets[0].bpacked.data_ptr()), vp(dys[0].data_ptr()), *arrs[0],
                                             ctypes.byref(nets[1].desc), vp(nets[1].bpacked.data_ptr()), vp(dys[1].data_ptr()), *arrs[1],
-                                            m, asp, vp(self.sat.data_ptr()), stream), "lt_mlp_backward_pair")
+                                            m, asp, vp(dy_amax[0].data_ptr()) if dzsp else vp(None), vp(dy_amax[1].data_ptr()) if dzsp else vp(None),
+                                            dzsp, vp(scales.data_ptr()), vp(self.sat.data_ptr()), stream), "lt_mlp_backward_pair")
         for k, net in enumerate(nets):
             for l in range(len(net.linears) - 2, -1, -1):
                 inp = acts[k][l - 1] if l > 0 else xs[k]
@@ -434,28 +440,30 @@ class PackedPair:
                 sp = int(lib.lt_wgrad_splits(m, n, kk))
                 slabs = torch.empty(sp * n * kk + sp * n, device=dev, dtype=torch.float32)
                 dbs = slabs[sp * n * kk:]
-                _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(inp.data_ptr()), asp if l > 0 else xsp, m, n, kk, vp(amaxs[k][l].data_ptr()), nblk,
-                                        vp(slabs.data_ptr()), vp(dbs.data_ptr()), stream), "lt_wgrad")
+                _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), dzsp, vp(scales[k:k + 1].data_ptr()), vp(inp.data_ptr()), asp if l > 0 else xsp, m, n, kk,
+                                        vp(amaxs[k][l].data_ptr()), nblk, vp(slabs.data_ptr()), vp(dbs.data_ptr()), stream), "lt_wgrad")
                 per_net[k].add(slabs, sp, n * kk, n * kk, n * kk, grad_of[net.linears[l].weight])
                 per_net[k].add(dbs, sp, n, n, n, grad_of[net.linears[l].bias])
             if after_first is not None:
                 per_net[k].launch()
                 if k == 0:
                     after_first()
-        self._keep_bwd = (dzs, amaxs, dys, per_net)
+        self._keep_bwd = (dzs, amaxs, dys, per_net, scales if dzsp else None)
         self._bpacked_fresh = False  # the optimizer steps next
 
     def saturated(self) -> torch.Tensor | None:
         """Device counter of saturated workgroups of the fused backward chain (None: that path has not run)."""
         return getattr(self, "sat", None)
 
-    def backward_raw(self, x0, x1, acts, dy0, dy1, grad_of, x_split_rows=None, after_first=None) -> None:
+    def backward_raw(self, x0, x1, acts, dy0, dy1, grad_of, x_split_rows=None, after_first=None, dy_amax=None) -> None:
         """Both stacks' backward passes, every parameter gradient written into `grad_of[param]` (the flat bucket's views).
-        `x_split_rows`: (x0, x1) in the split format (`split_rows`), if the caller has them.  `after_first()`: called when every
+        `x_split_rows`: (x0, x1) in the split format (`split_rows`), if the caller has them.  `dy_amax`: device scalars (max |dy0|,
+        max |dy1|), if the producer of the gradients left them (lt_ppo_loss: acc[20], acc[21]) - the hidden-layer gradients then travel
+        in the split format as well.  `after_first()`: called when every
         gradient of the FIRST stack (the actor) has been enqueued - before the second stack's weight gradients are."""
         sums = SumJobs()
         if self._fused_backward_ok(x0, x1, dy0, dy1):
-            self._backward_fused(x0, x1, acts, dy0, dy1, grad_of, sums, x_split_rows, after_first)
+            self._backward_fused(x0, x1, acts, dy0, dy1, grad_of, sums, x_split_rows, after_first, dy_amax)
             sums.launch()
             return
         if getattr(self, "acts_split", False):

@@ -230,7 +230,7 @@ class PPO:
             (mu, value), acts = pair.forward_raw(o, co)
             dmu = torch.empty_like(mu)
             dvalue = torch.empty(m, 1, device=dev, dtype=torch.float32)
-            acc = torch.empty(20, device=dev, dtype=torch.float32)
+            acc = torch.empty(24, device=dev, dtype=torch.float32)
             out = torch.empty(24, device=dev, dtype=torch.float32)
             stream = vp(torch.cuda.current_stream(dev).cuda_stream)
             _abi.check(lib.lt_ppo_loss(vp(mu.data_ptr()), vp(std_c.data_ptr()), vp(value.data_ptr()), *[vp(t.data_ptr()) for t in small],
@@ -249,13 +249,14 @@ class PPO:
                 # the bucket in two halves (std + actor | critic): the actor's all-reduce runs on RCCL's stream under the critic's
                 # three weight-gradient launches (~105 us at 24 576 rows), only the critic's half stays exposed
                 handles = []
-                pair.backward_raw(o, co, acts, dmu, dvalue, grad_of, xs, after_first=lambda: handles.append(self.dist.all_reduce_mean_begin(self._flat_grad[:critic_at])))
+                pair.backward_raw(o, co, acts, dmu, dvalue, grad_of, xs, after_first=lambda: handles.append(self.dist.all_reduce_mean_begin(self._flat_grad[:critic_at])),
+                                  dy_amax=(acc[20:21], acc[21:22]))
                 # (a backward pass on the library path never calls back: the whole bucket then)
                 handles.append(self.dist.all_reduce_mean_begin(self._flat_grad[critic_at:] if handles else self._flat_grad))
                 for h in handles:
                     self.dist.all_reduce_mean_end(h)
             else:
-                pair.backward_raw(o, co, acts, dmu, dvalue, grad_of, xs)
+                pair.backward_raw(o, co, acts, dmu, dvalue, grad_of, xs, dy_amax=(acc[20:21], acc[21:22]))
                 if self.dist.world_size > 1:
                     self.dist.all_reduce_mean_(self._flat_grad)  # RCCL all-reduce of the policy gradients over xGMI
             fa.step_dev(self.max_grad_norm, lr_dev)

@@ -80,6 +80,17 @@ def test_fused_backward_matches_float64(m, scale):
                 torch.cuda.synchronize()
                 for p in grads:
                     assert torch.equal(again[p], grads[p])
+                # ... and with the producer's maxima of |dy| (lt_ppo_loss leaves them): ONE scale per network, every dz in the split
+                # format - decoded here: (hi + lo / 64) / scale - and the same gradients to the f32-equivalent band
+                third = {p: torch.full_like(p, float("nan")) for p in grads}
+                pair.backward_raw(x0, x1, acts, dy0, dy1, third, (pair.split_rows(x0), pair.split_rows(x1)),
+                                  dy_amax=(dy0.abs().max().reshape(1), dy1.abs().max().reshape(1)))
+                torch.cuda.synchronize()
+                sdz, _, _, _, scales = pair._keep_bwd
+                split_dz = [[(t.view(torch.float16).view(t.shape[0], t.shape[1], 2).double() * torch.tensor([1.0, 1.0 / 64.0], device="cuda", dtype=torch.float64)).sum(-1)
+                             / float(scales[k]) for t in sdz[k]] for k in range(2)]
+                split_grads = third
+                assert float(pair.saturated()) == 0.0
         finally:
             M.USE_FUSED_BACKWARD = True
     for k, (net, x, dy) in enumerate(((actor, x0, dy0), (critic, x1, dy1))):
@@ -96,6 +107,13 @@ def test_fused_backward_matches_float64(m, scale):
             t64 = torch.nn.functional.pad(ref.abs(), (0, 0, 0, pad)).view(-1, 64 * ref.shape[1]).amax(1)
             assert bool((e64 <= 2e-6 * t64).all()), (k, l, float((e64 / t64.clamp_min(1e-300)).max()))
             assert float(amaxs[k][l].max()) == pytest.approx(top, rel=1e-6)
+        for l, ref in rdz.items():  # the split-format dz: one scale for the network, so the bound is relative to the layer's maximum
+            assert float((split_dz[k][l] - ref).abs().max()) <= 1e-6 * float(ref.abs().max()), (k, l)
+        for l in range(len(lin)):
+            for name, got, ref in (("dW", split_grads[lin[l].weight], rdw[l]), ("db", split_grads[lin[l].bias], rdb[l])):
+                top = float(ref.abs().max())
+                eu = float((res[False][lin[l].weight if name == "dW" else lin[l].bias].double() - ref).abs().max())
+                assert float((got.double() - ref).abs().max()) <= max(4.0 * eu, 1e-5 * top), (k, l, name, "split dz")
         for l in range(len(lin)):
             for name, got_f, got_u, ref in (("dW", res[True][lin[l].weight], res[False][lin[l].weight], rdw[l]), ("db", res[True][lin[l].bias], res[False][lin[l].bias], rdb[l])):
                 top = float(ref.abs().max())

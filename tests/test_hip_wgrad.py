@@ -22,7 +22,7 @@ def _wgrad(dz, x, amax=None, x_split=False):
     slabs = torch.empty(int(lib.lt_wgrad_ws_floats(m, n, k)), device=dz.device)
     assert slabs.numel() == sp * n * k
     st = vp(torch.cuda.current_stream().cuda_stream)
-    _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(x.data_ptr()), int(x_split), m, n, k, vp(amax.data_ptr()) if amax is not None else vp(None),
+    _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), 0, vp(None), vp(x.data_ptr()), int(x_split), m, n, k, vp(amax.data_ptr()) if amax is not None else vp(None),
                             0 if amax is None else amax.numel(), vp(slabs.data_ptr()), vp(None), st), "lt_wgrad")
     return slabs.view(sp, n, k).sum(0), sp
 
@@ -164,7 +164,7 @@ for (m, n, k) in ((6144, 512, 348), (4100, 128, 256), (1000, 200, 100)):
     sp = int(lib.lt_wgrad_splits(m, n, k))
     slabs = torch.empty(sp * n * k + sp * n, device="cuda")
     st = vp(torch.cuda.current_stream().cuda_stream)
-    _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(x.data_ptr()), 0, m, n, k, vp(am.data_ptr()), 1, vp(slabs.data_ptr()), vp(slabs[sp * n * k:].data_ptr()), st), "lt_wgrad")
+    _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), 0, vp(None), vp(x.data_ptr()), 0, m, n, k, vp(am.data_ptr()), 1, vp(slabs.data_ptr()), vp(slabs[sp * n * k:].data_ptr()), st), "lt_wgrad")
     ref = dz.double().t() @ x.double()
     got = slabs[:sp * n * k].view(sp, n, k).double().sum(0)
     db = slabs[sp * n * k:].view(sp, n).double().sum(0)

@@ -27,7 +27,7 @@ sat = torch.zeros(1, device="cuda")
 def run():
     M._abi.check(lib.lt_mlp_backward_pair(ctypes.byref(nets[0].desc), vp(nets[0].bpacked.data_ptr()), vp(dy0.data_ptr()), *arrs[0],
                                           ctypes.byref(nets[1].desc), vp(nets[1].bpacked.data_ptr()), vp(dy1.data_ptr()), *arrs[1],
-                                          m, int(pair.acts_split), vp(sat.data_ptr()), M.PackedMLP._stream()), "bwd")
+                                          m, int(pair.acts_split), vp(None), vp(None), 0, vp(None), vp(sat.data_ptr()), M.PackedMLP._stream()), "bwd")
 def fwd():
     pair.forward_raw(x0, x1)
 for name, fn in (("backward chain", run), ("forward pair", fwd)):

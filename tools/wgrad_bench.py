@@ -19,8 +19,23 @@ for (n, k) in [(512, 348), (256, 512), (128, 256)]:
     sp = int(lib.lt_wgrad_splits(M, n, k))
     slabs = torch.empty(sp * n * k + sp * n, device="cuda")
     ref = (dz.double().t() @ x.double())
+    # dz in the split format as the backward chain writes it: scaled by a power of two (max -> [1, 2)), then (hi | lo) dwords
+    import math
+    sc = torch.tensor([2.0 ** (-math.floor(math.log2(float(dz.abs().max()))))], device="cuda")
+    dzs = torch.empty_like(dz)
+    _abi.check(lib.lt_split_rows(vp((dz * sc).data_ptr()), vp(dzs.data_ptr()), dz.numel(), st), "split dz")
+    run2 = lambda: _abi.check(lib.lt_wgrad(vp(dzs.data_ptr()), 1, vp(sc.data_ptr()), vp(xs.data_ptr()), 1, M, n, k, vp(None), 0, vp(slabs.data_ptr()),
+                                           vp(slabs[sp * n * k:].data_ptr()), st), "lt_wgrad")
+    for _ in range(5): run2()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(40): run2()
+    torch.cuda.synchronize(); us = (time.perf_counter() - t0) / 40 * 1e6
+    got = slabs[:sp * n * k].view(sp, n, k).double().sum(0)
+    db = slabs[sp * n * k:].view(sp, n).double().sum(0)
+    print(f"[{tag} deep={os.environ.get('LT_WGRAD_DEEP', '0')}] dW {n} x {k} (split dz, split x): {us:6.1f} us, {sp} slices, err {float((got - ref).abs().max() / ref.abs().max()):.1e}, "
+          f"db err {float((db - dz.double().sum(0)).abs().max() / dz.double().sum(0).abs().max()):.1e}", flush=True)
     for name, xx, flag in (("split x", xs, 1), ("f32 x", x, 0)):
-        run = lambda: _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), vp(xx.data_ptr()), flag, M, n, k, vp(am.data_ptr()), 1, vp(slabs.data_ptr()),
+        run = lambda: _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), 0, vp(None), vp(xx.data_ptr()), flag, M, n, k, vp(am.data_ptr()), 1, vp(slabs.data_ptr()),
                                               vp(slabs[sp * n * k:].data_ptr()), st), "lt_wgrad")
         for _ in range(5): run()
         torch.cuda.synchronize(); t0 = time.perf_counter()
