@@ -102,14 +102,15 @@ __global__ __launch_bounds__(256) void lt_ppo_loss_kernel(const float* __restric
     amax_mu = fmaxf(amax_mu, __shfl_xor(amax_mu, off, 64));
     amax_v = fmaxf(amax_v, __shfl_xor(amax_v, off, 64));
   }
-  if (lane == 0) {
-    atomicMax((unsigned*)acc + 20, __float_as_uint(amax_mu));
-    atomicMax((unsigned*)acc + 21, __float_as_uint(amax_v));
-  }
+  __shared__ float redm[4][2];
+  if (lane == 0) { redm[wave][0] = amax_mu; redm[wave][1] = amax_v; }
   __syncthreads();
   if (threadIdx.x < 4 + A && threadIdx.x != 3) {
     const int i = threadIdx.x;
     atomicAdd(acc + i, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+  } else if (threadIdx.x >= 64 && threadIdx.x < 66) {  // (another wave: one atomic per block and maximum)
+    const int j = threadIdx.x - 64;
+    atomicMax((unsigned*)acc + 20 + j, __float_as_uint(fmaxf(fmaxf(redm[0][j], redm[1][j]), fmaxf(redm[2][j], redm[3][j]))));
   }
 }
 
