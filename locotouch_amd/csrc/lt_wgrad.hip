@@ -394,7 +394,9 @@ __global__ __launch_bounds__(256, 2) void lt_wgrad128_kernel(const WgradArgs a) 
   const long long steps = (a.M + 31) / 32;
   const long long s0 = steps * split / a.splits, s1 = steps * (split + 1) / a.splits;
   float scale = 1.f;
-  if (a.amax) {
+  if (a.dz_split) {
+    scale = *a.dz_scale;
+  } else if (a.amax) {
     float m = 0.f;
     for (int b = lane; b < a.nblk_amax; b += 64) m = fmaxf(m, a.amax[b]);
 #pragma unroll
@@ -444,8 +446,18 @@ __global__ __launch_bounds__(256, 2) void lt_wgrad128_kernel(const WgradArgs a) 
     for (int j = 0; j < 4; ++j) {
       const bool live = s * 32 + prow + 8 * j < a.M;  // rows beyond M contribute nothing
       const f32x4 va = live ? ga[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (colsum) cs += va;
-      *(u32x4*)&S.a[st][prow + 8 * j][pcol] = to_pair(va, scale);
+      if (colsum) {
+        if (a.dz_split) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned w = __float_as_uint(va[u]);
+            cs[u] += (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)) + (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)) * (1.f / LO_SCALE);
+          }
+        } else {
+          cs += va;
+        }
+      }
+      *(u32x4*)&S.a[st][prow + 8 * j][pcol] = a.dz_split ? __builtin_bit_cast(u32x4, va) : to_pair(va, scale);
       *(u32x4*)&S.b[st][prow + 8 * j][pcol] = a.x_split ? __builtin_bit_cast(u32x4, gb[j]) : to_pair(gb[j], 1.f);
     }
   };
@@ -497,6 +509,7 @@ __global__ __launch_bounds__(256, 2) void lt_wgrad128_kernel(const WgradArgs a) 
       f32x4 t = red[tid];
 #pragma unroll
       for (int r = 1; r < 8; ++r) t += red[r * 32 + tid];
+      if (a.dz_split) t *= 1.f / scale;
       if (n0 + 4 * tid < a.N) *(f32x4*)(a.db + (long long)split * a.N + n0 + 4 * tid) = t;
     }
   }
@@ -566,7 +579,7 @@ extern "C" int lt_wgrad(const float* dz, int dz_split, const float* dz_scale, co
   a.dz = dz; a.x = x; a.M = M; a.N = N; a.K = K;
   a.amax = amax_blocks; a.nblk_amax = amax_blocks ? nblk_amax : 0;
   a.slabs = slabs; a.db = db_slabs; a.x_split = x_split != 0; a.dz_split = dz_split != 0; a.dz_scale = dz_scale;
-  if (a.dz_split && (!dz_scale || use_tiled(N, K))) { lt_set_error("lt_wgrad: a split dz needs its scale (and the one-wave form)"); return LT_EINVAL; }
+  if (a.dz_split && !dz_scale) { lt_set_error("lt_wgrad: a split dz needs its scale"); return LT_EINVAL; }
   static const int probe = [] { const char* e = getenv("LT_WGRAD_PROBE"); return e ? atoi(e) : 0; }();
   a.probe = probe;
   if (use_tiled(N, K)) {
