@@ -314,3 +314,36 @@ def test_gae_kernel_matches_the_tensor_op_recursion(n, T):
         torch.testing.assert_close(gpu.returns.cpu(), cpu.returns, rtol=1e-5, atol=1e-5)
         if n * T > 1 or not norm:
             torch.testing.assert_close(gpu.advantages.cpu(), cpu.advantages, rtol=1e-4, atol=1e-5)
+
+
+def test_direct_update_on_shapes_outside_the_fused_backward_takes_the_library_path():
+    """Hidden widths that are not multiples of 8 (36) have no chain kernel (lt_mlp_backward_packed_floats refuses): the direct update
+    then keeps f32 activations and runs `dz @ W` / the weight gradients as library GEMMs - same results as the autograd form."""
+    import torch
+
+    from locotouch_amd.rl import PPO, ActorCritic, tuned_gemms
+    from tests.rl_synth import N_ACT, N_OBS, PPO_CFG
+
+    tuned_gemms.disable()
+    pol = dict(init_noise_std=1.0, actor_hidden_dims=[64, 36], critic_hidden_dims=[64, 36], activation="elu")
+    n, T = 256, 24
+    algs = []
+    for direct in (True, False):
+        torch.manual_seed(0)
+        alg = PPO(ActorCritic(N_OBS, N_OBS, N_ACT, **pol), device="cuda:0", direct_update=direct,
+                  **dict(PPO_CFG, num_learning_epochs=1, num_mini_batches=1, tuned_gemms=False))
+        alg.init_storage(n, T, [N_OBS], [N_OBS], [N_ACT])
+        algs.append(alg)
+    outs = []
+    for alg in algs:
+        _fill(alg, 400, n, T)
+        torch.manual_seed(3)
+        outs.append(alg.update())
+    a, b = algs
+    from locotouch_amd.rl.mlp import PackedPair
+
+    assert not PackedPair(a.actor_critic.actor, a.actor_critic.critic)._fused_backward_possible(torch.zeros(8, N_OBS, device="cuda"), torch.zeros(8, N_OBS, device="cuda"))
+    for x, y in zip(outs[0][:3], outs[1][:3]):
+        assert abs(x - y) <= 1e-5 * max(1.0, abs(y))
+    for pa, pb in zip(a.actor_critic.parameters(), b.actor_critic.parameters()):
+        assert float((pa.grad - pb.grad).abs().max()) <= 3e-6 * float(pb.grad.abs().max()) + 1e-12
