@@ -488,7 +488,7 @@ __device__ __forceinline__ float gate_pass(const MlpArgs& a, int l, float* s_act
     const int idx = tid + u * NT;
     row[u] = -1;
     if (idx < total) {  // (wave-uniform: total and NT are multiples of 64)
-      const unsigned r = __umulhi((unsigned)idx, magic), j = (unsigned)idx - r * gpr;
+      const unsigned r = gpr == 1u ? (unsigned)idx : __umulhi((unsigned)idx, magic), j = (unsigned)idx - r * gpr;  // (gpr == 1: the reciprocal wraps to 0)
       row[u] = (int)r;
       at[u] = (int)r * S + 8 * (int)j;
 #ifdef LT_GATE_NO_LOAD  // probe builds (tools/mlp_backward_probe.py)

@@ -219,6 +219,7 @@ class SumJobs:
 
     def __init__(self):
         self.jobs: list = []   # (ws tensor, nblk, stride, count, split, out0, out1 | None)
+        self.after: list = []  # (dst, src) copies to run behind the launch (a padded sum's useful columns)
 
     def add(self, ws, nblk, stride, count, split, out0, out1=None) -> None:
         self.jobs.append((ws, int(nblk), int(stride), int(count), int(split), out0, out1))
@@ -239,6 +240,9 @@ class SumJobs:
             split = (ctypes.c_int * n)(*[j[4] for j in batch])
             _abi.check(lib.lt_partial_sums(n, ws, nblk, stride, count, split, out0, out1, PackedMLP._stream()), "lt_partial_sums")
             self._keep = batch  # the launch reads the buffers asynchronously
+        for dst, src in self.after:
+            dst.copy_(src)
+        self.after = []
 
 
 def backward_chain(weights, biases_out, weights_out, x, acts, dy, sums: SumJobs):
@@ -366,8 +370,15 @@ class PackedPair:
         self._bpacked_fresh = bool(with_backward)
 
     def split_rows(self, x: torch.Tensor) -> torch.Tensor:
-        """Observation rows in the split format (lt_split_rows): converted once per PPO update for the first layer's weight gradient."""
+        """Observation rows in the split format (lt_split_rows): converted once per PPO update for the first layer's weight gradient.
+        A width that is not a multiple of 4 (the locomotion task's 270) is padded with zero columns to the next one: lt_wgrad's
+        16-byte operand pieces need it, and the padded columns of dW are dropped again (`_backward_fused`)."""
         lib = _abi.load()
+        k = x.shape[1]
+        if k % 4:
+            xp = torch.zeros(x.shape[0], k + (-k) % 4, device=x.device, dtype=torch.float32)
+            xp[:, :k] = x
+            x = xp
         out = torch.empty_like(x, dtype=torch.float32)
         _abi.check(lib.lt_split_rows(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), x.numel(), PackedMLP._stream()), "lt_split_rows")
         return out
@@ -379,7 +390,7 @@ class PackedPair:
             return False
         for net, x in ((self.a, x0), (self.b, x1)):
             dims = [net.desc.dims[i] for i in range(net.desc.num_layers + 1)]
-            if dims[0] % 4 or x.dtype != torch.float32 or not x.is_contiguous():
+            if dims[0] % 2 or x.dtype != torch.float32 or not x.is_contiguous():  # (2 mod 4: padded by split_rows)
                 return False
             if not _head_wgrad_ok(torch.empty(0, dims[-1], device=x.device), torch.empty(0, dims[-2], device=x.device)):
                 return False
@@ -399,6 +410,8 @@ class PackedPair:
         nets, xs = (self.a, self.b), (x0, x1)
         asp = int(getattr(self, "acts_split", False))   # format of `acts` (forward_raw)
         xsp = int(x_split_rows is not None)             # the observation rows in the split format, from the caller (once per update)
+        if not xsp and any(x.shape[1] % 4 for x in xs):  # widths 2 mod 4 reach lt_wgrad padded and split only
+            x_split_rows, xsp = (self.split_rows(x0), self.split_rows(x1)), 1
         if xsp:
             xs = x_split_rows
         dys = [d if d.is_contiguous() else d.contiguous() for d in (dy0, dy1)]
@@ -442,7 +455,13 @@ class PackedPair:
                 dbs = slabs[sp * n * kk:]
                 _abi.check(lib.lt_wgrad(vp(dz.data_ptr()), dzsp, vp(scales[k:k + 1].data_ptr()), vp(inp.data_ptr()), asp if l > 0 else xsp, m, n, kk,
                                         vp(amaxs[k][l].data_ptr()), nblk, vp(slabs.data_ptr()), vp(dbs.data_ptr()), stream), "lt_wgrad")
-                per_net[k].add(slabs, sp, n * kk, n * kk, n * kk, grad_of[net.linears[l].weight])
+                gw = grad_of[net.linears[l].weight]
+                if kk != gw.shape[1]:  # padded first layer: the sum lands in a [n][kk] scratch, its first columns are the gradient
+                    pad = torch.empty(n, kk, device=dev, dtype=torch.float32)
+                    per_net[k].add(slabs, sp, n * kk, n * kk, n * kk, pad)
+                    per_net[k].after.append((gw, pad[:, :gw.shape[1]]))
+                else:
+                    per_net[k].add(slabs, sp, n * kk, n * kk, n * kk, gw)
                 per_net[k].add(dbs, sp, n, n, n, grad_of[net.linears[l].bias])
             if after_first is not None:
                 per_net[k].launch()

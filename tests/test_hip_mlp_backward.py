@@ -155,3 +155,30 @@ def test_shapes_outside_the_chain_kernel_take_the_library_path():
     assert not pair._fused_backward_ok(x, x, torch.zeros(256, 12, device="cuda"), torch.zeros(256, 1, device="cuda"))
     lib, n = M._abi.load(), ctypes.c_size_t()
     assert lib.lt_mlp_backward_packed_floats(ctypes.byref(pair.a.desc), ctypes.byref(n)) != 0
+
+
+@pytest.mark.parametrize("hidden,out0,out1,d,m", [((200, 136, 72), 12, 1, 348, 3000), ((64, 64), 8, 3, 100, 777), ((512, 8), 8, 1, 270, 9000), ((128,), 12, 1, 348, 2048)])
+def test_fused_backward_on_other_network_shapes(hidden, out0, out1, d, m):
+    """Other widths (multiples of 8 that are not multiples of 32, one hidden layer, the 270-wide rows of the locomotion task - padded to 272 for the first weight gradient -, other heads): fused backward pass ==
+    float64 to the f32-equivalent band, split formats on every operand."""
+    import torch
+
+    from locotouch_amd.rl import mlp as M
+
+    actor, critic = _nets(out0=out0, out1=out1, hidden=hidden, d=d, seed=11)
+    pair = M.PackedPair(actor, critic)
+    g = torch.Generator(device="cuda").manual_seed(m)
+    x0, x1 = torch.randn(m, d, device="cuda", generator=g), torch.randn(m, d, device="cuda", generator=g)
+    dy0, dy1 = torch.randn(m, out0, device="cuda", generator=g) * 1e-4, torch.randn(m, out1, device="cuda", generator=g) * 1e-3
+    grads = {p: torch.full_like(p, float("nan")) for net in (actor, critic) for p in net.parameters()}
+    _, acts = pair.forward_raw(x0, x1)
+    assert pair._fused_backward_ok(x0, x1, dy0, dy1) and pair.acts_split
+    pair.backward_raw(x0, x1, acts, dy0, dy1, grads, (pair.split_rows(x0), pair.split_rows(x1)), dy_amax=(dy0.abs().max().reshape(1), dy1.abs().max().reshape(1)))
+    torch.cuda.synchronize()
+    assert float(pair.saturated()) == 0.0
+    for net, x, dy in ((actor, x0, dy0), (critic, x1, dy1)):
+        _, rdw, rdb = _ref_chain(net, x, dy)
+        lin = [mm for mm in net if isinstance(mm, torch.nn.Linear)]
+        for l in range(len(lin)):
+            for got, ref in ((grads[lin[l].weight], rdw[l]), (grads[lin[l].bias], rdb[l])):
+                assert float((got.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-30, (hidden, l)

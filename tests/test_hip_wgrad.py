@@ -175,3 +175,41 @@ print("ok")
     env = dict(os.environ, LT_WGRAD_TILED="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_random_shapes_all_operand_formats_against_float64():
+    """Twenty random (M, N, K) - ragged row counts, widths that leave partial tiles - in the three operand forms the update uses
+    (f32 / f32, f32 / split x, split dz / split x), bias partials included."""
+    import math
+    import random
+
+    import torch
+
+    from locotouch_amd import _abi
+
+    lib, vp = _abi.load(), ctypes.c_void_p
+    rnd = random.Random(7)
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    for case in range(20):
+        m = rnd.choice([33, 64, 97, 500, 1000, 2049, 4100, 6144])
+        n, k = 4 * rnd.randint(1, 128), 4 * rnd.randint(1, 128)
+        g = torch.Generator(device="cuda").manual_seed(case)
+        dz = torch.randn(m, n, device="cuda", generator=g) * 10.0 ** rnd.uniform(-8, -2)
+        dz[::5] *= 50.0
+        x = torch.randn(m, k, device="cuda", generator=g) * rnd.choice([0.1, 1.0, 30.0])
+        ref, refb = dz.double().t() @ x.double(), dz.double().sum(0)
+        am = dz.abs().max().reshape(1)
+        xs, dzs = torch.empty_like(x), torch.empty_like(dz)
+        sc = torch.tensor([2.0 ** (-math.floor(math.log2(float(am))))], device="cuda")
+        _abi.check(lib.lt_split_rows(vp(x.data_ptr()), vp(xs.data_ptr()), x.numel(), st), "split x")
+        _abi.check(lib.lt_split_rows(vp((dz * sc).data_ptr()), vp(dzs.data_ptr()), dz.numel(), st), "split dz")
+        sp = int(lib.lt_wgrad_splits(m, n, k))
+        for name, args in (("f32", (dz, 0, None, x, 0)), ("split x", (dz, 0, None, xs, 1)), ("split both", (dzs, 1, sc, xs, 1))):
+            slabs = torch.full((sp * n * k + sp * n,), float("nan"), device="cuda")
+            a_, asp, ascale, b_, bsp = args
+            _abi.check(lib.lt_wgrad(vp(a_.data_ptr()), asp, vp(ascale.data_ptr()) if ascale is not None else vp(None), vp(b_.data_ptr()), bsp, m, n, k,
+                                    vp(am.data_ptr()), 1, vp(slabs.data_ptr()), vp(slabs[sp * n * k:].data_ptr()), st), "lt_wgrad")
+            got = slabs[:sp * n * k].view(sp, n, k).double().sum(0)
+            db = slabs[sp * n * k:].view(sp, n).double().sum(0)
+            assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-30, (case, name, m, n, k)
+            assert float((db - refb).abs().max()) <= 2e-6 * float(dz.double().abs().sum(0).max()) + 1e-30, (case, name, m, n, k)
