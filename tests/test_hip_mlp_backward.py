@@ -182,3 +182,26 @@ def test_fused_backward_on_other_network_shapes(hidden, out0, out1, d, m):
         for l in range(len(lin)):
             for got, ref in ((grads[lin[l].weight], rdw[l]), (grads[lin[l].bias], rdb[l])):
                 assert float((got.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-30, (hidden, l)
+
+
+@pytest.mark.parametrize("m,hidden", [(24576, (512, 256, 128)), (6144, (512, 256, 128)), (1000, (200, 136, 72)), (16400, (200, 136, 72))])
+def test_activations_in_the_split_format_decode_to_the_f32_activations(m, hidden):
+    """lt_mlp_forward_pair(acts_split = 1): the dwords (f16 hi | f16 lo << 16) decode - hi + lo / 64 - to the activations the f32 form
+    writes, to the format's 2^-21 (every row-tile variant, widths that are and are not multiples of 32); same outputs."""
+    import torch
+
+    from locotouch_amd.rl import mlp as M
+
+    actor, critic = _nets(hidden=hidden, seed=5)
+    pair = M.PackedPair(actor, critic)
+    g = torch.Generator(device="cuda").manual_seed(m)
+    x0, x1 = torch.randn(m, 348, device="cuda", generator=g), 3.0 * torch.randn(m, 348, device="cuda", generator=g)
+    (y0, y1), acts = pair.forward_raw(x0, x1, split=False)
+    (z0, z1), sacts = pair.forward_raw(x0, x1, split=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, z0) and torch.equal(y1, z1)
+    for k in range(2):
+        for a, s in zip(acts[k], sacts[k]):
+            h = s.view(torch.float16).view(m, a.shape[1], 2).float()
+            dec = h[..., 0] + h[..., 1] / 64.0
+            assert float((dec - a).abs().max()) <= 2.0 ** -21 * max(1.0, float(a.abs().max())), (k, a.shape)
