@@ -205,3 +205,36 @@ def test_activations_in_the_split_format_decode_to_the_f32_activations(m, hidden
             h = s.view(torch.float16).view(m, a.shape[1], 2).float()
             dec = h[..., 0] + h[..., 1] / 64.0
             assert float((dec - a).abs().max()) <= 2.0 ** -21 * max(1.0, float(a.abs().max())), (k, a.shape)
+
+
+def test_one_launch_packing_equals_the_per_network_packs():
+    """lt_mlp_pack_training (forward + transposed streams of both networks, one launch) writes the same bytes as lt_mlp_pack and
+    lt_mlp_pack_backward per network (the buffers hold other weights' streams in between)."""
+    import torch
+
+    from locotouch_amd.rl import mlp as M
+
+    actor, critic = _nets(seed=9)
+    pair = M.PackedPair(actor, critic)
+    for net in (pair.a, pair.b):
+        net.pack()
+        net.pack_backward()
+    torch.cuda.synchronize()
+    want = [(net.packed.clone(), net.bpacked.clone()) for net in (pair.a, pair.b)]
+    saved = [p.detach().clone() for net in (actor, critic) for p in net.parameters()]
+    with torch.no_grad():
+        for net in (actor, critic):
+            for p in net.parameters():
+                p.add_(torch.randn_like(p))
+    for net in (pair.a, pair.b):  # other weights in the buffers
+        net.pack()
+        net.pack_backward()
+    torch.cuda.synchronize()
+    assert not torch.equal(pair.a.packed, want[0][0])
+    with torch.no_grad():
+        for p, v in zip([p for net in (actor, critic) for p in net.parameters()], saved):
+            p.copy_(v)
+    pair.pack_training(with_backward=True)
+    torch.cuda.synchronize()
+    for net, (p, bp) in zip((pair.a, pair.b), want):
+        assert torch.equal(net.packed.view(torch.int32), p.view(torch.int32)) and torch.equal(net.bpacked.view(torch.int32), bp.view(torch.int32))
