@@ -494,7 +494,13 @@ extern "C" int lt_head_wgrad(const float* dy, const float* x, int x_split, int64
   const int nblk = (int)((M + HW_ROWS - 1) / HW_ROWS), k4 = k / 4, lanes = 256 / k4;
   const int nn = n <= 1 ? 1 : (n <= 4 ? 4 : (n <= 8 ? 8 : (n <= 12 ? 12 : 16)));
   const size_t lds = (size_t)lanes * nn * k4 * 16 + (size_t)lanes * nn * 4;
-  if (lds > 64 * 1024) {
+  // (13 .. 16 outputs need 64 KiB + the bias lanes: more than the default dynamic-LDS limit)
+  static bool attr_set = false;
+  if (!attr_set) {
+    attr_set = true;
+    (void)hipFuncSetAttribute((const void*)lt_head_wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+  }
+  if (lds > 72 * 1024) {
     lt_set_error("lt_head_wgrad: n * k too large for one block's LDS partials");
     return LT_EINVAL;
   }

@@ -96,7 +96,7 @@ def _head_wgrad_ok(dy: torch.Tensor, x: torch.Tensor) -> bool:
     if not (dy.is_cuda and dy.dtype == torch.float32 and x.dtype == torch.float32 and n <= 16 and k % 4 == 0 and 4 <= k <= 1024 and x.is_contiguous()):
         return False
     lanes, nn = 256 // (k // 4), (1 if n <= 1 else 4 if n <= 4 else 8 if n <= 8 else 12 if n <= 12 else 16)
-    return lanes * nn * (k // 4) * 16 + lanes * nn * 4 <= 64 * 1024  # one block's LDS partials (csrc/lt_ppo.hip)
+    return lanes * nn * (k // 4) * 16 + lanes * nn * 4 <= 72 * 1024  # one block's LDS partials (csrc/lt_ppo.hip)
 
 
 def _head_wgrad(dy: torch.Tensor, x: torch.Tensor):

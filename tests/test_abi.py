@@ -131,10 +131,10 @@ def test_update_and_recurrence_entry_points_validate_their_arguments_before_touc
     assert lib.lt_elu_backward_bias(one, one, 64, 130, 1.0, one, one, one, null) == bad
     assert lib.lt_elu_backward_bias(one, one, 64, 2048, 1.0, one, one, one, null) == bad
     assert lib.lt_elu_backward_bias_ws_floats(96, 512) == 2 * 512 and lib.lt_elu_backward_bias_ws_floats(97, 512) == 3 * 512
-    # lt_head_wgrad: more than 16 outputs, k not a multiple of 4, partials beyond one block's LDS
+    # lt_head_wgrad: more than 16 outputs, k not a multiple of 4, k beyond 1024
     assert lib.lt_head_wgrad(one, one, 0, 64, 17, 128, one, one, one, null) == bad
     assert lib.lt_head_wgrad(one, one, 0, 64, 12, 130, one, one, one, null) == bad
-    assert lib.lt_head_wgrad(one, one, 0, 64, 16, 1024, one, one, one, null) == bad and b"LDS" in lib.lt_last_error()
+    assert lib.lt_head_wgrad(one, one, 0, 64, 16, 2048, one, one, one, null) == bad and b"lt_head_wgrad" in lib.lt_last_error()
     assert lib.lt_head_wgrad_ws_floats(96, 12, 128) == 12 * 128 + 16
     # lt_adam_clip_step: empty buffer, step 0
     assert lib.lt_adam_clip_step(one, one, one, one, 0, 1.0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, one, null, null) == bad
