@@ -9,19 +9,19 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _nets(out0=12, out1=1, hidden=(512, 256, 128), d=348, seed=0):
+def _nets(out0=12, out1=1, hidden=(512, 256, 128), d=348, seed=0, hidden1=None):
     import torch
     import torch.nn as nn
 
     torch.manual_seed(seed)
-    def stack(out):
+    def stack(out, hid):
         mods, prev = [], d
-        for h in hidden:
+        for h in hid:
             mods += [nn.Linear(prev, h), nn.ELU()]
             prev = h
         mods.append(nn.Linear(prev, out))
         return nn.Sequential(*mods).cuda()
-    return stack(out0), stack(out1)
+    return stack(out0, hidden), stack(out1, hidden1 or hidden)
 
 
 def _ref_chain(seq, x, dy):
@@ -238,3 +238,29 @@ def test_one_launch_packing_equals_the_per_network_packs():
     torch.cuda.synchronize()
     for net, (p, bp) in zip((pair.a, pair.b), want):
         assert torch.equal(net.packed.view(torch.int32), p.view(torch.int32)) and torch.equal(net.bpacked.view(torch.int32), bp.view(torch.int32))
+
+
+def test_actor_and_critic_of_different_depth_and_width():
+    """The two stacks of a launch need not look alike (the reference's agent cfgs allow different actor / critic hidden dims)."""
+    import torch
+
+    from locotouch_amd.rl import mlp as M
+
+    actor, critic = _nets(hidden=(256, 128), hidden1=(512, 256, 64, 32), seed=21)
+    pair = M.PackedPair(actor, critic)
+    m = 5000
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x0, x1 = torch.randn(m, 348, device="cuda", generator=g), torch.randn(m, 348, device="cuda", generator=g)
+    dy0, dy1 = torch.randn(m, 12, device="cuda", generator=g) * 1e-3, torch.randn(m, 1, device="cuda", generator=g) * 1e-5
+    grads = {p: torch.full_like(p, float("nan")) for net in (actor, critic) for p in net.parameters()}
+    _, acts = pair.forward_raw(x0, x1)
+    assert pair._fused_backward_ok(x0, x1, dy0, dy1)
+    pair.backward_raw(x0, x1, acts, dy0, dy1, grads, dy_amax=(dy0.abs().max().reshape(1), dy1.abs().max().reshape(1)))
+    torch.cuda.synchronize()
+    assert float(pair.saturated()) == 0.0
+    for net, x, dy in ((actor, x0, dy0), (critic, x1, dy1)):
+        _, rdw, rdb = _ref_chain(net, x, dy)
+        lin = [mm for mm in net if isinstance(mm, torch.nn.Linear)]
+        for l in range(len(lin)):
+            for got, ref in ((grads[lin[l].weight], rdw[l]), (grads[lin[l].bias], rdb[l])):
+                assert float((got.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-30, l
