@@ -386,15 +386,18 @@ class PackedPair:
     def _fused_backward_possible(self, x0, x1) -> bool:
         from .linear import _head_wgrad_ok
 
-        if not (USE_FUSED_BACKWARD and USE_SPLIT_F16_WGRAD and self.a.backward_ok() and self.b.backward_ok()):
+        if not (USE_FUSED_BACKWARD and USE_SPLIT_F16_WGRAD):
             return False
-        for net, x in ((self.a, x0), (self.b, x1)):
-            dims = [net.desc.dims[i] for i in range(net.desc.num_layers + 1)]
-            if dims[0] % 2 or x.dtype != torch.float32 or not x.is_contiguous():  # (2 mod 4: padded by split_rows)
-                return False
-            if not _head_wgrad_ok(torch.empty(0, dims[-1], device=x.device), torch.empty(0, dims[-2], device=x.device)):
-                return False
-        return True
+        if x0.dtype != torch.float32 or x1.dtype != torch.float32 or not x0.is_contiguous() or not x1.is_contiguous():
+            return False
+        if getattr(self, "_bwd_shapes_ok", None) is None:  # a property of the two networks: decided once
+            ok = self.a.backward_ok() and self.b.backward_ok()
+            for net in (self.a, self.b):
+                dims = [net.desc.dims[i] for i in range(net.desc.num_layers + 1)]
+                ok = ok and dims[0] % 2 == 0  # (2 mod 4: padded by split_rows)
+                ok = ok and _head_wgrad_ok(torch.empty(0, dims[-1], device=x0.device), torch.empty(0, dims[-2], device=x0.device))
+            self._bwd_shapes_ok = bool(ok)
+        return self._bwd_shapes_ok
 
     def _fused_backward_ok(self, x0, x1, dy0, dy1) -> bool:
         return self._fused_backward_possible(x0, x1) and dy0.dtype == torch.float32 and dy1.dtype == torch.float32
