@@ -223,17 +223,27 @@ struct SumJobs {
   int nblk[SUM_MAX_JOBS], count[SUM_MAX_JOBS], split[SUM_MAX_JOBS], first[SUM_MAX_JOBS + 1];
   int njobs;
 };
+// row lanes of a job: 4 for the usual handful of partials, 16 where there are hundreds (the head kernels leave one per 96 rows: with
+// 4 lanes their few blocks walked 64 dependent loads each and ended the launch alone - 41 us for 17 us of traffic)
+__host__ __device__ inline int sum_row_lanes(int nblk) { return nblk >= 96 ? 16 : 4; }
+
 __global__ __launch_bounds__(256) void lt_partial_sums_kernel(const SumJobs J) {
-  // A block owns 256 consecutive elements: thread (c = tid & 63, row lane = tid >> 6) adds elements 4 c .. 4 c + 3 of the partials
-  // b = lane, lane + 4, ... in four interleaved chains - a wave reads 1 KiB of one partial per instruction (the first version's 16
-  // lanes x 64 B moved 95 MB of slabs at 1.6 TB/s: 60 us of a PPO step).  Order per element: chain by chain, then the four row
-  // lanes in order - fixed.
-  int j = 0;
-  while (j + 1 < J.njobs && (int)blockIdx.x >= J.first[j + 1]) ++j;
+  // A block owns (256 / RL) * 4 consecutive elements: thread (c, row lane) adds elements 4 c .. 4 c + 3 of the partials b = lane,
+  // lane + RL, ... in four interleaved chains - a wave reads whole KiB stretches of a partial per instruction (the first version's 16
+  // lanes x 64 B moved 95 MB of slabs at 1.6 TB/s: 60 us of a PPO step).  Order per element: chain by chain, then the row lanes in
+  // order - fixed.
+  // which job: ONE load of the block-range table by the lanes of a wave + a ballot.  (A scalar loop over J.first[] is a chain of
+  // dependent reads of the kernel-argument segment - host-visible memory, a fabric round trip per miss: ~1.5 us x up to 14 per block,
+  // 36 us for a launch that moves 48 MB.)
+  const int ln = (int)threadIdx.x & 63;
+  const int f = (ln >= 1 && ln < J.njobs) ? J.first[ln] : 0x7fffffff;
+  const int j = __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(f <= (int)blockIdx.x)));
   const float* __restrict__ ws = J.ws[j];
   const int nblk = J.nblk[j], count = J.count[j], split = J.split[j];
   const long long stride = J.stride[j];
-  const int e = ((int)blockIdx.x - J.first[j]) * 256 + 4 * (int)(threadIdx.x & 63), lane = threadIdx.x >> 6;
+  const int RL = sum_row_lanes(nblk), cols = 256 / RL;
+  const int c = (int)threadIdx.x % cols, lane = (int)threadIdx.x / cols;
+  const int e = ((int)blockIdx.x - J.first[j]) * cols * 4 + 4 * c;
   const bool vec = e + 3 < count && ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0);
   float4 s[4];
 #pragma unroll
@@ -245,26 +255,29 @@ __global__ __launch_bounds__(256) void lt_partial_sums_kernel(const SumJobs J) {
       return make_float4(p[0], e + 1 < count ? p[1] : 0.f, e + 2 < count ? p[2] : 0.f, e + 3 < count ? p[3] : 0.f);
     };
     int b = lane;
-    for (; b + 12 < nblk; b += 16) {
+    for (; b + 3 * RL < nblk; b += 4 * RL) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float4 v = at(b + 4 * u);
+        const float4 v = at(b + u * RL);
         s[u].x += v.x; s[u].y += v.y; s[u].z += v.z; s[u].w += v.w;
       }
     }
-    for (int u = 0; b < nblk; b += 4, ++u) {
-      const float4 v = at(b);
-      s[u & 3].x += v.x; s[u & 3].y += v.y; s[u & 3].z += v.z; s[u & 3].w += v.w;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {  // at most three partials are left to this lane (static chain index: a run-time one puts s[] in scratch)
+      if (b < nblk) {
+        const float4 v = at(b);
+        s[u].x += v.x; s[u].y += v.y; s[u].z += v.z; s[u].w += v.w;
+        b += RL;
+      }
     }
   }
-  __shared__ float4 red[4][64];
-  red[lane][threadIdx.x & 63] = make_float4((s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
-                                            (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
+  __shared__ float4 red[256];
+  red[threadIdx.x] = make_float4((s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
+                                 (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
   __syncthreads();
   if (lane == 0 && e < count) {
-    float4 t = red[0][threadIdx.x];
-#pragma unroll
-    for (int l = 1; l < 4; ++l) { const float4 v = red[l][threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    float4 t = red[c];
+    for (int l = 1; l < RL; ++l) { const float4 v = red[l * cols + c]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
     const float o[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -536,7 +549,8 @@ extern "C" int lt_partial_sums(int njobs, const float* const* ws, const int* nbl
     J.ws[j] = ws[j]; J.out0[j] = out0[j]; J.out1[j] = out1[j]; J.stride[j] = stride[j];
     J.nblk[j] = nblk[j]; J.count[j] = count[j]; J.split[j] = split[j];
     J.first[j] = blocks;
-    blocks += (count[j] + 255) / 256;
+    const int epb = 256 / sum_row_lanes(nblk[j]) * 4;  // elements per block
+    blocks += (count[j] + epb - 1) / epb;
   }
   J.first[njobs] = blocks;
   hipLaunchKernelGGL(lt_partial_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J);

@@ -96,8 +96,9 @@ struct WgradArgs {
   float* db;            // optional [splits][N]: the slices' column sums of dz (the bias gradient's partials), by the tiles of the first k column
 };
 
-__global__ __launch_bounds__(128, 2) void lt_wgrad_kernel(const WgradArgs a) {
-  __shared__ f32x4 s_tile[TA * TB + 1][64];
+constexpr int WG_WAVES = 4;  // waves per workgroup, each on a quarter of the slice: a slab per FOUR waves (two: twice the slab bytes for lt_partial_sums)
+__global__ __launch_bounds__(64 * WG_WAVES, 2) void lt_wgrad_kernel(const WgradArgs a) {
+  __shared__ f32x4 s_tile[WG_WAVES - 1][TA * TB + 1][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -113,10 +114,10 @@ __global__ __launch_bounds__(128, 2) void lt_wgrad_kernel(const WgradArgs a) {
   const int split = item / tiles, tile = item - split * tiles;
   const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
   const int n0 = tn * 16 * TA, k0 = tk * 16 * TB;
-  // this slice's 32-row steps (the M / 32 steps are dealt as evenly as possible), first half to wave 0, second to wave 1
+  // this slice's 32-row steps (the M / 32 steps are dealt as evenly as possible), a quarter to each wave
   const long long steps = (a.M + 31) / 32;
-  const long long b0 = steps * split / a.splits, b1 = steps * (split + 1) / a.splits, mid = b0 + (b1 - b0 + 1) / 2;
-  const long long s0 = wave ? mid : b0, s1 = wave ? b1 : mid;
+  const long long b0 = steps * split / a.splits, b1 = steps * (split + 1) / a.splits;
+  const long long s0 = b0 + (b1 - b0) * wave / WG_WAVES, s1 = b0 + (b1 - b0) * (wave + 1) / WG_WAVES;
   // scale of dz: a power of two that brings max |dz| to [2^7, 2^8) - 64 x its hi half is still an f16 number
   float scale = 1.f;
   if (a.dz_split) {
@@ -200,21 +201,24 @@ __global__ __launch_bounds__(128, 2) void lt_wgrad_kernel(const WgradArgs a) {
       }
     }
   }
-  // wave 1 hands its tile and column sums to wave 0
-  if (wave == 1) {
+  // waves 1 .. hand their tiles and column sums to wave 0, which adds them in wave order
+  if (wave > 0) {
 #pragma unroll
     for (int p = 0; p < TA; ++p)
 #pragma unroll
-      for (int q = 0; q < TB; ++q) s_tile[p * TB + q][lane] = acc[p][q];
-    s_tile[TA * TB][lane] = cs;
+      for (int q = 0; q < TB; ++q) s_tile[wave - 1][p * TB + q][lane] = acc[p][q];
+    s_tile[wave - 1][TA * TB][lane] = cs;
   }
   __syncthreads();
-  if (wave == 1) return;
+  if (wave > 0) return;
 #pragma unroll
-  for (int p = 0; p < TA; ++p)
+  for (int w = 0; w < WG_WAVES - 1; ++w) {
 #pragma unroll
-    for (int q = 0; q < TB; ++q) acc[p][q] += s_tile[p * TB + q][lane];
-  cs += s_tile[TA * TB][lane];
+    for (int p = 0; p < TA; ++p)
+#pragma unroll
+      for (int q = 0; q < TB; ++q) acc[p][q] += s_tile[w][p * TB + q][lane];
+    cs += s_tile[w][TA * TB][lane];
+  }
   if (colsum) {  // lane (c, g) holds the sums of rows g mod 4 of columns n0 + 4 c .. + 3
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -550,12 +554,12 @@ int pick_splits_tiled(long long M, int tiles) {
 }
 
 int pick_splits(long long M, int tiles) {
-  // at most 1024 two-wave workgroups (four per CU, two waves per SIMD: a 1025th block would run alone after the others - 24 slices x
-  // 48 tiles = 1152 single-wave blocks took 97 us where 21 x 48 = 1008 took 69 us), at least 4 steps of 32 rows per slice
-  static const int target = [] { const char* e = getenv("LT_WGRAD_BLOCKS"); if (e) return atoi(e); const char* d = getenv("LT_WGRAD_DEEP"); return (d && atoi(d) >= 3) ? 512 : 1024; }();  // (measurements)
+  // at most 512 four-wave workgroups (two per CU, two waves per SIMD: a 513th block would run alone after the others - 24 slices x
+  // 48 tiles = 1152 single-wave blocks took 97 us where 21 x 48 = 1008 took 69 us), at least 2 steps of 32 rows per wave
+  static const int target = [] { const char* e = getenv("LT_WGRAD_BLOCKS"); if (e) return atoi(e); const char* d = getenv("LT_WGRAD_DEEP"); return (d && atoi(d) >= 3) ? 512 : 512; }();  // (measurements)
   const long long steps = (M + 31) / 32;
   long long s = target / tiles;
-  if (s > steps / 4) s = steps / 4;
+  if (s > steps / 8) s = steps / 8;
   return (int)(s < 1 ? 1 : s);
 }
 
@@ -599,7 +603,7 @@ extern "C" int lt_wgrad(const float* dz, int dz_split, const float* dz_scale, co
     if (both_split && deep == 3) hipLaunchKernelGGL(lt_wgrad_split_kernel<3>, grid, dim3(128), 0, (hipStream_t)stream, a);
     else if (both_split && deep == 4) hipLaunchKernelGGL(lt_wgrad_split_kernel<4>, grid, dim3(128), 0, (hipStream_t)stream, a);
     else if (both_split && deep == 5) hipLaunchKernelGGL(lt_wgrad_split_kernel<5>, grid, dim3(128), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(lt_wgrad_kernel, grid, dim3(128), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(lt_wgrad_kernel, grid, dim3(64 * WG_WAVES), 0, (hipStream_t)stream, a);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
