@@ -97,6 +97,8 @@ struct WgradArgs {
 };
 
 constexpr int WG_WAVES = 4;  // waves per workgroup, each on a quarter of the slice: a slab per FOUR waves (two: twice the slab bytes for lt_partial_sums)
+// AS / XS: dz / x arrive in the split format (compile-time: with both forms behind run-time branches the loop spilled 68 bytes)
+template <bool AS, bool XS>
 __global__ __launch_bounds__(64 * WG_WAVES, 2) void lt_wgrad_kernel(const WgradArgs a) {
   __shared__ f32x4 s_tile[WG_WAVES - 1][TA * TB + 1][64];
   const int lane = threadIdx.x & 63;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void lt_wgrad_kernel(const WgradA
   const long long s0 = b0 + (b1 - b0) * wave / WG_WAVES, s1 = b0 + (b1 - b0) * (wave + 1) / WG_WAVES;
   // scale of dz: a power of two that brings max |dz| to [2^7, 2^8) - 64 x its hi half is still an f16 number
   float scale = 1.f;
-  if (a.dz_split) {
+  if (AS) {
     scale = *a.dz_scale;
   } else if (a.amax) {
     float m = 0.f;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void lt_wgrad_kernel(const WgradA
       for (int t = 0; t < 8; ++t) if (s * 32 + 4 * t + g >= a.M) va[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (colsum) {
-      if (a.dz_split) {  // (uniform; the tiles of the first k column only) value = hi + lo / 64, still scaled
+      if (AS) {  // (the tiles of the first k column only) value = hi + lo / 64, still scaled
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -179,12 +181,12 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void lt_wgrad_kernel(const WgradA
       }
     }
     f16x8 ah[TA], al[TA], bh[TB], bl[TB];
-    if (a.dz_split) {  // (uniform)
+    if (AS) {
       unpack8<0>(va, ah[0], al[0]); unpack8<1>(va, ah[1], al[1]); unpack8<2>(va, ah[2], al[2]); unpack8<3>(va, ah[3], al[3]);
     } else {
       split8<0>(va, scale, ah[0], al[0]); split8<1>(va, scale, ah[1], al[1]); split8<2>(va, scale, ah[2], al[2]); split8<3>(va, scale, ah[3], al[3]);
     }
-    if (a.x_split) {  // (uniform)
+    if (XS) {
       unpack8<0>(vb, bh[0], bl[0]); unpack8<1>(vb, bh[1], bl[1]); unpack8<2>(vb, bh[2], bl[2]); unpack8<3>(vb, bh[3], bl[3]);
     } else {
       split8<0>(vb, 1.f, bh[0], bl[0]); split8<1>(vb, 1.f, bh[1], bl[1]); split8<2>(vb, 1.f, bh[2], bl[2]); split8<3>(vb, 1.f, bh[3], bl[3]);
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void lt_wgrad_kernel(const WgradA
       cs[u] += __shfl_xor(cs[u], 16, 64);
       cs[u] += __shfl_xor(cs[u], 32, 64);
     }
-    if (a.dz_split) cs *= 1.f / scale;
+    if (AS) cs *= 1.f / scale;
     if (g == 0 && n0 + 4 * i < a.N) *(f32x4*)(a.db + (long long)split * a.N + n0 + 4 * i) = cs;
   }
   // the partial tile: MFMA tile (p, q) holds C[row rho = 4 g + r][col kappa = i] = dW[n0 + 4 rho + p][k0 + 4 kappa + q]: a lane's four
@@ -603,7 +605,10 @@ extern "C" int lt_wgrad(const float* dz, int dz_split, const float* dz_scale, co
     if (both_split && deep == 3) hipLaunchKernelGGL(lt_wgrad_split_kernel<3>, grid, dim3(128), 0, (hipStream_t)stream, a);
     else if (both_split && deep == 4) hipLaunchKernelGGL(lt_wgrad_split_kernel<4>, grid, dim3(128), 0, (hipStream_t)stream, a);
     else if (both_split && deep == 5) hipLaunchKernelGGL(lt_wgrad_split_kernel<5>, grid, dim3(128), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(lt_wgrad_kernel, grid, dim3(64 * WG_WAVES), 0, (hipStream_t)stream, a);
+    else if (a.dz_split && a.x_split) hipLaunchKernelGGL((lt_wgrad_kernel<true, true>), grid, dim3(64 * WG_WAVES), 0, (hipStream_t)stream, a);
+    else if (a.x_split) hipLaunchKernelGGL((lt_wgrad_kernel<false, true>), grid, dim3(64 * WG_WAVES), 0, (hipStream_t)stream, a);
+    else if (a.dz_split) hipLaunchKernelGGL((lt_wgrad_kernel<true, false>), grid, dim3(64 * WG_WAVES), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((lt_wgrad_kernel<false, false>), grid, dim3(64 * WG_WAVES), 0, (hipStream_t)stream, a);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { lt_set_error(hipGetErrorString(e)); return LT_EHIP; }
