@@ -124,6 +124,18 @@ __host__ __device__ inline Plan plan_of(const int* dims, int L, int l, bool with
   p.G = pad32(K) / 32;
   int widest = 0;
   for (int i = 0; i <= L; ++i) widest = dims[i] > widest ? dims[i] : widest;
+#ifndef LT_MLP_WIDE_KSPLIT
+#define LT_MLP_WIDE_KSPLIT 0
+#endif
+  // A hidden layer of exactly two tiles per wave (256 outputs at eight waves) dealt as FOUR tiles to half of the waves, the k-groups
+  // split between the halves: every wave then reads half of the activation image for twice the tiles - the layer's LDS traffic halves
+  // (at four row tiles each wave of such a layer reads the whole 64 x 512 image for 2 tiles: 170 B/clk asked of a 128 B/clk LDS).
+  // MEASURED (probe build -DLT_MLP_WIDE_KSPLIT=1, r04): policy launch 175.8 against 176.0 us at 32768 envs, 29.8 against 29.3 us at
+  // 4096 - the layer is not bound by its LDS reads; left off.
+  if (LT_MLP_WIDE_KSPLIT && l < L - 1 && p.T == 2 && p.nact == NW && p.G >= 2 && (p.G & 1) == 0 && 2 * pad32(N) <= pad32(widest)) {
+    p.T = 4;
+    p.nact = NW / 2;
+  }
   p.ks = (l < L - 1 && 2 * p.nact <= NW && p.G >= 2 && (p.G & 1) == 0 && 2 * pad32(N) <= pad32(widest)) ? 2 : 1;
   p.Gl = p.G / p.ks;
   p.waves = p.nact * p.ks;
@@ -152,6 +164,7 @@ struct MlpArgs {
   int noise_off;              // MODE_POLICY: float offset inside the LDS image of the [rows][16] block of N(0,1) draws (launch())
   unsigned in_magic;          // dims[0] % 4 == 0: floor(2^32 / (dims[0] / 4)) + 1, the reciprocal the input staging divides by; else 0
   signed char l_first[LT_MLP_MAX_LAYERS], l_ks[LT_MLP_MAX_LAYERS];  // per layer: first active wave, k-split factor (plan_of, host side)
+  signed char l_T[LT_MLP_MAX_LAYERS], l_nact[LT_MLP_MAX_LAYERS];   // ... tiles per wave, waves per k-half
   unsigned in_magic2;         // dims[0] % 4 == 2 (f32 rows): the same for pairs, floor(2^32 / (dims[0] / 2)) + 1; else 0
   long long bias_chunk;       // chunk offset of the bias block inside `packed`
   long long wave_base[NW];    // chunk offset of each wave's stream inside `packed`
@@ -598,7 +611,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
   const int N = a.dims[l + 1];
   // the layer's deal (Plan): `nact` waves share the tiles; k-split layers are dealt twice, the second half of the k-groups to the
   // next nact waves, whose raw sums go `koff` columns to the right
-  const int first = a.l_first[l], ks = a.l_ks[l], nact = active_waves(N);
+  const int first = a.l_first[l], ks = a.l_ks[l], nact = a.l_nact[l];
   const int rel = wave - first, kh = rel >= nact ? 1 : 0;
   const int G = pad32(a.dims[l]) / 32 / ks;  // this wave's k-groups: [kh G, (kh + 1) G)
   const int tile0 = (rel - kh * nact) * T;
@@ -924,7 +937,7 @@ __global__ __launch_bounds__(64 * NW, LT_MLP_MIN_WAVES_PER_SIMD) void lt_mlp_ker
   int boff = 0;
 #pragma unroll 1
   for (int l = 0; l < a.L; ++l) {
-    const int T = tiles_per_wave(pad16(a.dims[l + 1]) / 16);
+    const int T = a.l_T[l];
     const bool last = KIND != KIND_GATE && l == a.L - 1;  // (the chain's last layer is gated and written like the others)
     const float* const bias_l = s_bias + boff;
     if (NW <= 4 && T == 8) mlp_layer<(NW <= 4 ? 8 : 4), RT, RG, KIND>(a, l, last, s_act, bias_l, s_noise, wave, lane, row_block, ring, stream, c0);  // (eight waves: at most 4 tiles each)
@@ -1050,7 +1063,7 @@ void fill_args(const lt_mlp_desc* d, MlpArgs& a) {
   for (int w = 0; w < NW; ++w) a.wave_base[w] = g.wave_base[w];
   for (int l = 0; l < d->num_layers; ++l) {
     const Plan pl = plan_of(d->dims, d->num_layers, l);
-    a.l_first[l] = (signed char)pl.first; a.l_ks[l] = (signed char)pl.ks;
+    a.l_first[l] = (signed char)pl.first; a.l_ks[l] = (signed char)pl.ks; a.l_T[l] = (signed char)pl.T; a.l_nact[l] = (signed char)pl.nact;
   }
   a.stride = pad32(widest) + 4;
   a.bias_total = g.bias_total;
