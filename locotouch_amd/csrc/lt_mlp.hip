@@ -624,11 +624,23 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
     for (int t = 0; t < T; ++t) am[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (active) {
     // software pipeline over items: the (hi, lo) fragments of item i+1 in flight from LDS while item i is in the MFMAs
-    f16x8 xh[2][RT], xl[2][RT];
+#ifndef LT_MLP_SINGLE_FRAG
+#define LT_MLP_SINGLE_FRAG 0
+#endif
+    // SF (four row tiles): ONE fragment set, fetched at the item's start instead of one item ahead - the 32 registers of the second
+    // set pay for a second ring round (16 slots: two items of the widest layer in flight instead of one; with 8 slots every item of a
+    // wide layer waits out an L2 round trip: 11 items x ~1.3 us = the 13.8 us of the first layer).  The LDS latency this exposes (~0.2
+    // us per item) hides behind the SIMD's other wave and the MFMAs still executing.  MEASURED (probe build -DLT_MLP_SINGLE_FRAG=1
+    // -DLT_MLP_RING4=16: 241 VGPRs, no scratch): policy launch 174 against 172 us at 32768 envs, training forward 154.6 against 156.0 us -
+    // the deeper ring buys nothing at four row tiles either; left off.
+    constexpr bool SF = RT >= 4 && LT_MLP_SINGLE_FRAG != 0;
+    f16x8 xh[SF ? 1 : 2][RT], xl[SF ? 1 : 2][RT];
+    if (!SF) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      xh[0][rt] = *(const f16x8*)(xrow + 16 * rt * S);
-      xl[0][rt] = *(const f16x8*)(xrow + 16 * rt * S + 4);
+      for (int rt = 0; rt < RT; ++rt) {
+        xh[0][rt] = *(const f16x8*)(xrow + 16 * rt * S);
+        xl[0][rt] = *(const f16x8*)(xrow + 16 * rt * S + 4);
+      }
     }
     // items incl. the zero-weight pad items of the last RING round: they are walked (refill only) to leave the ring on the
     // next layer's first chunk - except behind the last layer, where nothing follows
@@ -640,17 +652,17 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a, int l, bool last, fl
         const int sl = (j % R) * C;  // first ring slot of the item
         if (i < G) {
           // fetch item i+1's fragments (the last item re-reads itself)
-          const int gx = i + 1 < G ? i + 1 : G - 1;
+          const int gx = SF ? i : (i + 1 < G ? i + 1 : G - 1);
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
-            xh[(j & 1) ^ 1][rt] = *(const f16x8*)(xrow + 16 * rt * S + 32 * gx);
-            xl[(j & 1) ^ 1][rt] = *(const f16x8*)(xrow + 16 * rt * S + 32 * gx + 4);
+            xh[SF ? 0 : ((j & 1) ^ 1)][rt] = *(const f16x8*)(xrow + 16 * rt * S + 32 * gx);
+            xl[SF ? 0 : ((j & 1) ^ 1)][rt] = *(const f16x8*)(xrow + 16 * rt * S + 32 * gx + 4);
           }
           // the three products of the split, all into the one accumulator (product-major order - two MFMAs on the same
           // accumulator T x RT apart instead of T - measured the same within noise)
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
-            const f16x8 bh = xh[j & 1][rt], bl = xl[j & 1][rt];
+            const f16x8 bh = xh[SF ? 0 : (j & 1)][rt], bl = xl[SF ? 0 : (j & 1)][rt];
             const f16x8 bs1 = bh * (_Float16)LO_SCALE;  // exact: |x| <= F16_CLAMP
 #pragma unroll
             for (int t = 0; t < T; ++t) am[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[sl + 2 * t]), bs1, am[rt][t], 0, 0, 0);
